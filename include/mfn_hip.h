@@ -1,0 +1,175 @@
+/*
+ * mfn_hip.h -- C ABI of libmfn_hip.so: the MI355X (gfx950) implementation of MaskFlownet's
+ * per-pyramid-level matching hot path.  This is the drop-in boundary: every entry point
+ * replaces one MXNet operator call made by /root/reference (file:line cited per function)
+ * and is what a ctypes / MXNet-CustomOp binding on the reference side binds to
+ * (INTEGRATION.md shows the stubs).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch/MXNet types cross the boundary.
+ *   - every tensor is a contiguous fp32 NCHW buffer in DEVICE memory, owned by the caller.
+ *     Outputs are fully overwritten unless a `req` argument says otherwise.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *     enqueue work; they never synchronise and never allocate device memory.
+ *   - return value: 0 = ok; < 0 = bad argument (MFN_E_*); > 0 = a hipError_t from the
+ *     launch.  mfn_last_error() returns a thread-local description of the last failure.
+ *     Nothing throws across the boundary.
+ *   - the library is re-entrant; it keeps no per-call state.
+ *   - flow tensors use the network's channel order: channel 0 = dy (vertical),
+ *     channel 1 = dx (horizontal)   (/root/reference/network/pipeline.py:105,
+ *     /root/reference/network/layer.py:17).
+ */
+#ifndef MFN_HIP_H
+#define MFN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFN_ABI_VERSION 1
+
+/* status codes (< 0); > 0 are hipError_t values */
+#define MFN_OK 0
+#define MFN_E_NULL (-1)        /* a required pointer is NULL */
+#define MFN_E_SHAPE (-2)       /* a dimension is non-positive or inconsistent */
+#define MFN_E_PARAM (-3)       /* an operator parameter is outside what MXNet accepts */
+#define MFN_E_UNSUPPORTED (-4) /* valid for MXNet, not implemented by this library */
+#define MFN_E_WORKSPACE (-5)   /* workspace missing or too small */
+#define MFN_E_ALIGN (-6)       /* a pointer is not 4-byte aligned */
+
+/* OpReqType of MXNet (include/mxnet/op_attr_types.h) for gradient outputs */
+#define MFN_REQ_NULL 0
+#define MFN_REQ_WRITE 1
+#define MFN_REQ_ADD 3
+
+int mfn_abi_version(void);
+const char *mfn_version_string(void);
+/* Thread-local text for the last non-zero status returned on this thread ("" if none). */
+const char *mfn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Correlation  -- replaces F.Correlation(data1, data2, kernel_size, max_displacement, stride1,
+ * stride2, pad_size, is_multiply) at /root/reference/network/MaskFlownet.py:193-195 (md=4) and
+ * :440-441 (md=2).  Semantics: MXNet src/operator/correlation.cc:
+ *   out[n, (dy/s2 + r)*D + (dx/s2 + r), i, j] =
+ *       1/(K*K*C) * sum_{h,w<K} sum_c pad(data1)[n,c,y1+h,x1+w] * pad(data2)[n,c,y1+dy+h,x1+dx+w]
+ *   r = max_displacement/stride2, D = 2r+1, y1 = i*stride1 + max_displacement (padded coords).
+ * data1,data2: (N,C,H,W); out: (N, D*D, top_h, top_w) from mfn_correlation_out_shape.
+ * The reference configuration (kernel_size=1, strides 1, pad_size == max_displacement) runs
+ * the LDS-tiled kernel; any other valid configuration runs a generic kernel.
+ * ------------------------------------------------------------------------------------------- */
+int mfn_correlation_out_shape(int H, int W, int max_displacement, int kernel_size, int stride1,
+                              int stride2, int pad_size, int *top_channels, int *top_h, int *top_w);
+int mfn_correlation_fwd(const float *data1, const float *data2, float *out, int N, int C, int H,
+                        int W, int max_displacement, int kernel_size, int stride1, int stride2,
+                        int pad_size, int is_multiply, void *stream);
+/* Backward of the same call site (training, /root/reference/network/pipeline.py:112-113).
+ * g1/g2: (N,C,H,W); req1/req2 in {MFN_REQ_NULL, MFN_REQ_WRITE, MFN_REQ_ADD}. */
+int mfn_correlation_bwd(const float *gout, const float *data1, const float *data2, float *g1,
+                        float *g2, int N, int C, int H, int W, int max_displacement,
+                        int kernel_size, int stride1, int stride2, int pad_size, int is_multiply,
+                        int req1, int req2, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Warp -- replaces the operator pair of /root/reference/network/layer.py:14-18
+ * (Reconstruction2D) and :26-30 (Reconstruction2DSmooth):
+ *     grid = GridGenerator(flow.flip(axis=1), 'warp') [.clip(-1, 1)];  out = BilinearSampler(x, grid)
+ * fused into one kernel.  x,out: (N,C,H,W); flow_yx: (N,2,H,W).  clip_grid=1 is the Smooth
+ * variant (border replicate).  Semantics: MXNet grid_generator-inl.h (kWarp) +
+ * bilinear_sampler.cc, including the fp32 normalise/denormalise
+ * round trip and per-tap zero padding.
+ * ------------------------------------------------------------------------------------------- */
+int mfn_warp_fwd(const float *x, const float *flow_yx, float *out, int N, int C, int H, int W,
+                 int clip_grid, void *stream);
+/* gx: (N,C,H,W) data gradient, gflow_yx: (N,2,H,W) flow gradient (NULL / MFN_REQ_NULL to skip,
+ * which is what block_grad=True in layer.py:15-16 does). */
+int mfn_warp_bwd(const float *gout, const float *x, const float *flow_yx, float *gx,
+                 float *gflow_yx, int N, int C, int H, int W, int clip_grid, int req_x,
+                 int req_flow, void *stream);
+/* The two MXNet operators on their own (also used by /root/reference/augmentation.py:60-64,
+ * 306-321,333).  flow_xy/grid: (N,2,H,W) channel 0 = x.  theta: (N,6) row-major 2x3. */
+int mfn_grid_generator_warp(const float *flow_xy, float *grid, int N, int H, int W, void *stream);
+int mfn_grid_generator_affine(const float *theta, float *grid, int N, int H, int W, void *stream);
+int mfn_bilinear_sampler_fwd(const float *data, const float *grid, float *out, int N, int C,
+                             int iH, int iW, int oH, int oW, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DeformableConvolution -- replaces F.contrib.DeformableConvolution(x, offset, weight[, bias],
+ * kernel, stride, dilate, pad, num_filter, num_group, num_deformable_group, no_bias) at
+ * /root/reference/network/layer.py:117-124 (kwargs :91-95).  Semantics: MXNet
+ * contrib/nn/deformable_im2col.* + contrib/deformable_convolution-inl.h:
+ *   out[n,o,y,x] = bias[o] + sum_{c,i,j} w[o,c,i,j] * S(x[n,c], y*sh-ph+i*dh + off[n,2k,y,x],
+ *                                                        x*sw-pw+j*dw + off[n,2k+1,y,x]),  k=i*kw+j
+ *   S = 0 when a coordinate is < 0 or >= dim; bilinear with clamp-to-last inside [dim-1, dim).
+ * x: (N,Cin,H,W); offset: (N, 2*kh*kw*deform_groups, Ho, Wo); w: (Cout, Cin/groups, kh, kw);
+ * bias: (Cout) or NULL (no_bias); out: (N,Cout,Ho,Wo).
+ * The im2col buffer is never materialised: the gather feeds fp32 MFMA tiles directly.
+ * `workspace` holds the re-laid-out weights (mfn_deform_conv_workspace_bytes); it is scratch,
+ * valid only for the duration of the call's stream work.
+ * ------------------------------------------------------------------------------------------- */
+int mfn_deform_conv_out_shape(int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                              int dw, int *Ho, int *Wo);
+size_t mfn_deform_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw,
+                                       int groups, int deform_groups);
+int mfn_deform_conv_fwd(const float *x, const float *offset, const float *w,
+                        const float *bias_or_null, float *out, int N, int Cin, int H, int W,
+                        int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                        int groups, int deform_groups, void *workspace, size_t workspace_bytes,
+                        void *stream);
+/* Fused form of the reference's call pattern /root/reference/network/MaskFlownet.py:230,248,266,
+ * 284: offset = repeat9(flow * flow_scale / flow_stride) is never built; every tap of pixel
+ * (y,x) uses (flow[n,0,y,x], flow[n,1,y,x]) * flow_scale / flow_stride.  Same result as
+ * mfn_offsets_from_flow + mfn_deform_conv_fwd.  Requires stride 1 (Ho=H, Wo=W). */
+int mfn_deform_conv_shared_fwd(const float *x, const float *flow_yx, float flow_scale,
+                               float flow_stride, const float *w, const float *bias_or_null,
+                               float *out, int N, int Cin, int H, int W, int Cout, int kh, int kw,
+                               int ph, int pw, int dh, int dw, int groups, void *workspace,
+                               size_t workspace_bytes, void *stream);
+/* Backward (training).  gx,goffset,gw,gbias as the forward's x,offset,w,bias; req_* per output;
+ * workspace from mfn_deform_conv_bwd_workspace_bytes. */
+size_t mfn_deform_conv_bwd_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw,
+                                           int sh, int sw, int ph, int pw, int dh, int dw,
+                                           int groups, int deform_groups);
+int mfn_deform_conv_bwd(const float *gout, const float *x, const float *offset, const float *w,
+                        float *gx, float *goffset, float *gw, float *gbias_or_null, int N, int Cin,
+                        int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                        int dh, int dw, int groups, int deform_groups, int req_x, int req_offset,
+                        int req_w, int req_bias, void *workspace, size_t workspace_bytes,
+                        void *stream);
+/* Offset builder of /root/reference/network/MaskFlownet.py:230:
+ *   offset[n, 2k+t, y, x] = flow_yx[n, t, y, x] * scale / stride   for k < taps. */
+int mfn_offsets_from_flow(const float *flow_yx, float *offset, int N, int H, int W, int taps,
+                          float scale, float stride, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stream plumbing for the host side (no reference equivalent: MXNet's engine does this).
+ * A hot-path pass is ~10 short launches; capturing it once into a hipGraph and replaying it
+ * removes the per-launch host cost.  Capture is plain hipStreamBeginCapture on `stream`.
+ * ------------------------------------------------------------------------------------------- */
+int mfn_graph_begin_capture(void *stream);
+int mfn_graph_end_capture(void *stream, void **graph_exec_out);
+int mfn_graph_launch(void *graph_exec, void *stream);
+int mfn_graph_destroy(void *graph_exec);
+
+/* Built-in kernel timer: while enabled, every launch made by this library on this thread is
+ * bracketed by HIP events on ITS OWN stream (hipExtLaunchKernelGGL start/stop events) and
+ * accumulated per kernel name.  Used by bench.py for the roofline line. */
+int mfn_profile_enable(int on);
+int mfn_profile_reset(void);
+/* Synchronises the recorded events, then reports launches and summed milliseconds of every
+ * kernel whose name contains `name_substr`.  Returns the number of matching launches. */
+int mfn_profile_query(const char *name_substr, int *launches, double *total_ms);
+/* Writes up to `cap` bytes of "name launches total_ms\n" lines into buf; returns bytes needed. */
+int mfn_profile_dump(char *buf, int cap);
+
+/* Kernel-selection knobs for tuning sweeps (process-global, not part of the drop-in surface).
+ * Unknown keys return MFN_E_PARAM.  Keys: see maskflownet_amd/csrc/tuning.h. */
+int mfn_set_tuning(const char *key, int value);
+int mfn_get_tuning(const char *key, int *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFN_HIP_H */

@@ -1,0 +1,73 @@
+"""Loader of libmfn_hip.so -- the ONLY compute backend of this package.
+
+There is no CPU fallback and no alternative backend: if the HIP library is missing or lacks a
+symbol, importing the ops raises.  (The oracle under oracle/ and the emulation build under
+tests/emu/ are test infrastructure and are never imported from here.)
+"""
+import ctypes
+import os
+import subprocess
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libmfn_hip.so")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+
+_lib = None
+
+
+class MfnError(RuntimeError):
+    """Raised when a C-ABI call returns a non-zero status (the analogue of MXNetError)."""
+
+    def __init__(self, status, message):
+        super().__init__("mfn status %d: %s" % (status, message))
+        self.status = status
+
+
+def _sources():
+    out = []
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".inc"))]
+    out.append(os.path.join(os.path.dirname(_HERE), "include", "mfn_hip.h"))
+    return out
+
+
+def build(force=False, verbose=False):
+    """Compile libmfn_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    srcs = _sources()
+    if (not force and os.path.exists(SO_PATH)
+            and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH, os.path.join(CSRC, "api.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def lib():
+    """The bound library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+        cdll = ctypes.CDLL(SO_PATH)
+        _lib = _abi.bind(cdll, "mfn_", product=True)
+        if _lib.abi_version() != 1:
+            raise ImportError("libmfn_hip.so ABI version mismatch")
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().last_error().decode(errors="replace")
+        raise MfnError(status, msg or what)
+
+
+def set_tuning(**kw):
+    for k, v in kw.items():
+        check(lib().set_tuning(k.replace("_", ".", 1).encode(), int(v)), "set_tuning")

@@ -1,0 +1,374 @@
+// correlation.h -- cost-volume kernels for gfx950.
+//
+// Replaces MXNet Correlation at /root/reference/network/MaskFlownet.py:193-195 (md=4, 81 ch)
+// and :440-441 (md=2, 25 ch); semantics as oracle/mfn_ref_body.inc correlation_fwd.
+//
+// corr_tiled_kernel<D, TW, NCH, CK>  (kernel_size=1, stride1=stride2=1, pad=md, W%4==0)
+//   HBM-bound op (4*N*h*w*(2C + D*D) bytes), close to the fp32 ridge, so the
+//   design goal is to touch HBM once and keep VALU + LDS pressure low:
+//   * one workgroup = D waves; wave `wv` owns displacement row dy = wv - md, so all D*D outputs
+//     of a pixel live in registers of D different waves and never move;
+//   * a lane owns NCH chunks of 4 adjacent pixels and the D displacements dx of its dy:
+//     NCH*4*D fp32 accumulators, fed per channel by one ds_read_b128 of f1 and three of f2
+//     (12 consecutive f2 values serve 4 pixels x up to 9 dx) -> 9 FMA per 16-byte LDS read;
+//   * a tile is TW x (256*NCH/TW) pixels; channels stream through LDS in chunks of CK with the
+//     next chunk's global loads in flight while the current chunk is consumed (register
+//     prefetch); the f2 window carries a +-md row halo and a +-4 column halo so every global
+//     and LDS access is an aligned 16-byte vector;
+//   * lane -> (row, 4-px group) uses the ds_read_b128 service-group order of gfx950
+//     (MI355X_MICROARCH.md LDS table) so the four 16-lane groups of one read hit 16 distinct
+//     16-byte bank slots: conflict-free for every TW;
+//   * stores are 16 B per lane, 256 B contiguous per tile row.
+// corr_generic_kernel: any valid MXNet parameter set, one thread per output element.
+#pragma once
+#include "../mfn_rt.h"
+
+namespace mfn {
+
+// ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, and the
+// same +32.  Returns the lane's position in service-group-major order (group g -> 16g..16g+15).
+__device__ __forceinline__ int b128_service_pos(int lane) {
+  const unsigned long long tbl = 0x1C0C081804141000ull;  // per 4-lane quad: base position
+  const int q = (lane >> 2) & 7;
+  const int base = (int)((tbl >> (8 * q)) & 0xFFull);
+  return base + (lane & 3) + (lane & 32);
+}
+
+template <int TW>
+struct CorrGeom {
+  static constexpr int GX = TW / 4;     // 4-px groups per tile row
+  static constexpr int RPC = 256 / TW;  // tile rows covered by one chunk plane (64 lanes x 4 px)
+  // LDS row stride in floats: window is TW+8 columns; padded where the lane map needs it
+  static constexpr int RS = (TW == 64) ? 72 : (TW == 32 ? 40 : 24);
+  static constexpr int CW4 = (TW + 8) / 4;  // float4 per f2 window row
+  // position (service-group-major) -> (row within chunk plane, group within row), chosen so that
+  // the 16 lanes of one service group touch 16 distinct 16-byte slots mod 16 with stride RS/4
+  __device__ static __forceinline__ void map(int pos, int &row, int &gx) {
+    const int sg = pos >> 4, wi = pos & 15;
+    if (TW == 64) { row = sg; gx = wi; }
+    else if (TW == 32) { row = sg + 4 * (wi >> 3); gx = wi & 7; }
+    else if (TW == 16) { row = 2 * (wi >> 2) + (sg & 1) + 8 * (sg >> 1); gx = wi & 3; }
+    else { row = 8 * sg + (wi >> 1); gx = wi & 1; }
+  }
+};
+
+struct CorrParams {
+  const float *f1;
+  const float *f2;
+  float *out;
+  int N, C, H, W;
+  int tiles_x, tiles_y;
+  float inv_sumelems;  // 1/C
+  float sumelems;      // C
+  int exact_div;       // 1: divide (C not a power of two), 0: multiply by the exact reciprocal
+  int xcd_swizzle;     // 1: remap blockIdx so that neighbouring tiles share an XCD's L2
+  int leaky;           // fused epilogue (f-1): LeakyReLU(0.1) on the output (MaskFlownet.py:217)
+};
+
+// Variant knobs (swept on the GPU, see tools/sweep.py):
+//   NCH  4-px chunks per lane            DYW  displacement rows per wave (block = ceil(D/DYW) waves)
+//   CK   channels per LDS stage          PF   register prefetch of the next stage's global loads
+//   WPE  minimum waves per SIMD the register allocator must leave room for
+template <int D, int TW, int NCH, int CK, int DYW, bool PF, int WPE>
+__global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_kernel(CorrParams p) {
+  constexpr int MD = (D - 1) / 2;
+  constexpr int NW = (D + DYW - 1) / DYW;
+  constexpr int NT = NW * 64;
+  using G = CorrGeom<TW>;
+  constexpr int RS = G::RS;
+  constexpr int TH = G::RPC * NCH;
+  constexpr int ROWS2 = TH + 2 * MD;
+  constexpr int F1_PER_C = TH * RS;
+  constexpr int F2_PER_C = ROWS2 * RS;
+  constexpr int ITEMS1 = CK * TH * (TW / 4);
+  constexpr int ITEMS2 = CK * ROWS2 * G::CW4;
+  constexpr int NI1 = (ITEMS1 + NT - 1) / NT;
+  constexpr int NI2 = (ITEMS2 + NT - 1) / NT;
+
+  MFN_DYN_SHARED(float, lds);
+  float *f1s = lds;                  // [CK][TH][RS]
+  float *f2s = lds + CK * F1_PER_C;  // [CK][ROWS2][RS]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int dy0 = (tid >> 6) * DYW;  // first displacement row of this wave: dy = dy0 + e - MD
+
+  // ---- which tile ---------------------------------------------------------------------------
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if (p.xcd_swizzle && (nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int n = bid / tiles_per_img;
+  const int t = bid - n * tiles_per_img;
+  const int ty = t / p.tiles_x;
+  const int tx = t - ty * p.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int H = p.H, W = p.W, C = p.C;
+  const size_t plane = (size_t)H * W;
+  const float *f1n = p.f1 + (size_t)n * C * plane;
+  const float *f2n = p.f2 + (size_t)n * C * plane;
+
+  // ---- lane geometry ------------------------------------------------------------------------
+  int row, gx;
+  G::map(b128_service_pos(lane), row, gx);
+  const int f1_off = row * RS + 4 * gx;          // chunk plane 0; plane k adds k*RPC*RS
+  const int f2_off = (row + dy0) * RS + 4 * gx;  // window row = row + dy + MD; row e adds e*RS
+
+  float acc[DYW][NCH][D][4];
+  MFN_UNROLL
+  for (int e = 0; e < DYW; ++e)
+    MFN_UNROLL
+    for (int k = 0; k < NCH; ++k)
+      MFN_UNROLL
+      for (int d = 0; d < D; ++d)
+        MFN_UNROLL
+        for (int q = 0; q < 4; ++q) acc[e][k][d][q] = 0.f;
+
+  float4 pre1[NI1], pre2[NI2];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // global -> registers (zero fill implements MXNet's pad_size border and ragged tiles)
+  auto fetch = [&](int c0) {
+    MFN_UNROLL
+    for (int i = 0; i < NI1; ++i) {
+      const int it = tid + i * NT;
+      float4 v = zero4;
+      if (it < ITEMS1) {
+        const int c = it / (TH * (TW / 4));
+        const int rem = it - c * (TH * (TW / 4));
+        const int r = rem / (TW / 4);
+        const int q = rem - r * (TW / 4);
+        const int y = y0 + r, x = x0 + 4 * q;
+        if (c0 + c < C && y < H && x < W)
+          v = *reinterpret_cast<const float4 *>(f1n + (size_t)(c0 + c) * plane + (size_t)y * W + x);
+      }
+      pre1[i] = v;
+    }
+    MFN_UNROLL
+    for (int i = 0; i < NI2; ++i) {
+      const int it = tid + i * NT;
+      float4 v = zero4;
+      if (it < ITEMS2) {
+        const int c = it / (ROWS2 * G::CW4);
+        const int rem = it - c * (ROWS2 * G::CW4);
+        const int r = rem / G::CW4;
+        const int q = rem - r * G::CW4;
+        const int y = y0 - MD + r, x = x0 - 4 + 4 * q;
+        if (c0 + c < C && y >= 0 && y < H && x >= 0 && x < W)
+          v = *reinterpret_cast<const float4 *>(f2n + (size_t)(c0 + c) * plane + (size_t)y * W + x);
+      }
+      pre2[i] = v;
+    }
+  };
+  // registers -> LDS
+  auto stash = [&]() {
+    MFN_UNROLL
+    for (int i = 0; i < NI1; ++i) {
+      const int it = tid + i * NT;
+      if (it < ITEMS1) {
+        const int c = it / (TH * (TW / 4));
+        const int rem = it - c * (TH * (TW / 4));
+        const int r = rem / (TW / 4);
+        const int q = rem - r * (TW / 4);
+        *reinterpret_cast<float4 *>(f1s + c * F1_PER_C + r * RS + 4 * q) = pre1[i];
+      }
+    }
+    MFN_UNROLL
+    for (int i = 0; i < NI2; ++i) {
+      const int it = tid + i * NT;
+      if (it < ITEMS2) {
+        const int c = it / (ROWS2 * G::CW4);
+        const int rem = it - c * (ROWS2 * G::CW4);
+        const int r = rem / G::CW4;
+        const int q = rem - r * G::CW4;
+        *reinterpret_cast<float4 *>(f2s + c * F2_PER_C + r * RS + 4 * q) = pre2[i];
+      }
+    }
+  };
+  // One "unit" = (channel c, chunk plane k, displacement row e): 3 ds_read_b128 of f2 (+1 of f1 when
+  // e == 0) feeding 4*D FMAs.  Operands are double-buffered in registers by hand and fenced with
+  // sched_barrier so the compiler overlaps exactly one unit of LDS latency with one unit of FMAs
+  // instead of hoisting a whole stage of reads (which costs 40-60 VGPRs and a wave of occupancy).
+  auto consume = [&]() {
+    constexpr int NU = CK * NCH * DYW;
+    float4 A[2];
+    float4 B[2][3];
+    auto load_unit = [&](int u) {
+      const int e = u % DYW, k = (u / DYW) % NCH, c = u / (DYW * NCH);
+      if (e == 0)
+        A[(u / DYW) & 1] = *reinterpret_cast<const float4 *>(f1s + c * F1_PER_C + k * G::RPC * RS + f1_off);
+      if (dy0 + e < D) {  // wave-uniform
+        const float *b = f2s + c * F2_PER_C + (k * G::RPC + e) * RS + f2_off;
+        B[u & 1][0] = *reinterpret_cast<const float4 *>(b);
+        B[u & 1][1] = *reinterpret_cast<const float4 *>(b + 4);
+        B[u & 1][2] = *reinterpret_cast<const float4 *>(b + 8);
+      }
+    };
+    load_unit(0);
+    MFN_UNROLL
+    for (int u = 0; u < NU; ++u) {
+      if (u + 1 < NU) load_unit(u + 1);
+      const int e = u % DYW, k = (u / DYW) % NCH;
+      if (dy0 + e < D) {
+        const float4 a = A[(u / DYW) & 1];
+        const float4 b0 = B[u & 1][0], b1 = B[u & 1][1], b2 = B[u & 1][2];
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+        MFN_UNROLL
+        for (int d = 0; d < D; ++d)
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q) acc[e][k][d][q] = fmaf(av[q], bv[q + d + (4 - MD)], acc[e][k][d][q]);
+      }
+      MFN_SCHED_BARRIER();
+    }
+  };
+
+  const int nchunks = (C + CK - 1) / CK;
+  if (PF) {
+    fetch(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      stash();
+      __syncthreads();
+      if (ch + 1 < nchunks) fetch((ch + 1) * CK);  // in flight while this stage is consumed
+      consume();
+      __syncthreads();  // everyone is done reading before the next stash overwrites
+    }
+  } else {
+    for (int ch = 0; ch < nchunks; ++ch) {
+      fetch(ch * CK);
+      if (ch) __syncthreads();  // previous stage fully consumed
+      stash();
+      __syncthreads();
+      consume();
+    }
+  }
+
+  // ---- epilogue: normalise, optional LeakyReLU, 16-byte stores -----------------------------------
+  float *outn = p.out + (size_t)n * (D * D) * plane;
+  MFN_UNROLL
+  for (int e = 0; e < DYW; ++e) {
+    if (dy0 + e < D) {
+      MFN_UNROLL
+      for (int k = 0; k < NCH; ++k) {
+        const int y = y0 + k * G::RPC + row;
+        const int x = x0 + 4 * gx;
+        if (y < H && x < W) {
+          MFN_UNROLL
+          for (int d = 0; d < D; ++d) {
+            float v[4];
+            MFN_UNROLL
+            for (int q = 0; q < 4; ++q) {
+              float r = p.exact_div ? acc[e][k][d][q] / p.sumelems : acc[e][k][d][q] * p.inv_sumelems;
+              if (p.leaky) r = r > 0.f ? r : 0.1f * r;
+              v[q] = r;
+            }
+            *reinterpret_cast<float4 *>(outn + (size_t)((dy0 + e) * D + d) * plane + (size_t)y * W + x) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int D, int TW, int NCH, int CK>
+inline size_t corr_tiled_lds_bytes() {
+  constexpr int MD = (D - 1) / 2;
+  using G = CorrGeom<TW>;
+  constexpr int TH = G::RPC * NCH;
+  return (size_t)CK * (TH * G::RS + (TH + 2 * MD) * G::RS) * sizeof(float);
+}
+
+template <int D, int TW, int NCH, int CK, int DYW, bool PF, int WPE>
+inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name) {
+  using G = CorrGeom<TW>;
+  constexpr int TH = G::RPC * NCH;
+  constexpr int NW = (D + DYW - 1) / DYW;
+  p.tiles_x = cdiv(p.W, TW);
+  p.tiles_y = cdiv(p.H, TH);
+  const int nblk = p.N * p.tiles_x * p.tiles_y;
+  if (nblk <= 0) return 0;
+  return launch(name, corr_tiled_kernel<D, TW, NCH, CK, DYW, PF, WPE>, dim3(nblk), dim3(NW * 64),
+                corr_tiled_lds_bytes<D, TW, NCH, CK>(), stream, p);
+}
+
+// Named variants (corr.variant tuning key).  Each is one point of (NCH, CK, DYW, PF, WPE).
+//   0: 1 dy/wave, 1 chunk,  CK=8, no prefetch, >=4 waves/SIMD   (9-wave blocks)
+//   1: 1 dy/wave, 1 chunk,  CK=4, prefetch,    >=4 waves/SIMD
+//   2: 1 dy/wave, 2 chunks, CK=4, prefetch,    >=3 waves/SIMD   (512-px tiles)
+//   3: 3 dy/wave, 1 chunk,  CK=4, prefetch,    >=2 waves/SIMD   (3-wave blocks)
+//   4: 3 dy/wave, 1 chunk,  CK=8, no prefetch, >=2 waves/SIMD
+//   5: 2 dy/wave, 1 chunk,  CK=4, prefetch,    >=3 waves/SIMD   (5-wave blocks)
+//   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=5 waves/SIMD   (2 blocks of 9 waves per CU)
+//   7: 3 dy/wave, 1 chunk,  CK=4, no prefetch, >=2 waves/SIMD
+constexpr int kCorrVariants = 8;
+template <int D, int TW>
+inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
+  switch (variant) {
+    case 0: return corr_tiled_launch<D, TW, 1, 8, 1, false, 4>(p, s, "corr_tiled_v0");
+    case 1: return corr_tiled_launch<D, TW, 1, 4, 1, true, 4>(p, s, "corr_tiled_v1");
+    case 2: return corr_tiled_launch<D, TW, 2, 4, 1, true, 3>(p, s, "corr_tiled_v2");
+    case 3: return corr_tiled_launch<D, TW, 1, 4, 3, true, 2>(p, s, "corr_tiled_v3");
+    case 4: return corr_tiled_launch<D, TW, 1, 8, 3, false, 2>(p, s, "corr_tiled_v4");
+    case 5: return corr_tiled_launch<D, TW, 1, 4, 2, true, 3>(p, s, "corr_tiled_v5");
+    case 6: return corr_tiled_launch<D, TW, 1, 4, 1, false, 5>(p, s, "corr_tiled_v6");
+    default: return corr_tiled_launch<D, TW, 1, 4, 3, false, 2>(p, s, "corr_tiled_v7");
+  }
+}
+inline int corr_variant_tile_h(int tw, int variant) { return (256 / tw) * (variant == 2 ? 2 : 1); }
+
+// ---- generic fallback: any MXNet-valid parameter set ----------------------------------------------
+struct CorrGenericParams {
+  const float *f1;
+  const float *f2;
+  float *out;
+  int N, C, H, W;
+  int md, kernel, stride1, stride2, pad, is_multiply;
+  int top_c, top_h, top_w, radius, gw;
+};
+
+__global__ __launch_bounds__(256) void corr_generic_kernel(CorrGenericParams p) {
+  const size_t total = (size_t)p.N * p.top_c * p.top_h * p.top_w;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx % p.top_w);
+  const int i = (int)((idx / p.top_w) % p.top_h);
+  const int tc = (int)((idx / ((size_t)p.top_w * p.top_h)) % p.top_c);
+  const int n = (int)(idx / ((size_t)p.top_w * p.top_h * p.top_c));
+  // padded coordinates as in CorrelationForward; unpadded = padded - pad, zero outside
+  const int x1 = j * p.stride1 + p.md, y1 = i * p.stride1 + p.md;
+  const int x2 = x1 + (tc % p.gw - p.radius) * p.stride2;
+  const int y2 = y1 + (tc / p.gw - p.radius) * p.stride2;
+  const size_t plane = (size_t)p.H * p.W;
+  const float *a = p.f1 + (size_t)n * p.C * plane;
+  const float *b = p.f2 + (size_t)n * p.C * plane;
+  float s = 0.f;
+  for (int h = 0; h < p.kernel; ++h)
+    for (int w = 0; w < p.kernel; ++w) {
+      const int ya = y1 + h - p.pad, xa = x1 + w - p.pad;
+      const int yb = y2 + h - p.pad, xb = x2 + w - p.pad;
+      const bool ina = ya >= 0 && ya < p.H && xa >= 0 && xa < p.W;
+      const bool inb = yb >= 0 && yb < p.H && xb >= 0 && xb < p.W;
+      if (p.is_multiply) {
+        if (ina && inb)
+          for (int c = 0; c < p.C; ++c)
+            s = fmaf(a[c * plane + (size_t)ya * p.W + xa], b[c * plane + (size_t)yb * p.W + xb], s);
+      } else {
+        for (int c = 0; c < p.C; ++c) {
+          const float va = ina ? a[c * plane + (size_t)ya * p.W + xa] : 0.f;
+          const float vb = inb ? b[c * plane + (size_t)yb * p.W + xb] : 0.f;
+          s += fabsf(va - vb);
+        }
+      }
+    }
+  p.out[idx] = s / (float)(p.kernel * p.kernel * p.C);
+}
+
+inline int corr_generic_launch(CorrGenericParams p, hipStream_t stream) {
+  const size_t total = (size_t)p.N * p.top_c * p.top_h * p.top_w;
+  if (total == 0) return 0;
+  return launch("corr_generic", corr_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                stream, p);
+}
+
+}  // namespace mfn

@@ -1,0 +1,186 @@
+// warp.h -- flow warp (GridGenerator 'warp' + BilinearSampler fused) and the two MXNet operators
+// on their own, for gfx950.
+//
+// Replaces /root/reference/network/layer.py:14-18 (Reconstruction2D) and :26-30
+// (Reconstruction2DSmooth); semantics as oracle/mfn_ref_body.inc warp_fwd / bilinear_sampler_fwd.
+// Gather-bound (4*N*H*W*(2C+2) bytes): one thread owns VEC adjacent pixels, reads
+// the flow and writes the output with 16-byte vectors, computes the 4 tap addresses/weights once
+// and reuses them for every channel.  The grid never exists in memory.
+#pragma once
+#include "../mfn_rt.h"
+
+namespace mfn {
+
+struct WarpParams {
+  const float *x;
+  const float *flow;  // (N,2,H,W): ch0 = dy, ch1 = dx
+  float *out;
+  int N, C, H, W;
+  int clip;
+};
+
+struct Taps {
+  int i00, i01, i10, i11;  // element offsets inside one channel plane (clamped when masked)
+  float w00, w01, w10, w11;
+};
+
+// grid value -> taps, exactly the BilinearSamplerForward arithmetic (fp32 round trip included)
+__device__ __forceinline__ Taps sampler_taps(float gx, float gy, int iH, int iW) {
+  const float y_real = (gy + 1.f) * (float)(iH - 1) / 2.f;
+  const float x_real = (gx + 1.f) * (float)(iW - 1) / 2.f;
+  const float fy = floorf(y_real), fx = floorf(x_real);
+  // saturating float->int keeps absurd coordinates (|flow| ~ 1e9) out of range instead of UB
+  const int ty = (int)fminf(fmaxf(fy, -2.f), (float)iH + 1.f);
+  const int tx = (int)fminf(fmaxf(fx, -2.f), (float)iW + 1.f);
+  const float wy = 1.f - (y_real - fy);
+  const float wx = 1.f - (x_real - fx);
+  const bool y0 = ty >= 0 && ty <= iH - 1, y1 = ty + 1 >= 0 && ty + 1 <= iH - 1;
+  const bool x0 = tx >= 0 && tx <= iW - 1, x1 = tx + 1 >= 0 && tx + 1 <= iW - 1;
+  Taps t;
+  t.w00 = (y0 && x0) ? wy * wx : 0.f;
+  t.w01 = (y0 && x1) ? wy * (1.f - wx) : 0.f;
+  t.w10 = (y1 && x0) ? (1.f - wy) * wx : 0.f;
+  t.w11 = (y1 && x1) ? (1.f - wy) * (1.f - wx) : 0.f;
+  const int cy0 = min(max(ty, 0), iH - 1), cy1 = min(max(ty + 1, 0), iH - 1);
+  const int cx0 = min(max(tx, 0), iW - 1), cx1 = min(max(tx + 1, 0), iW - 1);
+  t.i00 = cy0 * iW + cx0;
+  t.i01 = cy0 * iW + cx1;
+  t.i10 = cy1 * iW + cx0;
+  t.i11 = cy1 * iW + cx1;
+  return t;
+}
+
+__device__ __forceinline__ float sample(const float *plane, const Taps &t) {
+  // masked taps have weight 0 and a clamped (valid) address; select instead of multiply so that
+  // a non-finite value at the clamped address cannot leak into the result
+  const float v00 = t.w00 != 0.f ? plane[t.i00] : 0.f;
+  const float v01 = t.w01 != 0.f ? plane[t.i01] : 0.f;
+  const float v10 = t.w10 != 0.f ? plane[t.i10] : 0.f;
+  const float v11 = t.w11 != 0.f ? plane[t.i11] : 0.f;
+  return v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
+}
+
+// GridGenerator kWarp for one pixel: (flow + index) / ((size-1)/2) - 1
+__device__ __forceinline__ void warp_grid(float fx, float fy, int x, int y, int H, int W, int clip, float &gx,
+                                          float &gy) {
+  const float nx = (float)((W - 1) / 2.0), ny = (float)((H - 1) / 2.0);
+  gx = (fx + (float)x) / nx - 1.f;
+  gy = (fy + (float)y) / ny - 1.f;
+  if (clip) {
+    gx = fminf(fmaxf(gx, -1.f), 1.f);
+    gy = fminf(fmaxf(gy, -1.f), 1.f);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void warp_fwd_kernel(WarpParams p) {
+  const int W = p.W, H = p.H;
+  const int wv = W / VEC;  // vectors per row (VEC divides W)
+  const size_t total = (size_t)p.N * H * wv;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int xv = (int)(idx % wv);
+  const int y = (int)((idx / wv) % H);
+  const int n = (int)(idx / ((size_t)wv * H));
+  const int x0 = xv * VEC;
+  const size_t plane = (size_t)H * W;
+  const float *fl = p.flow + (size_t)n * 2 * plane + (size_t)y * W + x0;
+  float fy[VEC], fx[VEC];
+  if (VEC == 4) {
+    const float4 a = *reinterpret_cast<const float4 *>(fl);
+    const float4 b = *reinterpret_cast<const float4 *>(fl + plane);
+    fy[0] = a.x; fy[1 % VEC] = a.y; fy[2 % VEC] = a.z; fy[3 % VEC] = a.w;
+    fx[0] = b.x; fx[1 % VEC] = b.y; fx[2 % VEC] = b.z; fx[3 % VEC] = b.w;
+  } else {
+    MFN_UNROLL
+    for (int k = 0; k < VEC; ++k) { fy[k] = fl[k]; fx[k] = fl[plane + k]; }
+  }
+  Taps t[VEC];
+  MFN_UNROLL
+  for (int k = 0; k < VEC; ++k) {
+    float gx, gy;
+    warp_grid(fx[k], fy[k], x0 + k, y, H, W, p.clip, gx, gy);
+    t[k] = sampler_taps(gx, gy, H, W);
+  }
+  const float *xin = p.x + (size_t)n * p.C * plane;
+  float *o = p.out + (size_t)n * p.C * plane + (size_t)y * W + x0;
+  for (int c = 0; c < p.C; ++c) {
+    const float *pl = xin + (size_t)c * plane;
+    float r[VEC];
+    MFN_UNROLL
+    for (int k = 0; k < VEC; ++k) r[k] = sample(pl, t[k]);
+    if (VEC == 4) {
+      *reinterpret_cast<float4 *>(o + (size_t)c * plane) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
+    } else {
+      MFN_UNROLL
+      for (int k = 0; k < VEC; ++k) o[(size_t)c * plane + k] = r[k];
+    }
+  }
+}
+
+inline int warp_fwd_launch(WarpParams p, hipStream_t stream) {
+  const bool vec4 = (p.W % 4 == 0) && (((uintptr_t)p.flow | (uintptr_t)p.out) % 16 == 0);
+  const size_t total = (size_t)p.N * p.H * (vec4 ? p.W / 4 : p.W);
+  if (total == 0) return 0;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (vec4) return launch("warp_fwd_v4", warp_fwd_kernel<4>, grid, dim3(256), 0, stream, p);
+  return launch("warp_fwd_v1", warp_fwd_kernel<1>, grid, dim3(256), 0, stream, p);
+}
+
+// ---- the MXNet operators on their own ----------------------------------------------------------
+struct GridWarpParams { const float *flow_xy; float *grid; int N, H, W; };
+__global__ __launch_bounds__(256) void grid_warp_kernel(GridWarpParams p) {
+  const size_t plane = (size_t)p.H * p.W;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)p.N * plane) return;
+  const int x = (int)(idx % p.W), y = (int)((idx / p.W) % p.H);
+  const size_t n = idx / plane, pix = idx - n * plane;
+  float gx, gy;
+  warp_grid(p.flow_xy[n * 2 * plane + pix], p.flow_xy[n * 2 * plane + plane + pix], x, y, p.H, p.W, 0, gx, gy);
+  p.grid[n * 2 * plane + pix] = gx;
+  p.grid[n * 2 * plane + plane + pix] = gy;
+}
+
+struct GridAffineParams { const float *theta; float *grid; int N, H, W; };
+__global__ __launch_bounds__(256) void grid_affine_kernel(GridAffineParams p) {
+  const size_t plane = (size_t)p.H * p.W;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)p.N * plane) return;
+  const int x = (int)(idx % p.W), y = (int)((idx / p.W) % p.H);
+  const size_t n = idx / plane, pix = idx - n * plane;
+  const float *t = p.theta + n * 6;
+  const float xn = -1.f + (float)x * (float)(2.0 / (p.W - 1));
+  const float yn = -1.f + (float)y * (float)(2.0 / (p.H - 1));
+  p.grid[n * 2 * plane + pix] = t[0] * xn + t[1] * yn + t[2];
+  p.grid[n * 2 * plane + plane + pix] = t[3] * xn + t[4] * yn + t[5];
+}
+
+struct SamplerParams { const float *data; const float *grid; float *out; int N, C, iH, iW, oH, oW; };
+__global__ __launch_bounds__(256) void bilinear_sampler_kernel(SamplerParams p) {
+  const size_t oplane = (size_t)p.oH * p.oW, iplane = (size_t)p.iH * p.iW;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)p.N * oplane) return;
+  const size_t n = idx / oplane, pix = idx - n * oplane;
+  const float gx = p.grid[n * 2 * oplane + pix], gy = p.grid[n * 2 * oplane + oplane + pix];
+  const Taps t = sampler_taps(gx, gy, p.iH, p.iW);
+  for (int c = 0; c < p.C; ++c)
+    p.out[(n * p.C + c) * oplane + pix] = sample(p.data + (n * p.C + c) * iplane, t);
+}
+
+inline int grid_warp_launch(GridWarpParams p, hipStream_t s) {
+  const size_t total = (size_t)p.N * p.H * p.W;
+  if (!total) return 0;
+  return launch("grid_generator_warp", grid_warp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+}
+inline int grid_affine_launch(GridAffineParams p, hipStream_t s) {
+  const size_t total = (size_t)p.N * p.H * p.W;
+  if (!total) return 0;
+  return launch("grid_generator_affine", grid_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+}
+inline int bilinear_sampler_launch(SamplerParams p, hipStream_t s) {
+  const size_t total = (size_t)p.N * p.oH * p.oW;
+  if (!total) return 0;
+  return launch("bilinear_sampler", bilinear_sampler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+}
+
+}  // namespace mfn

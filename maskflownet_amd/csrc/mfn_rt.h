@@ -1,0 +1,73 @@
+// mfn_rt.h -- the one place where the kernels meet the runtime.
+//
+// Product build (hipcc --offload-arch=gfx950): plain HIP for CDNA4, launches go through
+// mfn::launch() which optionally brackets each kernel with HIP events on its own stream
+// (hipExtLaunchKernelGGL) for the built-in profiler of include/mfn_hip.h.
+// Test build (g++ -DMFN_EMU): the same kernel sources run on tests/emu/hipemu.h so that the
+// CPU-only CI can check their logic against the oracle.  There is no other dual path: no CUDA,
+// no hipify, no fallback inside the product library.
+#pragma once
+
+#if defined(MFN_EMU)
+#include "hipemu.h"
+typedef f32x16_emu f32x16;
+typedef f32x4_emu f32x4;
+#define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_shared())
+#define MFN_MFMA_32x32x2(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
+#define MFN_MFMA_16x16x4(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
+#define MFN_LANE_ID() ((int)hipemu::t_lane)
+#define MFN_UNROLL
+#define MFN_OPAQUE(x) ((void)(x))
+#define MFN_SCHED_BARRIER() ((void)0)
+#else
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// all dynamic LDS hangs off ONE 16-byte aligned symbol (cdna_hip_programming.md G17)
+extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
+#define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(mfn_lds_raw)
+#define MFN_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MFN_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFN_LANE_ID() ((int)(threadIdx.x & 63))
+#define MFN_UNROLL _Pragma("unroll")
+#define MFN_OPAQUE(x) asm volatile("" : "+v"(x))
+#define MFN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mfn {
+
+// ---- launch plumbing -------------------------------------------------------------------------
+#if defined(MFN_EMU)
+template <class K, class... Args>
+inline int launch(const char * /*name*/, K kernel, dim3 grid, dim3 block, size_t shmem,
+                  hipStream_t /*stream*/, Args... args) {
+  hipemu::launch(grid, block, shmem, [=]() { kernel(args...); });
+  return 0;
+}
+#else
+// profiler hooks (api.hip)
+bool profile_enabled();
+void profile_record(const char *name, hipEvent_t start, hipEvent_t stop);
+
+template <class K, class... Args>
+inline int launch(const char *name, K kernel, dim3 grid, dim3 block, size_t shmem,
+                  hipStream_t stream, Args... args) {
+  if (profile_enabled()) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();
+    hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)shmem, stream, e0, e1, 0, args...);
+    profile_record(name, e0, e1);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, (unsigned)shmem, stream, args...);
+  }
+  return (int)hipGetLastError();
+}
+#endif
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace mfn

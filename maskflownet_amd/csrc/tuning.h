@@ -1,0 +1,29 @@
+// tuning.h -- kernel-selection knobs behind mfn_set_tuning()/mfn_get_tuning() (include/mfn_hip.h).
+// 0 (or any value a key does not list) means "let the library choose".
+//   corr.tw      tile width of the tiled correlation kernel: 64 | 32 | 16 | 8
+//   corr.variant named (NCH, CK, DYW, PF, WPE) point, see kernels/correlation.h; -1 = default
+//   corr.xcd     1: XCD-aware block remap (neighbouring tiles share an L2)
+//   corr.generic 1: force the generic one-thread-per-output kernel
+//   dc.mt        32-filter MFMA tiles per wave: 1 | 2 | 3 | 4 | 7
+//   dc.ks        split-K ways inside a block: 1 | 2 | 4
+//   dc.fast      0: disable the shared-offset 4x4-neighbourhood gather
+//   dc.generic   1: force the generic one-thread-per-output kernel
+#pragma once
+#include <string.h>
+namespace mfn {
+struct Tuning {
+  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0;
+  int dc_mt = 0, dc_ks = 0, dc_fast = 1, dc_generic = 0;
+  int *slot(const char *key) {
+    if (!strcmp(key, "corr.tw")) return &corr_tw;
+    if (!strcmp(key, "corr.variant")) return &corr_variant;
+    if (!strcmp(key, "corr.xcd")) return &corr_xcd;
+    if (!strcmp(key, "corr.generic")) return &corr_generic;
+    if (!strcmp(key, "dc.mt")) return &dc_mt;
+    if (!strcmp(key, "dc.ks")) return &dc_ks;
+    if (!strcmp(key, "dc.fast")) return &dc_fast;
+    if (!strcmp(key, "dc.generic")) return &dc_generic;
+    return nullptr;
+  }
+};
+}  // namespace mfn

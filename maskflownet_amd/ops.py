@@ -1,0 +1,287 @@
+"""Operator front-end: the MXNet operator signatures of the hot path, on top of the C ABI.
+
+Mirrors the operators /root/reference reaches (same names, argument meaning, shape inference and
+error conditions), so the parity tests read like MXNet operator tests:
+
+    Correlation(data1, data2, kernel_size, max_displacement, stride1, stride2, pad_size, is_multiply)
+        -- network/MaskFlownet.py:193-195, :440-441
+    GridGenerator(data, transform_type, target_shape) / BilinearSampler(data, grid)
+        -- network/layer.py:17-18, :29-30; augmentation.py:60-64, 306-321
+    DeformableConvolution(data, offset, weight, bias, kernel, stride, dilate, pad, num_filter,
+                          num_group, num_deformable_group, no_bias)  -- network/layer.py:117-124
+plus the fused forms the hot path actually wants: warp() (GridGenerator+clip+BilinearSampler in
+one kernel) and deformable_convolution_shared() (offset builder of MaskFlownet.py:230 folded in).
+
+`OpSet` is array-library agnostic: an adapter supplies raw addresses, allocation and the stream.
+The module-level functions bind it to torch-ROCm tensors (torch is plumbing: device memory and
+streams) and libmfn_hip.so.  There is no CPU implementation behind these functions.
+"""
+import ctypes
+
+from . import _lib
+
+
+class OpSet:
+    def __init__(self, ns, adapter, check):
+        self.ns = ns
+        self.ad = adapter
+        self.check = check
+        self._ws = {}
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def _in(self, *arrs):
+        return [self.ad.prepare(a) for a in arrs]
+
+    def _workspace(self, like, nbytes):
+        key = self.ad.device_key(like)
+        ws = self._ws.get(key)
+        if ws is None or self.ad.nbytes(ws) < nbytes:
+            ws = self.ad.empty_bytes(like, max(int(nbytes), 1 << 20))
+            self._ws[key] = ws
+        return ws
+
+    # ---- Correlation ---------------------------------------------------------------------------
+    def correlation_out_shape(self, H, W, kernel_size=1, max_displacement=1, stride1=1, stride2=1, pad_size=0):
+        c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.check(self.ns.correlation_out_shape(H, W, max_displacement, kernel_size, stride1, stride2, pad_size,
+                                                 ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)))
+        return c.value, h.value, w.value
+
+    def Correlation(self, data1, data2, kernel_size=1, max_displacement=1, stride1=1, stride2=1, pad_size=0,
+                    is_multiply=True, out=None):
+        d1, d2 = self._in(data1, data2)
+        if self.ad.ndim(d1) != 4 or self.ad.shape(d1) != self.ad.shape(d2):
+            raise ValueError("Correlation: data1 and data2 must be 4-D with identical shapes, got %s and %s"
+                             % (self.ad.shape(d1), self.ad.shape(d2)))
+        N, C, H, W = self.ad.shape(d1)
+        tc, th, tw = self.correlation_out_shape(H, W, kernel_size, max_displacement, stride1, stride2, pad_size)
+        if out is None:
+            out = self.ad.empty(d1, (N, tc, th, tw))
+        elif self.ad.shape(out) != (N, tc, th, tw):
+            raise ValueError("Correlation: out has shape %s, expected %s" % (self.ad.shape(out), (N, tc, th, tw)))
+        self.check(self.ns.correlation_fwd(self.ad.ptr(d1), self.ad.ptr(d2), self.ad.ptr(out), N, C, H, W,
+                                           int(max_displacement), int(kernel_size), int(stride1), int(stride2),
+                                           int(pad_size), int(bool(is_multiply)), self.ad.stream(d1)))
+        return out
+
+    # ---- warp ------------------------------------------------------------------------------------
+    def warp(self, x, flow, clip_grid=False, out=None):
+        """layer.py Reconstruction2D (clip_grid=False) / Reconstruction2DSmooth (True), fused.
+        flow: (N,2,H,W), channel 0 = dy, channel 1 = dx."""
+        xx, fl = self._in(x, flow)
+        if self.ad.ndim(xx) != 4:
+            raise ValueError("warp: x must be 4-D")
+        N, C, H, W = self.ad.shape(xx)
+        if self.ad.shape(fl) != (N, 2, H, W):
+            raise ValueError("warp: flow must have shape %s, got %s" % ((N, 2, H, W), self.ad.shape(fl)))
+        if out is None:
+            out = self.ad.empty(xx, (N, C, H, W))
+        self.check(self.ns.warp_fwd(self.ad.ptr(xx), self.ad.ptr(fl), self.ad.ptr(out), N, C, H, W,
+                                    int(bool(clip_grid)), self.ad.stream(xx)))
+        return out
+
+    def GridGenerator(self, data, transform_type, target_shape=None):
+        (d,) = self._in(data)
+        if transform_type == "warp":
+            if self.ad.ndim(d) != 4 or self.ad.shape(d)[1] != 2:
+                raise ValueError("GridGenerator(warp): data must be (N,2,H,W)")
+            N, _, H, W = self.ad.shape(d)
+            grid = self.ad.empty(d, (N, 2, H, W))
+            self.check(self.ns.grid_generator_warp(self.ad.ptr(d), self.ad.ptr(grid), N, H, W, self.ad.stream(d)))
+            return grid
+        if transform_type == "affine":
+            if target_shape is None or len(target_shape) != 2:
+                raise ValueError("GridGenerator(affine): target_shape=(H,W) is required")
+            shp = self.ad.shape(d)
+            if len(shp) != 2 or shp[1] != 6:
+                raise ValueError("GridGenerator(affine): data must be (N,6)")
+            H, W = int(target_shape[0]), int(target_shape[1])
+            grid = self.ad.empty(d, (shp[0], 2, H, W))
+            self.check(self.ns.grid_generator_affine(self.ad.ptr(d), self.ad.ptr(grid), shp[0], H, W,
+                                                     self.ad.stream(d)))
+            return grid
+        raise ValueError("GridGenerator: transform_type must be 'affine' or 'warp'")
+
+    def BilinearSampler(self, data, grid):
+        d, g = self._in(data, grid)
+        if self.ad.ndim(d) != 4 or self.ad.ndim(g) != 4 or self.ad.shape(g)[1] != 2 or \
+                self.ad.shape(g)[0] != self.ad.shape(d)[0]:
+            raise ValueError("BilinearSampler: data (N,C,H,W) and grid (N,2,H',W') expected")
+        N, C, iH, iW = self.ad.shape(d)
+        _, _, oH, oW = self.ad.shape(g)
+        out = self.ad.empty(d, (N, C, oH, oW))
+        self.check(self.ns.bilinear_sampler_fwd(self.ad.ptr(d), self.ad.ptr(g), self.ad.ptr(out), N, C, iH, iW, oH,
+                                                oW, self.ad.stream(d)))
+        return out
+
+    # ---- DeformableConvolution -----------------------------------------------------------------------
+    @staticmethod
+    def _pair(v):
+        if isinstance(v, (tuple, list)):
+            if len(v) != 2:
+                raise ValueError("2-D kernel/stride/pad/dilate expected, got %r" % (v,))
+            return int(v[0]), int(v[1])
+        return int(v), int(v)
+
+    def deform_conv_out_shape(self, H, W, kernel, stride=(1, 1), pad=(0, 0), dilate=(1, 1)):
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw) = map(self._pair, (kernel, stride, pad, dilate))
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        self.check(self.ns.deform_conv_out_shape(H, W, kh, kw, sh, sw, ph, pw, dh, dw, ctypes.byref(ho),
+                                                 ctypes.byref(wo)))
+        return ho.value, wo.value
+
+    def DeformableConvolution(self, data, offset, weight, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
+                              pad=(0, 0), num_filter=None, num_group=1, num_deformable_group=1, no_bias=False,
+                              layout="NCHW", out=None):
+        if layout not in (None, "NCHW"):
+            raise ValueError("DeformableConvolution: only layout='NCHW' is supported")
+        if no_bias:
+            bias = None
+        elif bias is None:
+            raise ValueError("DeformableConvolution: bias is required unless no_bias=True")
+        x, off, w = self._in(data, offset, weight)
+        b = self._in(bias)[0] if bias is not None else None
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw) = map(self._pair, (kernel, stride, pad, dilate))
+        if self.ad.ndim(x) != 4:
+            raise ValueError("DeformableConvolution: data must be 4-D")
+        N, Cin, H, W = self.ad.shape(x)
+        Cout = self.ad.shape(w)[0]
+        if num_filter is not None and int(num_filter) != Cout:
+            raise ValueError("DeformableConvolution: num_filter=%s but weight has %d filters" % (num_filter, Cout))
+        if Cin % num_group or Cout % num_group or Cin % num_deformable_group:
+            raise ValueError("DeformableConvolution: channels must divide num_group / num_deformable_group")
+        if self.ad.shape(w) != (Cout, Cin // num_group, kh, kw):
+            raise ValueError("DeformableConvolution: weight shape %s, expected %s"
+                             % (self.ad.shape(w), (Cout, Cin // num_group, kh, kw)))
+        Ho, Wo = self.deform_conv_out_shape(H, W, (kh, kw), (sh, sw), (ph, pw), (dh, dw))
+        exp_off = (N, 2 * kh * kw * num_deformable_group, Ho, Wo)
+        if self.ad.shape(off) != exp_off:
+            raise ValueError("DeformableConvolution: offset shape %s, expected %s" % (self.ad.shape(off), exp_off))
+        if b is not None and self.ad.shape(b) != (Cout,):
+            raise ValueError("DeformableConvolution: bias shape %s, expected (%d,)" % (self.ad.shape(b), Cout))
+        if out is None:
+            out = self.ad.empty(x, (N, Cout, Ho, Wo))
+        nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, num_group, num_deformable_group)
+        ws = self._workspace(x, nbytes)
+        self.check(self.ns.deform_conv_fwd(self.ad.ptr(x), self.ad.ptr(off), self.ad.ptr(w),
+                                           self.ad.ptr(b) if b is not None else None, self.ad.ptr(out), N, Cin, H, W,
+                                           Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group, num_deformable_group,
+                                           self.ad.ptr(ws), self.ad.nbytes(ws), self.ad.stream(x)))
+        return out
+
+    def deformable_convolution_shared(self, data, flow, flow_scale, flow_stride, weight, bias=None, kernel=(3, 3),
+                                      dilate=(1, 1), pad=(1, 1), num_group=1, out=None):
+        """DeformableConvolution with offset = repeat9(flow*flow_scale/flow_stride) (MaskFlownet.py:230)
+        without materialising the offset tensor."""
+        x, fl, w = self._in(data, flow, weight)
+        b = self._in(bias)[0] if bias is not None else None
+        (kh, kw), (ph, pw), (dh, dw) = map(self._pair, (kernel, pad, dilate))
+        N, Cin, H, W = self.ad.shape(x)
+        Cout = self.ad.shape(w)[0]
+        if self.ad.shape(w) != (Cout, Cin // num_group, kh, kw):
+            raise ValueError("deformable_convolution_shared: bad weight shape %s" % (self.ad.shape(w),))
+        if self.ad.shape(fl) != (N, 2, H, W):
+            raise ValueError("deformable_convolution_shared: flow must be %s" % ((N, 2, H, W),))
+        if out is None:
+            out = self.ad.empty(x, (N, Cout, H, W))
+        nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, num_group, 1)
+        ws = self._workspace(x, nbytes)
+        self.check(self.ns.deform_conv_shared_fwd(self.ad.ptr(x), self.ad.ptr(fl), float(flow_scale),
+                                                  float(flow_stride), self.ad.ptr(w),
+                                                  self.ad.ptr(b) if b is not None else None, self.ad.ptr(out), N, Cin,
+                                                  H, W, Cout, kh, kw, ph, pw, dh, dw, num_group, self.ad.ptr(ws),
+                                                  self.ad.nbytes(ws), self.ad.stream(x)))
+        return out
+
+    def offsets_from_flow(self, flow, scale, stride, taps=9, out=None):
+        (fl,) = self._in(flow)
+        N, two, H, W = self.ad.shape(fl)
+        if two != 2:
+            raise ValueError("offsets_from_flow: flow must be (N,2,H,W)")
+        if out is None:
+            out = self.ad.empty(fl, (N, 2 * taps, H, W))
+        self.check(self.ns.offsets_from_flow(self.ad.ptr(fl), self.ad.ptr(out), N, H, W, int(taps), float(scale),
+                                             float(stride), self.ad.stream(fl)))
+        return out
+
+
+class TorchAdapter:
+    """torch-ROCm tensors as device buffers; launches go to torch's current stream."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+
+    def prepare(self, a):
+        t = self.torch
+        if not isinstance(a, t.Tensor):
+            raise TypeError("expected a torch.Tensor on a ROCm device, got %r" % type(a))
+        if not a.is_cuda:
+            raise RuntimeError("maskflownet_amd ops run on the MI355X only: tensor is on %s (there is no CPU "
+                               "fallback)" % a.device)
+        if a.dtype != t.float32:
+            raise TypeError("float32 expected, got %s" % a.dtype)
+        return a if a.is_contiguous() else a.contiguous()
+
+    def ptr(self, a):
+        return a.data_ptr()
+
+    def shape(self, a):
+        return tuple(a.shape)
+
+    def ndim(self, a):
+        return a.dim()
+
+    def empty(self, like, shape):
+        return self.torch.empty(shape, dtype=self.torch.float32, device=like.device)
+
+    def empty_bytes(self, like, nbytes):
+        return self.torch.empty((int(nbytes) + 3) // 4, dtype=self.torch.float32, device=like.device)
+
+    def nbytes(self, a):
+        return a.numel() * a.element_size()
+
+    def device_key(self, a):
+        return (a.device.index, self.torch.cuda.current_stream(a.device).cuda_stream)
+
+    def stream(self, a):
+        return self.torch.cuda.current_stream(a.device).cuda_stream
+
+
+_default = None
+
+
+def default_ops():
+    """The product OpSet: libmfn_hip.so + torch tensors.  Raises if the library is not built."""
+    global _default
+    if _default is None:
+        _default = OpSet(_lib.lib(), TorchAdapter(), _lib.check)
+    return _default
+
+
+def Correlation(*a, **k):
+    return default_ops().Correlation(*a, **k)
+
+
+def GridGenerator(*a, **k):
+    return default_ops().GridGenerator(*a, **k)
+
+
+def BilinearSampler(*a, **k):
+    return default_ops().BilinearSampler(*a, **k)
+
+
+def DeformableConvolution(*a, **k):
+    return default_ops().DeformableConvolution(*a, **k)
+
+
+def warp(*a, **k):
+    return default_ops().warp(*a, **k)
+
+
+def deformable_convolution_shared(*a, **k):
+    return default_ops().deformable_convolution_shared(*a, **k)
+
+
+def offsets_from_flow(*a, **k):
+    return default_ops().offsets_from_flow(*a, **k)

@@ -1,0 +1,66 @@
+"""numpy front-end of the kernel-logic emulation build (tests/emu/libmfn_emu.so).
+TEST INFRASTRUCTURE ONLY: runs the REAL kernel sources (maskflownet_amd/csrc/kernels/*.h) on the
+hipemu CPU model through the REAL OpSet marshalling code, so CPU CI can check them against the
+oracle.  Never imported by the product package."""
+import ctypes
+
+import numpy as np
+
+from maskflownet_amd import _abi
+from maskflownet_amd.ops import OpSet
+from . import build_emu
+
+
+class NumpyAdapter:
+    def prepare(self, a):
+        a = np.asarray(a)
+        if a.dtype != np.float32:
+            raise TypeError("float32 expected, got %s" % a.dtype)
+        return np.ascontiguousarray(a)
+
+    def ptr(self, a):
+        return a.ctypes.data
+
+    def shape(self, a):
+        return tuple(a.shape)
+
+    def ndim(self, a):
+        return a.ndim
+
+    def empty(self, like, shape):
+        return np.full(shape, np.nan, dtype=np.float32)  # NaN-poisoned: unwritten outputs are caught
+
+    def empty_bytes(self, like, nbytes):
+        return np.zeros((int(nbytes) + 3) // 4, dtype=np.float32)
+
+    def nbytes(self, a):
+        return a.nbytes
+
+    def device_key(self, a):
+        return 0
+
+    def stream(self, a):
+        return None
+
+
+_ops = None
+
+
+def emu_ops():
+    global _ops
+    if _ops is None:
+        so = build_emu.build()
+        ns = _abi.bind(ctypes.CDLL(so), "mfn_emu_", product=False)
+
+        def check(status, what=""):
+            if status != 0:
+                raise RuntimeError("mfn_emu status %d: %s" % (status, ns.last_error().decode()))
+
+        _ops = OpSet(ns, NumpyAdapter(), check)
+    return _ops
+
+
+def set_tuning(**kw):
+    ops = emu_ops()
+    for k, v in kw.items():
+        ops.check(ops.ns.set_tuning(k.replace("_", ".", 1).encode(), int(v)))

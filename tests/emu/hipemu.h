@@ -1,0 +1,206 @@
+// hipemu.h -- a tiny CPU emulation of the HIP execution model (TEST INFRASTRUCTURE ONLY).
+//
+// The kernels under maskflownet_amd/csrc/kernels/ are written against a small subset of HIP
+// (threadIdx/blockIdx, dynamic LDS, __syncthreads, wave shuffles, fp32 MFMA).  This header
+// lets g++ compile the SAME kernel sources for the host so that tests/test_emu_*.py can check
+// the index arithmetic, tiling, LDS staging and barrier placement of the real kernels
+// against the oracle in the CPU-only container, before any GPU minute is spent.  It is not a
+// fallback: the product (maskflownet_amd/_lib.py) only ever loads libmfn_hip.so and fails
+// loudly without it; libmfn_emu.so exports mfn_emu_* symbols and is loaded by tests only.
+//
+// Model: one OS thread per HIP thread of a block, blocks run one after another.
+// __syncthreads = std::barrier over the block; wave collectives (shuffle, ballot, MFMA)
+// exchange through a per-wave buffer guarded by a 64-thread barrier.  Wave = 64 lanes.
+// The MFMA emulation follows the operand / accumulator lane maps of
+// /opt/skills/guides/cdna_hip_programming.md section 3 (v_mfma_f32_32x32x2_f32, 16x16x4_f32).
+#pragma once
+#include <algorithm>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+struct f32x4_emu { float v[4]; float &operator[](int i) { return v[i]; } const float &operator[](int i) const { return v[i]; } };
+struct f32x16_emu { float v[16]; float &operator[](int i) { return v[i]; } const float &operator[](int i) const { return v[i]; } };
+
+typedef void *hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+
+namespace hipemu {
+
+struct Wave {
+  std::barrier<> bar{64};
+  float f[64];
+  float g[64];
+  unsigned long long mask;
+  int votes[64];
+};
+
+struct Block {
+  unsigned nthreads = 0;
+  std::unique_ptr<std::barrier<>> bar;
+  std::vector<std::unique_ptr<Wave>> waves;
+  std::vector<unsigned char> lds;
+};
+
+extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local Block *t_block;
+extern thread_local unsigned t_lane, t_wave;
+
+inline void *dyn_shared() { return t_block->lds.data(); }
+inline Wave &wave() { return *t_block->waves[t_wave]; }
+
+template <class F>
+void launch(dim3 grid, dim3 block, size_t shmem, F &&body) {
+  const unsigned nthreads = block.x * block.y * block.z;
+  if (nthreads % 64 != 0) {
+    fprintf(stderr, "hipemu: block size %u is not a multiple of 64\n", nthreads);
+    abort();
+  }
+  Block blk;
+  blk.nthreads = nthreads;
+  blk.bar.reset(new std::barrier<>(nthreads));
+  for (unsigned w = 0; w < nthreads / 64; ++w) blk.waves.emplace_back(new Wave());
+  blk.lds.assign(shmem + 64, 0);
+  std::vector<std::thread> pool;
+  pool.reserve(nthreads);
+  for (unsigned t = 0; t < nthreads; ++t) {
+    pool.emplace_back([&, t]() {
+      t_block = &blk;
+      t_blockDim = block;
+      t_gridDim = grid;
+      t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+      t_lane = t % 64;
+      t_wave = t / 64;
+      for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+          for (unsigned bx = 0; bx < grid.x; ++bx) {
+            t_blockIdx = dim3(bx, by, bz);
+            body();
+            blk.bar->arrive_and_wait();  // block boundary: LDS is reused by the next block
+          }
+    });
+  }
+  for (auto &th : pool) th.join();
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::t_threadIdx)
+#define blockIdx (hipemu::t_blockIdx)
+#define blockDim (hipemu::t_blockDim)
+#define gridDim (hipemu::t_gridDim)
+
+static inline void __syncthreads() { hipemu::t_block->bar->arrive_and_wait(); }
+
+static inline float __shfl(float v, int src, int width = 64) {
+  hipemu::Wave &w = hipemu::wave();
+  const unsigned lane = hipemu::t_lane;
+  w.f[lane] = v;
+  w.bar.arrive_and_wait();
+  const int base = (int)(lane / width) * width;
+  const float r = w.f[base + (src % width)];
+  w.bar.arrive_and_wait();
+  return r;
+}
+static inline int __shfl(int v, int src, int width = 64) {
+  float f;
+  memcpy(&f, &v, 4);
+  f = __shfl(f, src, width);
+  memcpy(&v, &f, 4);
+  return v;
+}
+template <class T> static inline T __shfl_xor(T v, int m, int width = 64) { return __shfl(v, (int)(hipemu::t_lane % width) ^ m, width); }
+template <class T> static inline T __shfl_down(T v, int d, int width = 64) {
+  const int l = (int)(hipemu::t_lane % width);
+  return __shfl(v, (l + d < width) ? l + d : l, width);
+}
+static inline unsigned long long __ballot(int pred) {
+  hipemu::Wave &w = hipemu::wave();
+  w.votes[hipemu::t_lane] = pred ? 1 : 0;
+  w.bar.arrive_and_wait();
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; ++i) m |= (unsigned long long)w.votes[i] << i;
+  w.bar.arrive_and_wait();
+  return m;
+}
+static inline int __all(int pred) { return __ballot(pred) == ~0ull; }
+static inline int __any(int pred) { return __ballot(pred) != 0ull; }
+static inline int __syncthreads_and(int pred) {
+  // emulated through LDS-free voting: ballot per wave, then a block-wide reduction
+  static thread_local int dummy;
+  (void)dummy;
+  hipemu::Block *b = hipemu::t_block;
+  int wave_ok = __all(pred);
+  // publish per-wave result in the wave buffer, then read all after a block barrier
+  hipemu::wave().votes[0] = wave_ok;
+  b->bar->arrive_and_wait();
+  int ok = 1;
+  for (auto &w : b->waves) ok &= w->votes[0];
+  b->bar->arrive_and_wait();
+  return ok;
+}
+
+// v_mfma_f32_32x32x2_f32: A lane l = A[i=l&31][k=l>>5], B lane l = B[k=l>>5][j=l&31],
+// D reg r of lane l = D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].  k-ordered fmaf chain.
+static inline f32x16_emu hipemu_mfma_32x32x2(float a, float b, f32x16_emu c) {
+  hipemu::Wave &w = hipemu::wave();
+  const unsigned lane = hipemu::t_lane;
+  w.f[lane] = a;
+  w.g[lane] = b;
+  w.bar.arrive_and_wait();
+  const int col = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) acc = fmaf(w.f[row + 32 * k], w.g[col + 32 * k], acc);
+    c[r] = acc;
+  }
+  w.bar.arrive_and_wait();
+  return c;
+}
+// v_mfma_f32_16x16x4_f32: A lane l = A[i=l&15][k=l>>4], B lane l = B[k=l>>4][j=l&15],
+// D reg r of lane l = D[row=(l>>4)*4+r][col=l&15].
+static inline f32x4_emu hipemu_mfma_16x16x4(float a, float b, f32x4_emu c) {
+  hipemu::Wave &w = hipemu::wave();
+  const unsigned lane = hipemu::t_lane;
+  w.f[lane] = a;
+  w.g[lane] = b;
+  w.bar.arrive_and_wait();
+  const int col = lane & 15, grp = lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = grp * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(w.f[row + 16 * k], w.g[col + 16 * k], acc);
+    c[r] = acc;
+  }
+  w.bar.arrive_and_wait();
+  return c;
+}

@@ -1,0 +1,109 @@
+"""Parity cases shared by the CPU emulation tests (small shapes) and the GPU tests (full shapes).
+
+Every case runs an operator of an `OpSet` (maskflownet_amd.ops) and compares it with the CPU
+oracle on the same seeded input.  `to_dev` / `to_host` move numpy arrays to whatever the OpSet's
+adapter wants (identity for the emulation build, torch ROCm tensors on the GPU).
+Tolerance (BASELINE.json north_star): max|a-b| <= 1e-4 * max|ref| per tensor; we assert a 10x
+tighter 1e-5 and keep the 1e-4 contract in TOL_CONTRACT for the report.
+"""
+import numpy as np
+
+TOL_CONTRACT = 1e-4
+TOL = 1e-5
+
+
+def feat(rng, shape):
+    """post-activation pyramid features: leaky_relu(N(0,1), 0.1)  """
+    x = rng.standard_normal(shape).astype(np.float32)
+    return np.where(x > 0, x, 0.1 * x).astype(np.float32)
+
+
+def flow_field(rng, N, H, W, sigma=2.0, outlier_frac=0.02):
+    f = (rng.standard_normal((N, 2, H, W)) * sigma).astype(np.float32)
+    m = rng.random((N, 1, H, W)) < outlier_frac
+    big = rng.uniform(-max(H, W), max(H, W), (N, 2, H, W)).astype(np.float32)
+    return np.where(m, big, f).astype(np.float32)
+
+
+def rel_err(got, want):
+    want = np.asarray(want, np.float64)
+    got = np.asarray(got, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.isfinite(got).all(), "non-finite / unwritten output"
+    return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def check_close(got, want, tol=TOL, what=""):
+    e = rel_err(got, want)
+    assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+    return e
+
+
+def case_correlation(ops, oracle, to_dev, to_host, shape, md, seed=0, **tuning):
+    rng = np.random.default_rng(20260925 + seed)
+    f1, f2 = feat(rng, shape), feat(rng, shape)
+    got = to_host(ops.Correlation(to_dev(f1), to_dev(f2), kernel_size=1, max_displacement=md, stride1=1,
+                                  stride2=1, pad_size=md, is_multiply=True))
+    want = oracle.correlation(f1, f2, max_displacement=md, pad_size=md)
+    return check_close(got, want, what="correlation %s md=%d" % (shape, md))
+
+
+def case_correlation_generic(ops, oracle, to_dev, to_host, shape, seed=0, **kw):
+    rng = np.random.default_rng(77 + seed)
+    f1, f2 = feat(rng, shape), feat(rng, shape)
+    got = to_host(ops.Correlation(to_dev(f1), to_dev(f2), **kw))
+    want = oracle.correlation(f1, f2, **kw)
+    return check_close(got, want, what="correlation generic %s %s" % (shape, kw))
+
+
+def case_warp(ops, oracle, to_dev, to_host, shape, clip, seed=0):
+    rng = np.random.default_rng(4242 + seed)
+    N, C, H, W = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    fl = flow_field(rng, N, H, W, sigma=3.0)
+    got = to_host(ops.warp(to_dev(x), to_dev(fl), clip_grid=clip))
+    want = oracle.warp(x, fl, clip_grid=clip)
+    return check_close(got, want, what="warp %s clip=%s" % (shape, clip))
+
+
+def msra_weight(rng, cout, cin, k=3, slope=0.1):
+    fan_avg = (cin * k * k + cout * k * k) / 2.0
+    std = np.sqrt(2.0 / ((1 + slope * slope) * fan_avg))  # MSRAPrelu('avg'), pipeline.py:26
+    return (rng.standard_normal((cout, cin, k, k)) * std).astype(np.float32)
+
+
+def case_deform_shared(ops, oracle, to_dev, to_host, N, C, H, W, scale=20.0, stride=8.0, seed=0, fused=True,
+                       bias=True):
+    """The reference's call pattern: offset = repeat9(flow*scale/stride) (MaskFlownet.py:230)."""
+    rng = np.random.default_rng(9000 + seed)
+    x = feat(rng, (N, C, H, W))
+    w = msra_weight(rng, C, C)
+    b = (rng.standard_normal((C,)) * 0.1).astype(np.float32) if bias else None
+    fl = (flow_field(rng, N, H, W, sigma=2.0) * np.float32(stride / scale)).astype(np.float32)
+    off = oracle.offsets_from_flow(fl, scale, stride)
+    want = oracle.deformable_convolution(x, off, w, b, kernel=(3, 3), pad=(1, 1))
+    if fused:
+        got = ops.deformable_convolution_shared(to_dev(x), to_dev(fl), scale, stride, to_dev(w),
+                                                to_dev(b) if b is not None else None)
+    else:
+        off_dev = ops.offsets_from_flow(to_dev(fl), scale, stride)
+        np.testing.assert_array_equal(to_host(off_dev), off)  # bit-exact: one mul and one div
+        got = ops.DeformableConvolution(to_dev(x), off_dev, to_dev(w), to_dev(b) if b is not None else None,
+                                        kernel=(3, 3), pad=(1, 1), num_filter=C, no_bias=b is None)
+    return check_close(to_host(got), want, what="deform shared N%d C%d %dx%d fused=%s" % (N, C, H, W, fused))
+
+
+def case_deform_pertap(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, **kw):
+    rng = np.random.default_rng(555 + seed)
+    ng, ndg = kw.get("num_group", 1), kw.get("num_deformable_group", 1)
+    kernel = kw.get("kernel", (3, 3))
+    x = feat(rng, (N, Cin, H, W))
+    w = (rng.standard_normal((Cout, Cin // ng) + tuple(kernel)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
+    Ho, Wo = oracle.deform_conv_out_shape(H, W, kernel, kw.get("stride", (1, 1)), kw.get("pad", (0, 0)),
+                                          kw.get("dilate", (1, 1)))
+    off = (rng.standard_normal((N, 2 * kernel[0] * kernel[1] * ndg, Ho, Wo)) * 1.5).astype(np.float32)
+    off[:, :, 0, 0] = 3.0 * max(H, W)  # far outside
+    got = to_host(ops.DeformableConvolution(to_dev(x), to_dev(off), to_dev(w), to_dev(b), num_filter=Cout, **kw))
+    want = oracle.deformable_convolution(x, off, w, b, **kw)
+    return check_close(got, want, what="deform per-tap %s" % (kw,))

@@ -1,0 +1,125 @@
+"""CPU checks of the REAL kernel sources through the hipemu execution model (tests/emu/).
+
+These do not replace the GPU parity tests (tests/test_gpu_parity.py): they pin the kernels'
+index arithmetic, LDS staging, barrier placement, MFMA operand mapping and the C-ABI argument
+handling against the oracle at small shapes, in the GPU-less container."""
+import numpy as np
+import pytest
+
+from tests import parity_cases as pc
+from tests.emu import emu_ops
+
+ident = lambda a: a
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return emu_ops.emu_ops()
+
+
+@pytest.fixture(autouse=True)
+def _reset_tuning():
+    yield
+    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, dc_mt=0, dc_ks=0, dc_fast=1,
+                       dc_generic=0)
+
+
+@pytest.mark.parametrize("variant", range(8))
+def test_correlation_variants_md4(ops, oracle, variant):
+    emu_ops.set_tuning(corr_variant=variant)
+    # ragged tiles in both directions: H=10 is not a multiple of any tile height, W=72 > TW=64
+    pc.case_correlation(ops, oracle, ident, ident, (1, 6, 10, 72), 4)
+
+
+@pytest.mark.parametrize("tw,shape", [(32, (2, 5, 9, 36)), (16, (1, 9, 18, 20)), (8, (1, 3, 6, 8)), (64, (1, 4, 5, 64))])
+@pytest.mark.parametrize("md", [4, 2])
+def test_correlation_tile_widths(ops, oracle, tw, shape, md):
+    emu_ops.set_tuning(corr_tw=tw, corr_variant=1)
+    pc.case_correlation(ops, oracle, ident, ident, shape, md)
+
+
+@pytest.mark.parametrize("variant", [3, 5, 6])
+def test_correlation_md2_variants(ops, oracle, variant):
+    emu_ops.set_tuning(corr_variant=variant)
+    pc.case_correlation(ops, oracle, ident, ident, (2, 7, 6, 16), 2)
+
+
+def test_correlation_xcd_swizzle_is_a_permutation(ops, oracle):
+    emu_ops.set_tuning(corr_variant=6, corr_tw=16, corr_xcd=1)
+    pc.case_correlation(ops, oracle, ident, ident, (4, 4, 32, 16), 4)  # 8 blocks -> swizzle active
+
+
+def test_correlation_non_pow2_channels_divide(ops, oracle):
+    pc.case_correlation(ops, oracle, ident, ident, (1, 12, 6, 8), 4)
+
+
+@pytest.mark.parametrize("kw", [dict(kernel_size=1, max_displacement=4, stride1=1, stride2=2, pad_size=4),
+                                dict(kernel_size=3, max_displacement=2, stride1=2, stride2=1, pad_size=3),
+                                dict(kernel_size=1, max_displacement=3, stride1=1, stride2=1, pad_size=3),
+                                dict(kernel_size=1, max_displacement=2, stride1=1, stride2=1, pad_size=2,
+                                     is_multiply=False)])
+def test_correlation_generic_parameters(ops, oracle, kw):
+    pc.case_correlation_generic(ops, oracle, ident, ident, (2, 3, 9, 10), **kw)
+
+
+def test_correlation_odd_width_uses_generic(ops, oracle):
+    pc.case_correlation(ops, oracle, ident, ident, (1, 3, 5, 7), 4)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 8, 12), (1, 2, 5, 7)])
+@pytest.mark.parametrize("clip", [False, True])
+def test_warp(ops, oracle, shape, clip):
+    pc.case_warp(ops, oracle, ident, ident, shape, clip)
+
+
+def test_grid_generator_and_sampler(ops, oracle):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 3, 6, 9)).astype(np.float32)
+    flow_xy = rng.standard_normal((2, 2, 6, 9)).astype(np.float32) * 2
+    grid = ops.GridGenerator(flow_xy, "warp")
+    np.testing.assert_allclose(grid, oracle.grid_generator_warp(flow_xy), rtol=0, atol=1e-6)
+    pc.check_close(ops.BilinearSampler(x, grid), oracle.bilinear_sampler(x, grid), what="sampler")
+    theta = rng.standard_normal((2, 6)).astype(np.float32)
+    ga = ops.GridGenerator(theta, "affine", target_shape=(5, 7))
+    np.testing.assert_allclose(ga, oracle.grid_generator_affine(theta, (5, 7)), rtol=0, atol=1e-6)
+    pc.check_close(ops.BilinearSampler(x, ga), oracle.bilinear_sampler(x, ga), what="sampler affine")
+
+
+@pytest.mark.parametrize("mt,ks", [(1, 1), (1, 4), (2, 2), (1, 2)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_deform_shared_offsets(ops, oracle, mt, ks, fused):
+    emu_ops.set_tuning(dc_mt=mt, dc_ks=ks)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 64 if mt == 2 else 32, 6, 7, fused=fused)
+
+
+def test_deform_shared_odd_channels_and_padding_of_filters(ops, oracle):
+    # Cin odd -> zero half-pair; Cout=5 -> 27 padded filter rows; P=20 px -> partial pixel tile
+    pc.case_deform_pertap(ops, oracle, ident, ident, 1, 3, 5, 4, 5, kernel=(3, 3), pad=(1, 1))
+
+
+def test_deform_fast_path_off_matches(ops, oracle):
+    emu_ops.set_tuning(dc_fast=0)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 8, 5, 6, bias=False)
+
+
+@pytest.mark.parametrize("kw", [dict(kernel=(3, 3), pad=(1, 1), stride=(2, 2)),
+                                dict(kernel=(3, 3), pad=(2, 2), dilate=(2, 2)),
+                                dict(kernel=(3, 3), pad=(1, 1), num_group=2),
+                                dict(kernel=(3, 3), pad=(1, 1), num_deformable_group=2),
+                                dict(kernel=(1, 1), pad=(0, 0)),
+                                dict(kernel=(5, 3), pad=(2, 1))])
+def test_deform_per_tap_parameter_space(ops, oracle, kw):
+    pc.case_deform_pertap(ops, oracle, ident, ident, 1, 4, 6, 6, 7, **kw)
+
+
+def test_errors_read_like_mxnet(ops):
+    x = np.zeros((1, 2, 4, 4), np.float32)
+    with pytest.raises(RuntimeError, match="odd"):
+        ops.Correlation(x, x, kernel_size=2, max_displacement=1, pad_size=1)
+    with pytest.raises(ValueError, match="identical shapes"):
+        ops.Correlation(x, np.zeros((1, 2, 4, 5), np.float32))
+    with pytest.raises(ValueError, match="offset shape"):
+        ops.DeformableConvolution(x, np.zeros((1, 18, 3, 3), np.float32), np.zeros((2, 2, 3, 3), np.float32),
+                                  np.zeros((2,), np.float32), kernel=(3, 3), pad=(1, 1))
+    with pytest.raises(RuntimeError, match="fit in blob"):
+        ops.Correlation(x, x, kernel_size=1, max_displacement=4, pad_size=0)
