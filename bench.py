@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- image-pairs/s of the MaskFlownet-S matching hot path on MI355X.
+
+A "step" is one pass of the hot path (5 x Correlation md=4, 4 x DeformableConvolution, 1 x warp --
+the operator sequence of one MaskFlownet_S forward, /root/reference/network/MaskFlownet.py:215-311)
+over one synthetic batch already resident in HBM: BASELINE.json configs[1] = batch 8 of 384x512
+per GPU.  One process per GPU; the batch shards across ranks with no data-path collective
+(weak scaling); RCCL is used only for the barrier, the MAX over rank times and the 2-float
+checksum all-reduce.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3] [--mode dropin|fused]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (the level-2 correlation launch): algorithmic bytes
+                / mean launch duration from HIP events on the kernel's own stream
+                (hipExtLaunchKernelGGL start/stop events), against 8 TB/s HBM.
+  cpu_baseline  the CPU oracle (oracle/, kind "port": loop-faithful restatement of the MXNet CPU
+                operators, 1 thread) timed on rank 0 on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--mode", default="dropin", choices=["dropin", "fused"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs of the batch the CPU oracle is timed on")
+    ap.add_argument("--roofline-iters", type=int, default=200)
+    return ap.parse_args()
+
+
+def timed_steps(wl, steps, dist, torch):
+    """barrier + sync | K steps | barrier + sync; returns the MAX over ranks in seconds."""
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.replay()
+    wl.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def roofline_of_dominant_kernel(wl, iters, torch):
+    """Level-2 correlation (N,32,H/4,W/4) -> (N,81,H/4,W/4): the largest byte mover of the pass."""
+    import ctypes
+    from maskflownet_amd import _lib, hotpath
+    lib = _lib.lib()
+    t, o = wl.t, wl.o
+    n, c, h, w = hotpath.level_shapes(wl.N, wl.H, wl.W)[2]
+    nbytes = 4 * n * h * w * (2 * c + 81)
+    nflops = 2 * n * h * w * c * 81
+    with torch.cuda.stream(wl.stream):
+        for _ in range(10):
+            wl.ops.Correlation(t["c1_2"], o["deform2"], 1, 4, 1, 1, 4, True, out=o["corr2"])
+        wl.stream.synchronize()
+        lib.profile_reset()
+        lib.profile_enable(1)
+        for _ in range(iters):
+            wl.ops.Correlation(t["c1_2"], o["deform2"], 1, 4, 1, 1, 4, True, out=o["corr2"])
+        lib.profile_enable(0)
+        wl.stream.synchronize()
+    cnt, ms = ctypes.c_int(), ctypes.c_double()
+    lib.profile_query(b"corr_tiled", ctypes.byref(cnt), ctypes.byref(ms))
+    lib.profile_reset()
+    if cnt.value == 0:
+        return None
+    avg_s = ms.value / cnt.value * 1e-3
+    achieved = nbytes / avg_s / 1e9
+    return {"bound": "hbm", "kernel": "corr_tiled (level 2: N=%d C=%d %dx%d -> 81 ch)" % (n, c, h, w),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg_s * 1e6, 3),
+            "launches_timed": cnt.value, "fp32_tflops": round(nflops / avg_s / 1e12, 2),
+            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)}
+
+
+def per_kernel_breakdown(wl, iters, torch):
+    """Mean duration of every kernel of one eager pass (HIP events on the launch stream)."""
+    from maskflownet_amd import _lib
+    lib = _lib.lib()
+    lib.profile_reset()
+    lib.profile_enable(1)
+    with torch.cuda.stream(wl.stream):
+        for _ in range(iters):
+            wl._enqueue()
+    lib.profile_enable(0)
+    wl.stream.synchronize()
+    buf = (b"\0" * 8192)
+    import ctypes
+    cbuf = ctypes.create_string_buffer(8192)
+    lib.profile_dump(cbuf, 8192)
+    lib.profile_reset()
+    out = {}
+    for line in cbuf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = {"launches_per_pass": int(cnt) // iters, "us_per_pass": round(float(ms) / iters * 1e3, 2)}
+    return out
+
+
+def cpu_baseline(wl, n_pairs):
+    """The oracle's pass on `n_pairs` samples of the same batch, 1 thread (reported baseline only)."""
+    from oracle import hotpath_ref
+    n_pairs = max(1, min(n_pairs, wl.N))
+    t0 = time.perf_counter()
+    hotpath_ref.oracle_pass(wl.host, n_pairs)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_pairs / dt, 4), "unit": "image-pairs/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": "%d of %d pairs of the same synthetic batch, full hot-path pass, oracle/libmfn_ref.so "
+                      "(loop-faithful restatement of the MXNet 1.5 CPU operators), %.1f s" % (n_pairs, wl.N, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+
+    from maskflownet_amd import hotpath
+    from maskflownet_amd.dist import allreduce_checksum
+
+    wl = hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode)
+    if not args.no_graph:
+        wl.capture()
+    else:
+        wl.run_eager()
+
+    for _ in range(args.warmup):
+        wl.replay()
+    wl.synchronize()
+    dt = timed_steps(wl, args.steps, dist, torch)
+
+    # 2-float record all-reduced over RCCL (the only collective: SURVEY.md 8e)
+    local_ck = wl.checksum()
+    global_ck = allreduce_checksum(local_ck, dist)
+    ck_ok = bool(abs(float(global_ck[0]) - world * float(local_ck[0])) <= 1e-9 * abs(float(global_ck[0])))
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    pairs_per_step = wl.N * world
+    value = pairs_per_step * args.steps / dt
+    ms_per_step = dt / args.steps * 1e3
+    ab = hotpath.algorithmic_bytes(wl.N, wl.H, wl.W, args.mode)
+    af = hotpath.algorithmic_flops(wl.N, wl.H, wl.W)
+    res = {
+        "metric": "image-pairs/s MaskFlownet-S 384x512 fwd hot path (correlation + deformable conv + warp)"
+                  if args.config == "cfg2" else "image-pairs/s MaskFlownet-S 448x1024 fwd hot path",
+        "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MaskFlownet-S forward hot path: 5x Correlation(md=4) + 4x DeformableConvolution"
+                               "(3x3, shared 9-tap offsets) + 1x warp, batch=%d synthetic %dx%d per GPU (BASELINE "
+                               "configs[%d])" % (wl.N, wl.H, wl.W, 1 if args.config == "cfg2" else 2),
+                   "per_gpu_batch": wl.N, "global_batch": pairs_per_step, "mode": args.mode,
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "batch shard x%d" % world},
+        "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
+        "algorithmic_GFLOP_per_step_per_gpu": round(sum(af.values()) / 1e9, 3),
+        "aggregate_GBps_per_gpu": round(sum(ab.values()) / (dt / args.steps) / 1e9, 1),
+        "checksum_allreduce_ok": ck_ok,
+    }
+    try:
+        res["roofline"] = roofline_of_dominant_kernel(wl, args.roofline_iters, torch)
+        res["kernels"] = per_kernel_breakdown(wl, 20, torch)
+    except Exception as e:  # the headline number must survive a profiler problem
+        res["roofline"] = None
+        res["roofline_error"] = repr(e)
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(wl, args.cpu_pairs)
+        res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)
+    print(json.dumps(res))
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

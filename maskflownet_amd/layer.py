@@ -1,0 +1,154 @@
+"""Host-side mirror of /root/reference/network/layer.py -- same class names, constructor
+arguments and call signatures -- backed by the HIP kernels through the C ABI.
+
+The reference classes are MXNet Gluon HybridBlocks; MXNet has no ROCm build and is not
+installable here, so the mirror uses torch.nn.Module purely as the parameter/tensor container
+(device memory + streams).  `mxnet_ops.py` holds the mx.operator.CustomOp registration that
+plugs the same C ABI into a real MXNet process.
+
+    Reconstruction2D(in_channels, block_grad)(x, flow)             layer.py:8-18
+    Reconstruction2DSmooth(in_channels, block_grad)(x, flow)       layer.py:20-30
+    DeformableConv2D(channels, kernel_size, strides, padding, dilation, groups, layout,
+                     num_deformable_group, in_channels, activation, use_bias, ...)(x, offset)
+                                                                    layer.py:32-144
+    correlation(im1, im2, md)   the body of MaskFlownet_S.corr / MaskFlownet.corr
+                                                                    MaskFlownet.py:193-195, :440-441
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Reconstruction2D(nn.Module):
+    """flow.flip(axis=1) -> GridGenerator('warp') -> BilinearSampler, fused (layer.py:14-18).
+    `flow` channel 0 = dy, channel 1 = dx.  `in_channels` is unused, as in the reference."""
+
+    def __init__(self, in_channels=1, block_grad=False, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.block_grad = block_grad
+
+    def forward(self, x, flow):
+        if self.block_grad:
+            flow = flow.detach()
+        return ops.warp(x, flow, clip_grid=False)
+
+
+class Reconstruction2DSmooth(nn.Module):
+    """Same with the grid clipped to [-1, 1] (border replicate), layer.py:26-30."""
+
+    def __init__(self, in_channels=1, block_grad=False, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.block_grad = block_grad
+
+    def forward(self, x, flow):
+        if self.block_grad:
+            flow = flow.detach()
+        return ops.warp(x, flow, clip_grid=True)
+
+
+def _tuple2(v):
+    return (int(v), int(v)) if isinstance(v, (int, float)) else (int(v[0]), int(v[1]))
+
+
+class DeformableConv2D(nn.Module):
+    """Deformable Convolution 2D (layer.py:32-144): owns `weight` (channels, in_channels/groups,
+    kh, kw) and optional `bias` (channels,) and calls contrib.DeformableConvolution(x, offset,
+    weight[, bias], kernel, stride, dilate, pad, num_filter, num_group, num_deformable_group,
+    no_bias).  Parameter names stay `weight` / `bias` so reference checkpoint keys
+    ('deform5.weight', ...) map one-to-one.  in_channels=0 defers weight creation to the first
+    call, like Gluon's deferred initialisation."""
+
+    def __init__(self, channels, kernel_size, strides=1, padding=0, dilation=1, groups=1, layout="NCHW",
+                 num_deformable_group=1, in_channels=0, activation=None, use_bias=True, weight_initializer=None,
+                 bias_initializer="zeros", prefix=None, params=None):
+        super().__init__()
+        if layout != "NCHW":
+            raise ValueError("DeformableConv2D: only layout='NCHW' is supported")
+        self._channels = int(channels)
+        self._in_channels = int(in_channels)
+        self._kwargs = {
+            "kernel": _tuple2(kernel_size), "stride": _tuple2(strides), "dilate": _tuple2(dilation),
+            "pad": _tuple2(padding), "num_filter": int(channels), "num_group": int(groups),
+            "no_bias": not use_bias, "layout": layout, "num_deformable_group": int(num_deformable_group)}
+        self.prefix = prefix
+        self.slope = 0.1  # MSRAPrelu(slope=0.1), /root/reference/network/pipeline.py:26
+        self.weight = None
+        self.bias = None
+        self._use_bias = bool(use_bias)
+        if self._in_channels > 0:
+            self._materialize(self._in_channels, torch.device("cpu"))
+        if activation is None:
+            self.act = None
+        elif activation == "relu":
+            self.act = nn.ReLU()
+        elif activation == "sigmoid":
+            self.act = nn.Sigmoid()
+        elif activation == "tanh":
+            self.act = nn.Tanh()
+        else:
+            raise ValueError("unsupported activation %r" % (activation,))
+
+    def _materialize(self, in_channels, device):
+        kh, kw = self._kwargs["kernel"]
+        g = self._kwargs["num_group"]
+        w = torch.empty(self._channels, in_channels // g, kh, kw, device=device)
+        fan_in, fan_out = (in_channels // g) * kh * kw, self._channels * kh * kw
+        std = math.sqrt(2.0 / ((1 + self.slope ** 2) * (fan_in + fan_out) / 2.0))  # MSRAPrelu 'avg'
+        nn.init.normal_(w, 0.0, std)
+        self.weight = nn.Parameter(w)
+        if self._use_bias:
+            self.bias = nn.Parameter(torch.zeros(self._channels, device=device))
+        self._in_channels = in_channels
+
+    def forward(self, x, offset):
+        if self.weight is None:
+            self._materialize(x.shape[1], x.device)
+        kw = self._kwargs
+        out = ops.DeformableConvolution(x, offset, self.weight, self.bias, kernel=kw["kernel"], stride=kw["stride"],
+                                        dilate=kw["dilate"], pad=kw["pad"], num_filter=kw["num_filter"],
+                                        num_group=kw["num_group"], num_deformable_group=kw["num_deformable_group"],
+                                        no_bias=kw["no_bias"], layout=kw["layout"])
+        return self.act(out) if self.act is not None else out
+
+    def forward_shared(self, x, flow, flow_scale, flow_stride):
+        """Fused form of the reference's call pattern (MaskFlownet.py:230):
+        self(x, repeat9(flow*flow_scale/flow_stride)) without building the offset tensor."""
+        if self.weight is None:
+            self._materialize(x.shape[1], x.device)
+        kw = self._kwargs
+        if kw["stride"] != (1, 1) or kw["num_deformable_group"] != 1:
+            raise ValueError("forward_shared needs stride 1 and one deformable group")
+        out = ops.deformable_convolution_shared(x, flow, flow_scale, flow_stride, self.weight, self.bias,
+                                                kernel=kw["kernel"], dilate=kw["dilate"], pad=kw["pad"],
+                                                num_group=kw["num_group"])
+        return self.act(out) if self.act is not None else out
+
+    def _alias(self):
+        return "deformable_conv"
+
+    def __repr__(self):
+        kw = self._kwargs
+        s = "{name}({mapping}, kernel_size={kernel}, stride={stride}"
+        n = len(kw["kernel"])
+        if kw["pad"] != (0,) * n:
+            s += ", padding={pad}"
+        if kw["dilate"] != (1,) * n:
+            s += ", dilation={dilate}"
+        if kw["num_group"] != 1:
+            s += ", groups={num_group}"
+        if self.bias is None:
+            s += ", bias=False"
+        s += ")"
+        cin = self.weight.shape[1] if self.weight is not None else None
+        return s.format(name=self.__class__.__name__, mapping="{0} -> {1}".format(cin, self._channels), **kw)
+
+
+def correlation(im1, im2, md, stride1=1, stride2=1):
+    """Body of MaskFlownet_S.corr / MaskFlownet.corr (MaskFlownet.py:193-195, :440-441)."""
+    return ops.Correlation(im1, im2, pad_size=md, kernel_size=1, max_displacement=md, stride1=stride1,
+                           stride2=stride2, is_multiply=1)

@@ -1,0 +1,90 @@
+"""The C-ABI library builds, loads and exports every symbol include/mfn_hip.h declares.
+No compute calls here (there is no GPU in the CPU CI); argument checking is host-side and is
+exercised because it must fail BEFORE anything touches the device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from maskflownet_amd import _abi, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.lib()
+
+
+def test_header_and_binding_agree(lib):
+    hdr = open(os.path.join(ROOT, "include", "mfn_hip.h")).read()
+    declared = set(re.findall(r"\b(mfn_[a-z0-9_]+)\s*\(", hdr))
+    bound = {"mfn_" + n for n in _abi.exported_names(product=True)}
+    assert declared == bound, (declared - bound, bound - declared)
+    cdll = ctypes.CDLL(_lib.SO_PATH)
+    for name in sorted(declared):
+        assert hasattr(cdll, name), "libmfn_hip.so does not export %s" % name
+
+
+def test_version_and_error_channel(lib):
+    assert lib.abi_version() == 1
+    assert b"gfx950" in lib.version_string()
+    assert lib.correlation_fwd(None, None, None, 1, 1, 8, 8, 4, 1, 1, 1, 4, 1, None) == -1
+    assert b"NULL" in lib.last_error()
+
+
+def test_shape_inference_matches_mxnet_rules(lib):
+    c, h, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.correlation_out_shape(96, 128, 4, 1, 1, 1, 4, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)) == 0
+    assert (c.value, h.value, w.value) == (81, 96, 128)
+    assert lib.correlation_out_shape(48, 64, 20, 1, 1, 2, 20, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)) == 0
+    assert (c.value, h.value, w.value) == (441, 48, 64)
+    assert lib.correlation_out_shape(8, 8, 4, 2, 1, 1, 4, ctypes.byref(c), ctypes.byref(h), ctypes.byref(w)) == -3
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    assert lib.deform_conv_out_shape(12, 16, 3, 3, 1, 1, 1, 1, 1, 1, ctypes.byref(ho), ctypes.byref(wo)) == 0
+    assert (ho.value, wo.value) == (12, 16)
+    assert lib.deform_conv_out_shape(12, 16, 3, 3, 2, 2, 1, 1, 1, 1, ctypes.byref(ho), ctypes.byref(wo)) == 0
+    assert (ho.value, wo.value) == (6, 8)
+    assert lib.deform_conv_out_shape(2, 2, 5, 5, 1, 1, 0, 0, 1, 1, ctypes.byref(ho), ctypes.byref(wo)) == -2
+    assert lib.deform_conv_workspace_bytes(8, 128, 12, 16, 128, 3, 3, 1, 1) == 64 * 9 * 2 * 128 * 4
+    assert lib.deform_conv_workspace_bytes(8, 196, 6, 8, 196, 3, 3, 1, 1) == 98 * 9 * 2 * 224 * 4
+
+
+def test_bad_arguments_fail_before_any_launch(lib):
+    one = ctypes.c_void_p(16)  # never dereferenced: argument checks come first
+    assert lib.deform_conv_fwd(one, one, one, None, one, 1, 4, 8, 8, 6, 3, 3, 1, 1, 1, 1, 1, 1, 4, 1, None, 0, None) == -2
+    assert b"group" in lib.last_error()
+    assert lib.deform_conv_fwd(one, None, one, None, one, 1, 4, 8, 8, 4, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, None, 0, None) == -1
+    assert lib.deform_conv_shared_fwd(one, one, 20.0, 0.0, one, None, one, 1, 4, 8, 8, 4, 3, 3, 1, 1, 1, 1, 1, None, 0,
+                                      None) == -3
+    assert lib.deform_conv_shared_fwd(one, one, 20.0, 8.0, one, None, one, 1, 4, 8, 8, 4, 3, 3, 0, 0, 1, 1, 1, None, 0,
+                                      None) == -2  # pad 0 -> Ho != H
+    assert lib.warp_fwd(one, one, one, 1, 0, 8, 8, 0, None) == -2
+    assert lib.set_tuning(b"no.such.key", 1) == -3
+    v = ctypes.c_int()
+    assert lib.set_tuning(b"corr.variant", 3) == 0 and lib.get_tuning(b"corr.variant", ctypes.byref(v)) == 0
+    assert v.value == 3
+    lib.set_tuning(b"corr.variant", -1)
+
+
+def test_product_never_touches_the_oracle():
+    """The product package must not import, link or shell out to oracle/ or tests/emu/."""
+    pkg = os.path.join(ROOT, "maskflownet_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".inc")):
+                src = open(os.path.join(d, f)).read()
+                code = "\n".join(l for l in src.splitlines()
+                                 if not l.lstrip().startswith(("#", "//", "*", '"""', "'")))
+                assert "import oracle" not in code and "from oracle" not in code, f
+                assert "libmfn_ref" not in code and "libmfn_emu" not in code, f
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from maskflownet_amd import ops
+    x = torch.zeros(1, 2, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ops.Correlation(x, x, 1, 4, 1, 1, 4)
