@@ -65,6 +65,17 @@ int mfn_correlation_out_shape(int H, int W, int max_displacement, int kernel_siz
 int mfn_correlation_fwd(const float *data1, const float *data2, float *out, int N, int C, int H,
                         int W, int max_displacement, int kernel_size, int stride1, int stride2,
                         int pad_size, int is_multiply, void *stream);
+/* Same operator with a scratch buffer: levels with few pixels and many channels (L6..L3 of the
+ * pyramid) are split into channel slices across workgroups, partial sums go to `workspace` and a
+ * second kernel reduces them in a fixed order (deterministic).  workspace may be NULL / too small:
+ * the call then runs the single-pass kernel.  mfn_correlation_workspace_bytes returns the size the
+ * heuristic wants (0 when slicing would not be used). */
+size_t mfn_correlation_workspace_bytes(int N, int C, int H, int W, int max_displacement, int kernel_size,
+                                       int stride1, int stride2, int pad_size, int is_multiply);
+int mfn_correlation_fwd_ws(const float *data1, const float *data2, float *out, int N, int C, int H,
+                           int W, int max_displacement, int kernel_size, int stride1, int stride2,
+                           int pad_size, int is_multiply, void *workspace, size_t workspace_bytes,
+                           void *stream);
 /* Backward of the same call site (training, /root/reference/network/pipeline.py:112-113).
  * g1/g2: (N,C,H,W); req1/req2 in {MFN_REQ_NULL, MFN_REQ_WRITE, MFN_REQ_ADD}. */
 int mfn_correlation_bwd(const float *gout, const float *data1, const float *data2, float *g1,

@@ -17,6 +17,8 @@ SIGNATURES = {
     "last_error": (C.c_char_p, []),
     "correlation_out_shape": (_i, [_i] * 7 + [_pi, _pi, _pi]),
     "correlation_fwd": (_i, [_f, _f, _f] + [_i] * 10 + [_s]),
+    "correlation_workspace_bytes": (C.c_size_t, [_i] * 10),
+    "correlation_fwd_ws": (_i, [_f, _f, _f] + [_i] * 10 + [C.c_void_p, C.c_size_t, _s]),
     "warp_fwd": (_i, [_f, _f, _f] + [_i] * 5 + [_s]),
     "grid_generator_warp": (_i, [_f, _f, _i, _i, _i, _s]),
     "grid_generator_affine": (_i, [_f, _f, _i, _i, _i, _s]),

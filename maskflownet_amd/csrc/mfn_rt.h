@@ -12,6 +12,9 @@
 #include "hipemu.h"
 typedef f32x16_emu f32x16;
 typedef f32x4_emu f32x4;
+struct f32x2 { float x, y; };
+static inline f32x2 mfn_f2(float x, float y) { return f32x2{x, y}; }
+static inline f32x2 mfn_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 #define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_shared())
 #define MFN_MFMA_32x32x2(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
 #define MFN_MFMA_16x16x4(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
@@ -19,11 +22,17 @@ typedef f32x4_emu f32x4;
 #define MFN_UNROLL
 #define MFN_OPAQUE(x) ((void)(x))
 #define MFN_SCHED_BARRIER() ((void)0)
+#define MFN_UNIFORM(x) (x)
 #else
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// packed fp32: v_pk_fma_f32 does two FMAs per lane per issue; hipcc folds the element swizzles of
+// its operands into op_sel/op_sel_hi, so building pairs from registers costs no moves
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 mfn_f2(float x, float y) { return (f32x2){x, y}; }
+#define mfn_fma2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 // all dynamic LDS hangs off ONE 16-byte aligned symbol (cdna_hip_programming.md G17)
 extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
 #define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(mfn_lds_raw)
@@ -33,6 +42,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
 #define MFN_UNROLL _Pragma("unroll")
 #define MFN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MFN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define MFN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
 #include <stddef.h>
@@ -56,6 +66,11 @@ void profile_record(const char *name, hipEvent_t start, hipEvent_t stop);
 template <class K, class... Args>
 inline int launch(const char *name, K kernel, dim3 grid, dim3 block, size_t shmem,
                   hipStream_t stream, Args... args) {
+  if (shmem > 65536) {  // gfx950 has 160 KiB per CU; above 64 KiB the runtime wants an opt-in
+    hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (a != hipSuccess) return (int)a;
+  }
   if (profile_enabled()) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();

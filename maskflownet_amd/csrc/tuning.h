@@ -2,8 +2,13 @@
 // 0 (or any value a key does not list) means "let the library choose".
 //   corr.tw      tile width of the tiled correlation kernel: 64 | 32 | 16 | 8
 //   corr.variant named (NCH, CK, DYW, PF, WPE) point, see kernels/correlation.h; -1 = default
+//   corr.slices  channel slices per tile (partial sums + reduce kernel); 0 = heuristic
+//   corr.lanemap 0: ds_read_b128 service-group lane order, 1: natural lane order
 //   corr.xcd     1: XCD-aware block remap (neighbouring tiles share an L2)
 //   corr.generic 1: force the generic one-thread-per-output kernel
+//   corr.ablate  measurement only: 1 no stores, 2 no global loads
+//   warp.vec     pixels per thread of the warp kernel: 1 | 4
+//   dc.ablate    measurement only: 1 no gather loads, 2 no weight loads, 3 no MFMA
 //   dc.mt        32-filter MFMA tiles per wave: 1 | 2 | 3 | 4 | 7
 //   dc.ks        split-K ways inside a block: 1 | 2 | 4
 //   dc.fast      0: disable the shared-offset 4x4-neighbourhood gather
@@ -12,13 +17,19 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0;
+  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0;
+  int warp_vec = 0, dc_ablate = 0;
   int dc_mt = 0, dc_ks = 0, dc_fast = 1, dc_generic = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
     if (!strcmp(key, "corr.xcd")) return &corr_xcd;
     if (!strcmp(key, "corr.generic")) return &corr_generic;
+    if (!strcmp(key, "corr.ablate")) return &corr_ablate;
+    if (!strcmp(key, "corr.slices")) return &corr_slices;
+    if (!strcmp(key, "corr.lanemap")) return &corr_lanemap;
+    if (!strcmp(key, "warp.vec")) return &warp_vec;
+    if (!strcmp(key, "dc.ablate")) return &dc_ablate;
     if (!strcmp(key, "dc.mt")) return &dc_mt;
     if (!strcmp(key, "dc.ks")) return &dc_ks;
     if (!strcmp(key, "dc.fast")) return &dc_fast;

@@ -59,9 +59,13 @@ class OpSet:
             out = self.ad.empty(d1, (N, tc, th, tw))
         elif self.ad.shape(out) != (N, tc, th, tw):
             raise ValueError("Correlation: out has shape %s, expected %s" % (self.ad.shape(out), (N, tc, th, tw)))
-        self.check(self.ns.correlation_fwd(self.ad.ptr(d1), self.ad.ptr(d2), self.ad.ptr(out), N, C, H, W,
-                                           int(max_displacement), int(kernel_size), int(stride1), int(stride2),
-                                           int(pad_size), int(bool(is_multiply)), self.ad.stream(d1)))
+        args = (N, C, H, W, int(max_displacement), int(kernel_size), int(stride1), int(stride2), int(pad_size),
+                int(bool(is_multiply)))
+        nbytes = self.ns.correlation_workspace_bytes(*args)
+        ws = self._workspace(d1, nbytes) if nbytes else None
+        self.check(self.ns.correlation_fwd_ws(self.ad.ptr(d1), self.ad.ptr(d2), self.ad.ptr(out), *args,
+                                              self.ad.ptr(ws) if ws is not None else None,
+                                              self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(d1)))
         return out
 
     # ---- warp ------------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ def ops():
 @pytest.fixture(autouse=True)
 def _reset_tuning():
     yield
-    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, dc_mt=0, dc_ks=0, dc_fast=1,
+    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, dc_mt=0, dc_ks=0, dc_fast=1,
                        dc_generic=0)
 
 
@@ -47,6 +47,15 @@ def test_correlation_md2_variants(ops, oracle, variant):
 def test_correlation_xcd_swizzle_is_a_permutation(ops, oracle):
     emu_ops.set_tuning(corr_variant=6, corr_tw=16, corr_xcd=1)
     pc.case_correlation(ops, oracle, ident, ident, (4, 4, 32, 16), 4)  # 8 blocks -> swizzle active
+
+
+@pytest.mark.parametrize("slices,C", [(2, 16), (3, 20), (4, 13), (8, 9)])
+def test_correlation_channel_slices_and_reduce(ops, oracle, slices, C):
+    # partial sums per slice + fixed-order reduce; ragged last slice; slice count clipped to C/4
+    emu_ops.set_tuning(corr_slices=slices, corr_variant=6, corr_tw=16)
+    pc.case_correlation(ops, oracle, ident, ident, (2, C, 7, 16), 4)
+    emu_ops.set_tuning(corr_variant=3)
+    pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 16), 2, seed=3)
 
 
 def test_correlation_non_pow2_channels_divide(ops, oracle):

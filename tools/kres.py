@@ -3,7 +3,7 @@
 usage: tools/kres.py [filter-substring]"""
 import re, subprocess, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
        "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_kres.so",
        os.path.join(root, "maskflownet_amd/csrc/api.hip")]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr

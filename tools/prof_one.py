@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Run one kernel a few times (for rocprofv3 --pmc / --kernel-trace).  usage: prof_one.py corr|deform|warp [level]
+env: MFN_TUNE="corr_variant=1,corr_tw=64" ITERS=20"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from maskflownet_amd import _lib, hotpath
+from maskflownet_amd.ops import default_ops
+ops = default_ops()
+tune = os.environ.get("MFN_TUNE", "")
+if tune:
+    _lib.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in tune.split(","))})
+what = sys.argv[1] if len(sys.argv) > 1 else "corr"
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+iters = int(os.environ.get("ITERS", "20"))
+wl = hotpath.HotPathWorkload("cfg2", mode="fused")
+t, o = wl.t, wl.o
+for _ in range(iters):
+    if what == "corr":
+        ops.Correlation(t["c1_%d" % level], t["c2_%d" % level], 1, 4, 1, 1, 4, True, out=o["corr%d" % level])
+    elif what == "deform":
+        ops.deformable_convolution_shared(t["c2_%d" % level], t["flow_%d" % level], 20.0, hotpath.STRIDES[level],
+                                          t["w_%d" % level], t["b_%d" % level], out=o["deform%d" % level])
+    else:
+        ops.warp(t["img2"], t["flow_full"], False, out=o["warp"])
+torch.cuda.synchronize()
+print("done", what, level, tune)

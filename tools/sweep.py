@@ -55,20 +55,30 @@ for tag, n, c, h, w in corr_shapes:
     tws = [t for t in (64, 32, 16, 8) if t <= max(w, 8)]
     if h * w > 2000:
         tws = tws[:2]
+    big = h * w > 2000
     for tw in tws:
         for variant in range(8):
-            for xcd in ((1, 0) if tag == "cfg2.L2" and tw == 64 else (1,)):
-                _lib.set_tuning(corr_tw=tw, corr_variant=variant, corr_xcd=xcd)
-                try:
-                    us = timeit(lambda: ops.Correlation(f1, f2, 1, 4, 1, 1, 4, True, out=out), "corr_tiled")
-                except Exception as e:
-                    us = None
-                    print("ERR", tag, tw, variant, e, flush=True)
-                r = {"shape": tag, "tw": tw, "variant": variant, "xcd": xcd, "us": us,
-                     "GBps": (nbytes / us / 1e3) if us else None}
-                res["corr"].append(r)
-                print(json.dumps(r), flush=True)
-_lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1)
+            for slices in ((1,) if big else (1, 2, 4, 8, 16, 32)):
+                if slices > c // 4:
+                    continue
+                for xcd in ((1, 0) if tag == "cfg2.L2" and tw == 64 else (1,)):
+                    _lib.set_tuning(corr_tw=tw, corr_variant=variant, corr_xcd=xcd, corr_slices=slices)
+                    try:
+                        us = timeit(lambda: ops.Correlation(f1, f2, 1, 4, 1, 1, 4, True, out=out), "corr_", iters=30)
+                        nl = 2 if slices > 1 else 1
+                        us *= nl  # profile_query averages over launches: tiled + reduce
+                    except Exception as e:
+                        us = None
+                        print("ERR", tag, tw, variant, e, flush=True)
+                    r = {"shape": tag, "tw": tw, "variant": variant, "xcd": xcd, "slices": slices, "us": us,
+                         "GBps": (nbytes / us / 1e3) if us else None}
+                    res["corr"].append(r)
+                    print(json.dumps(r), flush=True)
+    _lib.set_tuning(corr_generic=1)
+    us = timeit(lambda: ops.Correlation(f1, f2, 1, 4, 1, 1, 4, True, out=out), "corr_generic", iters=10)
+    _lib.set_tuning(corr_generic=0)
+    res["corr"].append({"shape": tag, "tw": 0, "variant": -1, "slices": 0, "us": us, "GBps": nbytes / us / 1e3})
+_lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_slices=0)
 
 # md=2 (full model) sanity timing
 f1, f2 = rnd(8, 32, 96, 128), rnd(8, 32, 96, 128)
