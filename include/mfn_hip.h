@@ -177,6 +177,9 @@ int mfn_profile_dump(char *buf, int cap);
 
 /* Kernel-selection knobs for tuning sweeps (process-global, not part of the drop-in surface).
  * Unknown keys return MFN_E_PARAM.  Keys: see maskflownet_amd/csrc/tuning.h. */
+/* Measurement only: when non-NULL, instrumented kernels write 4 x uint64 wall-clock stamps (100 MHz)
+ * per workgroup into this device buffer (caller sizes it: 32 bytes x workgroups). */
+int mfn_debug_set_timeline(void *device_buffer);
 int mfn_set_tuning(const char *key, int value);
 int mfn_get_tuning(const char *key, int *value);
 

@@ -28,6 +28,7 @@ SIGNATURES = {
     "deform_conv_fwd": (_i, [_f] * 5 + [_i] * 15 + [C.c_void_p, C.c_size_t, _s]),
     "deform_conv_shared_fwd": (_i, [_f, _f, C.c_float, C.c_float, _f, _f, _f] + [_i] * 12 + [C.c_void_p, C.c_size_t, _s]),
     "offsets_from_flow": (_i, [_f, _f, _i, _i, _i, _i, C.c_float, C.c_float, _s]),
+    "debug_set_timeline": (_i, [C.c_void_p]),
     "set_tuning": (_i, [C.c_char_p, _i]),
     "get_tuning": (_i, [C.c_char_p, _pi]),
 }

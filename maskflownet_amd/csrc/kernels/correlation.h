@@ -74,6 +74,7 @@ struct CorrParams {
   // corr_reduce_kernel then sums the slices in a fixed order and normalises (deterministic).
   int nslices, slice_channels;
   int lanemap;         // 0: ds_read_b128 service-group order (guide), 1: natural lane order
+  unsigned long long *timeline;  // measurement only: 4 wall-clock stamps (100 MHz) per block, or NULL
   float *partial;
 };
 
@@ -352,7 +353,7 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
 //   5: 2 dy/wave, 1 chunk,  CK=4, prefetch,    >=3 waves/SIMD   (5-wave blocks)
 //   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=4 waves/SIMD
 //   7: 3 dy/wave, 1 chunk,  CK=4, no prefetch, >=2 waves/SIMD
-constexpr int kCorrVariants = 8;
+constexpr int kCorrVariants = 16;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-15: corr_dma_kernel
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
@@ -366,7 +367,402 @@ inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
     default: return corr_tiled_launch<D, TW, 1, 4, 3, false, 2>(p, s, "corr_tiled_v7");
   }
 }
-inline int corr_variant_tile_h(int tw, int variant) { return (256 / tw) * (variant == 2 ? 2 : 1); }
+inline int corr_variant_tile_h(int tw, int variant) { return variant >= 8 ? 4 : (256 / tw) * (variant == 2 ? 2 : 1); }
+
+// One stage of the half-wave kernels: CK channels, operands double-buffered in registers so the
+// ds_read_b128 of channel c+1 are in flight while channel c's 16 v_pk_fma_f32 + 4 v_fma_f32 issue
+// (measured: without this a lone wave spends ~300 cycles per channel, 80 of them issuing VALU).
+template <int D, int CK, int F1_PER_C, int F2_PER_C>
+__device__ __forceinline__ void corr_hw_consume(const float *f1p, const float *f2p, f32x2 (&accp)[D - 1][2],
+                                                float (&accs)[4]) {
+  constexpr int MD = (D - 1) / 2, OFF = 4 - MD;
+  float4 A[2], B[2][3];
+  A[0] = *reinterpret_cast<const float4 *>(f1p);
+  B[0][0] = *reinterpret_cast<const float4 *>(f2p);
+  B[0][1] = *reinterpret_cast<const float4 *>(f2p + 4);
+  B[0][2] = *reinterpret_cast<const float4 *>(f2p + 8);
+  MFN_UNROLL
+  for (int c = 0; c < CK; ++c) {
+    if (c + 1 < CK) {
+      A[(c + 1) & 1] = *reinterpret_cast<const float4 *>(f1p + (c + 1) * F1_PER_C);
+      B[(c + 1) & 1][0] = *reinterpret_cast<const float4 *>(f2p + (c + 1) * F2_PER_C);
+      B[(c + 1) & 1][1] = *reinterpret_cast<const float4 *>(f2p + (c + 1) * F2_PER_C + 4);
+      B[(c + 1) & 1][2] = *reinterpret_cast<const float4 *>(f2p + (c + 1) * F2_PER_C + 8);
+    }
+    const float4 a = A[c & 1];
+    const float4 b0 = B[c & 1][0], b1 = B[c & 1][1], b2 = B[c & 1][2];
+    const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+    const f32x2 asw[2] = {mfn_f2(a.y, a.x), mfn_f2(a.w, a.z)};
+    MFN_UNROLL
+    for (int d = 0; d < D - 1; ++d)
+      MFN_UNROLL
+      for (int h = 0; h < 2; ++h) {
+        const float bb = bv[2 * h + 1 + d + OFF];
+        accp[d][h] = mfn_fma2(asw[h], mfn_f2(bb, bb), accp[d][h]);
+      }
+    accs[0] = fmaf(a.x, bv[0 + OFF], accs[0]);
+    accs[1] = fmaf(a.z, bv[2 + OFF], accs[1]);
+    accs[2] = fmaf(a.y, bv[1 + (D - 1) + OFF], accs[2]);
+    accs[3] = fmaf(a.w, bv[3 + (D - 1) + OFF], accs[3]);
+    MFN_SCHED_BARRIER();
+  }
+}
+
+// ---- corr_hw_kernel: 32x4-pixel tiles, two displacement rows per wave (one per half-wave) ----------
+// Measured on MI355X (profiles/): the 256-px/9-wave blocks above leave one block per CU, so each
+// CU walks its channel stages serially and the kernel is bound by global-load latency, not by HBM,
+// LDS (conflict-free) or VALU.  This variant trades tile size for residency:
+//   * tile = 32 x 4 px (128 px): lanes 0-31 own the 32 four-pixel groups for displacement row
+//     2*wave, lanes 32-63 the same groups for row 2*wave+1 -> ceil(D/2) waves per block (5 for D=9);
+//   * 768 blocks for the level-2 shape = 3 per CU, all resident (<= 80 VGPRs, 12 KB LDS per stage);
+//   * LDS row stride 48 floats: the two rows {r, r+2} of one ds_read_b128 service group land on
+//     16 distinct 16-byte slots (2*12 = 24 = 8 mod 16) -> conflict-free.
+template <int D, int CK, bool PF, int WPE>
+__global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_hw_kernel(CorrParams p) {
+  constexpr int MD = (D - 1) / 2;
+  constexpr int NW = (D + 1) / 2;
+  constexpr int NT = NW * 64;
+  constexpr int TW = 32, TH = 4, RS = 48, CW4 = 10;  // window = 40 floats of each 48-float row
+  constexpr int ROWS2 = TH + 2 * MD;
+  constexpr int F1_PER_C = TH * RS;
+  constexpr int F2_PER_C = ROWS2 * RS;
+  constexpr int ITEMS1 = CK * TH * (TW / 4);
+  constexpr int ITEMS2 = CK * ROWS2 * CW4;
+  constexpr int NI1 = (ITEMS1 + NT - 1) / NT;
+  constexpr int NI2 = (ITEMS2 + NT - 1) / NT;
+  constexpr int OFF = 4 - MD;
+
+  MFN_DYN_SHARED(float, lds);
+  float *f1s = lds;
+  float *f2s = lds + CK * F1_PER_C;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int dyi = MFN_UNIFORM(tid >> 6) * 2 + (lane >> 5);  // displacement row of this half-wave
+  const bool live = dyi < D;                                // upper half of the last wave idles
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if (p.xcd_swizzle && (nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int n = bid / tiles_per_img;
+  const int t = bid - n * tiles_per_img;
+  const int ty = t / p.tiles_x;
+  const int tx = t - ty * p.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int H = p.H, W = p.W, C = p.C;
+  const size_t plane = (size_t)H * W;
+  const int c_begin = blockIdx.y * p.slice_channels;
+  const int c_end = min(C, c_begin + p.slice_channels);
+  const float *f1n = p.f1 + (size_t)n * C * plane;
+  const float *f2n = p.f2 + (size_t)n * C * plane;
+
+  // half-wave lane -> (row, group): service-group order of ds_read_b128 inside each 32-lane half
+  const int pos = b128_service_pos(lane) & 31;
+  const int sg = pos >> 4, wi = pos & 15;
+  const int row = sg + 2 * (wi >> 3), gx = wi & 7;
+  const int f1_off = row * RS + 4 * gx;
+  const int f2_off = (row + (live ? dyi : 0)) * RS + 4 * gx;
+
+  f32x2 accp[D - 1][2];
+  float accs[4];
+  MFN_UNROLL
+  for (int d = 0; d < D - 1; ++d) { accp[d][0] = mfn_f2(0.f, 0.f); accp[d][1] = mfn_f2(0.f, 0.f); }
+  MFN_UNROLL
+  for (int q = 0; q < 4; ++q) accs[q] = 0.f;
+
+  // staging plan (see corr_tiled_kernel)
+  float4 pre1[NI1], pre2[NI2];
+  int goff1[NI1], goff2[NI2], lofc1[NI1], lofc2[NI2];
+  MFN_UNROLL
+  for (int i = 0; i < NI1; ++i) {
+    const int it = tid + i * NT;
+    const int c = it / (TH * (TW / 4));
+    const int rem = it - c * (TH * (TW / 4));
+    const int r = rem / (TW / 4);
+    const int q = rem - r * (TW / 4);
+    const int y = y0 + r, x = x0 + 4 * q;
+    const bool ok = (i < NI1 - 1 || ITEMS1 % NT == 0 || it < ITEMS1) && y < H && x < W;
+    goff1[i] = ok ? c * (int)plane + y * W + x : -1;
+    lofc1[i] = (c * F1_PER_C + r * RS + 4 * q) | (c << 20);
+  }
+  MFN_UNROLL
+  for (int i = 0; i < NI2; ++i) {
+    const int it = tid + i * NT;
+    const int c = it / (ROWS2 * CW4);
+    const int rem = it - c * (ROWS2 * CW4);
+    const int r = rem / CW4;
+    const int q = rem - r * CW4;
+    const int y = y0 - MD + r, x = x0 - 4 + 4 * q;
+    const bool ok = (i < NI2 - 1 || ITEMS2 % NT == 0 || it < ITEMS2) && y >= 0 && y < H && x >= 0 && x < W;
+    goff2[i] = ok ? c * (int)plane + y * W + x : -1;
+    lofc2[i] = (c * F2_PER_C + r * RS + 4 * q) | (c << 20);
+  }
+  const bool loads_on = p.ablate != 2;
+  auto fetch = [&](int c0) {
+    const float *b1 = f1n + (size_t)c0 * plane;
+    const float *b2 = f2n + (size_t)c0 * plane;
+    const int cleft = c_end - c0;
+    MFN_UNROLL
+    for (int i = 0; i < NI1; ++i) {
+      const bool ok = goff1[i] >= 0 && (lofc1[i] >> 20) < cleft && loads_on;
+      pre1[i] = zero_unless(ok, *reinterpret_cast<const float4 *>(b1 + (ok ? goff1[i] : 0)));
+    }
+    MFN_UNROLL
+    for (int i = 0; i < NI2; ++i) {
+      const bool ok = goff2[i] >= 0 && (lofc2[i] >> 20) < cleft && loads_on;
+      pre2[i] = zero_unless(ok, *reinterpret_cast<const float4 *>(b2 + (ok ? goff2[i] : 0)));
+    }
+  };
+  auto stash = [&]() {
+    MFN_UNROLL
+    for (int i = 0; i < NI1; ++i)
+      if (i < NI1 - 1 || ITEMS1 % NT == 0 || tid + i * NT < ITEMS1)
+        *reinterpret_cast<float4 *>(f1s + (lofc1[i] & 0xFFFFF)) = pre1[i];
+    MFN_UNROLL
+    for (int i = 0; i < NI2; ++i)
+      if (i < NI2 - 1 || ITEMS2 % NT == 0 || tid + i * NT < ITEMS2)
+        *reinterpret_cast<float4 *>(f2s + (lofc2[i] & 0xFFFFF)) = pre2[i];
+  };
+  auto consume = [&]() { corr_hw_consume<D, CK, F1_PER_C, F2_PER_C>(f1s + f1_off, f2s + f2_off, accp, accs); };
+
+  const int nchunks = (c_end - c_begin + CK - 1) / CK;
+  if (PF) {
+    fetch(c_begin);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      stash();
+      __syncthreads();
+      if (ch + 1 < nchunks) fetch(c_begin + (ch + 1) * CK);
+      consume();
+      __syncthreads();
+    }
+  } else {
+    for (int ch = 0; ch < nchunks; ++ch) {
+      fetch(c_begin + ch * CK);
+      if (ch) __syncthreads();
+      stash();
+      __syncthreads();
+      consume();
+    }
+  }
+
+#define ACC1(d, q)                                                                        \
+  (((q) & 1) ? ((d) < D - 1 ? accp[(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[2 + ((q) - 1) / 2]) \
+             : ((d) > 0 ? accp[(d) > 0 ? (d) - 1 : 0][(q) / 2].y : accs[(q) / 2]))
+  const bool raw = p.nslices > 1;
+  float *outn = (raw ? p.partial + (size_t)blockIdx.y * p.N * (D * D) * plane : p.out) + (size_t)n * (D * D) * plane;
+  const bool use_div = p.exact_div && !raw;
+  const float scale = raw ? 1.f : p.inv_sumelems;
+  const float slope = (p.leaky && !raw) ? 0.1f : 1.f;
+  const int y = y0 + row, x = x0 + 4 * gx;
+  if (live && y < H && x < W) {
+    float *dst = outn + (size_t)(dyi * D) * plane + (size_t)y * W + x;
+    MFN_UNROLL
+    for (int d = 0; d < D; ++d) {
+      float v[4];
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) {
+        const float r = use_div ? ACC1(d, q) / p.sumelems : ACC1(d, q) * scale;
+        v[q] = fmaxf(r, slope * r);
+      }
+      if (p.ablate != 1 || v[0] != v[0])
+        *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+#undef ACC1
+}
+
+template <int D, int CK, bool PF, int WPE>
+inline int corr_hw_launch(CorrParams p, hipStream_t stream, const char *name) {
+  constexpr int MD = (D - 1) / 2;
+  p.tiles_x = cdiv(p.W, 32);
+  p.tiles_y = cdiv(p.H, 4);
+  const int nblk = p.N * p.tiles_x * p.tiles_y;
+  if (nblk <= 0) return 0;
+  const size_t lds = (size_t)CK * (4 * 48 + (4 + 2 * MD) * 48) * sizeof(float);
+  return launch(name, corr_hw_kernel<D, CK, PF, WPE>, dim3(nblk, p.nslices), dim3(((D + 1) / 2) * 64), lds, stream, p);
+}
+// variants 8..11 of corr.variant
+template <int D>
+inline int corr_hw_variant(const CorrParams &p, int variant, hipStream_t s) {
+  switch (variant) {
+    case 8: return corr_hw_launch<D, 4, false, 4>(p, s, "corr_hw_v8");
+    case 9: return corr_hw_launch<D, 4, true, 4>(p, s, "corr_hw_v9");
+    case 10: return corr_hw_launch<D, 8, false, 4>(p, s, "corr_hw_v10");
+    default: return corr_hw_launch<D, 8, true, 4>(p, s, "corr_hw_v11");
+  }
+}
+
+// ---- corr_dma_kernel: corr_hw_kernel's tile/lane geometry fed by an LDS-DMA staging ring -----------
+// The register-staged kernels pay one full global-load latency per channel stage (measured: ~1.2-1.5
+// us per stage, 8-16 stages per block).  Here the loads of NS-1 stages are always in flight:
+//   * a stage = CK channels of the f1 tile (4 x 48-float rows) and the f2 window (12 rows), laid
+//     out exactly in item order, so buffer_load_dwordx4 ... lds (16 B per lane, 1 KB per wave
+//     instruction, no VGPRs) fills it; padding columns / the pad_size border / ragged tiles /
+//     missing tail channels are items whose byte offset is out of the descriptor's range -> the
+//     hardware writes zeros;
+//   * per stage: counted s_waitcnt vmcnt, ONE raw s_barrier, issue stage ch+NS-1, consume stage ch.
+template <int D, int CK, int NS, int WPE>
+__global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrParams p) {
+  constexpr int MD = (D - 1) / 2;
+  constexpr int NW = (D + 1) / 2;
+  constexpr int NT = NW * 64;
+  constexpr int TH = 4, RS = 48, R4 = 12;  // 12 float4 per LDS row (f1 uses 8, f2 uses 10)
+  constexpr int ROWS2 = TH + 2 * MD;
+  constexpr int F1_PER_C = TH * RS, F2_PER_C = ROWS2 * RS;
+  constexpr int ITEMS1 = CK * TH * R4;     // multiple of 64 for CK % 4 == 0 (CK*48)
+  constexpr int ITEMS2 = CK * ROWS2 * R4;
+  constexpr int ITEMS = ITEMS1 + ITEMS2;
+  constexpr int NI = (ITEMS + NT - 1) / NT;  // DMA instructions per thread per stage
+  constexpr int STAGE_F = NI * NT * 4;       // floats per stage slot (tail = write-only padding)
+  constexpr int OFF = 4 - MD;
+  static_assert(CK % 4 == 0 && (ITEMS1 % 64) == 0, "f1/f2 split must fall on a wave boundary");
+
+  MFN_DYN_SHARED(float, lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = MFN_UNIFORM(tid >> 6);
+  MFN_STAMP(p.timeline, 0);
+  const int dyi = wave * 2 + (lane >> 5);
+  const bool live = dyi < D;
+
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if (p.xcd_swizzle && (nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int n = bid / tiles_per_img;
+  const int t = bid - n * tiles_per_img;
+  const int ty = t / p.tiles_x;
+  const int tx = t - ty * p.tiles_x;
+  const int y0 = ty * TH, x0 = tx * 32;
+  const int H = p.H, W = p.W, C = p.C;
+  const size_t plane = (size_t)H * W;
+  const int c_begin = blockIdx.y * p.slice_channels;
+  const int c_end = min(C, c_begin + p.slice_channels);
+  const float *f1n = p.f1 + (size_t)n * C * plane;
+  const float *f2n = p.f2 + (size_t)n * C * plane;
+
+  const int pos = b128_service_pos(lane) & 31;
+  const int sg = pos >> 4, wi = pos & 15;
+  const int row = sg + 2 * (wi >> 3), gx = wi & 7;
+  const int f1_off = row * RS + 4 * gx;
+  const int f2_off = ITEMS1 * 4 + (row + (live ? dyi : 0)) * RS + 4 * gx;
+
+  f32x2 accp[D - 1][2];
+  float accs[4];
+  MFN_UNROLL
+  for (int d = 0; d < D - 1; ++d) { accp[d][0] = mfn_f2(0.f, 0.f); accp[d][1] = mfn_f2(0.f, 0.f); }
+  MFN_UNROLL
+  for (int q = 0; q < 4; ++q) accs[q] = 0.f;
+
+  // per-thread byte offsets of its NI items inside a stage's channel group (stage-invariant)
+  constexpr unsigned INVALID = 0xFFFFFF00u;
+  unsigned voff[NI];
+  MFN_UNROLL
+  for (int i = 0; i < NI; ++i) {
+    const int it = tid + i * NT;
+    unsigned v = INVALID;
+    if (it < ITEMS1) {
+      const int c = it / (TH * R4), rem = it - c * (TH * R4);
+      const int r = rem / R4, q = rem - r * R4;
+      const int y = y0 + r, x = x0 + 4 * q;
+      if (q < 8 && y < H && x < W) v = (unsigned)(c * (int)plane + y * W + x) * 4u;
+    } else if (it < ITEMS) {
+      const int it2 = it - ITEMS1;
+      const int c = it2 / (ROWS2 * R4), rem = it2 - c * (ROWS2 * R4);
+      const int r = rem / R4, q = rem - r * R4;
+      const int y = y0 - MD + r, x = x0 - 4 + 4 * q;
+      if (q < 10 && y >= 0 && y < H && x >= 0 && x < W) v = (unsigned)(c * (int)plane + y * W + x) * 4u;
+    }
+    voff[i] = (p.ablate == 2) ? INVALID : v;
+  }
+
+  auto issue = [&](int ch) {  // stage ch -> ring slot ch % NS
+    const int c0 = c_begin + ch * CK;
+    const int cleft = min(CK, c_end - c0);
+    const unsigned nrec = (unsigned)((size_t)cleft * plane * 4);
+    const mfn_rsrc_t r1 = mfn_make_rsrc(f1n + (size_t)c0 * plane, nrec);
+    const mfn_rsrc_t r2 = mfn_make_rsrc(f2n + (size_t)c0 * plane, nrec);
+    float *slot = lds + (ch % NS) * STAGE_F;
+    MFN_UNROLL
+    for (int i = 0; i < NI; ++i) {
+      const int first = (i * NW + wave) * 64;  // first item of this wave instruction (uniform)
+      mfn_dma16(first < ITEMS1 ? r1 : r2, slot + first * 4, voff[i]);
+    }
+  };
+  auto consume = [&](int ch) {
+    const float *slot = lds + (ch % NS) * STAGE_F;
+    corr_hw_consume<D, CK, F1_PER_C, F2_PER_C>(slot + f1_off, slot + f2_off, accp, accs);
+  };
+
+  const int nchunks = (c_end - c_begin + CK - 1) / CK;
+  MFN_UNROLL
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nchunks) issue(s0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    // stages issued so far: 0 .. min(nchunks, ch+NS-1)-1; stage ch must have landed
+    const int after = min(nchunks - 1, ch + NS - 2) - ch;  // stages issued after stage ch (uniform)
+    if (NS >= 4 && after >= 2) MFN_WAIT_VM(2 * NI);
+    else if (after >= 1) MFN_WAIT_VM(NI);
+    else MFN_WAIT_VM(0);
+    MFN_WAIT_LGKM0();      // this wave's reads of the previous stage are complete
+    MFN_RAW_BARRIER();     // stage ch landed for every wave; slot (ch-1)%NS is free
+    if (ch == 0) MFN_STAMP(p.timeline, 1);
+    if (ch + NS - 1 < nchunks) issue(ch + NS - 1);
+    consume(ch);
+  }
+  MFN_STAMP(p.timeline, 2);
+
+#define ACC1(d, q)                                                                        \
+  (((q) & 1) ? ((d) < D - 1 ? accp[(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[2 + ((q) - 1) / 2]) \
+             : ((d) > 0 ? accp[(d) > 0 ? (d) - 1 : 0][(q) / 2].y : accs[(q) / 2]))
+  const bool raw = p.nslices > 1;
+  float *outn = (raw ? p.partial + (size_t)blockIdx.y * p.N * (D * D) * plane : p.out) + (size_t)n * (D * D) * plane;
+  const bool use_div = p.exact_div && !raw;
+  const float scale = raw ? 1.f : p.inv_sumelems;
+  const float slope = (p.leaky && !raw) ? 0.1f : 1.f;
+  const int y = y0 + row, x = x0 + 4 * gx;
+  if (live && y < H && x < W) {
+    float *dst = outn + (size_t)(dyi * D) * plane + (size_t)y * W + x;
+    MFN_UNROLL
+    for (int d = 0; d < D; ++d) {
+      float v[4];
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) {
+        const float r = use_div ? ACC1(d, q) / p.sumelems : ACC1(d, q) * scale;
+        v[q] = fmaxf(r, slope * r);
+      }
+      if (p.ablate != 1 || v[0] != v[0])
+        *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  MFN_STAMP(p.timeline, 3);
+#undef ACC1
+}
+
+template <int D, int CK, int NS, int WPE>
+inline int corr_dma_launch(CorrParams p, hipStream_t stream, const char *name) {
+  constexpr int MD = (D - 1) / 2;
+  constexpr int NT = ((D + 1) / 2) * 64;
+  constexpr int ITEMS = CK * (4 + 4 + 2 * MD) * 12;
+  constexpr int NI = (ITEMS + NT - 1) / NT;
+  p.tiles_x = cdiv(p.W, 32);
+  p.tiles_y = cdiv(p.H, 4);
+  const int nblk = p.N * p.tiles_x * p.tiles_y;
+  if (nblk <= 0) return 0;
+  const size_t lds = (size_t)NS * NI * NT * 16;
+  return launch(name, corr_dma_kernel<D, CK, NS, WPE>, dim3(nblk, p.nslices), dim3(NT), lds, stream, p);
+}
+// variants 12..15 of corr.variant
+template <int D>
+inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
+  switch (variant) {
+    case 12: return corr_dma_launch<D, 4, 3, 4>(p, s, "corr_dma_v12");
+    case 13: return corr_dma_launch<D, 4, 4, 4>(p, s, "corr_dma_v13");
+    case 14: return corr_dma_launch<D, 8, 3, 4>(p, s, "corr_dma_v14");
+    default: return corr_dma_launch<D, 8, 2, 4>(p, s, "corr_dma_v15");
+  }
+}
 
 // ---- slice reduction: out = (sum_s partial[s]) / C, slices summed in index order ------------------
 struct CorrReduceParams { const float *partial; float *out; size_t n4; int nslices; float inv, sumelems; int exact_div, leaky; };

@@ -23,6 +23,18 @@ static inline f32x2 mfn_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x,
 #define MFN_OPAQUE(x) ((void)(x))
 #define MFN_SCHED_BARRIER() ((void)0)
 #define MFN_UNIFORM(x) (x)
+// LDS-DMA emulation: synchronous copy (ordering of the real asynchronous engine is checked on the GPU)
+struct mfn_rsrc_t { const char *base; unsigned nrec; };
+static inline mfn_rsrc_t mfn_make_rsrc(const void *p, unsigned nbytes) { return mfn_rsrc_t{(const char *)p, nbytes}; }
+static inline void mfn_dma16(mfn_rsrc_t r, float *lds_wave_base, unsigned voff) {
+  char *dst = (char *)lds_wave_base + hipemu::t_lane * 16;
+  if ((unsigned long long)voff + 16 <= r.nrec) memcpy(dst, r.base + voff, 16);
+  else memset(dst, 0, 16);
+}
+#define MFN_WAIT_VM(n) ((void)0)
+#define MFN_WAIT_LGKM0() ((void)0)
+#define MFN_RAW_BARRIER() __syncthreads()
+#define MFN_STAMP(buf, k) ((void)0)
 #else
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -43,6 +55,35 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
 #define MFN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MFN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define MFN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds): global -> LDS without a VGPR round trip ------------------
+// Issued through inline asm on purpose: hipcc waits vmcnt(0) before any ds_read that follows a DMA it
+// knows about, which would serialise the staging ring.  Counting is therefore ours: MFN_WAIT_VM(n).
+// A raw buffer descriptor gives zero fill for free: lanes whose byte offset is >= num_records read 0.
+typedef int mfn_rsrc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mfn_rsrc_t mfn_make_rsrc(const void *p, unsigned nbytes) {
+  const unsigned long long a = (unsigned long long)p;
+  mfn_rsrc_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
+  r.z = __builtin_amdgcn_readfirstlane((int)nbytes);
+  r.w = 0x00020000;
+  return r;
+}
+// every lane of the wave writes 16 bytes at lds_wave_base + lane*16 (the base must be wave-uniform)
+__device__ __forceinline__ void mfn_dma16(mfn_rsrc_t rsrc, float *lds_wave_base, unsigned voff) {
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
+               : "memory", "m0");
+}
+#define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
+// measurement only: constant-rate (100 MHz) wall clock stamps, one writer per block
+#define MFN_STAMP(buf, k)                                                                              \
+  do {                                                                                                 \
+    if ((buf) && threadIdx.x == 0)                                                                     \
+      (buf)[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (k)] = wall_clock64();                 \
+  } while (0)
 #endif
 
 #include <stddef.h>

@@ -24,7 +24,7 @@ def _reset_tuning():
                        dc_generic=0)
 
 
-@pytest.mark.parametrize("variant", range(8))
+@pytest.mark.parametrize("variant", range(16))
 def test_correlation_variants_md4(ops, oracle, variant):
     emu_ops.set_tuning(corr_variant=variant)
     # ragged tiles in both directions: H=10 is not a multiple of any tile height, W=72 > TW=64
@@ -38,10 +38,11 @@ def test_correlation_tile_widths(ops, oracle, tw, shape, md):
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
 
 
-@pytest.mark.parametrize("variant", [3, 5, 6])
+@pytest.mark.parametrize("variant", [3, 5, 6, 8, 11, 12, 15])
 def test_correlation_md2_variants(ops, oracle, variant):
     emu_ops.set_tuning(corr_variant=variant)
     pc.case_correlation(ops, oracle, ident, ident, (2, 7, 6, 16), 2)
+    pc.case_correlation(ops, oracle, ident, ident, (1, 5, 7, 36), 2, seed=1)
 
 
 def test_correlation_xcd_swizzle_is_a_permutation(ops, oracle):
@@ -56,6 +57,8 @@ def test_correlation_channel_slices_and_reduce(ops, oracle, slices, C):
     pc.case_correlation(ops, oracle, ident, ident, (2, C, 7, 16), 4)
     emu_ops.set_tuning(corr_variant=3)
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 16), 2, seed=3)
+    emu_ops.set_tuning(corr_variant=9, corr_tw=0)
+    pc.case_correlation(ops, oracle, ident, ident, (1, C, 6, 32), 4, seed=4)
 
 
 def test_correlation_non_pow2_channels_divide(ops, oracle):

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the DMA correlation kernel: launch ramp, first-stage latency, loop, epilogue."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from maskflownet_amd import _lib
+from maskflownet_amd.ops import default_ops
+lib = _lib.lib(); ops = default_ops()
+for (n, c, h, w) in [(8, 32, 96, 128), (8, 64, 48, 64)]:
+    f1, f2 = torch.randn(n, c, h, w, device="cuda"), torch.randn(n, c, h, w, device="cuda")
+    out = torch.empty(n, 81, h, w, device="cuda")
+    for variant in (12, 13, 15):
+        _lib.set_tuning(corr_variant=variant, corr_slices=1)
+        nblk = n * (h // 4) * (w // 32)
+        tl = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            ops.Correlation(f1, f2, 1, 4, 1, 1, 4, True, out=out)
+        torch.cuda.synchronize()
+        lib.debug_set_timeline(tl.data_ptr())
+        ops.Correlation(f1, f2, 1, 4, 1, 1, 4, True, out=out)
+        torch.cuda.synchronize()
+        lib.debug_set_timeline(None)
+        t = tl.cpu().numpy().reshape(nblk, 4).astype(np.float64) * 0.01  # us
+        t0 = t[:, 0].min()
+        t -= t0
+        print("shape", (n, c, h, w), "variant", variant, "blocks", nblk)
+        print("  block start   : min %.2f  median %.2f  p90 %.2f  max %.2f us" % (t[:,0].min(), np.median(t[:,0]), np.percentile(t[:,0],90), t[:,0].max()))
+        print("  first stage   : median %.2f  p90 %.2f us after block start" % (np.median(t[:,1]-t[:,0]), np.percentile(t[:,1]-t[:,0],90)))
+        print("  main loop     : median %.2f  p90 %.2f us" % (np.median(t[:,2]-t[:,1]), np.percentile(t[:,2]-t[:,1],90)))
+        print("  epilogue issue: median %.2f  p90 %.2f us" % (np.median(t[:,3]-t[:,2]), np.percentile(t[:,3]-t[:,2],90)))
+        print("  block end     : median %.2f  max %.2f us (kernel >= this + store drain)" % (np.median(t[:,3]), t[:,3].max()))
