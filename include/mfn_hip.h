@@ -117,13 +117,15 @@ int mfn_bilinear_sampler_fwd(const float *data, const float *grid, float *out, i
  * x: (N,Cin,H,W); offset: (N, 2*kh*kw*deform_groups, Ho, Wo); w: (Cout, Cin/groups, kh, kw);
  * bias: (Cout) or NULL (no_bias); out: (N,Cout,Ho,Wo).
  * The im2col buffer is never materialised: the gather feeds fp32 MFMA tiles directly.
- * `workspace` holds the re-laid-out weights (mfn_deform_conv_workspace_bytes); it is scratch,
+ * `workspace` holds the re-laid-out weights and, for coarse levels whose reduction dimension is
+ * split across workgroups, the partial sums (mfn_deform_conv_workspace_bytes); it is scratch,
  * valid only for the duration of the call's stream work.
  * ------------------------------------------------------------------------------------------- */
 int mfn_deform_conv_out_shape(int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
                               int dw, int *Ho, int *Wo);
-size_t mfn_deform_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw,
-                                       int groups, int deform_groups);
+size_t mfn_deform_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh,
+                                       int sw, int ph, int pw, int dh, int dw, int groups,
+                                       int deform_groups);
 int mfn_deform_conv_fwd(const float *x, const float *offset, const float *w,
                         const float *bias_or_null, float *out, int N, int Cin, int H, int W,
                         int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,

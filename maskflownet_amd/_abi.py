@@ -24,7 +24,7 @@ SIGNATURES = {
     "grid_generator_affine": (_i, [_f, _f, _i, _i, _i, _s]),
     "bilinear_sampler_fwd": (_i, [_f, _f, _f] + [_i] * 6 + [_s]),
     "deform_conv_out_shape": (_i, [_i] * 10 + [_pi, _pi]),
-    "deform_conv_workspace_bytes": (C.c_size_t, [_i] * 9),
+    "deform_conv_workspace_bytes": (C.c_size_t, [_i] * 15),
     "deform_conv_fwd": (_i, [_f] * 5 + [_i] * 15 + [C.c_void_p, C.c_size_t, _s]),
     "deform_conv_shared_fwd": (_i, [_f, _f, C.c_float, C.c_float, _f, _f, _f] + [_i] * 12 + [C.c_void_p, C.c_size_t, _s]),
     "offsets_from_flow": (_i, [_f, _f, _i, _i, _i, _i, C.c_float, C.c_float, _s]),

@@ -29,28 +29,33 @@ struct DeformParams {
   const float *flow;    // shared-flow mode: (N,2,Ho,Wo); offset of every tap = flow*scale/stride
   float flow_scale, flow_stride;
   const float *w;   // original (Cout, Cin/groups, kh, kw)   [generic kernel]
-  const float *wt;  // packed [ceil(Cin/2)][kh*kw][2][CoutP]  [MFMA kernel]
+  const float *wt;  // packed [mgroup][ncp_pad][9][2][32*MT]      [MFMA kernel]
   const float *bias;
   float *out;
   int N, Cin, H, W, Cout, CoutP, Ho, Wo;
   int kh, kw, sh, sw, ph, pw, dh, dw, groups, dg;
   int P;  // N*Ho*Wo
   int allow_fast;  // tuning: 0 forces the per-tap path
-  int ablate;      // measurement only: 1 = no gather loads, 2 = no weight loads, 3 = no MFMA
+  unsigned long long *timeline;  // measurement only (mfn_debug_set_timeline)
+  int stage_window;              // tuning: 0 disables the LDS source-window staging
+  int ncp_pad, cps_per_slice, ksb, mgroups;  // packed-weight rows per M-group, K-slice length, cross-block K split
+  float *partial;                             // ksb > 1: raw partial sums [ksb][N][Cout][Ho][Wo]
 };
 
-// weights (Cout, Cin, T) -> wt[((cp*T + t)*2 + half)*CoutP + o], zero padded in c and o
-struct PackParams { const float *w; float *wt; int Cin, Cout, CoutP, T; };
+// weights (Cout, Cin, 9) -> wt[mg][cp][t][half][RL]: filter o = mg*RL + r, channel c = 2*cp + half; zero padded
+// in c (odd Cin, rows up to ncp_pad) and o (Cout not a multiple of RL).  One M-group is one linear
+// array, so a K-chunk of it is one contiguous LDS-DMA transfer.
+struct PackParams { const float *w; float *wt; int Cin, Cout, RL, mgroups, ncp_pad, T; };
 __global__ __launch_bounds__(256) void dc_pack_weights_kernel(PackParams p) {
-  const int ncp = (p.Cin + 1) / 2;
-  const size_t total = (size_t)ncp * p.T * 2 * p.CoutP;
+  const size_t total = (size_t)p.mgroups * p.ncp_pad * p.T * 2 * p.RL;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const int o = (int)(idx % p.CoutP);
-  const int half = (int)((idx / p.CoutP) & 1);
-  const int t = (int)((idx / ((size_t)2 * p.CoutP)) % p.T);
-  const int cp = (int)(idx / ((size_t)2 * p.CoutP * p.T));
-  const int c = 2 * cp + half;
+  const int r = (int)(idx % p.RL);
+  const int half = (int)((idx / p.RL) & 1);
+  const int t = (int)((idx / ((size_t)2 * p.RL)) % p.T);
+  const int cp = (int)((idx / ((size_t)2 * p.RL * p.T)) % p.ncp_pad);
+  const int mg = (int)(idx / ((size_t)2 * p.RL * p.T * p.ncp_pad));
+  const int c = 2 * cp + half, o = mg * p.RL + r;
   p.wt[idx] = (c < p.Cin && o < p.Cout) ? p.w[((size_t)o * p.Cin + c) * p.T + t] : 0.f;
 }
 
@@ -96,19 +101,44 @@ __device__ __forceinline__ DcTap dc_make_tap(float off_h, float off_w, int h_in,
 // per-axis descriptor of the shared-offset fast path: weights of tap row i on slots i and i+1
 struct DcAxis3 { float a[3], b[3]; int idx[4]; };
 
-template <int MT, int KS>
-__global__ __launch_bounds__(256) void dc_mfma_kernel(DeformParams p) {
+// ---- geometry shared by host and device ------------------------------------------------------------
+// chunk = KC channel pairs of one M-group's packed weights = KC*18*RL floats, RL = 32*MT filters
+// KC is sized so that one weight stage buffer (all KW in-block slices) is <= 9 KB: with the x windows a
+// block then needs ~42 KB of LDS and three blocks fit a CU.
+constexpr int dc_kc(int mt, int kw) {
+  const int q = 8 / (mt * kw);  // 9 KB per stage buffer at most
+  return q >= 4 ? 4 : (q >= 2 ? 2 : 1);
+}
+template <int MT, int KW> struct DcGeom {
+  static constexpr int RL = 32 * MT;
+  static constexpr int KC = dc_kc(MT, KW);
+  static constexpr int CHUNK_F = KC * 18 * RL;  // floats
+  static constexpr int CH4 = CHUNK_F / 4;       // float4 items
+};
+
+template <int MT, int PT>
+__global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   constexpr int T = 9;
-  constexpr int TILES_PER_BLOCK = 4 / KS;
-  MFN_DYN_SHARED(float, red);  // [4 waves][MT*16][64] partial accumulators (KS > 1 only)
+  constexpr int KW = 4 / PT;  // K-slices handled inside the block (one wave each per pixel tile)
+  using G = DcGeom<MT, KW>;
+  constexpr int RL = G::RL, KC = G::KC, CH4 = G::CH4;
+  constexpr int NI = (KW * CH4 + 255) / 256;  // DMA instructions per thread per stage
+  constexpr int STAGE_F = NI * 256 * 4;       // floats per stage buffer
+  MFN_DYN_SHARED(float, lds);                 // 2 weight stage buffers (reused for the K-slice reduction) + x windows
+  constexpr int XW_ROWS = 10, XW_COLS = 48;   // staged source window per wave and channel: 10 rows x 48 floats
+  constexpr int XW_NI = 4;                    // wave DMA instructions per channel pair (240 of 256 slots used)
+  constexpr int XW_F = XW_NI * 256;           // floats per channel-pair buffer
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = MFN_UNIFORM(tid >> 6);
   const int half = lane >> 5, j = lane & 31;
-  const int ks = wave % KS;
-  const int tile = blockIdx.x * TILES_PER_BLOCK + wave / KS;
-  const int m0 = blockIdx.y * (32 * MT);
+  MFN_STAMP(p.timeline, 0);
+  const int pt = wave / KW, kw = wave % KW;
+  const int tile = blockIdx.x * PT + pt;
+  const int gs = blockIdx.y * KW + kw;        // global K-slice of this wave
+  const int mg = blockIdx.z;                  // M-group: filters [mg*RL, mg*RL + RL)
+  const int m0 = mg * RL;
 
   const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
   const size_t plane = (size_t)H * W;
@@ -120,6 +150,24 @@ __global__ __launch_bounds__(256) void dc_mfma_kernel(DeformParams p) {
   const int rem = pc - n * (Ho * Wo);
   const int ho = rem / Wo, wo = rem - ho * Wo;
   const int h_in = ho * p.sh - p.ph, w_in = wo * p.sw - p.pw;
+
+  // ---- weight staging plan: item -> byte offset inside this M-group's packed array -----------------
+  const size_t mg_floats = (size_t)p.ncp_pad * 18 * RL;
+  const mfn_rsrc_t wrsrc = mfn_make_rsrc(p.wt + (size_t)mg * mg_floats, (unsigned)(mg_floats * 4));
+  unsigned voff[NI];
+  MFN_UNROLL
+  for (int i = 0; i < NI; ++i) {
+    const int it = (i * 4 + wave) * 64 + lane;
+    const int k = it / CH4, idx = it - k * CH4;
+    voff[i] = k < KW ? (unsigned)(((size_t)(blockIdx.y * KW + k) * p.cps_per_slice * 18 * RL + (size_t)idx * 4) * 4)
+                     : 0xFFFFFF00u;
+  }
+  auto issue = [&](int ch) {
+    float *buf = lds + (ch & 1) * STAGE_F;
+    const unsigned soff = (unsigned)((size_t)ch * G::CHUNK_F * 4);
+    MFN_UNROLL
+    for (int i = 0; i < NI; ++i) mfn_dma16_so(wrsrc, buf + (i * 4 + wave) * 256, voff[i], soff);
+  };
 
   // ---- offsets of the 9 taps ---------------------------------------------------------------------
   float offh[T], offw[T];
@@ -151,8 +199,7 @@ __global__ __launch_bounds__(256) void dc_mfma_kernel(DeformParams p) {
       bool v; int lo, hi; float l;
       dc_axis(offh[0], h_in, i, H, v, lo, hi, l);
       v = v && px_valid;
-      // unclamped floor for the regularity test
-      const int ulo = (int)fminf(fmaxf(floorf((float)i + offh[0]), -1.0e6f), 1.0e6f);
+      const int ulo = (int)fminf(fmaxf(floorf((float)i + offh[0]), -1.0e6f), 1.0e6f);  // unclamped floor
       if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i);
       ay.a[i] = v ? 1.f - l : 0.f;
       ay.b[i] = v ? l : 0.f;
@@ -174,121 +221,276 @@ __global__ __launch_bounds__(256) void dc_mfma_kernel(DeformParams p) {
   }
   const bool fast = __all(regular || !px_valid) != 0;  // wave-uniform
 
+  // ---- source-window staging (fast path): with a smooth flow the 4x4 neighbourhoods of a wave's 32
+  // pixels overlap almost completely.  Gathering them lane by lane costs ~41 L1 accesses per wave
+  // instruction and keeps the texture addresser ~65% busy (profiles/r01_deform_pmc.md); instead the
+  // wave DMAs the bounding box of its neighbourhoods (full rows, <= 8 x 48 floats per channel) into a
+  // private LDS window and gathers from there with ds_read_b32.  Windows that do not fit (large or
+  // discontinuous flow, tiles spanning two images, W % 4 != 0) take the lean per-tap path instead.
+  int wr0, wc0;
+  bool staged;
+  {
+    const int big = 1 << 28;
+    int rlo = px_valid ? ay.idx[0] / W : big, rhi = px_valid ? ay.idx[3] / W : -big;
+    int clo = px_valid ? ax.idx[0] : big, chi = px_valid ? ax.idx[3] : -big;
+    int nlo = px_valid ? n : big, nhi = px_valid ? n : -big;
+    MFN_UNROLL
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      rlo = min(rlo, __shfl_xor(rlo, sft)); rhi = max(rhi, __shfl_xor(rhi, sft));
+      clo = min(clo, __shfl_xor(clo, sft)); chi = max(chi, __shfl_xor(chi, sft));
+      nlo = min(nlo, __shfl_xor(nlo, sft)); nhi = max(nhi, __shfl_xor(nhi, sft));
+    }
+    wr0 = rlo;
+    wc0 = clo & ~3;  // 16-byte aligned window origin
+    staged = fast && p.stage_window && (W % 4 == 0) && nlo == nhi && (rhi - wr0 < XW_ROWS) && (chi - wc0 < XW_COLS);
+#ifdef MFN_EMU_DEBUG
+    if (lane == 0) printf("tile %d wave %d: rows %d..%d cols %d..%d n %d..%d staged %d fast %d\n", tile, wave, rlo, rhi, clo, chi, nlo, nhi, (int)staged, (int)fast);
+#endif
+  }
+
   f32x16 acc[MT];
   MFN_UNROLL
   for (int mt = 0; mt < MT; ++mt)
     MFN_UNROLL
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  const int ncp = (p.Cin + 1) / 2;
   const float *xn = p.x + (size_t)n * p.Cin * plane;
-  const float *wt_lane = p.wt + (size_t)half * p.CoutP + m0 + j;
-  const size_t wt_step = (size_t)2 * p.CoutP;  // between taps
+  const int cp_base = gs * p.cps_per_slice;
+  const int nchunks = p.cps_per_slice / KC;  // cps_per_slice is a multiple of KC
 
-  if (fast) {
-    for (int cp = ks; cp < ncp; cp += KS) {
-      const int c = 2 * cp + half;
-      float colv[T];
-      if (c < p.Cin) {
-        const float *pl = xn + (size_t)c * plane;
-        float v[4][4];
+  const int full_pairs = p.Cin / 2;  // pairs whose two channels both exist; an odd Cin adds one half pair
+  // one channel pair on the fast path: separable bilinear interpolation of the 4x4 neighbourhood into
+  // the 9 column values, which ARE the B operands of the 9 k-steps
+  auto fast_pair = [&](const float (&v)[4][4], const float *ap) {
+    float tr[4][3];
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m)
+      MFN_UNROLL
+      for (int q = 0; q < 3; ++q) tr[m][q] = ax.a[q] * v[m][q] + ax.b[q] * v[m][q + 1];
+    MFN_UNROLL
+    for (int i = 0; i < 3; ++i)
+      MFN_UNROLL
+      for (int q = 0; q < 3; ++q) {
+        const float cv = ay.a[i] * tr[i][q] + ay.b[i] * tr[i + 1][q];
         MFN_UNROLL
-        for (int m = 0; m < 4; ++m)
-          MFN_UNROLL
-          for (int q = 0; q < 4; ++q) v[m][q] = p.ablate == 1 ? 1.f : pl[ay.idx[m] + ax.idx[q]];
-        float tr[4][3];
-        MFN_UNROLL
-        for (int m = 0; m < 4; ++m)
-          MFN_UNROLL
-          for (int q = 0; q < 3; ++q) tr[m][q] = ax.a[q] * v[m][q] + ax.b[q] * v[m][q + 1];
-        MFN_UNROLL
-        for (int i = 0; i < 3; ++i)
-          MFN_UNROLL
-          for (int q = 0; q < 3; ++q) colv[i * 3 + q] = ay.a[i] * tr[i][q] + ay.b[i] * tr[i + 1][q];
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = MFN_MFMA_32x32x2(ap[((i * 3 + q) * 2) * RL + mt * 32], cv, acc[mt]);
+      }
+  };
+  // second tier (window does not fit, e.g. a rough or discontinuous flow): gather each row of the 4x4
+  // neighbourhood with ONE dword-aligned global_load_dwordx4, straight from global memory, when the
+  // 4 columns are not clamped (consecutive) for every lane; uniform base + 32-bit lane offset.
+  const bool cols_consecutive = (ax.idx[1] - ax.idx[0] == 1) && (ax.idx[2] - ax.idx[1] == 1) && (ax.idx[3] - ax.idx[2] == 1);
+  const bool small = (size_t)p.N * p.Cin * plane < ((size_t)1 << 30);
+  const bool rowgather = !staged && fast && small && __all(cols_consecutive || !px_valid) != 0;
+  const bool dwgather = !staged && fast && small && !rowgather;  // third tier: clamped columns, 16 dword gathers
+  unsigned rowoff[4];
+  MFN_UNROLL
+  for (int m = 0; m < 4; ++m)
+    rowoff[m] = (unsigned)(n * p.Cin * (int)plane + half * (int)plane + ay.idx[m] + ax.idx[0]);
+  auto rowgather_pair = [&](int cp, const float *ap) {
+    const float *base = p.x + (size_t)(2 * cp) * plane;  // uniform
+    float v[4][4];
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m) {
+      const f4u r = mfn_load4u(base + rowoff[m]);
+      v[m][0] = r.x; v[m][1] = r.y; v[m][2] = r.z; v[m][3] = r.w;
+    }
+    fast_pair(v, ap);
+  };
+  auto dwgather_pair = [&](int cp, const float *ap) {
+    const float *base = p.x + (size_t)(2 * cp) * plane;  // uniform
+    float v[4][4];
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m)
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) v[m][q] = base[rowoff[m] + (unsigned)(ax.idx[q] - ax.idx[0])];
+    fast_pair(v, ap);
+  };
+  // per-tap path (arbitrary offsets, and the half pair of an odd Cin; never hot in the reference
+  // network).  Deliberately lean in registers, not fast: a rolled tap loop that re-reads its offset,
+  // rebuilds the tap geometry and feeds the MFMA at once, so the fast path sets the VGPR budget.
+  auto slow_pair = [&](int cp, const float *ap) {
+    const int c = 2 * cp + half;
+    const bool cvalid = c < p.Cin;
+    const float *pl = xn + (size_t)(cvalid ? c : 0) * plane;
+    MFN_NOUNROLL
+    for (int t = 0; t < T; ++t) {
+      float oh, ow;
+      if (p.offset) {
+        const float *op = p.offset + (size_t)n * 2 * T * oplane + (size_t)ho * Wo + wo;
+        oh = op[(size_t)(2 * t) * oplane];
+        ow = op[(size_t)(2 * t + 1) * oplane];
       } else {
-        MFN_UNROLL
-        for (int t = 0; t < T; ++t) colv[t] = 0.f;
+        oh = offh[0];
+        ow = offw[0];
       }
-      const float *wp = wt_lane + (size_t)cp * T * wt_step;
+      const int ti = t / 3, tj = t - 3 * ti;
+      const DcTap tp = dc_make_tap(oh, ow, h_in, w_in, ti * p.dh, tj * p.dw, H, W, px_valid && cvalid);
+      const int bb = tp.base & 0x3FFFFFFF, dwi = (tp.base >> 30) & 1;
+      const float v1 = pl[bb], v2 = pl[bb + dwi], v3 = pl[bb + tp.dhW], v4 = pl[bb + tp.dhW + dwi];
+      const float cv = tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4;
       MFN_UNROLL
-      for (int t = 0; t < T; ++t) {
-        MFN_UNROLL
-        for (int mt = 0; mt < MT; ++mt) {
-          const float a = p.ablate == 2 ? 1.f : wp[t * wt_step + mt * 32];
-          if (p.ablate == 3) acc[mt][t] += a * colv[t];
-          else acc[mt] = MFN_MFMA_32x32x2(a, colv[t], acc[mt]);
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], cv, acc[mt]);
+    }
+  };
+
+  // ---- staged-window plumbing ---------------------------------------------------------------------------
+  float *xwin = lds + 2 * STAGE_F + wave * (2 * XW_F);  // this wave's two pair buffers
+  const mfn_rsrc_t xrsrc = mfn_make_rsrc(p.x, (unsigned)((size_t)p.N * p.Cin * plane * 4));
+  unsigned xvoff[XW_NI];  // byte offset of this lane's window slots, relative to channel 2*cp of image 0
+  int loff[4][4];      // LDS float offset of the 16 neighbourhood values inside a pair buffer
+  if (staged) {
+    const int nimg = MFN_UNIFORM(n);
+    MFN_UNROLL
+    for (int i = 0; i < XW_NI; ++i) {
+      const int slot = i * 64 + lane;               // float4 slots: [channel 0/1][XW_ROWS][12 float4]
+      const int chs = slot / (XW_ROWS * 12), rem = slot - chs * (XW_ROWS * 12);
+      const int row = rem / 12, c4 = rem - row * 12;
+      const int r = wr0 + row, c = wc0 + 4 * c4;
+      xvoff[i] = (chs < 2 && r <= H - 1 && c <= W - 4)
+                     ? (unsigned)(((size_t)nimg * p.Cin * plane + (size_t)chs * plane + (size_t)r * W + c) * 4)
+                     : 0xFFFFFF00u;                  // outside the image: never read, the DMA writes zeros
+    }
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m)
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q)
+        loff[m][q] = half * (XW_ROWS * XW_COLS) + (ay.idx[m] / W - wr0) * XW_COLS + (ax.idx[q] - wc0);
+  }
+  auto issue_x = [&](int cp, int buf) {
+    const unsigned soff = (unsigned)((size_t)(2 * cp) * plane * 4);
+    MFN_UNROLL
+    for (int i = 0; i < XW_NI; ++i) mfn_dma16_so(xrsrc, xwin + buf * XW_F + i * 256, xvoff[i], soff);
+  };
+  auto staged_pair = [&](int buf, const float *ap) {
+    const float *xb = xwin + buf * XW_F;
+    float v[4][4];
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m)
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) v[m][q] = xb[loff[m][q]];
+    fast_pair(v, ap);
+  };
+
+  issue(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    MFN_WAIT_VM(0);      // chunk ch's DMA (issued one chunk of MFMA work ago) has landed for this wave
+    MFN_WAIT_LGKM0();
+    MFN_RAW_BARRIER();   // ... and for every wave; everyone is done reading the other buffer
+    if (ch == 0) MFN_STAMP(p.timeline, 1);
+    const float *abuf = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j;
+    const int cp0 = cp_base + ch * KC;
+    // pairs of this chunk on the fast path (uniform); the rest is either the odd half pair or padding
+    const int nfast = staged ? max(0, min(KC, full_pairs - cp0)) : 0;
+    int k = 0;
+    if (staged) {
+      // DMA order per chunk: x(0), weights(ch+1), x(1), then x(k+1) one pair ahead.  Waits are counted
+      // so that only the newest window (XW_NI instructions) may still be in flight.
+      if (nfast > 0) issue_x(cp0, 0);
+      if (ch + 1 < nchunks) issue(ch + 1);
+      MFN_NOUNROLL
+      for (; k < nfast; ++k) {
+        MFN_WAIT_LGKM0();  // our reads of the buffer we are about to refill have returned
+        if (k + 1 < nfast) {
+          issue_x(cp0 + k + 1, (k + 1) & 1);
+          if (k == 0 && ch + 1 < nchunks) MFN_WAIT_VM(NI + XW_NI);
+          else MFN_WAIT_VM(XW_NI);
+        } else {
+          MFN_WAIT_VM(0);
         }
+        staged_pair(k & 1, abuf + (size_t)k * T * 2 * RL);
+        MFN_SCHED_BARRIER();
       }
+    } else {
+      if (ch + 1 < nchunks) issue(ch + 1);
+      if (rowgather) {
+        const int nrow = max(0, min(KC, full_pairs - cp0));
+        MFN_NOUNROLL
+        for (; k < nrow; ++k) rowgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
+      } else if (dwgather) {
+        const int nrow = max(0, min(KC, full_pairs - cp0));
+        MFN_NOUNROLL
+        for (; k < nrow; ++k) dwgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
+      }  // otherwise (arbitrary per-tap offsets) every pair of this chunk takes the per-tap path below
     }
-  } else {
-    // per-tap path (arbitrary offsets; never taken by the reference network).  Tap geometry is
-    // recomputed per channel pair on purpose: keeping 9 descriptors live would cost ~50 VGPRs
-    // and halve the occupancy of the fast path that shares this kernel.
-    for (int cp = ks; cp < ncp; cp += KS) {
-      const int c = 2 * cp + half;
-      const bool cvalid = c < p.Cin;
-      const float *pl = xn + (size_t)(cvalid ? c : 0) * plane;
-      float colv[T];
-      MFN_UNROLL
-      for (int t = 0; t < T; ++t) {
-        float oh = offh[t], ow = offw[t];
-        MFN_OPAQUE(oh);  // stops LICM from hoisting the geometry out of the channel loop
-        const DcTap tp = dc_make_tap(oh, ow, h_in, w_in, (t / 3) * p.dh, (t % 3) * p.dw, H, W, px_valid && cvalid);
-        const int b = tp.base & 0x3FFFFFFF, dwi = (tp.base >> 30) & 1;
-        const float v1 = pl[b], v2 = pl[b + dwi], v3 = pl[b + tp.dhW], v4 = pl[b + tp.dhW + dwi];
-        colv[t] = tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4;
-      }
-      const float *wp = wt_lane + (size_t)cp * T * wt_step;
-      MFN_UNROLL
-      for (int t = 0; t < T; ++t) {
-        MFN_UNROLL
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(wp[t * wt_step + mt * 32], colv[t], acc[mt]);
-      }
-    }
+    MFN_NOUNROLL
+    for (; k < KC; ++k)
+      if (2 * (cp0 + k) < p.Cin) slow_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);  // padded pairs: zero weights, skip
   }
 
-  // ---- split-K reduction across the waves of the block ---------------------------------------------
-  if (KS > 1) {
-    if (ks != 0) {
+  MFN_STAMP(p.timeline, 2);
+  // ---- in-block K-slice reduction through LDS ----------------------------------------------------------
+  if (KW > 1) {
+    MFN_WAIT_LGKM0();
+    MFN_RAW_BARRIER();  // staging buffers are dead from here on
+    float *red = lds;   // [pt][kw-1][MT*16][64]
+    if (kw != 0) {
       MFN_UNROLL
       for (int mt = 0; mt < MT; ++mt)
         MFN_UNROLL
-        for (int r = 0; r < 16; ++r) red[(size_t)((wave * MT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+        for (int r = 0; r < 16; ++r) red[(size_t)(((pt * (KW - 1) + (kw - 1)) * MT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
     }
     __syncthreads();
-    if (ks != 0) return;
-    for (int k = 1; k < KS; ++k) {
+    if (kw != 0) return;
+    for (int k = 1; k < KW; ++k) {
       MFN_UNROLL
       for (int mt = 0; mt < MT; ++mt)
         MFN_UNROLL
-        for (int r = 0; r < 16; ++r) acc[mt][r] += red[(size_t)(((wave + k) * MT + mt) * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[mt][r] += red[(size_t)(((pt * (KW - 1) + (k - 1)) * MT + mt) * 16 + r) * 64 + lane];
     }
   }
 
-  // ---- epilogue: + bias, store.  D reg r of lane (j,half): filter row (r&3)+8*(r>>2)+4*half, pixel j
+  // ---- epilogue.  D reg r of lane (j,half): filter row (r&3)+8*(r>>2)+4*half, pixel j ------------------
   if (!px_valid) return;
-  float *on = p.out + (size_t)n * p.Cout * oplane + (size_t)ho * Wo + wo;
+  const bool raw = p.ksb > 1;  // cross-block K split: raw partial sums, bias added by dc_reduce_kernel
+  float *on = (raw ? p.partial + (size_t)blockIdx.y * p.N * p.Cout * oplane : p.out) + (size_t)n * p.Cout * oplane +
+              (size_t)ho * Wo + wo;
   MFN_UNROLL
   for (int mt = 0; mt < MT; ++mt)
     MFN_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (o < p.Cout) on[(size_t)o * oplane] = acc[mt][r] + (p.bias ? p.bias[o] : 0.f);
+      if (o < p.Cout) on[(size_t)o * oplane] = acc[mt][r] + ((p.bias && !raw) ? p.bias[o] : 0.f);
     }
+  MFN_STAMP(p.timeline, 3);
 }
 
-template <int MT, int KS>
-inline int dc_mfma_launch(const DeformParams &p, hipStream_t stream, const char *name) {
+template <int MT, int PT>
+inline size_t dc_lds_bytes() {
+  constexpr int KW = 4 / PT;
+  constexpr int NI = (KW * DcGeom<MT, KW>::CH4 + 255) / 256;
+  const size_t stage = (size_t)2 * NI * 256 * 16;
+  const size_t red = KW > 1 ? (size_t)PT * (KW - 1) * MT * 16 * 64 * 4 : 0;
+  const size_t xwin = (size_t)4 * 2 * (4 * 256) * 4;  // 4 waves x 2 buffers x one channel-pair window (XW_F floats)
+  return (stage > red ? stage : red) + xwin;
+}
+
+template <int MT, int PT>
+inline int dc_lds_launch(const DeformParams &p, hipStream_t stream, const char *name) {
   const int tiles = cdiv(p.P, 32);
-  const int bx = cdiv(tiles, 4 / KS);
-  const int by = p.CoutP / (32 * MT);
-  if (bx <= 0 || by <= 0) return 0;
-  const size_t lds = KS > 1 ? (size_t)4 * MT * 16 * 64 * sizeof(float) : 0;
-  return launch(name, dc_mfma_kernel<MT, KS>, dim3(bx, by), dim3(256), lds, stream, p);
+  const int bx = cdiv(tiles, PT);
+  if (bx <= 0) return 0;
+  return launch(name, dc_lds_kernel<MT, PT>, dim3(bx, p.ksb, p.mgroups), dim3(256), dc_lds_bytes<MT, PT>(), stream, p);
+}
+
+// cross-block K-split reduction: out = bias + sum_s partial[s], slices in index order (deterministic)
+struct DcReduceParams { const float *partial; const float *bias; float *out; size_t total; int ksb, Cout; size_t oplane; };
+__global__ __launch_bounds__(256) void dc_reduce_kernel(DcReduceParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.total) return;
+  float s = p.partial[i];
+  for (int k = 1; k < p.ksb; ++k) s += p.partial[(size_t)k * p.total + i];
+  const int o = (int)((i / p.oplane) % p.Cout);
+  p.out[i] = s + (p.bias ? p.bias[o] : 0.f);
+}
+inline int dc_reduce_launch(DcReduceParams rp, hipStream_t stream) {
+  if (!rp.total) return 0;
+  return launch("dc_reduce", dc_reduce_kernel, dim3((unsigned)((rp.total + 255) / 256)), dim3(256), 0, stream, rp);
 }
 
 inline int dc_pack_launch(PackParams pp, hipStream_t stream) {
-  const size_t total = (size_t)((pp.Cin + 1) / 2) * pp.T * 2 * pp.CoutP;
+  const size_t total = (size_t)pp.mgroups * pp.ncp_pad * pp.T * 2 * pp.RL;
   return launch("dc_pack_weights", dc_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                 stream, pp);
 }

@@ -12,6 +12,8 @@
 #include "hipemu.h"
 typedef f32x16_emu f32x16;
 typedef f32x4_emu f32x4;
+struct f4u { float x, y, z, w; };  // 16 bytes at 4-byte alignment
+static inline f4u mfn_load4u(const float *p) { f4u v; memcpy(&v, p, 16); return v; }
 struct f32x2 { float x, y; };
 static inline f32x2 mfn_f2(float x, float y) { return f32x2{x, y}; }
 static inline f32x2 mfn_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
@@ -20,6 +22,7 @@ static inline f32x2 mfn_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x,
 #define MFN_MFMA_16x16x4(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
 #define MFN_LANE_ID() ((int)hipemu::t_lane)
 #define MFN_UNROLL
+#define MFN_NOUNROLL
 #define MFN_OPAQUE(x) ((void)(x))
 #define MFN_SCHED_BARRIER() ((void)0)
 #define MFN_UNIFORM(x) (x)
@@ -31,8 +34,13 @@ static inline void mfn_dma16(mfn_rsrc_t r, float *lds_wave_base, unsigned voff) 
   if ((unsigned long long)voff + 16 <= r.nrec) memcpy(dst, r.base + voff, 16);
   else memset(dst, 0, 16);
 }
-#define MFN_WAIT_VM(n) ((void)0)
-#define MFN_WAIT_LGKM0() ((void)0)
+static inline void mfn_dma16_so(mfn_rsrc_t r, float *lds_wave_base, unsigned voff, unsigned soff) {
+  mfn_dma16(r, lds_wave_base, voff > 0xFFFFFF00u - soff ? 0xFFFFFF00u : voff + soff);
+}
+// emulated lanes are independent threads: a wave-private DMA hand-off needs a wave barrier where the
+// hardware needs only the issuing wave's vmcnt wait (lock-step lanes)
+#define MFN_WAIT_VM(n) (hipemu::wave().bar.arrive_and_wait())
+#define MFN_WAIT_LGKM0() (hipemu::wave().bar.arrive_and_wait())
 #define MFN_RAW_BARRIER() __syncthreads()
 #define MFN_STAMP(buf, k) ((void)0)
 #else
@@ -42,6 +50,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // packed fp32: v_pk_fma_f32 does two FMAs per lane per issue; hipcc folds the element swizzles of
 // its operands into op_sel/op_sel_hi, so building pairs from registers costs no moves
+// four consecutive floats at 4-byte alignment: one global_load_dwordx4 (gfx950 allows dword-aligned
+// vector loads) instead of four global_load_dword -- a quarter of the L1 (TA/TCP) accesses
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f4u mfn_load4u(const float *p) { return *reinterpret_cast<const f4u *>(p); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 mfn_f2(float x, float y) { return (f32x2){x, y}; }
 #define mfn_fma2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
@@ -52,6 +64,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
 #define MFN_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define MFN_LANE_ID() ((int)(threadIdx.x & 63))
 #define MFN_UNROLL _Pragma("unroll")
+#define MFN_NOUNROLL _Pragma("nounroll")
 #define MFN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MFN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define MFN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
@@ -75,6 +88,13 @@ __device__ __forceinline__ void mfn_dma16(mfn_rsrc_t rsrc, float *lds_wave_base,
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
                : "memory", "m0");
 }
+// same with a wave-uniform byte offset added by the instruction's soffset operand
+__device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_base, unsigned voff, unsigned soff) {
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  const unsigned so = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(so)
+               : "memory", "m0");
+}
 #define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
@@ -82,7 +102,7 @@ __device__ __forceinline__ void mfn_dma16(mfn_rsrc_t rsrc, float *lds_wave_base,
 #define MFN_STAMP(buf, k)                                                                              \
   do {                                                                                                 \
     if ((buf) && threadIdx.x == 0)                                                                     \
-      (buf)[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (k)] = wall_clock64();                 \
+      (buf)[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (k)] = wall_clock64();                 \
   } while (0)
 #endif
 

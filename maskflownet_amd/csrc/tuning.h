@@ -8,9 +8,10 @@
 //   corr.generic 1: force the generic one-thread-per-output kernel
 //   corr.ablate  measurement only: 1 no stores, 2 no global loads
 //   warp.vec     pixels per thread of the warp kernel: 1 | 4
-//   dc.ablate    measurement only: 1 no gather loads, 2 no weight loads, 3 no MFMA
-//   dc.mt        32-filter MFMA tiles per wave: 1 | 2 | 3 | 4 | 7
-//   dc.ks        split-K ways inside a block: 1 | 2 | 4
+//   dc.mt        32-filter MFMA tiles per wave: 1 | 2 | 3 | 4
+//   dc.pt        pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
+//   dc.ksb       K split across blocks (partial sums + reduce kernel); 0 = heuristic
+//   dc.stage     0: disable the LDS source-window staging of the shared-offset path
 //   dc.fast      0: disable the shared-offset 4x4-neighbourhood gather
 //   dc.generic   1: force the generic one-thread-per-output kernel
 #pragma once
@@ -18,8 +19,8 @@
 namespace mfn {
 struct Tuning {
   int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0;
-  int warp_vec = 0, dc_ablate = 0;
-  int dc_mt = 0, dc_ks = 0, dc_fast = 1, dc_generic = 0;
+  int warp_vec = 0;
+  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
@@ -29,10 +30,11 @@ struct Tuning {
     if (!strcmp(key, "corr.slices")) return &corr_slices;
     if (!strcmp(key, "corr.lanemap")) return &corr_lanemap;
     if (!strcmp(key, "warp.vec")) return &warp_vec;
-    if (!strcmp(key, "dc.ablate")) return &dc_ablate;
     if (!strcmp(key, "dc.mt")) return &dc_mt;
-    if (!strcmp(key, "dc.ks")) return &dc_ks;
+    if (!strcmp(key, "dc.pt")) return &dc_pt;
+    if (!strcmp(key, "dc.ksb")) return &dc_ksb;
     if (!strcmp(key, "dc.fast")) return &dc_fast;
+    if (!strcmp(key, "dc.stage")) return &dc_stage;
     if (!strcmp(key, "dc.generic")) return &dc_generic;
     return nullptr;
   }

@@ -65,6 +65,20 @@ def algorithmic_flops(N, H, W):
     return out
 
 
+def upsample2(a):
+    """Upsample(2) of /root/reference/network/MaskFlownet.py:35-62: out[2i] = in[i],
+    out[2i+1] = (in[i] + in[i+1]) / 2 with the last row/column replicated."""
+    a = np.asarray(a, np.float64)
+    p = np.pad(a, ((0, 0), (0, 0), (0, 1), (0, 1)), mode="edge")
+    n, c, h, w = a.shape
+    out = np.empty((n, c, 2 * h, 2 * w))
+    out[:, :, 0::2, 0::2] = p[:, :, :h, :w]
+    out[:, :, 0::2, 1::2] = 0.5 * (p[:, :, :h, :w] + p[:, :, :h, 1:w + 1])
+    out[:, :, 1::2, 0::2] = 0.5 * (p[:, :, :h, :w] + p[:, :, 1:h + 1, :w])
+    out[:, :, 1::2, 1::2] = 0.25 * (p[:, :, :h, :w] + p[:, :, :h, 1:w + 1] + p[:, :, 1:h + 1, :w] + p[:, :, 1:h + 1, 1:w + 1])
+    return out
+
+
 def synth_inputs(N, H, W, seed=20260925):
     """Seeded synthetic tensors (numpy) for every level -- SURVEY.md 8(d) 'op level'."""
     data = {}
@@ -75,9 +89,14 @@ def synth_inputs(N, H, W, seed=20260925):
             data[name] = np.where(x > 0, x, np.float32(0.1) * x).astype(np.float32)
         if l != 6:
             n, c, h, w = shp
-            fl = (rng.standard_normal((n, 2, h, w)) * 2.0).astype(np.float32)
-            far = rng.random((n, 1, h, w)) < 0.02
-            fl = np.where(far, rng.uniform(-h, h, (n, 2, h, w)).astype(np.float32), fl)
+            # flow_l = Upsample(2)(flow_{l+1}) in the network (MaskFlownet.py:228), recursively: a smooth,
+            # piecewise-linear field.  Model: N(0, 2 level-px) noise three levels up (1/8 resolution),
+            # upsampled 3x with the reference's Upsample(2), plus a global shift per sample.
+            ch8, cw8 = max(1, (h + 7) // 8), max(1, (w + 7) // 8)
+            fl = rng.standard_normal((n, 2, ch8, cw8)) * 2.0 + rng.uniform(-3, 3, (n, 2, 1, 1))
+            for _ in range(3):
+                fl = upsample2(fl)
+            fl = fl[:, :, :h, :w].astype(np.float32)
             # level-pixel offsets = flow * SCALE / stride  ->  store the network-unit flow
             data["flow_%d" % l] = (fl * np.float32(STRIDES[l] / SCALE)).astype(np.float32)
             fan = 9.0 * c
@@ -85,7 +104,11 @@ def synth_inputs(N, H, W, seed=20260925):
             data["b_%d" % l] = (rng.standard_normal((c,)) * 0.1).astype(np.float32)
     rng = np.random.default_rng(seed)
     data["img2"] = rng.standard_normal((N, 3, H, W)).astype(np.float32)
-    data["flow_full"] = (rng.standard_normal((N, 2, H, W)) * 4.0).astype(np.float32)
+    # Upsample(4)(flow2) * scale (MaskFlownet.py:311): the same smooth level-2 field, 8 full-res px sigma
+    ff = rng.standard_normal((N, 2, max(1, H // 32), max(1, W // 32))) * 2.0
+    for _ in range(5):
+        ff = upsample2(ff)
+    data["flow_full"] = (ff[:, :, :H, :W] * 4.0).astype(np.float32)
     return data
 
 

@@ -115,7 +115,8 @@ if mx is not None:  # pragma: no cover
             cout = w.shape[0]
             p = self.p
             lib = _lib.lib()
-            need = lib.deform_conv_workspace_bytes(n, cin, h, wd, cout, p["kh"], p["kw"], p["g"], p["dg"])
+            need = lib.deform_conv_workspace_bytes(n, cin, h, wd, cout, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"],
+                                                   p["dh"], p["dw"], p["g"], p["dg"])
             if self.ws is None or self.ws.size * 4 < need:
                 self.ws = mx.nd.empty(((need + 3) // 4,), ctx=x.context)
             out = mx.nd.empty(out_data[0].shape, ctx=x.context)

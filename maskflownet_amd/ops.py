@@ -165,7 +165,8 @@ class OpSet:
             raise ValueError("DeformableConvolution: bias shape %s, expected (%d,)" % (self.ad.shape(b), Cout))
         if out is None:
             out = self.ad.empty(x, (N, Cout, Ho, Wo))
-        nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, num_group, num_deformable_group)
+        nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group,
+                                                     num_deformable_group)
         ws = self._workspace(x, nbytes)
         self.check(self.ns.deform_conv_fwd(self.ad.ptr(x), self.ad.ptr(off), self.ad.ptr(w),
                                            self.ad.ptr(b) if b is not None else None, self.ad.ptr(out), N, Cin, H, W,
@@ -188,7 +189,7 @@ class OpSet:
             raise ValueError("deformable_convolution_shared: flow must be %s" % ((N, 2, H, W),))
         if out is None:
             out = self.ad.empty(x, (N, Cout, H, W))
-        nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, num_group, 1)
+        nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, 1, 1, ph, pw, dh, dw, num_group, 1)
         ws = self._workspace(x, nbytes)
         self.check(self.ns.deform_conv_shared_fwd(self.ad.ptr(x), self.ad.ptr(fl), float(flow_scale),
                                                   float(flow_stride), self.ad.ptr(w),

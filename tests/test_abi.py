@@ -48,8 +48,10 @@ def test_shape_inference_matches_mxnet_rules(lib):
     assert lib.deform_conv_out_shape(12, 16, 3, 3, 2, 2, 1, 1, 1, 1, ctypes.byref(ho), ctypes.byref(wo)) == 0
     assert (ho.value, wo.value) == (6, 8)
     assert lib.deform_conv_out_shape(2, 2, 5, 5, 1, 1, 0, 0, 1, 1, ctypes.byref(ho), ctypes.byref(wo)) == -2
-    assert lib.deform_conv_workspace_bytes(8, 128, 12, 16, 128, 3, 3, 1, 1) == 64 * 9 * 2 * 128 * 4
-    assert lib.deform_conv_workspace_bytes(8, 196, 6, 8, 196, 3, 3, 1, 1) == 98 * 9 * 2 * 224 * 4
+    ws = lib.deform_conv_workspace_bytes(8, 128, 12, 16, 128, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+    assert ws >= 64 * 9 * 2 * 128 * 4 and ws % 4 == 0      # at least the re-laid-out weights
+    assert lib.deform_conv_workspace_bytes(8, 196, 6, 8, 196, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1) >= 98 * 9 * 2 * 196 * 4
+    assert lib.deform_conv_workspace_bytes(8, 16, 6, 8, 16, 5, 5, 1, 1, 2, 2, 1, 1, 1, 1) == 0  # generic kernel
 
 
 def test_bad_arguments_fail_before_any_launch(lib):

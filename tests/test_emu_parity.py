@@ -20,7 +20,7 @@ def ops():
 @pytest.fixture(autouse=True)
 def _reset_tuning():
     yield
-    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, dc_mt=0, dc_ks=0, dc_fast=1,
+    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
                        dc_generic=0)
 
 
@@ -97,16 +97,31 @@ def test_grid_generator_and_sampler(ops, oracle):
     pc.check_close(ops.BilinearSampler(x, ga), oracle.bilinear_sampler(x, ga), what="sampler affine")
 
 
-@pytest.mark.parametrize("mt,ks", [(1, 1), (1, 4), (2, 2), (1, 2)])
+@pytest.mark.parametrize("mt,pt,ksb", [(1, 1, 1), (1, 4, 1), (2, 2, 1), (1, 2, 2), (2, 1, 2), (1, 1, 0)])
 @pytest.mark.parametrize("fused", [True, False])
-def test_deform_shared_offsets(ops, oracle, mt, ks, fused):
-    emu_ops.set_tuning(dc_mt=mt, dc_ks=ks)
+def test_deform_shared_offsets(ops, oracle, mt, pt, ksb, fused):
+    # pt pixel tiles per block, 4/pt in-block K slices, ksb cross-block K slices (partials + reduce)
+    emu_ops.set_tuning(dc_mt=mt, dc_pt=pt, dc_ksb=ksb)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 64 if mt == 2 else 32, 6, 7, fused=fused)
+
+
+def test_deform_three_filter_tiles_and_two_mgroups(ops, oracle):
+    emu_ops.set_tuning(dc_mt=3)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 96, 4, 5)      # MT=3, one M-group
+    emu_ops.set_tuning(dc_mt=2)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 72, 3, 4)      # 3 filter tiles as 2 M-groups of MT=2
 
 
 def test_deform_shared_odd_channels_and_padding_of_filters(ops, oracle):
     # Cin odd -> zero half-pair; Cout=5 -> 27 padded filter rows; P=20 px -> partial pixel tile
     pc.case_deform_pertap(ops, oracle, ident, ident, 1, 3, 5, 4, 5, kernel=(3, 3), pad=(1, 1))
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_deform_window_staging_and_per_tap_fallback(ops, oracle, stage):
+    emu_ops.set_tuning(dc_stage=stage)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8)      # W % 4 == 0: window staging eligible
+    pc.case_deform_shared(ops, oracle, ident, ident, 2, 8, 12, 16, seed=3)
 
 
 def test_deform_fast_path_off_matches(ops, oracle):

@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, warp_vec=0, dc_mt=0, dc_ks=0, dc_fast=1, dc_generic=0)
+    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, warp_vec=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -153,10 +153,11 @@ def test_deform_conv_sintel_level_and_full_model_l6(ops, oracle, dev):
     pc.case_deform_shared(ops, oracle, dev, host, 2, 196, 6, 8, stride=64.0)  # full model deform6, C=196 -> 224 padded
 
 
-@pytest.mark.parametrize("mt,ks", [(1, 1), (1, 2), (1, 4), (2, 1), (2, 4), (4, 1), (4, 4)])
-def test_deform_conv_every_tiling(ops, oracle, dev, mt, ks):
+@pytest.mark.parametrize("mt,pt,ksb", [(1, 1, 1), (1, 2, 1), (1, 4, 1), (2, 1, 2), (2, 4, 4), (4, 1, 1), (4, 4, 8),
+                                        (3, 2, 1), (4, 1, 0)])
+def test_deform_conv_every_tiling(ops, oracle, dev, mt, pt, ksb):
     from maskflownet_amd import _lib
-    _lib.set_tuning(dc_mt=mt, dc_ks=ks)
+    _lib.set_tuning(dc_mt=mt, dc_pt=pt, dc_ksb=ksb)
     pc.case_deform_shared(ops, oracle, dev, host, 2, 128, 12, 16, stride=32.0)
 
 

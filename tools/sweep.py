@@ -97,23 +97,25 @@ for l in (5, 4, 3, 2):
     flops = 2 * n * h * w * c * c * 9
     nbytes = 4 * (n * h * w * (2 * c + 18) + 9 * c * c + c)
     mtiles = c // 32
-    for mt in [m for m in (1, 2, 3, 4) if mtiles % m == 0]:
-        for ks in (1, 2, 4):
-            for fast in (1, 0) if (mt == 1 and ks == 4) else (1,):
-                _lib.set_tuning(dc_mt=mt, dc_ks=ks, dc_fast=fast)
-                fn = lambda: ops.deformable_convolution_shared(wl.t["c2_%d" % l], wl.t["flow_%d" % l], 20.0,
-                                                               hotpath.STRIDES[l], wl.t["w_%d" % l],
-                                                               wl.t["b_%d" % l], out=wl.o["deform%d" % l])
+    fn = lambda: ops.deformable_convolution_shared(wl.t["c2_%d" % l], wl.t["flow_%d" % l], 20.0,
+                                                   hotpath.STRIDES[l], wl.t["w_%d" % l],
+                                                   wl.t["b_%d" % l], out=wl.o["deform%d" % l])
+    for mt in [m for m in (1, 2, 3, 4) if mtiles % m == 0 or m == mtiles]:
+        for pt in (1, 2, 4):
+            for ksb in (1, 2, 4, 8):
+                if ksb > 1 and n * h * w > 20000:
+                    continue
+                _lib.set_tuning(dc_mt=mt, dc_pt=pt, dc_ksb=ksb, dc_fast=1)
                 try:
-                    us = timeit(fn, "dc_mfma", iters=30)
+                    us = timeit(fn, "dc_lds", iters=20) + (timeit(fn, "dc_reduce", iters=5) if ksb > 1 else 0.0)
                 except Exception as e:
                     us = None
-                    print("ERR deform", l, mt, ks, e, flush=True)
-                r = {"level": l, "mt": mt, "ks": ks, "fast": fast, "us": us,
+                    print("ERR deform", l, mt, pt, ksb, e, flush=True)
+                r = {"level": l, "mt": mt, "pt": pt, "ksb": ksb, "us": us,
                      "TFLOPs": flops / us / 1e6 if us else None, "GBps": nbytes / us / 1e3 if us else None}
                 res["deform"].append(r)
                 print(json.dumps(r), flush=True)
-    _lib.set_tuning(dc_mt=0, dc_ks=0, dc_fast=1)
+    _lib.set_tuning(dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1)
     res["misc"]["pack_us_L%d" % l] = timeit(fn, "dc_pack", iters=10)
 
 # ---- warp --------------------------------------------------------------------------------------------

@@ -30,3 +30,25 @@ for (n, c, h, w) in [(8, 32, 96, 128), (8, 64, 48, 64)]:
         print("  main loop     : median %.2f  p90 %.2f us" % (np.median(t[:,2]-t[:,1]), np.percentile(t[:,2]-t[:,1],90)))
         print("  epilogue issue: median %.2f  p90 %.2f us" % (np.median(t[:,3]-t[:,2]), np.percentile(t[:,3]-t[:,2],90)))
         print("  block end     : median %.2f  max %.2f us (kernel >= this + store drain)" % (np.median(t[:,3]), t[:,3].max()))
+
+# ---- deformable convolution ---------------------------------------------------------------------------
+from maskflownet_amd import hotpath
+wl = hotpath.HotPathWorkload("cfg2", mode="fused")
+for l, cfgs in ((2, [(1, 4), (1, 2)]), (3, [(2, 2)])):
+    for mt, pt in cfgs:
+        _lib.set_tuning(dc_mt=mt, dc_pt=pt, dc_ksb=1)
+        n, c, h, w = hotpath.level_shapes(wl.N, wl.H, wl.W)[l]
+        nblk = ((n * h * w + 31) // 32 + pt - 1) // pt
+        tl = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+        fn = lambda: ops.deformable_convolution_shared(wl.t["c2_%d" % l], wl.t["flow_%d" % l], 20.0, hotpath.STRIDES[l], wl.t["w_%d" % l], wl.t["b_%d" % l], out=wl.o["deform%d" % l])
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        lib.debug_set_timeline(tl.data_ptr()); fn(); torch.cuda.synchronize(); lib.debug_set_timeline(None)
+        t = tl.cpu().numpy().reshape(nblk, 4).astype(np.float64) * 0.01
+        t -= t[:, 0].min()
+        print("deform L%d mt=%d pt=%d blocks %d" % (l, mt, pt, nblk))
+        print("  block start   : median %.2f  p90 %.2f  max %.2f us" % (np.median(t[:,0]), np.percentile(t[:,0],90), t[:,0].max()))
+        print("  setup+1st DMA : median %.2f  p90 %.2f us" % (np.median(t[:,1]-t[:,0]), np.percentile(t[:,1]-t[:,0],90)))
+        print("  main loop     : median %.2f  p90 %.2f us" % (np.median(t[:,2]-t[:,1]), np.percentile(t[:,2]-t[:,1],90)))
+        print("  epilogue      : median %.2f  p90 %.2f us" % (np.median(t[:,3]-t[:,2]), np.percentile(t[:,3]-t[:,2],90)))
+        print("  block end     : median %.2f  max %.2f us" % (np.median(t[:,3]), t[:,3].max()))
