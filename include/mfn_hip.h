@@ -140,8 +140,11 @@ int mfn_deform_conv_shared_fwd(const float *x, const float *flow_yx, float flow_
                                float *out, int N, int Cin, int H, int W, int Cout, int kh, int kw,
                                int ph, int pw, int dh, int dw, int groups, void *workspace,
                                size_t workspace_bytes, void *stream);
-/* Backward (training).  gx,goffset,gw,gbias as the forward's x,offset,w,bias; req_* per output;
- * workspace from mfn_deform_conv_bwd_workspace_bytes. */
+/* Backward (training).  gx,goffset,gw,gbias as the forward's x,offset,w,bias; req_* per output
+ * (MFN_REQ_NULL skips it and the pointer may be NULL).  The column gradient is formed on the fly,
+ * so mfn_deform_conv_bwd_workspace_bytes currently returns 0 and workspace may be NULL.  gx and
+ * goffset are accumulated with fp32 atomics (as MXNet's GPU kernels do): bit-level results can
+ * differ from run to run by summation order. */
 size_t mfn_deform_conv_bwd_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw,
                                            int sh, int sw, int ph, int pw, int dh, int dw,
                                            int groups, int deform_groups);

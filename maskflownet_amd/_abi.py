@@ -29,6 +29,10 @@ SIGNATURES = {
     "deform_conv_shared_fwd": (_i, [_f, _f, C.c_float, C.c_float, _f, _f, _f] + [_i] * 12 + [C.c_void_p, C.c_size_t, _s]),
     "offsets_from_flow": (_i, [_f, _f, _i, _i, _i, _i, C.c_float, C.c_float, _s]),
     "debug_set_timeline": (_i, [C.c_void_p]),
+    "correlation_bwd": (_i, [_f] * 5 + [_i] * 12 + [_s]),
+    "warp_bwd": (_i, [_f] * 5 + [_i] * 7 + [_s]),
+    "deform_conv_bwd_workspace_bytes": (C.c_size_t, [_i] * 15),
+    "deform_conv_bwd": (_i, [_f] * 8 + [_i] * 19 + [C.c_void_p, C.c_size_t, _s]),
     "set_tuning": (_i, [C.c_char_p, _i]),
     "get_tuning": (_i, [C.c_char_p, _pi]),
 }
@@ -37,10 +41,6 @@ SIGNATURES = {
 PRODUCT_ONLY = {
     "abi_version": (_i, []),
     "version_string": (C.c_char_p, []),
-    "correlation_bwd": (_i, [_f] * 5 + [_i] * 12 + [_s]),
-    "warp_bwd": (_i, [_f] * 5 + [_i] * 7 + [_s]),
-    "deform_conv_bwd_workspace_bytes": (C.c_size_t, [_i] * 15),
-    "deform_conv_bwd": (_i, [_f] * 8 + [_i] * 19 + [C.c_void_p, C.c_size_t, _s]),
     "graph_begin_capture": (_i, [_s]),
     "graph_end_capture": (_i, [_s, C.POINTER(C.c_void_p)]),
     "graph_launch": (_i, [C.c_void_p, _s]),

@@ -31,24 +31,6 @@ extern "C" {
 int mfn_abi_version(void) { return MFN_ABI_VERSION; }
 const char *mfn_version_string(void) { return "mfn_hip 0.1 (gfx950)"; }
 
-int mfn_correlation_bwd(const float *, const float *, const float *, float *, float *, int, int, int, int, int, int,
-                        int, int, int, int, int, int, void *) {
-  return fail(MFN_E_UNSUPPORTED, "correlation_bwd: not implemented yet");
-}
-int mfn_warp_bwd(const float *, const float *, const float *, float *, float *, int, int, int, int, int, int, int,
-                 void *) {
-  return fail(MFN_E_UNSUPPORTED, "warp_bwd: not implemented yet");
-}
-size_t mfn_deform_conv_bwd_workspace_bytes(int, int, int, int, int, int, int, int, int, int, int, int, int, int,
-                                           int) {
-  return 0;
-}
-int mfn_deform_conv_bwd(const float *, const float *, const float *, const float *, float *, float *, float *,
-                        float *, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int,
-                        int, int, void *, size_t, void *) {
-  return fail(MFN_E_UNSUPPORTED, "deform_conv_bwd: not implemented yet");
-}
-
 // ---- hipGraph plumbing -------------------------------------------------------------------------------
 int mfn_graph_begin_capture(void *stream) {
   return hipfail((int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal), "graph_begin_capture");

@@ -1,0 +1,359 @@
+// backward.h -- gradients of the hot-path operators for gfx950 (the training
+// step of /root/reference/network/pipeline.py:112-113 reaches them through MXNet autograd).
+// Semantics as oracle/mfn_ref_body.inc: correlation_bwd, bilinear_sampler_bwd + grid generator backward
+// (warp_bwd), deform_conv_bwd (deformable_col2im / col2im_coord / weight + bias gradients).
+//
+// Round-1 scope: correct and parallel, not yet tuned (the forward path is the benchmarked one):
+//   * correlation: both gradients are GATHERS for the reference configuration (kernel_size=1, strides 1,
+//     pad == max_displacement) -- one thread per input element, no atomics, deterministic; any other
+//     parameter set scatters with atomics exactly like MXNet's GPU kernels;
+//   * warp: data gradient = 4-tap atomic scatter, flow gradient accumulated per pixel in registers;
+//   * deformable conv: input/offset gradients in one kernel (column gradient formed on the fly from
+//     W^T x gout, never written), weight gradient by a block-reduction kernel, bias by a row reduction.
+// req semantics (MXNet OpReqType): 0 = skip, 1 = write, 3 = add to the existing contents.
+#pragma once
+#include "../mfn_rt.h"
+#include "deform_conv.h"
+#include "warp.h"
+
+namespace mfn {
+
+struct FillParams { float *p; size_t n; };
+__global__ __launch_bounds__(256) void fill_zero_kernel(FillParams f) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < f.n) f.p[i] = 0.f;
+}
+inline int fill_zero_launch(float *p, size_t n, hipStream_t s) {
+  if (!n) return 0;
+  return launch("fill_zero", fill_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, FillParams{p, n});
+}
+
+// ---- correlation -----------------------------------------------------------------------------------
+struct CorrBwdParams {
+  const float *gout, *f1, *f2;
+  float *g1, *g2;
+  int N, C, H, W, md, D;  // D = 2*md+1 (kernel 1, strides 1, pad == md: top_h = H, top_w = W)
+  int req1, req2;
+};
+// g1[n,c,y,x] = 1/C sum_d gout[n,d,y,x]       * f2[n,c,y+dy,x+dx]
+// g2[n,c,y,x] = 1/C sum_d gout[n,d,y-dy,x-dx] * f1[n,c,y-dy,x-dx]      (terms outside the image vanish)
+__global__ __launch_bounds__(256) void corr_bwd_gather_kernel(CorrBwdParams p) {
+  const size_t plane = (size_t)p.H * p.W;
+  const size_t total = (size_t)p.N * p.C * plane;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % p.W), y = (int)((idx / p.W) % p.H);
+  const int c = (int)((idx / plane) % p.C), n = (int)(idx / (plane * p.C));
+  const float *go = p.gout + (size_t)n * p.D * p.D * plane;
+  const float *a = p.f1 + ((size_t)n * p.C + c) * plane;
+  const float *b = p.f2 + ((size_t)n * p.C + c) * plane;
+  const float sumelems = (float)p.C;
+  float s1 = 0.f, s2 = 0.f;
+  for (int iy = 0; iy < p.D; ++iy) {
+    const int dy = iy - p.md;
+    const int y2 = y + dy, ys = y - dy;
+    for (int ix = 0; ix < p.D; ++ix) {
+      const int dx = ix - p.md;
+      const int x2 = x + dx, xs = x - dx;
+      const float *gd = go + (size_t)(iy * p.D + ix) * plane;
+      if (y2 >= 0 && y2 < p.H && x2 >= 0 && x2 < p.W) s1 += gd[(size_t)y * p.W + x] * b[(size_t)y2 * p.W + x2] / sumelems;
+      if (ys >= 0 && ys < p.H && xs >= 0 && xs < p.W) s2 += gd[(size_t)ys * p.W + xs] * a[(size_t)ys * p.W + xs] / sumelems;
+    }
+  }
+  if (p.req1) p.g1[idx] = (p.req1 == 3 ? p.g1[idx] : 0.f) + s1;
+  if (p.req2) p.g2[idx] = (p.req2 == 3 ? p.g2[idx] : 0.f) + s2;
+}
+
+struct CorrBwdGenericParams {
+  const float *gout, *f1, *f2;
+  float *g1, *g2;
+  int N, C, H, W, md, kernel, s1, s2, pad, is_multiply, top_c, top_h, top_w, radius, gw;
+  int req1, req2;
+};
+// any MXNet-valid parameter set: one thread per (n, top_channel, i, j), atomic scatter over channels
+__global__ __launch_bounds__(256) void corr_bwd_scatter_kernel(CorrBwdGenericParams p) {
+  const size_t total = (size_t)p.N * p.top_c * p.top_h * p.top_w;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx % p.top_w), i = (int)((idx / p.top_w) % p.top_h);
+  const int tc = (int)((idx / ((size_t)p.top_w * p.top_h)) % p.top_c);
+  const int n = (int)(idx / ((size_t)p.top_w * p.top_h * p.top_c));
+  const int x1 = j * p.s1 + p.md, y1 = i * p.s1 + p.md;
+  const int x2 = x1 + (tc % p.gw - p.radius) * p.s2, y2 = y1 + (tc / p.gw - p.radius) * p.s2;
+  const size_t plane = (size_t)p.H * p.W;
+  const float g = p.gout[idx];
+  const float sumelems = (float)(p.kernel * p.kernel * p.C);
+  for (int h = 0; h < p.kernel; ++h)
+    for (int w = 0; w < p.kernel; ++w) {
+      const int ya = y1 + h - p.pad, xa = x1 + w - p.pad, yb = y2 + h - p.pad, xb = x2 + w - p.pad;
+      const bool ina = ya >= 0 && ya < p.H && xa >= 0 && xa < p.W;
+      const bool inb = yb >= 0 && yb < p.H && xb >= 0 && xb < p.W;
+      for (int c = 0; c < p.C; ++c) {
+        const size_t base = ((size_t)n * p.C + c) * plane;
+        const float va = ina ? p.f1[base + (size_t)ya * p.W + xa] : 0.f;
+        const float vb = inb ? p.f2[base + (size_t)yb * p.W + xb] : 0.f;
+        float c1, c2;
+        if (p.is_multiply) { c1 = g * vb / sumelems; c2 = g * va / sumelems; }
+        else { const float sg = (va - vb) >= 0.f ? 1.f : -1.f; c1 = g * sg / sumelems; c2 = -c1; }
+        if (ina && p.req1) atomicAdd(p.g1 + base + (size_t)ya * p.W + xa, c1);
+        if (inb && p.req2) atomicAdd(p.g2 + base + (size_t)yb * p.W + xb, c2);
+      }
+    }
+}
+
+// ---- warp ---------------------------------------------------------------------------------------------
+struct WarpBwdParams {
+  const float *gout, *x, *flow;
+  float *gx, *gflow;
+  int N, C, H, W, clip, req_x, req_flow;
+};
+__global__ __launch_bounds__(256) void warp_bwd_kernel(WarpBwdParams p) {
+  const size_t plane = (size_t)p.H * p.W;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)p.N * plane) return;
+  const int x = (int)(idx % p.W), y = (int)((idx / p.W) % p.H);
+  const size_t n = idx / plane, pix = idx - n * plane;
+  const float fy = p.flow[n * 2 * plane + pix], fx = p.flow[n * 2 * plane + plane + pix];
+  float gxr, gyr;  // unclipped grid (for the clip mask)
+  warp_grid(fx, fy, x, y, p.H, p.W, 0, gxr, gyr);
+  float gxc = gxr, gyc = gyr;
+  if (p.clip) { gxc = fminf(fmaxf(gxr, -1.f), 1.f); gyc = fminf(fmaxf(gyr, -1.f), 1.f); }
+  // BilinearSamplerBackward
+  const float y_real = (gyc + 1.f) * (float)(p.H - 1) / 2.f, x_real = (gxc + 1.f) * (float)(p.W - 1) / 2.f;
+  const float fyr = floorf(y_real), fxr = floorf(x_real);
+  const int ty = (int)fminf(fmaxf(fyr, -2.f), (float)p.H + 1.f), tx = (int)fminf(fmaxf(fxr, -2.f), (float)p.W + 1.f);
+  const float wy = 1.f - (y_real - fyr), wx = 1.f - (x_real - fxr);
+  const bool y0 = ty >= 0 && ty <= p.H - 1, y1 = ty + 1 >= 0 && ty + 1 <= p.H - 1;
+  const bool x0 = tx >= 0 && tx <= p.W - 1, x1 = tx + 1 >= 0 && tx + 1 <= p.W - 1;
+  float gwy = 0.f, gwx = 0.f;
+  for (int c = 0; c < p.C; ++c) {
+    const size_t cb = (n * p.C + c) * plane;
+    const float g = p.gout[cb + pix];
+    const float *pl = p.x + cb;
+    const size_t i00 = (size_t)min(max(ty, 0), p.H - 1) * p.W + min(max(tx, 0), p.W - 1);
+    const float tl = (y0 && x0) ? pl[(size_t)ty * p.W + tx] : 0.f;
+    const float tr = (y0 && x1) ? pl[(size_t)ty * p.W + tx + 1] : 0.f;
+    const float bl = (y1 && x0) ? pl[(size_t)(ty + 1) * p.W + tx] : 0.f;
+    const float br = (y1 && x1) ? pl[(size_t)(ty + 1) * p.W + tx + 1] : 0.f;
+    (void)i00;
+    if (p.req_x) {
+      float *gp = p.gx + cb;
+      if (y0 && x0) atomicAdd(gp + (size_t)ty * p.W + tx, g * wy * wx);
+      if (y0 && x1) atomicAdd(gp + (size_t)ty * p.W + tx + 1, g * wy * (1.f - wx));
+      if (y1 && x0) atomicAdd(gp + (size_t)(ty + 1) * p.W + tx, g * (1.f - wy) * wx);
+      if (y1 && x1) atomicAdd(gp + (size_t)(ty + 1) * p.W + tx + 1, g * (1.f - wy) * (1.f - wx));
+    }
+    gwy -= g * (tr - br + (tl - tr - bl + br) * wx);
+    gwx -= g * (bl - br + (tl - tr - bl + br) * wy);
+  }
+  if (p.req_flow) {
+    float ggy = gwy * (float)(p.H - 1) / 2.f, ggx = gwx * (float)(p.W - 1) / 2.f;
+    if (p.clip) {  // clip backward: gradient passes only inside [-1, 1]
+      if (!(gxr >= -1.f && gxr <= 1.f)) ggx = 0.f;
+      if (!(gyr >= -1.f && gyr <= 1.f)) ggy = 0.f;
+    }
+    const float nx = (float)((p.W - 1) / 2.0), ny = (float)((p.H - 1) / 2.0);
+    float *gfy = p.gflow + n * 2 * plane + pix, *gfx = gfy + plane;  // channel 0 = dy, 1 = dx
+    const float vy = ggy / ny, vx = ggx / nx;
+    *gfy = (p.req_flow == 3 ? *gfy : 0.f) + vy;
+    *gfx = (p.req_flow == 3 ? *gfx : 0.f) + vx;
+  }
+}
+
+// ---- deformable convolution -------------------------------------------------------------------------------
+struct DcBwdParams {
+  const float *gout, *x, *offset, *w;
+  float *gx, *goffset, *gw, *gbias;
+  int N, Cin, H, W, Cout, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg;
+  int req_x, req_offset, req_w, req_bias;
+  int cchunk;  // input channels per thread of the input/offset gradient kernel
+};
+
+// get_gradient_weight of deformable_im2col.cuh
+__device__ __forceinline__ float dc_gradient_weight(float ah, float aw, int h, int w, int H, int W) {
+  if (ah < 0.f || ah > (float)H || aw < 0.f || aw > (float)W) return 0.f;
+  ah = fmaxf(ah, 0.f);
+  aw = fmaxf(aw, 0.f);
+  int hl = (int)ah, wl = (int)aw, hh, wh;
+  if (hl >= H - 1) { hh = hl = H - 1; ah = (float)hl; } else hh = hl + 1;
+  if (wl >= W - 1) { wh = wl = W - 1; aw = (float)wl; } else wh = wl + 1;
+  float wt = 0.f;
+  if (h == hl) {
+    if (w == wl) wt = ((float)(h + 1) - ah) * ((float)(w + 1) - aw);
+    else if (w == wh) wt = ((float)(h + 1) - ah) * (aw + 1.f - (float)w);
+  } else if (h == hh) {
+    if (w == wl) wt = (ah + 1.f - (float)h) * ((float)(w + 1) - aw);
+    else if (w == wh) wt = (ah + 1.f - (float)h) * (aw + 1.f - (float)w);
+  }
+  return wt;
+}
+// get_coordinate_weight of deformable_im2col.cuh
+__device__ __forceinline__ float dc_coordinate_weight(float ah, float aw, int H, int W, const float *im, int bp_dir) {
+  if (ah < 0.f || ah > (float)H || aw < 0.f || aw > (float)W) return 0.f;
+  int hl = (int)ah, wl = (int)aw, hh, wh;
+  if (hl >= H - 1) { hh = hl = H - 1; ah = (float)hl; } else hh = hl + 1;
+  if (wl >= W - 1) { wh = wl = W - 1; aw = (float)wl; } else wh = wl + 1;
+  const float v11 = im[(size_t)hl * W + wl], v12 = im[(size_t)hl * W + wh];
+  const float v21 = im[(size_t)hh * W + wl], v22 = im[(size_t)hh * W + wh];
+  float wt = 0.f;
+  if (bp_dir == 0) {
+    wt += -1.f * ((float)(wl + 1) - aw) * v11;
+    wt += -1.f * (aw - (float)wl) * v12;
+    wt += ((float)(wl + 1) - aw) * v21;
+    wt += (aw - (float)wl) * v22;
+  } else {
+    wt += -1.f * ((float)(hl + 1) - ah) * v11;
+    wt += ((float)(hl + 1) - ah) * v12;
+    wt += -1.f * (ah - (float)hl) * v21;
+    wt += (ah - (float)hl) * v22;
+  }
+  return wt;
+}
+
+// input + offset gradients: one thread per (n, output pixel, chunk of input channels).  The column
+// gradient cg[(c,k),p] = sum_o W[o,c,k] * gout[n,o,p] is formed on the fly; gx is an atomic scatter
+// (deformable_col2im), goffset accumulates in registers over the chunk, then one atomic per offset channel.
+__global__ __launch_bounds__(256) void dc_bwd_input_kernel(DcBwdParams p) {
+  const size_t oplane = (size_t)p.Ho * p.Wo, plane = (size_t)p.H * p.W;
+  const int T = p.kh * p.kw;
+  const int nchunks = (p.Cin + p.cchunk - 1) / p.cchunk;
+  const size_t total = (size_t)p.N * oplane * nchunks;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t pix = idx % oplane;
+  const int chunk = (int)((idx / oplane) % nchunks);
+  const int n = (int)(idx / (oplane * nchunks));
+  const int wo = (int)(pix % p.Wo), ho = (int)(pix / p.Wo);
+  const int h_in = ho * p.sh - p.ph, w_in = wo * p.sw - p.pw;
+  const int cpg = p.Cin / p.groups, opg = p.Cout / p.groups, cpd = p.Cin / p.dg;
+  const float *go = p.gout + (size_t)n * p.Cout * oplane + pix;
+  const int c_lo = chunk * p.cchunk, c_hi = min(p.Cin, c_lo + p.cchunk);
+  for (int t = 0; t < T; ++t) {
+    const int ti = t / p.kw, tj = t - ti * p.kw;
+    // a chunk may straddle deformable groups: accumulate per group
+    int cur_dg = -1;
+    float acc_h = 0.f, acc_w = 0.f, oh = 0.f, ow = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const int dgi = c / cpd;
+      if (dgi != cur_dg) {
+        if (cur_dg >= 0 && p.req_offset) {
+          float *gof = p.goffset + ((size_t)n * p.dg + cur_dg) * 2 * T * oplane + pix;
+          atomicAdd(gof + (size_t)(2 * t) * oplane, acc_h);
+          atomicAdd(gof + (size_t)(2 * t + 1) * oplane, acc_w);
+        }
+        cur_dg = dgi;
+        acc_h = acc_w = 0.f;
+        const float *op = p.offset + ((size_t)n * p.dg + dgi) * 2 * T * oplane + pix;
+        oh = op[(size_t)(2 * t) * oplane];
+        ow = op[(size_t)(2 * t + 1) * oplane];
+      }
+      // column gradient of (c, t) at this pixel
+      const int g = c / cpg, cl = c - g * cpg;
+      float cg = 0.f;
+      for (int ol = 0; ol < opg; ++ol) {
+        const int o = g * opg + ol;
+        cg = fmaf(p.w[((size_t)o * cpg + cl) * T + t], go[(size_t)o * oplane], cg);
+      }
+      const float inv_h = (float)(h_in + ti * p.dh) + oh, inv_w = (float)(w_in + tj * p.dw) + ow;
+      const float *im = p.x + ((size_t)n * p.Cin + c) * plane;
+      if (p.req_offset) {
+        float ch_ = inv_h, cw_ = inv_w;
+        if (inv_h < 0.f || inv_w < 0.f || inv_h >= (float)p.H || inv_w >= (float)p.W) ch_ = cw_ = -1.f;
+        acc_h += dc_coordinate_weight(ch_, cw_, p.H, p.W, im, 0) * cg;
+        acc_w += dc_coordinate_weight(ch_, cw_, p.H, p.W, im, 1) * cg;
+      }
+      if (p.req_x) {
+        const int cur_h = (int)inv_h, cur_w = (int)inv_w;  // truncation, as deformable_col2im
+        float *gim = p.gx + ((size_t)n * p.Cin + c) * plane;
+        for (int dy = -2; dy <= 2; ++dy)
+          for (int dx = -2; dx <= 2; ++dx) {
+            const int hy = cur_h + dy, wx = cur_w + dx;
+            if (hy >= 0 && hy < p.H && wx >= 0 && wx < p.W && fabsf(inv_h - (float)hy) < 1.f &&
+                fabsf(inv_w - (float)wx) < 1.f) {
+              const float wt = dc_gradient_weight(inv_h, inv_w, hy, wx, p.H, p.W);
+              if (wt != 0.f) atomicAdd(gim + (size_t)hy * p.W + wx, wt * cg);
+            }
+          }
+      }
+    }
+    if (cur_dg >= 0 && p.req_offset) {
+      float *gof = p.goffset + ((size_t)n * p.dg + cur_dg) * 2 * T * oplane + pix;
+      atomicAdd(gof + (size_t)(2 * t) * oplane, acc_h);
+      atomicAdd(gof + (size_t)(2 * t + 1) * oplane, acc_w);
+    }
+  }
+}
+
+// weight gradient: block per (input channel c (within group), tap t, chunk of 16 filters of ONE group);
+// threads stride over (n, pixel), rebuild the column value once and keep 16 partial sums; LDS tree
+// reduction.  gw[o, cl, t] (+)= sum_{n,p} gout[n,o,p] * col[n,(c,t),p]
+constexpr int DC_BW_OC = 16;
+__global__ __launch_bounds__(256) void dc_bwd_weight_kernel(DcBwdParams p) {
+  MFN_DYN_SHARED(float, red);  // [DC_BW_OC][256]
+  const int T = p.kh * p.kw;
+  const int cpg = p.Cin / p.groups, opg = p.Cout / p.groups, cpd = p.Cin / p.dg;
+  const int ochunks = (opg + DC_BW_OC - 1) / DC_BW_OC;
+  int b = blockIdx.x;
+  const int oc = b % ochunks; b /= ochunks;
+  const int t = b % T; b /= T;
+  const int c = b;  // global input channel
+  const int g = c / cpg, cl = c - g * cpg, dgi = c / cpd;
+  const int o0 = g * opg + oc * DC_BW_OC;
+  const int no = min(DC_BW_OC, g * opg + opg - o0);
+  const int ti = t / p.kw, tj = t - ti * p.kw;
+  const size_t oplane = (size_t)p.Ho * p.Wo, plane = (size_t)p.H * p.W;
+  float s[DC_BW_OC];
+  MFN_UNROLL
+  for (int k = 0; k < DC_BW_OC; ++k) s[k] = 0.f;
+  const size_t npix = (size_t)p.N * oplane;
+  for (size_t q = threadIdx.x; q < npix; q += 256) {
+    const int n = (int)(q / oplane);
+    const size_t pix = q - (size_t)n * oplane;
+    const int wo = (int)(pix % p.Wo), ho = (int)(pix / p.Wo);
+    const float *op = p.offset + ((size_t)n * p.dg + dgi) * 2 * T * oplane + pix;
+    const DcTap tp = dc_make_tap(op[(size_t)(2 * t) * oplane], op[(size_t)(2 * t + 1) * oplane], ho * p.sh - p.ph,
+                                 wo * p.sw - p.pw, ti * p.dh, tj * p.dw, p.H, p.W, true);
+    const float *pl = p.x + ((size_t)n * p.Cin + c) * plane;
+    const int bb = tp.base & 0x3FFFFFFF, dwi = (tp.base >> 30) & 1;
+    const float col = tp.w1 * pl[bb] + tp.w2 * pl[bb + dwi] + tp.w3 * pl[bb + tp.dhW] + tp.w4 * pl[bb + tp.dhW + dwi];
+    const float *go = p.gout + ((size_t)n * p.Cout + o0) * oplane + pix;
+    MFN_UNROLL
+    for (int k = 0; k < DC_BW_OC; ++k)
+      if (k < no) s[k] = fmaf(go[(size_t)k * oplane], col, s[k]);
+  }
+  MFN_UNROLL
+  for (int k = 0; k < DC_BW_OC; ++k) red[k * 256 + threadIdx.x] = s[k];
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      MFN_UNROLL
+      for (int k = 0; k < DC_BW_OC; ++k) red[k * 256 + threadIdx.x] += red[k * 256 + threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < no) {
+    float *dst = p.gw + ((size_t)(o0 + threadIdx.x) * cpg + cl) * T + t;
+    *dst = (p.req_w == 3 ? *dst : 0.f) + red[threadIdx.x * 256];
+  }
+}
+
+// bias gradient: block per filter, sum over (n, pixel)
+__global__ __launch_bounds__(256) void dc_bwd_bias_kernel(DcBwdParams p) {
+  MFN_DYN_SHARED(float, red);
+  const int o = blockIdx.x;
+  const size_t oplane = (size_t)p.Ho * p.Wo;
+  float s = 0.f;
+  for (size_t q = threadIdx.x; q < (size_t)p.N * oplane; q += 256) {
+    const size_t n = q / oplane, pix = q - n * oplane;
+    s += p.gout[(n * p.Cout + o) * oplane + pix];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.gbias[o] = (p.req_bias == 3 ? p.gbias[o] : 0.f) + red[0];
+}
+
+}  // namespace mfn

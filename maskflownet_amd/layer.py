@@ -22,6 +22,71 @@ from torch import nn
 from . import ops
 
 
+# ---- autograd plumbing: forward and backward both cross the C ABI (MXNet's autograd does this in the reference,
+# /root/reference/network/pipeline.py:97-113) -------------------------------------------------------------------
+class _WarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flow, clip):
+        ctx.save_for_backward(x, flow)
+        ctx.clip = clip
+        return ops.warp(x, flow, clip_grid=clip)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, flow = ctx.saved_tensors
+        gx, gf = ops.default_ops().warp_backward(gout, x, flow, clip_grid=ctx.clip,
+                                                 req_x="write" if ctx.needs_input_grad[0] else "null",
+                                                 req_flow="write" if ctx.needs_input_grad[1] else "null")
+        return gx, gf, None
+
+
+class _CorrelationFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d1, d2, md, stride1, stride2):
+        ctx.save_for_backward(d1, d2)
+        ctx.p = (md, stride1, stride2)
+        return ops.Correlation(d1, d2, kernel_size=1, max_displacement=md, stride1=stride1, stride2=stride2,
+                               pad_size=md, is_multiply=True)
+
+    @staticmethod
+    def backward(ctx, gout):
+        d1, d2 = ctx.saved_tensors
+        md, s1, s2 = ctx.p
+        g1, g2 = ops.default_ops().Correlation_backward(gout, d1, d2, kernel_size=1, max_displacement=md, stride1=s1,
+                                                        stride2=s2, pad_size=md, is_multiply=True,
+                                                        req1="write" if ctx.needs_input_grad[0] else "null",
+                                                        req2="write" if ctx.needs_input_grad[1] else "null")
+        return g1, g2, None, None, None
+
+
+class _DeformConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, offset, weight, bias, kw):
+        ctx.save_for_backward(x, offset, weight)
+        ctx.kw = kw
+        ctx.has_bias = bias is not None
+        return ops.DeformableConvolution(x, offset, weight, bias, kernel=kw["kernel"], stride=kw["stride"],
+                                         dilate=kw["dilate"], pad=kw["pad"], num_filter=kw["num_filter"],
+                                         num_group=kw["num_group"], num_deformable_group=kw["num_deformable_group"],
+                                         no_bias=bias is None)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, offset, weight = ctx.saved_tensors
+        kw = ctx.kw
+        need = ctx.needs_input_grad
+        req = ["write" if need[i] else "null" for i in range(3)] + ["write" if (ctx.has_bias and need[3]) else "null"]
+        gx, goff, gw, gb = ops.default_ops().DeformableConvolution_backward(
+            gout, x, offset, weight, kernel=kw["kernel"], stride=kw["stride"], dilate=kw["dilate"], pad=kw["pad"],
+            num_group=kw["num_group"], num_deformable_group=kw["num_deformable_group"], no_bias=not ctx.has_bias,
+            req=tuple(req))
+        return gx, goff, gw, gb, None
+
+
+def _any_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
 class Reconstruction2D(nn.Module):
     """flow.flip(axis=1) -> GridGenerator('warp') -> BilinearSampler, fused (layer.py:14-18).
     `flow` channel 0 = dy, channel 1 = dx.  `in_channels` is unused, as in the reference."""
@@ -34,7 +99,7 @@ class Reconstruction2D(nn.Module):
     def forward(self, x, flow):
         if self.block_grad:
             flow = flow.detach()
-        return ops.warp(x, flow, clip_grid=False)
+        return _WarpFn.apply(x, flow, False) if _any_grad(x, flow) else ops.warp(x, flow, clip_grid=False)
 
 
 class Reconstruction2DSmooth(nn.Module):
@@ -48,7 +113,7 @@ class Reconstruction2DSmooth(nn.Module):
     def forward(self, x, flow):
         if self.block_grad:
             flow = flow.detach()
-        return ops.warp(x, flow, clip_grid=True)
+        return _WarpFn.apply(x, flow, True) if _any_grad(x, flow) else ops.warp(x, flow, clip_grid=True)
 
 
 def _tuple2(v):
@@ -109,10 +174,14 @@ class DeformableConv2D(nn.Module):
         if self.weight is None:
             self._materialize(x.shape[1], x.device)
         kw = self._kwargs
-        out = ops.DeformableConvolution(x, offset, self.weight, self.bias, kernel=kw["kernel"], stride=kw["stride"],
-                                        dilate=kw["dilate"], pad=kw["pad"], num_filter=kw["num_filter"],
-                                        num_group=kw["num_group"], num_deformable_group=kw["num_deformable_group"],
-                                        no_bias=kw["no_bias"], layout=kw["layout"])
+        if _any_grad(x, offset, self.weight, self.bias):
+            out = _DeformConvFn.apply(x, offset, self.weight, self.bias, kw)
+        else:
+            out = ops.DeformableConvolution(x, offset, self.weight, self.bias, kernel=kw["kernel"], stride=kw["stride"],
+                                            dilate=kw["dilate"], pad=kw["pad"], num_filter=kw["num_filter"],
+                                            num_group=kw["num_group"],
+                                            num_deformable_group=kw["num_deformable_group"], no_bias=kw["no_bias"],
+                                            layout=kw["layout"])
         return self.act(out) if self.act is not None else out
 
     def forward_shared(self, x, flow, flow_scale, flow_stride):
@@ -150,5 +219,7 @@ class DeformableConv2D(nn.Module):
 
 def correlation(im1, im2, md, stride1=1, stride2=1):
     """Body of MaskFlownet_S.corr / MaskFlownet.corr (MaskFlownet.py:193-195, :440-441)."""
+    if _any_grad(im1, im2):
+        return _CorrelationFn.apply(im1, im2, md, stride1, stride2)
     return ops.Correlation(im1, im2, pad_size=md, kernel_size=1, max_displacement=md, stride1=stride1,
                            stride2=stride2, is_multiply=1)

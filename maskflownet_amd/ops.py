@@ -20,6 +20,8 @@ import ctypes
 
 from . import _lib
 
+_REQ = {"null": 0, None: 0, "write": 1, "add": 3}  # MXNet OpReqType
+
 
 class OpSet:
     def __init__(self, ns, adapter, check):
@@ -68,6 +70,25 @@ class OpSet:
                                               self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(d1)))
         return out
 
+    def Correlation_backward(self, out_grad, data1, data2, kernel_size=1, max_displacement=1, stride1=1, stride2=1,
+                             pad_size=0, is_multiply=True, req1="write", req2="write", g1=None, g2=None):
+        """Gradients of Correlation w.r.t. data1 / data2 (MXNet CorrelationBackward)."""
+        go, d1, d2 = self._in(out_grad, data1, data2)
+        N, C, H, W = self.ad.shape(d1)
+        tc, th, tw = self.correlation_out_shape(H, W, kernel_size, max_displacement, stride1, stride2, pad_size)
+        if self.ad.shape(go) != (N, tc, th, tw):
+            raise ValueError("Correlation_backward: out_grad shape %s, expected %s" % (self.ad.shape(go), (N, tc, th, tw)))
+        r1, r2 = _REQ[req1], _REQ[req2]
+        if g1 is None and r1:
+            g1 = self.ad.empty(d1, (N, C, H, W))
+        if g2 is None and r2:
+            g2 = self.ad.empty(d1, (N, C, H, W))
+        self.check(self.ns.correlation_bwd(self.ad.ptr(go), self.ad.ptr(d1), self.ad.ptr(d2),
+                                           self.ad.ptr(g1) if r1 else None, self.ad.ptr(g2) if r2 else None, N, C, H, W,
+                                           int(max_displacement), int(kernel_size), int(stride1), int(stride2),
+                                           int(pad_size), int(bool(is_multiply)), r1, r2, self.ad.stream(d1)))
+        return g1, g2
+
     # ---- warp ------------------------------------------------------------------------------------
     def warp(self, x, flow, clip_grid=False, out=None):
         """layer.py Reconstruction2D (clip_grid=False) / Reconstruction2DSmooth (True), fused.
@@ -83,6 +104,20 @@ class OpSet:
         self.check(self.ns.warp_fwd(self.ad.ptr(xx), self.ad.ptr(fl), self.ad.ptr(out), N, C, H, W,
                                     int(bool(clip_grid)), self.ad.stream(xx)))
         return out
+
+    def warp_backward(self, out_grad, x, flow, clip_grid=False, req_x="write", req_flow="write", gx=None, gflow=None):
+        """Gradients of warp() w.r.t. x and flow (BilinearSamplerBackward + GridGenerator 'warp' backward + flip)."""
+        go, xx, fl = self._in(out_grad, x, flow)
+        N, C, H, W = self.ad.shape(xx)
+        rx, rf = _REQ[req_x], _REQ[req_flow]
+        if gx is None and rx:
+            gx = self.ad.empty(xx, (N, C, H, W))
+        if gflow is None and rf:
+            gflow = self.ad.empty(xx, (N, 2, H, W))
+        self.check(self.ns.warp_bwd(self.ad.ptr(go), self.ad.ptr(xx), self.ad.ptr(fl), self.ad.ptr(gx) if rx else None,
+                                    self.ad.ptr(gflow) if rf else None, N, C, H, W, int(bool(clip_grid)), rx, rf,
+                                    self.ad.stream(xx)))
+        return gx, gflow
 
     def GridGenerator(self, data, transform_type, target_shape=None):
         (d,) = self._in(data)
@@ -173,6 +208,28 @@ class OpSet:
                                            Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group, num_deformable_group,
                                            self.ad.ptr(ws), self.ad.nbytes(ws), self.ad.stream(x)))
         return out
+
+    def DeformableConvolution_backward(self, out_grad, data, offset, weight, kernel=(3, 3), stride=(1, 1),
+                                       dilate=(1, 1), pad=(0, 0), num_group=1, num_deformable_group=1, no_bias=False,
+                                       req=("write", "write", "write", "write")):
+        """Gradients w.r.t. (data, offset, weight, bias) -- MXNet DeformableConvolutionOp::Backward."""
+        go, x, off, w = self._in(out_grad, data, offset, weight)
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw) = map(self._pair, (kernel, stride, pad, dilate))
+        N, Cin, H, W = self.ad.shape(x)
+        Cout = self.ad.shape(w)[0]
+        rq = [_REQ[r] for r in req]
+        if no_bias:
+            rq[3] = 0
+        gx = self.ad.empty(x, self.ad.shape(x)) if rq[0] else None
+        goff = self.ad.empty(x, self.ad.shape(off)) if rq[1] else None
+        gw = self.ad.empty(x, self.ad.shape(w)) if rq[2] else None
+        gb = self.ad.empty(x, (Cout,)) if rq[3] else None
+        p = lambda a: self.ad.ptr(a) if a is not None else None
+        self.check(self.ns.deform_conv_bwd(self.ad.ptr(go), self.ad.ptr(x), self.ad.ptr(off), self.ad.ptr(w), p(gx),
+                                           p(goff), p(gw), p(gb), N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw,
+                                           num_group, num_deformable_group, rq[0], rq[1], rq[2], rq[3], None, 0,
+                                           self.ad.stream(x)))
+        return gx, goff, gw, gb
 
     def deformable_convolution_shared(self, data, flow, flow_scale, flow_stride, weight, bias=None, kernel=(3, 3),
                                       dilate=(1, 1), pad=(1, 1), num_group=1, out=None):

@@ -15,6 +15,7 @@
 // /opt/skills/guides/cdna_hip_programming.md section 3 (v_mfma_f32_32x32x2_f32, 16x16x4_f32).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <barrier>
 #include <cmath>
 #include <cstdint>
@@ -167,6 +168,8 @@ static inline int __syncthreads_and(int pred) {
   b->bar->arrive_and_wait();
   return ok;
 }
+
+static inline float atomicAdd(float *p, float v) { return std::atomic_ref<float>(*p).fetch_add(v, std::memory_order_relaxed); }
 
 // v_mfma_f32_32x32x2_f32: A lane l = A[i=l&31][k=l>>5], B lane l = B[k=l>>5][j=l&31],
 // D reg r of lane l = D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].  k-ordered fmaf chain.

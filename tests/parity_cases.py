@@ -107,3 +107,45 @@ def case_deform_pertap(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0,
     got = to_host(ops.DeformableConvolution(to_dev(x), to_dev(off), to_dev(w), to_dev(b), num_filter=Cout, **kw))
     want = oracle.deformable_convolution(x, off, w, b, **kw)
     return check_close(got, want, what="deform per-tap %s" % (kw,))
+
+
+# ---- backward ------------------------------------------------------------------
+def case_correlation_bwd(ops, oracle, to_dev, to_host, shape, seed=0, **kw):
+    rng = np.random.default_rng(31 + seed)
+    f1, f2 = feat(rng, shape), feat(rng, shape)
+    okw = dict(kernel_size=1, max_displacement=4, stride1=1, stride2=1, pad_size=4, is_multiply=True)
+    okw.update(kw)
+    tc, th, tw = oracle.correlation_out_shape(shape[2], shape[3], okw["max_displacement"], okw["kernel_size"],
+                                              okw["stride1"], okw["stride2"], okw["pad_size"])
+    go = rng.standard_normal((shape[0], tc, th, tw)).astype(np.float32)
+    g1, g2 = ops.Correlation_backward(to_dev(go), to_dev(f1), to_dev(f2), **okw)
+    w1, w2 = oracle.correlation_backward(go, f1, f2, **okw)
+    return max(check_close(to_host(g1), w1, what="corr g1 %s" % (okw,)), check_close(to_host(g2), w2, what="corr g2"))
+
+
+def case_warp_bwd(ops, oracle, to_dev, to_host, shape, clip, seed=0):
+    rng = np.random.default_rng(41 + seed)
+    N, C, H, W = shape
+    x = rng.standard_normal(shape).astype(np.float32)
+    fl = flow_field(rng, N, H, W, sigma=2.0)
+    go = rng.standard_normal(shape).astype(np.float32)
+    gx, gf = ops.warp_backward(to_dev(go), to_dev(x), to_dev(fl), clip_grid=clip)
+    wx, wf = oracle.warp_backward(go, x, fl, clip_grid=clip)
+    return max(check_close(to_host(gx), wx, what="warp gx"), check_close(to_host(gf), wf, tol=5e-5, what="warp gflow"))
+
+
+def case_deform_bwd(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, **kw):
+    rng = np.random.default_rng(51 + seed)
+    ng, ndg = kw.get("num_group", 1), kw.get("num_deformable_group", 1)
+    kernel = kw.get("kernel", (3, 3))
+    x = feat(rng, (N, Cin, H, W))
+    w = (rng.standard_normal((Cout, Cin // ng) + tuple(kernel)) * 0.2).astype(np.float32)
+    Ho, Wo = oracle.deform_conv_out_shape(H, W, kernel, kw.get("stride", (1, 1)), kw.get("pad", (0, 0)),
+                                          kw.get("dilate", (1, 1)))
+    off = (rng.standard_normal((N, 2 * kernel[0] * kernel[1] * ndg, Ho, Wo)) * 1.5).astype(np.float32)
+    go = rng.standard_normal((N, Cout, Ho, Wo)).astype(np.float32)
+    gx, goff, gw, gb = ops.DeformableConvolution_backward(to_dev(go), to_dev(x), to_dev(off), to_dev(w), **kw)
+    wx, woff, ww, wb = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, **kw)
+    errs = [check_close(to_host(gx), wx, what="deform gx %s" % (kw,)), check_close(to_host(goff), woff, tol=5e-5, what="deform goffset"),
+            check_close(to_host(gw), ww, tol=5e-5, what="deform gw"), check_close(to_host(gb), wb, tol=5e-5, what="deform gbias")]
+    return max(errs)

@@ -139,6 +139,37 @@ def test_deform_per_tap_parameter_space(ops, oracle, kw):
     pc.case_deform_pertap(ops, oracle, ident, ident, 1, 4, 6, 6, 7, **kw)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(max_displacement=2, pad_size=2),
+                                dict(max_displacement=4, stride2=2, pad_size=4),
+                                dict(kernel_size=3, max_displacement=2, stride1=2, pad_size=3),
+                                dict(max_displacement=2, pad_size=2, is_multiply=False)])
+def test_correlation_backward(ops, oracle, kw):
+    pc.case_correlation_bwd(ops, oracle, ident, ident, (2, 5, 9, 10), **kw)
+
+
+@pytest.mark.parametrize("clip", [False, True])
+def test_warp_backward(ops, oracle, clip):
+    pc.case_warp_bwd(ops, oracle, ident, ident, (2, 3, 8, 11), clip)
+
+
+@pytest.mark.parametrize("kw", [dict(kernel=(3, 3), pad=(1, 1)), dict(kernel=(3, 3), pad=(1, 1), stride=(2, 2)),
+                                dict(kernel=(3, 3), pad=(2, 2), dilate=(2, 2)), dict(kernel=(3, 3), pad=(1, 1), num_group=2),
+                                dict(kernel=(3, 3), pad=(1, 1), num_deformable_group=2), dict(kernel=(1, 1), pad=(0, 0))])
+def test_deform_conv_backward(ops, oracle, kw):
+    pc.case_deform_bwd(ops, oracle, ident, ident, 2, 4, 6, 6, 7, **kw)
+
+
+def test_backward_req_add_and_null(ops, oracle):
+    rng = np.random.default_rng(2)
+    f1, f2 = pc.feat(rng, (1, 3, 6, 8)), pc.feat(rng, (1, 3, 6, 8))
+    go = rng.standard_normal((1, 81, 6, 8)).astype(np.float32)
+    w1, w2 = oracle.correlation_backward(go, f1, f2, max_displacement=4, pad_size=4)
+    base = np.ones_like(f1)
+    g1, g2 = ops.Correlation_backward(go, f1, f2, 1, 4, 1, 1, 4, True, req1="add", req2="null", g1=base.copy())
+    assert g2 is None
+    pc.check_close(g1, w1 + 1.0, what="req add")
+
+
 def test_errors_read_like_mxnet(ops):
     x = np.zeros((1, 2, 4, 4), np.float32)
     with pytest.raises(RuntimeError, match="odd"):

@@ -207,6 +207,74 @@ def test_deform_conv_zero_offset_is_conv2d_at_full_size(ops, T):
     assert (got[:, :, 2:90, 6:120] - want[:, :, 2:90, 6:120]).abs().max().item() <= 1e-4 * want.abs().max().item()
 
 
+# ---- backward: the gradients config 5 (train step) needs, at the network's level shapes ---------------------
+@pytest.mark.parametrize("shape", [(2, 196, 6, 8), (2, 128, 12, 16), (2, 64, 48, 64), (2, 32, 96, 128)])
+def test_correlation_backward_levels(ops, oracle, dev, shape):
+    pc.case_correlation_bwd(ops, oracle, dev, host, shape)
+
+
+@pytest.mark.parametrize("kw", [dict(max_displacement=2, pad_size=2), dict(max_displacement=4, stride2=2, pad_size=4),
+                                dict(kernel_size=3, max_displacement=2, stride1=2, pad_size=3),
+                                dict(max_displacement=2, pad_size=2, is_multiply=False)])
+def test_correlation_backward_parameters(ops, oracle, dev, kw):
+    pc.case_correlation_bwd(ops, oracle, dev, host, (2, 6, 17, 20), **kw)
+
+
+@pytest.mark.parametrize("clip", [False, True])
+def test_warp_backward(ops, oracle, dev, clip):
+    pc.case_warp_bwd(ops, oracle, dev, host, (2, 3, 96, 128), clip)
+
+
+@pytest.mark.parametrize("C,H,W", [(128, 12, 16), (64, 24, 32), (32, 48, 64)])
+def test_deform_conv_backward_levels(ops, oracle, dev, C, H, W):
+    pc.case_deform_bwd(ops, oracle, dev, host, 2, C, C, H, W, kernel=(3, 3), pad=(1, 1))
+
+
+@pytest.mark.parametrize("kw", [dict(kernel=(3, 3), pad=(1, 1), stride=(2, 2)), dict(kernel=(3, 3), pad=(2, 2), dilate=(2, 2)),
+                                dict(kernel=(3, 3), pad=(1, 1), num_group=2), dict(kernel=(3, 3), pad=(1, 1), num_deformable_group=2)])
+def test_deform_conv_backward_parameters(ops, oracle, dev, kw):
+    pc.case_deform_bwd(ops, oracle, dev, host, 2, 8, 12, 13, 15, **kw)
+
+
+def test_layer_mirror_trains_through_the_c_abi(oracle, T):
+    """maskflownet_amd.layer (same class names as network/layer.py): one level of the network's matching module
+    -- deform -> correlation, plus a warp -- forward and backward through autograd, against the oracle."""
+    from maskflownet_amd import layer
+    rng = np.random.default_rng(9)
+    N, C, H, W = 2, 32, 24, 32
+    x1, x2 = pc.feat(rng, (N, C, H, W)), pc.feat(rng, (N, C, H, W))
+    fl = (pc.flow_field(rng, N, H, W) * np.float32(8.0 / 20.0)).astype(np.float32)
+    dc = layer.DeformableConv2D(C, kernel_size=3, strides=1, padding=1, in_channels=C, prefix="deform3").cuda()
+    with T.no_grad():
+        dc.bias.copy_(T.from_numpy((rng.standard_normal(C) * 0.1).astype(np.float32)))
+    t1, t2 = T.from_numpy(x1).cuda().requires_grad_(), T.from_numpy(x2).cuda().requires_grad_()
+    off = T.from_numpy(oracle.offsets_from_flow(fl, 20.0, 8.0)).cuda().requires_grad_()
+    warped = dc(t2, off)
+    corr = layer.correlation(t1, warped, 4)
+    gcorr = rng.standard_normal(tuple(corr.shape)).astype(np.float32)
+    corr.backward(T.from_numpy(gcorr).cuda())
+    w, b = dc.weight.detach().cpu().numpy(), dc.bias.detach().cpu().numpy()
+    o_w = oracle.deformable_convolution(x2, off.detach().cpu().numpy(), w, b, kernel=(3, 3), pad=(1, 1))
+    pc.check_close(warped.detach().cpu().numpy(), o_w, what="layer fwd deform")
+    pc.check_close(corr.detach().cpu().numpy(), oracle.correlation(x1, o_w, max_displacement=4, pad_size=4), what="layer fwd corr")
+    g1, gwarp = oracle.correlation_backward(gcorr, x1, o_w, max_displacement=4, pad_size=4)
+    gx, goff, gw, gb = oracle.deformable_convolution_backward(gwarp, x2, off.detach().cpu().numpy(), w, kernel=(3, 3), pad=(1, 1))
+    pc.check_close(t1.grad.cpu().numpy(), g1, what="layer bwd d/dc1")
+    pc.check_close(t2.grad.cpu().numpy(), gx, tol=5e-5, what="layer bwd d/dc2")
+    pc.check_close(off.grad.cpu().numpy(), goff, tol=5e-5, what="layer bwd d/doffset")
+    pc.check_close(dc.weight.grad.cpu().numpy(), gw, tol=5e-5, what="layer bwd d/dW")
+    pc.check_close(dc.bias.grad.cpu().numpy(), gb, tol=5e-5, what="layer bwd d/db")
+    img = T.from_numpy(rng.standard_normal((N, 3, H, W)).astype(np.float32)).cuda().requires_grad_()
+    flt = T.from_numpy(pc.flow_field(rng, N, H, W)).cuda().requires_grad_()
+    out = layer.Reconstruction2D(2)(img, flt)
+    go = rng.standard_normal((N, 3, H, W)).astype(np.float32)
+    out.backward(T.from_numpy(go).cuda())
+    ox, of = oracle.warp_backward(go, img.detach().cpu().numpy(), flt.detach().cpu().numpy())
+    pc.check_close(img.grad.cpu().numpy(), ox, what="layer bwd warp d/dx")
+    pc.check_close(flt.grad.cpu().numpy(), of, tol=5e-5, what="layer bwd warp d/dflow")
+    assert layer.Reconstruction2D(2, block_grad=True)(img, flt).requires_grad  # grad still flows into x
+
+
 def test_hot_path_pass_graph_replay_matches_eager(T):
     from maskflownet_amd import hotpath
     wl = hotpath.HotPathWorkload("cfg2", device="cuda")
