@@ -353,7 +353,7 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
 //   5: 2 dy/wave, 1 chunk,  CK=4, prefetch,    >=3 waves/SIMD   (5-wave blocks)
 //   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=4 waves/SIMD
 //   7: 3 dy/wave, 1 chunk,  CK=4, no prefetch, >=2 waves/SIMD
-constexpr int kCorrVariants = 16;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-15: corr_dma_kernel
+constexpr int kCorrVariants = 20;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-19: corr_dma_kernel
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
@@ -372,10 +372,34 @@ inline int corr_variant_tile_h(int tw, int variant) { return variant >= 8 ? 4 : 
 // One stage of the half-wave kernels: CK channels, operands double-buffered in registers so the
 // ds_read_b128 of channel c+1 are in flight while channel c's 16 v_pk_fma_f32 + 4 v_fma_f32 issue
 // (measured: without this a lone wave spends ~300 cycles per channel, 80 of them issuing VALU).
-template <int D, int CK, int F1_PER_C, int F2_PER_C>
+template <int D, int CK, int F1_PER_C, int F2_PER_C, bool DBUF = true>
 __device__ __forceinline__ void corr_hw_consume(const float *f1p, const float *f2p, f32x2 (&accp)[D - 1][2],
                                                 float (&accs)[4]) {
   constexpr int MD = (D - 1) / 2, OFF = 4 - MD;
+  if (!DBUF) {  // single operand set: ~16 fewer VGPRs (one more resident block per CU); LDS latency is hidden by TLP
+    MFN_UNROLL
+    for (int c = 0; c < CK; ++c) {
+      const float4 a = *reinterpret_cast<const float4 *>(f1p + c * F1_PER_C);
+      const float4 b0 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C);
+      const float4 b1 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C + 4);
+      const float4 b2 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C + 8);
+      const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+      const f32x2 asw[2] = {mfn_f2(a.y, a.x), mfn_f2(a.w, a.z)};
+      MFN_UNROLL
+      for (int d = 0; d < D - 1; ++d)
+        MFN_UNROLL
+        for (int h = 0; h < 2; ++h) {
+          const float bb = bv[2 * h + 1 + d + OFF];
+          accp[d][h] = mfn_fma2(asw[h], mfn_f2(bb, bb), accp[d][h]);
+        }
+      accs[0] = fmaf(a.x, bv[0 + OFF], accs[0]);
+      accs[1] = fmaf(a.z, bv[2 + OFF], accs[1]);
+      accs[2] = fmaf(a.y, bv[1 + (D - 1) + OFF], accs[2]);
+      accs[3] = fmaf(a.w, bv[3 + (D - 1) + OFF], accs[3]);
+      MFN_SCHED_BARRIER();
+    }
+    return;
+  }
   float4 A[2], B[2][3];
   A[0] = *reinterpret_cast<const float4 *>(f1p);
   B[0][0] = *reinterpret_cast<const float4 *>(f2p);
@@ -602,7 +626,7 @@ inline int corr_hw_variant(const CorrParams &p, int variant, hipStream_t s) {
 //     missing tail channels are items whose byte offset is out of the descriptor's range -> the
 //     hardware writes zeros;
 //   * per stage: counted s_waitcnt vmcnt, ONE raw s_barrier, issue stage ch+NS-1, consume stage ch.
-template <int D, int CK, int NS, int WPE>
+template <int D, int CK, int NS, int WPE, bool DBUF>
 __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrParams p) {
   constexpr int MD = (D - 1) / 2;
   constexpr int NW = (D + 1) / 2;
@@ -692,7 +716,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrP
   };
   auto consume = [&](int ch) {
     const float *slot = lds + (ch % NS) * STAGE_F;
-    corr_hw_consume<D, CK, F1_PER_C, F2_PER_C>(slot + f1_off, slot + f2_off, accp, accs);
+    corr_hw_consume<D, CK, F1_PER_C, F2_PER_C, DBUF>(slot + f1_off, slot + f2_off, accp, accs);
   };
 
   const int nchunks = (c_end - c_begin + CK - 1) / CK;
@@ -740,7 +764,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrP
 #undef ACC1
 }
 
-template <int D, int CK, int NS, int WPE>
+template <int D, int CK, int NS, int WPE, bool DBUF>
 inline int corr_dma_launch(CorrParams p, hipStream_t stream, const char *name) {
   constexpr int MD = (D - 1) / 2;
   constexpr int NT = ((D + 1) / 2) * 64;
@@ -751,16 +775,20 @@ inline int corr_dma_launch(CorrParams p, hipStream_t stream, const char *name) {
   const int nblk = p.N * p.tiles_x * p.tiles_y;
   if (nblk <= 0) return 0;
   const size_t lds = (size_t)NS * NI * NT * 16;
-  return launch(name, corr_dma_kernel<D, CK, NS, WPE>, dim3(nblk, p.nslices), dim3(NT), lds, stream, p);
+  return launch(name, corr_dma_kernel<D, CK, NS, WPE, DBUF>, dim3(nblk, p.nslices), dim3(NT), lds, stream, p);
 }
-// variants 12..15 of corr.variant
+// variants 12..19 of corr.variant: (CK, ring stages, min waves/SIMD, double-buffered operands)
 template <int D>
 inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
-    case 12: return corr_dma_launch<D, 4, 3, 4>(p, s, "corr_dma_v12");
-    case 13: return corr_dma_launch<D, 4, 4, 4>(p, s, "corr_dma_v13");
-    case 14: return corr_dma_launch<D, 8, 3, 4>(p, s, "corr_dma_v14");
-    default: return corr_dma_launch<D, 8, 2, 4>(p, s, "corr_dma_v15");
+    case 12: return corr_dma_launch<D, 4, 3, 4, true>(p, s, "corr_dma_v12");
+    case 13: return corr_dma_launch<D, 4, 4, 4, true>(p, s, "corr_dma_v13");
+    case 14: return corr_dma_launch<D, 8, 3, 4, true>(p, s, "corr_dma_v14");
+    case 15: return corr_dma_launch<D, 8, 2, 4, true>(p, s, "corr_dma_v15");
+    case 16: return corr_dma_launch<D, 4, 2, 5, false>(p, s, "corr_dma_v16");
+    case 17: return corr_dma_launch<D, 8, 2, 5, false>(p, s, "corr_dma_v17");
+    case 18: return corr_dma_launch<D, 4, 3, 5, false>(p, s, "corr_dma_v18");
+    default: return corr_dma_launch<D, 4, 4, 5, false>(p, s, "corr_dma_v19");
   }
 }
 

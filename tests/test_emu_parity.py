@@ -24,7 +24,7 @@ def _reset_tuning():
                        dc_generic=0)
 
 
-@pytest.mark.parametrize("variant", range(16))
+@pytest.mark.parametrize("variant", range(20))
 def test_correlation_variants_md4(ops, oracle, variant):
     emu_ops.set_tuning(corr_variant=variant)
     # ragged tiles in both directions: H=10 is not a multiple of any tile height, W=72 > TW=64
@@ -38,7 +38,7 @@ def test_correlation_tile_widths(ops, oracle, tw, shape, md):
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
 
 
-@pytest.mark.parametrize("variant", [3, 5, 6, 8, 11, 12, 15])
+@pytest.mark.parametrize("variant", [3, 5, 6, 8, 11, 12, 15, 16, 19])
 def test_correlation_md2_variants(ops, oracle, variant):
     emu_ops.set_tuning(corr_variant=variant)
     pc.case_correlation(ops, oracle, ident, ident, (2, 7, 6, 16), 2)
