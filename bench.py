@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--mode", default="dropin", choices=["dropin", "fused"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--repack", action="store_true",
+                    help="re-lay-out the deformable-conv weights inside every call (stateless operator) instead of "
+                         "once per weight version as layer.DeformableConv2D does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the oracle baseline")
     ap.add_argument("--roofline-iters", type=int, default=200)
@@ -176,7 +179,8 @@ def main():
     from maskflownet_amd import hotpath
     from maskflownet_amd.dist import allreduce_checksum
 
-    wl = hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode)
+    wl = hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
+                                 prepack=not args.repack)
     if not args.no_graph:
         wl.capture()
     else:
@@ -213,6 +217,7 @@ def main():
                                "(3x3, shared 9-tap offsets) + 1x warp, batch=%d synthetic %dx%d per GPU (BASELINE "
                                "configs[%d])" % (wl.N, wl.H, wl.W, 1 if args.config == "cfg2" else 2),
                    "per_gpu_batch": wl.N, "global_batch": pairs_per_step, "mode": args.mode,
+                   "deform_weights": "re-packed every call" if args.repack else "packed once per weight version",
                    "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "batch shard x%d" % world},
         "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
         "algorithmic_GFLOP_per_step_per_gpu": round(sum(af.values()) / 1e9, 3),

@@ -140,6 +140,33 @@ int mfn_deform_conv_shared_fwd(const float *x, const float *flow_yx, float flow_
                                float *out, int N, int Cin, int H, int W, int Cout, int kh, int kw,
                                int ph, int pw, int dh, int dw, int groups, void *workspace,
                                size_t workspace_bytes, void *stream);
+/* Inference: a Gluon block (/root/reference/network/layer.py:97-124) owns constant weights, so
+ * their re-layout can be done once instead of on every call.  mfn_deform_conv_pack_weights writes
+ * the layout the kernels stream (an opaque function of the 15 shape ints and of mfn_set_tuning;
+ * mfn_deform_conv_packed_weight_bytes gives its size) and the *_packed entry points take it in
+ * place of `w`, with the layout tag pack_weights returned; their workspace then only holds split-K
+ * partial sums (the value returned by mfn_deform_conv_workspace_bytes is always enough).  Results
+ * are bit-identical to the unpacked calls.  A tag that does not match the layout the current
+ * shape/tuning needs is refused with MFN_E_WORKSPACE, never silently used. */
+size_t mfn_deform_conv_packed_weight_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw,
+                                           int sh, int sw, int ph, int pw, int dh, int dw,
+                                           int groups, int deform_groups);
+int mfn_deform_conv_pack_weights(const float *w, int N, int Cin, int H, int W, int Cout, int kh,
+                                 int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups,
+                                 int deform_groups, void *packed, size_t packed_bytes,
+                                 unsigned long long *layout_tag, void *stream);
+int mfn_deform_conv_fwd_packed(const float *x, const float *offset, const void *packed,
+                               size_t packed_bytes, unsigned long long layout_tag,
+                               const float *bias_or_null, float *out, int N,
+                               int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw,
+                               int ph, int pw, int dh, int dw, int groups, int deform_groups,
+                               void *workspace, size_t workspace_bytes, void *stream);
+int mfn_deform_conv_shared_fwd_packed(const float *x, const float *flow_yx, float flow_scale,
+                                      float flow_stride, const void *packed, size_t packed_bytes,
+                                      unsigned long long layout_tag, const float *bias_or_null, float *out, int N, int Cin, int H,
+                                      int W, int Cout, int kh, int kw, int ph, int pw, int dh,
+                                      int dw, int groups, void *workspace, size_t workspace_bytes,
+                                      void *stream);
 /* Backward (training).  gx,goffset,gw,gbias as the forward's x,offset,w,bias; req_* per output
  * (MFN_REQ_NULL skips it and the pointer may be NULL).  The column gradient is formed on the fly,
  * so mfn_deform_conv_bwd_workspace_bytes currently returns 0 and workspace may be NULL.  gx and

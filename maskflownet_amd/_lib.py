@@ -12,7 +12,8 @@ from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libmfn_hip.so")
+# MFN_HIP_SO: measurement builds of the same HIP library (tools/ablate.py); never a different backend
+SO_PATH = os.environ.get("MFN_HIP_SO") or os.path.join(CSRC, "libmfn_hip.so")
 # -fno-slp-vectorize: the SLP vectoriser rewrites the correlation inner product into v_pk_fma_f32 fed by
 # dozens of re-issued ds_read2_b32 (unaligned operand pairs re-read from LDS), which made the kernel
 # LDS-bound with 64% bank-conflict cycles (profiles/r01_corr_pmc.md)
@@ -71,6 +72,16 @@ def check(status, what=""):
         raise MfnError(status, msg or what)
 
 
+_tuning_epoch = 0
+
+
+def tuning_epoch():
+    """Bumped by every set_tuning(): caches of tuning-dependent device layouts key on it."""
+    return _tuning_epoch
+
+
 def set_tuning(**kw):
+    global _tuning_epoch
+    _tuning_epoch += 1
     for k, v in kw.items():
         check(lib().set_tuning(k.replace("_", ".", 1).encode(), int(v)), "set_tuning")

@@ -21,6 +21,11 @@
 #pragma once
 #include "../mfn_rt.h"
 
+// measurement builds only (tools/ablate.py): 1 no MFMA, 2 no LDS gather, 4 no window DMA, 8 no stores
+#ifndef MFN_DC_ABLATE
+#define MFN_DC_ABLATE 0
+#endif
+
 namespace mfn {
 
 struct DeformParams {
@@ -39,6 +44,8 @@ struct DeformParams {
   unsigned long long *timeline;  // measurement only (mfn_debug_set_timeline)
   int stage_window;              // tuning: 0 disables the LDS source-window staging
   int ncp_pad, cps_per_slice, ksb, mgroups;  // packed-weight rows per M-group, K-slice length, cross-block K split
+  int tile_w, tiles_x, tiles_y, ntiles;      // 32-pixel tiles: (32/tile_w) x tile_w output pixels (tile_w 16 or 8), or
+                                             // tile_w == 0: 32 consecutive pixels of the flattened (n,ho,wo) index
   float *partial;                             // ksb > 1: raw partial sums [ksb][N][Cout][Ho][Wo]
 };
 
@@ -103,10 +110,10 @@ struct DcAxis3 { float a[3], b[3]; int idx[4]; };
 
 // ---- geometry shared by host and device ------------------------------------------------------------
 // chunk = KC channel pairs of one M-group's packed weights = KC*18*RL floats, RL = 32*MT filters
-// KC is sized so that one weight stage buffer (all KW in-block slices) is <= 9 KB: with the x windows a
-// block then needs ~42 KB of LDS and three blocks fit a CU.
+// KC is sized so that the two weight stage buffers take <= 24 KB: with the 24 KB of x windows a block then
+// needs <= 48 KB of LDS and three blocks fit a CU (which is also what the VGPR budget allows).
 constexpr int dc_kc(int mt, int kw) {
-  const int q = 8 / (mt * kw);  // 9 KB per stage buffer at most
+  const int q = 4 / (mt * kw);
   return q >= 4 ? 4 : (q >= 2 ? 2 : 1);
 }
 template <int MT, int KW> struct DcGeom {
@@ -124,10 +131,12 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   constexpr int RL = G::RL, KC = G::KC, CH4 = G::CH4;
   constexpr int NI = (KW * CH4 + 255) / 256;  // DMA instructions per thread per stage
   constexpr int STAGE_F = NI * 256 * 4;       // floats per stage buffer
-  MFN_DYN_SHARED(float, lds);                 // 2 weight stage buffers (reused for the K-slice reduction) + x windows
-  constexpr int XW_ROWS = 10, XW_COLS = 48;   // staged source window per wave and channel: 10 rows x 48 floats
-  constexpr int XW_NI = 4;                    // wave DMA instructions per channel pair (240 of 256 slots used)
+  MFN_DYN_SHARED(float, lds);                 // 2 weight stage buffers + x windows (all reused for the K-slice reduction)
+  // staged source window per wave and channel: 10 rows x 24 floats under a 2x16 pixel tile, 12 rows x 20 floats
+  // under a 4x8 tile -- 60 float4 slots per channel, one channel pair = 2 wave DMA instructions (120 of 128 lanes)
+  constexpr int XW_NI = 2;
   constexpr int XW_F = XW_NI * 256;           // floats per channel-pair buffer
+  const int XW_ROWS = p.tile_w == 16 ? 10 : 12, XW_C4 = p.tile_w == 16 ? 6 : 5, XW_COLS = 4 * XW_C4;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,12 +152,31 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
   const size_t plane = (size_t)H * W;
   const size_t oplane = (size_t)Ho * Wo;
-  const int plin = tile * 32 + j;
-  const bool px_valid = plin < p.P;
-  const int pc = px_valid ? plin : 0;
-  const int n = pc / (Ho * Wo);
-  const int rem = pc - n * (Ho * Wo);
-  const int ho = rem / Wo, wo = rem - ho * Wo;
+  // 2-D pixel tiles keep the source window of a wave small (4x8 px: 7 rows x 11 columns plus the flow's
+  // variation, against 4 rows x 35 columns for 32 px of one row) and never span two images.
+  int n, ho, wo;
+  bool px_valid;
+  if (p.tile_w) {
+    const int tpi = p.tiles_y * p.tiles_x;
+    const int tl = min(tile, p.ntiles - 1);
+    n = tl / tpi;
+    const int rt = tl - n * tpi;
+    const int ty = rt / p.tiles_x, tx = rt - ty * p.tiles_x;
+    const int sh16 = p.tile_w == 16 ? 4 : 3;
+    ho = ty * (32 >> sh16) + (j >> sh16);
+    wo = tx * p.tile_w + (j & (p.tile_w - 1));
+    px_valid = tile < p.ntiles && ho < Ho && wo < Wo;
+    ho = min(ho, Ho - 1);
+    wo = min(wo, Wo - 1);
+  } else {
+    const int plin = tile * 32 + j;
+    px_valid = plin < p.P;
+    const int pc = px_valid ? plin : 0;
+    n = pc / (Ho * Wo);
+    const int rem = pc - n * (Ho * Wo);
+    ho = rem / Wo;
+    wo = rem - ho * Wo;
+  }
   const int h_in = ho * p.sh - p.ph, w_in = wo * p.sw - p.pw;
 
   // ---- weight staging plan: item -> byte offset inside this M-group's packed array -----------------
@@ -168,6 +196,8 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
     MFN_UNROLL
     for (int i = 0; i < NI; ++i) mfn_dma16_so(wrsrc, buf + (i * 4 + wave) * 256, voff[i], soff);
   };
+
+  issue(0);  // the first weight chunk lands while the tap geometry below is computed
 
   // ---- offsets of the 9 taps ---------------------------------------------------------------------
   float offh[T], offw[T];
@@ -242,7 +272,7 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
     }
     wr0 = rlo;
     wc0 = clo & ~3;  // 16-byte aligned window origin
-    staged = fast && p.stage_window && (W % 4 == 0) && nlo == nhi && (rhi - wr0 < XW_ROWS) && (chi - wc0 < XW_COLS);
+    staged = fast && p.stage_window && p.tile_w && (W % 4 == 0) && nlo == nhi && (rhi - wr0 < XW_ROWS) && (chi - wc0 < XW_COLS);
 #ifdef MFN_EMU_DEBUG
     if (lane == 0) printf("tile %d wave %d: rows %d..%d cols %d..%d n %d..%d staged %d fast %d\n", tile, wave, rlo, rhi, clo, chi, nlo, nhi, (int)staged, (int)fast);
 #endif
@@ -336,7 +366,7 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   };
 
   // ---- staged-window plumbing ---------------------------------------------------------------------------
-  float *xwin = lds + 2 * STAGE_F + wave * (2 * XW_F);  // this wave's two pair buffers
+  float *xwin = lds + 2 * STAGE_F + wave * (3 * XW_F);  // this wave's three pair buffers (ring)
   const mfn_rsrc_t xrsrc = mfn_make_rsrc(p.x, (unsigned)((size_t)p.N * p.Cin * plane * 4));
   unsigned xvoff[XW_NI];  // byte offset of this lane's window slots, relative to channel 2*cp of image 0
   int loff[4][4];      // LDS float offset of the 16 neighbourhood values inside a pair buffer
@@ -344,9 +374,9 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
     const int nimg = MFN_UNIFORM(n);
     MFN_UNROLL
     for (int i = 0; i < XW_NI; ++i) {
-      const int slot = i * 64 + lane;               // float4 slots: [channel 0/1][XW_ROWS][12 float4]
-      const int chs = slot / (XW_ROWS * 12), rem = slot - chs * (XW_ROWS * 12);
-      const int row = rem / 12, c4 = rem - row * 12;
+      const int slot = i * 64 + lane;               // float4 slots: [channel 0/1][XW_ROWS][XW_C4 float4]
+      const int chs = slot / (XW_ROWS * XW_C4), rem = slot - chs * (XW_ROWS * XW_C4);
+      const int row = rem / XW_C4, c4 = rem - row * XW_C4;
       const int r = wr0 + row, c = wc0 + 4 * c4;
       xvoff[i] = (chs < 2 && r <= H - 1 && c <= W - 4)
                      ? (unsigned)(((size_t)nimg * p.Cin * plane + (size_t)chs * plane + (size_t)r * W + c) * 4)
@@ -360,60 +390,122 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   }
   auto issue_x = [&](int cp, int buf) {
     const unsigned soff = (unsigned)((size_t)(2 * cp) * plane * 4);
+    if (MFN_DC_ABLATE & 4) return;
     MFN_UNROLL
     for (int i = 0; i < XW_NI; ++i) mfn_dma16_so(xrsrc, xwin + buf * XW_F + i * 256, xvoff[i], soff);
   };
-  auto staged_pair = [&](int buf, const float *ap) {
-    const float *xb = xwin + buf * XW_F;
-    float v[4][4];
-    MFN_UNROLL
-    for (int m = 0; m < 4; ++m)
+  // ---- staged waves: one flat software pipeline over the channel pairs of this K-slice ---------------------
+  // iteration k issues the MFMAs of pair k interleaved with the interpolation of pair k+1 (whose 16 window
+  // values were requested from LDS just before), while the windows of pairs k+2 and k+3 are in flight as LDS-DMA
+  // and the next weight chunk streams into the other stage buffer.  DMA completion is in issue order, so every
+  // wait below is a count of the newer transfers that may still be outstanding.
+  int k_done = 0;  // pairs of this slice already accumulated
+  if (staged) {
+    const int nf = max(0, min(nchunks * KC, full_pairs - cp_base));  // uniform
+    auto gather = [&](int buf, float (&v)[4][4]) {
+      const float *xb = xwin + buf * XW_F;
       MFN_UNROLL
-      for (int q = 0; q < 4; ++q) v[m][q] = xb[loff[m][q]];
-    fast_pair(v, ap);
-  };
-
-  issue(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    MFN_WAIT_VM(0);      // chunk ch's DMA (issued one chunk of MFMA work ago) has landed for this wave
-    MFN_WAIT_LGKM0();
-    MFN_RAW_BARRIER();   // ... and for every wave; everyone is done reading the other buffer
-    if (ch == 0) MFN_STAMP(p.timeline, 1);
-    const float *abuf = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j;
-    const int cp0 = cp_base + ch * KC;
-    // pairs of this chunk on the fast path (uniform); the rest is either the odd half pair or padding
-    const int nfast = staged ? max(0, min(KC, full_pairs - cp0)) : 0;
-    int k = 0;
-    if (staged) {
-      // DMA order per chunk: x(0), weights(ch+1), x(1), then x(k+1) one pair ahead.  Waits are counted
-      // so that only the newest window (XW_NI instructions) may still be in flight.
-      if (nfast > 0) issue_x(cp0, 0);
-      if (ch + 1 < nchunks) issue(ch + 1);
-      MFN_NOUNROLL
-      for (; k < nfast; ++k) {
-        MFN_WAIT_LGKM0();  // our reads of the buffer we are about to refill have returned
-        if (k + 1 < nfast) {
-          issue_x(cp0 + k + 1, (k + 1) & 1);
-          if (k == 0 && ch + 1 < nchunks) MFN_WAIT_VM(NI + XW_NI);
-          else MFN_WAIT_VM(XW_NI);
+      for (int m = 0; m < 4; ++m)
+        MFN_UNROLL
+        for (int q = 0; q < 4; ++q) v[m][q] = (MFN_DC_ABLATE & 2) ? (float)(m + q + buf) : xb[loff[m][q]];
+    };
+    auto interp_row = [&](const float (&v)[4][4], float (&tr)[4][3], int m) {
+      MFN_UNROLL
+      for (int q = 0; q < 3; ++q) tr[m][q] = ax.a[q] * v[m][q] + ax.b[q] * v[m][q + 1];
+    };
+    auto interp_col = [&](const float (&tr)[4][3], float (&cv)[9], int i) {
+      MFN_UNROLL
+      for (int q = 0; q < 3; ++q) cv[i * 3 + q] = ay.a[i] * tr[i][q] + ay.b[i] * tr[i + 1][q];
+    };
+    auto mfma_tap = [&](const float *ap, int t, float b) {
+      if (MFN_DC_ABLATE & 1) { acc[0][t] += b; return; }
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], b, acc[mt]);
+    };
+    float v[4][4], tr[4][3], cv[9], cvn[9];
+    if (nf > 0) issue_x(cp_base, 0);
+    if (nf > 1) issue_x(cp_base + 1, 1);
+    if (nf > 2) issue_x(cp_base + 2, 2);
+    if (nf > 0) {
+      if (nf > 2) MFN_WAIT_VM(2 * XW_NI); else MFN_WAIT_VM(0);  // window 0 (and the first weight chunk) landed
+      gather(0, v);
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m) interp_row(v, tr, m);
+      MFN_UNROLL
+      for (int i = 0; i < 3; ++i) interp_col(tr, cv, i);
+    }
+    int xb_next = 1, xb_free = 0;  // pair p lives in window buffer p % 3: pair k+1 is read, pair k+3 goes where k was
+    bool w_in_flight = false;      // a weight chunk was issued in the previous iteration
+    MFN_NOUNROLL
+    for (int k = 0; k < nf; ++k) {
+      const int ch = k / KC, kk = k - ch * KC;
+      const bool more3 = k + 3 < nf;
+      bool w_now = false;
+      if (kk == 0) {
+        // weights of chunk ch and window k+1 landed (window k+2 may still fly); every wave is past chunk ch-1
+        if (k + 2 < nf) MFN_WAIT_VM(XW_NI); else MFN_WAIT_VM(0);
+        MFN_WAIT_LGKM0();
+        MFN_RAW_BARRIER();
+        if (k == 0) MFN_STAMP(p.timeline, 1);
+        if (ch + 1 < nchunks) { issue(ch + 1); w_now = true; }
+        if (more3) issue_x(cp_base + k + 3, xb_free);
+      } else {
+        if (more3) {
+          issue_x(cp_base + k + 3, xb_free);
+          // outstanding, oldest first: window k+1, [weights issued last iteration], window k+2, window k+3
+          if (w_in_flight) MFN_WAIT_VM(NI + 2 * XW_NI); else MFN_WAIT_VM(2 * XW_NI);
         } else {
           MFN_WAIT_VM(0);
         }
-        staged_pair(k & 1, abuf + (size_t)k * T * 2 * RL);
-        MFN_SCHED_BARRIER();
       }
-    } else {
-      if (ch + 1 < nchunks) issue(ch + 1);
-      if (rowgather) {
-        const int nrow = max(0, min(KC, full_pairs - cp0));
-        MFN_NOUNROLL
-        for (; k < nrow; ++k) rowgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
-      } else if (dwgather) {
-        const int nrow = max(0, min(KC, full_pairs - cp0));
-        MFN_NOUNROLL
-        for (; k < nrow; ++k) dwgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
-      }  // otherwise (arbitrary per-tap offsets) every pair of this chunk takes the per-tap path below
+      w_in_flight = w_now;
+      const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
+      if (k + 1 < nf) {
+        gather(xb_next, v);
+        mfma_tap(ap, 0, cv[0]); interp_row(v, tr, 0);
+        mfma_tap(ap, 1, cv[1]); interp_row(v, tr, 1);
+        mfma_tap(ap, 2, cv[2]); interp_row(v, tr, 2);
+        mfma_tap(ap, 3, cv[3]); interp_row(v, tr, 3);
+        mfma_tap(ap, 4, cv[4]); interp_col(tr, cvn, 0);
+        mfma_tap(ap, 5, cv[5]); interp_col(tr, cvn, 1);
+        mfma_tap(ap, 6, cv[6]); interp_col(tr, cvn, 2);
+        mfma_tap(ap, 7, cv[7]);
+        mfma_tap(ap, 8, cv[8]);
+        MFN_UNROLL
+        for (int t = 0; t < T; ++t) cv[t] = cvn[t];
+      } else {
+        MFN_UNROLL
+        for (int t = 0; t < T; ++t) mfma_tap(ap, t, cv[t]);
+      }
+      xb_free = xb_next;
+      xb_next = xb_next == 2 ? 0 : xb_next + 1;
+      MFN_SCHED_BARRIER();
     }
+    k_done = nf;
+  }
+
+  // ---- everything else: waves whose window does not fit, the odd half pair, padding -------------------------
+  for (int ch = k_done / KC; ch < nchunks; ++ch) {
+    const bool resumed = ch * KC < k_done;  // chunk already opened (barrier passed, next chunk issued) above
+    if (!resumed) {
+      MFN_WAIT_VM(0);      // chunk ch's DMA (issued one chunk of MFMA work ago) has landed for this wave
+      MFN_WAIT_LGKM0();
+      MFN_RAW_BARRIER();   // ... and for every wave; everyone is done reading the other buffer
+      if (ch == 0) MFN_STAMP(p.timeline, 1);
+      if (ch + 1 < nchunks) issue(ch + 1);
+    }
+    const float *abuf = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j;
+    const int cp0 = cp_base + ch * KC;
+    int k = resumed ? k_done - ch * KC : 0;
+    if (rowgather) {
+      const int nrow = max(0, min(KC, full_pairs - cp0));
+      MFN_NOUNROLL
+      for (; k < nrow; ++k) rowgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
+    } else if (dwgather) {
+      const int nrow = max(0, min(KC, full_pairs - cp0));
+      MFN_NOUNROLL
+      for (; k < nrow; ++k) dwgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
+    }  // otherwise (arbitrary per-tap offsets) every pair of this chunk takes the per-tap path below
     MFN_NOUNROLL
     for (; k < KC; ++k)
       if (2 * (cp0 + k) < p.Cin) slow_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);  // padded pairs: zero weights, skip
@@ -451,7 +543,8 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
     MFN_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (o < p.Cout) on[(size_t)o * oplane] = acc[mt][r] + ((p.bias && !raw) ? p.bias[o] : 0.f);
+      if (o < p.Cout && !((MFN_DC_ABLATE & 8) && acc[mt][r] != 123.f))
+        on[(size_t)o * oplane] = acc[mt][r] + ((p.bias && !raw) ? p.bias[o] : 0.f);
     }
   MFN_STAMP(p.timeline, 3);
 }
@@ -462,13 +555,13 @@ inline size_t dc_lds_bytes() {
   constexpr int NI = (KW * DcGeom<MT, KW>::CH4 + 255) / 256;
   const size_t stage = (size_t)2 * NI * 256 * 16;
   const size_t red = KW > 1 ? (size_t)PT * (KW - 1) * MT * 16 * 64 * 4 : 0;
-  const size_t xwin = (size_t)4 * 2 * (4 * 256) * 4;  // 4 waves x 2 buffers x one channel-pair window (XW_F floats)
-  return (stage > red ? stage : red) + xwin;
+  const size_t xwin = (size_t)4 * 3 * (2 * 256) * 4;  // 4 waves x 3 buffers x one channel-pair window (XW_F floats)
+  return stage + xwin > red ? stage + xwin : red;
 }
 
 template <int MT, int PT>
 inline int dc_lds_launch(const DeformParams &p, hipStream_t stream, const char *name) {
-  const int tiles = cdiv(p.P, 32);
+  const int tiles = p.tile_w ? p.ntiles : cdiv(p.P, 32);
   const int bx = cdiv(tiles, PT);
   if (bx <= 0) return 0;
   return launch(name, dc_lds_kernel<MT, PT>, dim3(bx, p.ksb, p.mgroups), dim3(256), dc_lds_bytes<MT, PT>(), stream, p);
@@ -493,6 +586,17 @@ inline int dc_pack_launch(PackParams pp, hipStream_t stream) {
   const size_t total = (size_t)pp.mgroups * pp.ncp_pad * pp.T * 2 * pp.RL;
   return launch("dc_pack_weights", dc_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                 stream, pp);
+}
+
+struct DcCopyParams { const float *src; float *dst; size_t n; };
+__global__ __launch_bounds__(256) void dc_copy_kernel(DcCopyParams c) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < c.n) c.dst[i] = c.src[i];
+}
+inline int dc_copy_launch(const float *src, float *dst, size_t n, hipStream_t stream) {
+  if (!n) return 0;
+  return launch("dc_copy_weights", dc_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                DcCopyParams{src, dst, n});
 }
 
 // ---- generic fallback: groups / deformable groups / any kernel size -----------------------------------

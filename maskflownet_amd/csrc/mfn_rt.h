@@ -99,10 +99,15 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
 // measurement only: constant-rate (100 MHz) wall clock stamps, one writer per block
-#define MFN_STAMP(buf, k)                                                                              \
-  do {                                                                                                 \
-    if ((buf) && threadIdx.x == 0)                                                                     \
-      (buf)[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (k)] = wall_clock64();                 \
+// measurement only: bit 0 of the buffer address selects the shader-cycle counter instead of the 100 MHz wall clock
+#define MFN_STAMP(buf, k)                                                                                   \
+  do {                                                                                                      \
+    if ((buf) && threadIdx.x == 0) {                                                                        \
+      const bool cyc_ = ((unsigned long long)(buf)) & 1ull;                                                 \
+      unsigned long long *b_ = (unsigned long long *)(((unsigned long long)(buf)) & ~1ull);                 \
+      b_[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (k)] =              \
+          cyc_ ? (unsigned long long)clock64() : (unsigned long long)wall_clock64();                        \
+    }                                                                                                       \
   } while (0)
 #endif
 

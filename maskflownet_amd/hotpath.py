@@ -113,7 +113,10 @@ def synth_inputs(N, H, W, seed=20260925):
 
 
 class HotPathWorkload:
-    def __init__(self, cfg="cfg2", device="cuda", mode="dropin", seed=20260925):
+    def __init__(self, cfg="cfg2", device="cuda", mode="dropin", seed=20260925, prepack=True):
+        """prepack=True: the deformable-conv weights are laid out once here, as layer.DeformableConv2D does
+        for a block's constant parameters at inference; False re-packs inside every operator call (what a
+        stateless MXNet operator sees).  Outputs are bit-identical either way."""
         import torch
         self.torch = torch
         if isinstance(cfg, str):
@@ -137,6 +140,11 @@ class HotPathWorkload:
                     self.o["offset%d" % l] = torch.empty((n, 18, h, w), device=self.device)
         self.o["warp"] = torch.empty((self.N, 3, self.H, self.W), device=self.device)
         self.graph = None
+        self.prepack = bool(prepack)
+        self.packed = {}
+        if self.prepack:
+            for l in (5, 4, 3, 2):
+                self.packed[l] = self.ops.pack_deform_weights(self.t["w_%d" % l], shp[l], kernel=(3, 3), pad=(1, 1))
         torch.cuda.synchronize(self.device)
 
     # the operator sequence of one forward
@@ -148,10 +156,11 @@ class HotPathWorkload:
                 ops.offsets_from_flow(t["flow_%d" % l], SCALE, STRIDES[l], out=o["offset%d" % l])
                 ops.DeformableConvolution(t["c2_%d" % l], o["offset%d" % l], t["w_%d" % l], t["b_%d" % l],
                                           kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(1, 1),
-                                          num_filter=CHANNELS[l], out=o["deform%d" % l])
+                                          num_filter=CHANNELS[l], out=o["deform%d" % l], packed=self.packed.get(l))
             else:
                 ops.deformable_convolution_shared(t["c2_%d" % l], t["flow_%d" % l], SCALE, STRIDES[l],
-                                                  t["w_%d" % l], t["b_%d" % l], out=o["deform%d" % l])
+                                                  t["w_%d" % l], t["b_%d" % l], out=o["deform%d" % l],
+                                                  packed=self.packed.get(l))
             ops.Correlation(t["c1_%d" % l], o["deform%d" % l], 1, MD, 1, 1, MD, True, out=o["corr%d" % l])
         ops.warp(t["img2"], t["flow_full"], clip_grid=False, out=o["warp"])
 

@@ -170,6 +170,20 @@ class DeformableConv2D(nn.Module):
             self.bias = nn.Parameter(torch.zeros(self._channels, device=device))
         self._in_channels = in_channels
 
+    def _packed(self, x):
+        """Inference-time cache of the kernel's weight layout (mfn_deform_conv_pack_weights), keyed on the
+        parameter's identity/version, the input shape and the tuning epoch so that an optimizer step, a
+        load_state_dict or a set_tuning() call can never leave a stale pack in use."""
+        from . import _lib
+        kw = self._kwargs
+        key = (self.weight.data_ptr(), self.weight._version, tuple(x.shape), str(x.device), _lib.tuning_epoch())
+        if getattr(self, "_pack_key", None) != key:
+            self._pack = ops.default_ops().pack_deform_weights(
+                self.weight.detach(), tuple(x.shape), kernel=kw["kernel"], stride=kw["stride"], dilate=kw["dilate"],
+                pad=kw["pad"], num_group=kw["num_group"], num_deformable_group=kw["num_deformable_group"])
+            self._pack_key = key
+        return self._pack
+
     def forward(self, x, offset):
         if self.weight is None:
             self._materialize(x.shape[1], x.device)
@@ -181,7 +195,7 @@ class DeformableConv2D(nn.Module):
                                             dilate=kw["dilate"], pad=kw["pad"], num_filter=kw["num_filter"],
                                             num_group=kw["num_group"],
                                             num_deformable_group=kw["num_deformable_group"], no_bias=kw["no_bias"],
-                                            layout=kw["layout"])
+                                            layout=kw["layout"], packed=self._packed(x))
         return self.act(out) if self.act is not None else out
 
     def forward_shared(self, x, flow, flow_scale, flow_stride):
@@ -194,7 +208,7 @@ class DeformableConv2D(nn.Module):
             raise ValueError("forward_shared needs stride 1 and one deformable group")
         out = ops.deformable_convolution_shared(x, flow, flow_scale, flow_stride, self.weight, self.bias,
                                                 kernel=kw["kernel"], dilate=kw["dilate"], pad=kw["pad"],
-                                                num_group=kw["num_group"])
+                                                num_group=kw["num_group"], packed=self._packed(x))
         return self.act(out) if self.act is not None else out
 
     def _alias(self):

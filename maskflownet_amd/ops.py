@@ -171,7 +171,9 @@ class OpSet:
 
     def DeformableConvolution(self, data, offset, weight, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1),
                               pad=(0, 0), num_filter=None, num_group=1, num_deformable_group=1, no_bias=False,
-                              layout="NCHW", out=None):
+                              layout="NCHW", out=None, packed=None):
+        """packed: a PackedDeformWeights from pack_deform_weights() for these constant weights (inference);
+        the per-call re-layout of `weight` is skipped, results are bit-identical."""
         if layout not in (None, "NCHW"):
             raise ValueError("DeformableConvolution: only layout='NCHW' is supported")
         if no_bias:
@@ -203,11 +205,40 @@ class OpSet:
         nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group,
                                                      num_deformable_group)
         ws = self._workspace(x, nbytes)
+        dims = (N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group, num_deformable_group)
+        if packed is not None:
+            packed.require(dims)
+            self.check(self.ns.deform_conv_fwd_packed(self.ad.ptr(x), self.ad.ptr(off), self.ad.ptr(packed.buf),
+                                                      packed.nbytes, packed.tag, self.ad.ptr(b) if b is not None else None,
+                                                      self.ad.ptr(out), *dims, self.ad.ptr(ws), self.ad.nbytes(ws),
+                                                      self.ad.stream(x)))
+            return out
         self.check(self.ns.deform_conv_fwd(self.ad.ptr(x), self.ad.ptr(off), self.ad.ptr(w),
-                                           self.ad.ptr(b) if b is not None else None, self.ad.ptr(out), N, Cin, H, W,
-                                           Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group, num_deformable_group,
+                                           self.ad.ptr(b) if b is not None else None, self.ad.ptr(out), *dims,
                                            self.ad.ptr(ws), self.ad.nbytes(ws), self.ad.stream(x)))
         return out
+
+    def pack_deform_weights(self, weight, data_shape, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0),
+                            num_group=1, num_deformable_group=1):
+        """Lay constant DeformableConvolution weights out once for inputs of `data_shape` (N,Cin,H,W);
+        mfn_deform_conv_pack_weights.  The layout depends on the shape and on set_tuning(): re-pack after
+        changing either (a stale pack is refused, never silently used)."""
+        (w,) = self._in(weight)
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw) = map(self._pair, (kernel, stride, pad, dilate))
+        N, Cin, H, W = (int(v) for v in data_shape)
+        Cout = self.ad.shape(w)[0]
+        if self.ad.shape(w) != (Cout, Cin // num_group, kh, kw):
+            raise ValueError("pack_deform_weights: weight shape %s, expected %s"
+                             % (self.ad.shape(w), (Cout, Cin // num_group, kh, kw)))
+        dims = (N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, int(num_group), int(num_deformable_group))
+        nbytes = self.ns.deform_conv_packed_weight_bytes(*dims)
+        if not nbytes:
+            raise ValueError("pack_deform_weights: bad shape %s" % (dims,))
+        buf = self.ad.empty_bytes(w, nbytes)
+        tag = ctypes.c_ulonglong()
+        self.check(self.ns.deform_conv_pack_weights(self.ad.ptr(w), *dims, self.ad.ptr(buf), nbytes,
+                                                    ctypes.byref(tag), self.ad.stream(w)))
+        return PackedDeformWeights(buf, nbytes, dims, tag.value)
 
     def DeformableConvolution_backward(self, out_grad, data, offset, weight, kernel=(3, 3), stride=(1, 1),
                                        dilate=(1, 1), pad=(0, 0), num_group=1, num_deformable_group=1, no_bias=False,
@@ -232,9 +263,9 @@ class OpSet:
         return gx, goff, gw, gb
 
     def deformable_convolution_shared(self, data, flow, flow_scale, flow_stride, weight, bias=None, kernel=(3, 3),
-                                      dilate=(1, 1), pad=(1, 1), num_group=1, out=None):
+                                      dilate=(1, 1), pad=(1, 1), num_group=1, out=None, packed=None):
         """DeformableConvolution with offset = repeat9(flow*flow_scale/flow_stride) (MaskFlownet.py:230)
-        without materialising the offset tensor."""
+        without materialising the offset tensor.  packed: see DeformableConvolution."""
         x, fl, w = self._in(data, flow, weight)
         b = self._in(bias)[0] if bias is not None else None
         (kh, kw), (ph, pw), (dh, dw) = map(self._pair, (kernel, pad, dilate))
@@ -248,6 +279,14 @@ class OpSet:
             out = self.ad.empty(x, (N, Cout, H, W))
         nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, 1, 1, ph, pw, dh, dw, num_group, 1)
         ws = self._workspace(x, nbytes)
+        if packed is not None:
+            packed.require((N, Cin, H, W, Cout, kh, kw, 1, 1, ph, pw, dh, dw, num_group, 1))
+            self.check(self.ns.deform_conv_shared_fwd_packed(
+                self.ad.ptr(x), self.ad.ptr(fl), float(flow_scale), float(flow_stride), self.ad.ptr(packed.buf),
+                packed.nbytes, packed.tag, self.ad.ptr(b) if b is not None else None, self.ad.ptr(out), N, Cin, H, W, Cout,
+                kh, kw,
+                ph, pw, dh, dw, num_group, self.ad.ptr(ws), self.ad.nbytes(ws), self.ad.stream(x)))
+            return out
         self.check(self.ns.deform_conv_shared_fwd(self.ad.ptr(x), self.ad.ptr(fl), float(flow_scale),
                                                   float(flow_stride), self.ad.ptr(w),
                                                   self.ad.ptr(b) if b is not None else None, self.ad.ptr(out), N, Cin,
@@ -265,6 +304,18 @@ class OpSet:
         self.check(self.ns.offsets_from_flow(self.ad.ptr(fl), self.ad.ptr(out), N, H, W, int(taps), float(scale),
                                              float(stride), self.ad.stream(fl)))
         return out
+
+
+class PackedDeformWeights:
+    """Opaque device buffer made by OpSet.pack_deform_weights for one (shape, hyper-parameter) tuple."""
+
+    def __init__(self, buf, nbytes, dims, tag):
+        self.buf, self.nbytes, self.dims, self.tag = buf, int(nbytes), tuple(dims), int(tag)
+
+    def require(self, dims):
+        if tuple(int(d) for d in dims) != self.dims:
+            raise ValueError("packed DeformableConvolution weights were laid out for %s, called with %s"
+                             % (self.dims, tuple(dims)))
 
 
 class TorchAdapter:

@@ -109,6 +109,33 @@ def case_deform_pertap(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0,
     return check_close(got, want, what="deform per-tap %s" % (kw,))
 
 
+def case_deform_packed(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, **kw):
+    """Weights packed once (mfn_deform_conv_pack_weights) give bit-identical results to the per-call path,
+    for the MFMA path, its fused-offset form and the shapes that fall to the generic kernel."""
+    rng = np.random.default_rng(777 + seed)
+    ng, ndg = kw.get("num_group", 1), kw.get("num_deformable_group", 1)
+    kernel = kw.get("kernel", (3, 3))
+    x = feat(rng, (N, Cin, H, W))
+    w = (rng.standard_normal((Cout, Cin // ng) + tuple(kernel)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal((Cout,)) * 0.1).astype(np.float32)
+    Ho, Wo = oracle.deform_conv_out_shape(H, W, kernel, kw.get("stride", (1, 1)), kw.get("pad", (0, 0)),
+                                          kw.get("dilate", (1, 1)))
+    off = (rng.standard_normal((N, 2 * kernel[0] * kernel[1] * ndg, Ho, Wo)) * 1.5).astype(np.float32)
+    xd, od, wd, bd = to_dev(x), to_dev(off), to_dev(w), to_dev(b)
+    pk = ops.pack_deform_weights(wd, (N, Cin, H, W), **kw)
+    plain = to_host(ops.DeformableConvolution(xd, od, wd, bd, num_filter=Cout, **kw))
+    packed = to_host(ops.DeformableConvolution(xd, od, wd, bd, num_filter=Cout, packed=pk, **kw))
+    np.testing.assert_array_equal(packed, plain)
+    check_close(packed, oracle.deformable_convolution(x, off, w, b, **kw), what="deform packed %s" % (kw,))
+    if kw.get("stride", (1, 1)) == (1, 1) and ndg == 1 and (Ho, Wo) == (H, W):
+        fl = (flow_field(rng, N, H, W, sigma=2.0) * np.float32(8.0 / 20.0)).astype(np.float32)
+        skw = {k: v for k, v in kw.items() if k in ("kernel", "pad", "dilate", "num_group")}
+        a = to_host(ops.deformable_convolution_shared(xd, to_dev(fl), 20.0, 8.0, wd, bd, **skw))
+        c = to_host(ops.deformable_convolution_shared(xd, to_dev(fl), 20.0, 8.0, wd, bd, packed=pk, **skw))
+        np.testing.assert_array_equal(c, a)
+    return pk
+
+
 # ---- backward (SURVEY.md section 8 row a7) ------------------------------------------------------------------
 def case_correlation_bwd(ops, oracle, to_dev, to_host, shape, seed=0, **kw):
     rng = np.random.default_rng(31 + seed)

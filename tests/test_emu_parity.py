@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0)
+                       dc_generic=0, dc_tile=0)
 
 
 @pytest.mark.parametrize("variant", range(20))
@@ -124,6 +124,14 @@ def test_deform_window_staging_and_per_tap_fallback(ops, oracle, stage):
     pc.case_deform_shared(ops, oracle, ident, ident, 2, 8, 12, 16, seed=3)
 
 
+@pytest.mark.parametrize("tile", [0, 16, 1])
+@pytest.mark.parametrize("hw", [(6, 32), (5, 20), (3, 18), (9, 12)])
+def test_deform_pixel_tile_shapes(ops, oracle, tile, hw):
+    # 2x16 / 4x8 / flattened pixel tiles, full and ragged (partial tiles at the right and bottom edges)
+    emu_ops.set_tuning(dc_tile=tile)
+    pc.case_deform_shared(ops, oracle, ident, ident, 2, 8, hw[0], hw[1], seed=hw[1])
+
+
 def test_deform_fast_path_off_matches(ops, oracle):
     emu_ops.set_tuning(dc_fast=0)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 8, 5, 6, bias=False)
@@ -137,6 +145,27 @@ def test_deform_fast_path_off_matches(ops, oracle):
                                 dict(kernel=(5, 3), pad=(2, 1))])
 def test_deform_per_tap_parameter_space(ops, oracle, kw):
     pc.case_deform_pertap(ops, oracle, ident, ident, 1, 4, 6, 6, 7, **kw)
+
+
+@pytest.mark.parametrize("shape,kw", [((1, 32, 32, 6, 7), dict(kernel=(3, 3), pad=(1, 1))),
+                                      ((1, 6, 40, 5, 8), dict(kernel=(3, 3), pad=(1, 1))),
+                                      ((1, 4, 6, 6, 7), dict(kernel=(3, 3), pad=(1, 1), num_group=2)),
+                                      ((1, 4, 6, 6, 7), dict(kernel=(1, 1), pad=(0, 0)))])
+def test_deform_packed_weights_bit_identical(ops, oracle, shape, kw):
+    pc.case_deform_packed(ops, oracle, ident, ident, *shape, **kw)
+
+
+def test_deform_stale_pack_is_refused(ops, oracle):
+    pk = pc.case_deform_packed(ops, oracle, ident, ident, 1, 64, 64, 6, 7, kernel=(3, 3), pad=(1, 1))
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1, 64, 6, 7)).astype(np.float32)
+    off = np.zeros((1, 18, 6, 7), np.float32)
+    w = rng.standard_normal((64, 64, 3, 3)).astype(np.float32)
+    with pytest.raises(ValueError, match="laid out for"):        # host-side shape key
+        ops.DeformableConvolution(x[:, :, :5], off[:, :, :5], w, None, kernel=(3, 3), pad=(1, 1), no_bias=True, packed=pk)
+    emu_ops.set_tuning(dc_mt=2)                                   # same shape, different tiling: the C ABI refuses
+    with pytest.raises(Exception, match="do not match this shape/tuning"):
+        ops.DeformableConvolution(x, off, w, None, kernel=(3, 3), pad=(1, 1), no_bias=True, packed=pk)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(max_displacement=2, pad_size=2),

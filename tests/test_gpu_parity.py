@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, warp_vec=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0)
+    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, warp_vec=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -273,6 +273,56 @@ def test_layer_mirror_trains_through_the_c_abi(oracle, T):
     pc.check_close(img.grad.cpu().numpy(), ox, what="layer bwd warp d/dx")
     pc.check_close(flt.grad.cpu().numpy(), of, tol=5e-5, what="layer bwd warp d/dflow")
     assert layer.Reconstruction2D(2, block_grad=True)(img, flt).requires_grad  # grad still flows into x
+
+
+@pytest.mark.parametrize("shape,kw", [((8, 64, 64, 48, 64), dict(kernel=(3, 3), pad=(1, 1))),     # level 3: mt=2
+                                      ((8, 196, 196, 6, 8), dict(kernel=(3, 3), pad=(1, 1))),     # level 6: split K
+                                      ((2, 5, 40, 9, 11), dict(kernel=(3, 3), pad=(1, 1))),
+                                      ((2, 8, 12, 13, 15), dict(kernel=(3, 3), pad=(1, 1), num_group=2)),
+                                      ((2, 8, 12, 13, 15), dict(kernel=(5, 3), pad=(2, 1)))])
+def test_deform_conv_packed_weights_bit_identical(ops, oracle, dev, shape, kw):
+    pc.case_deform_packed(ops, oracle, dev, host, *shape, **kw)
+
+
+def test_layer_packed_weight_cache_follows_the_parameter(oracle, T):
+    """layer.DeformableConv2D packs its weights once per (version, input shape, tuning): an in-place update of the
+    parameter, a new input shape or a set_tuning() call must each produce a fresh pack."""
+    from maskflownet_amd import layer, _lib
+    rng = np.random.default_rng(4)
+    N, C, H, W = 2, 64, 24, 32
+    x = pc.feat(rng, (N, C, H, W))
+    off = (rng.standard_normal((N, 18, H, W)) * 1.5).astype(np.float32)
+    dc = layer.DeformableConv2D(C, kernel_size=3, strides=1, padding=1, in_channels=C).cuda()
+    xt, ot = T.from_numpy(x).cuda(), T.from_numpy(off).cuda()
+
+    def ref():
+        return oracle.deformable_convolution(x, off, host(dc.weight), host(dc.bias), kernel=(3, 3), pad=(1, 1))
+
+    with T.no_grad():
+        pc.check_close(host(dc(xt, ot)), ref(), what="first call")
+        first = dc._pack
+        dc(xt, ot)
+        assert dc._pack is first                              # cached
+        dc.weight.mul_(-0.5)                                   # optimizer-style in-place update bumps _version
+        pc.check_close(host(dc(xt, ot)), ref(), what="after in-place weight update")
+        assert dc._pack is not first
+        dc.load_state_dict({"weight": T.from_numpy(pc.msra_weight(rng, C, C)), "bias": T.zeros(C)})
+        pc.check_close(host(dc(xt, ot)), ref(), what="after load_state_dict")
+        second = dc._pack
+        _lib.set_tuning(dc_mt=1)
+        pc.check_close(host(dc(xt, ot)), ref(), what="after set_tuning")
+        assert dc._pack is not second
+        pc.check_close(host(dc(xt[:, :, :20], ot[:, :, :20])),
+                       oracle.deformable_convolution(x[:, :, :20], off[:, :, :20], host(dc.weight), host(dc.bias),
+                                                     kernel=(3, 3), pad=(1, 1)), what="new input shape")
+
+
+def test_hot_path_prepacked_equals_stateless(T):
+    from maskflownet_amd import hotpath
+    a = hotpath.HotPathWorkload("tiny", device="cuda", prepack=True).run_eager()
+    b = hotpath.HotPathWorkload("tiny", device="cuda", prepack=False).run_eager()
+    for u, v in zip(a, b):
+        assert T.equal(u, v)
 
 
 def test_hot_path_pass_graph_replay_matches_eager(T):
