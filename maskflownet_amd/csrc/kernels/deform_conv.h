@@ -44,6 +44,7 @@ struct DeformParams {
   unsigned long long *timeline;  // measurement only (mfn_debug_set_timeline)
   int stage_window;              // tuning: 0 disables the LDS source-window staging
   int ncp_pad, cps_per_slice, ksb, mgroups;  // packed-weight rows per M-group, K-slice length, cross-block K split
+  float inv_tpi, inv_tiles_x;                // 1 / (tiles_y * tiles_x), 1 / tiles_x
   int tile_w, tiles_x, tiles_y, ntiles;      // 32-pixel tiles: (32/tile_w) x tile_w output pixels (tile_w 16 or 8), or
                                              // tile_w == 0: 32 consecutive pixels of the flattened (n,ho,wo) index
   float *partial;                             // ksb > 1: raw partial sums [ksb][N][Cout][Ho][Wo]
@@ -106,7 +107,7 @@ __device__ __forceinline__ DcTap dc_make_tap(float off_h, float off_w, int h_in,
 }
 
 // per-axis descriptor of the shared-offset fast path: weights of tap row i on slots i and i+1
-struct DcAxis3 { float a[3], b[3]; int idx[4]; };
+struct DcAxis3 { float a[3], b[3]; int idx[4]; };  // idx: clamped row / column numbers of the 4 neighbourhood lines
 
 // ---- geometry shared by host and device ------------------------------------------------------------
 // chunk = KC channel pairs of one M-group's packed weights = KC*18*RL floats, RL = 32*MT filters
@@ -116,6 +117,7 @@ constexpr int dc_kc(int mt, int kw) {
   const int q = 4 / (mt * kw);
   return q >= 4 ? 4 : (q >= 2 ? 2 : 1);
 }
+template <int V> struct DcInt { static constexpr int value = V; };
 template <int MT, int KW> struct DcGeom {
   static constexpr int RL = 32 * MT;
   static constexpr int KC = dc_kc(MT, KW);
@@ -123,8 +125,14 @@ template <int MT, int KW> struct DcGeom {
   static constexpr int CH4 = CHUNK_F / 4;       // float4 items
 };
 
+// waves per SIMD the register allocator is held to (three for one or two filter tiles per wave: LDS allows
+// three blocks per CU, and a level-2 or level-3 launch is then resident in one round)
+constexpr int dc_min_waves(int mt, int pt) {
+  return mt <= 2 ? 3 : (mt == 3 ? 2 : (pt >= 2 ? 2 : 1));
+}
+
 template <int MT, int PT>
-__global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
+__global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(DeformParams p) {
   constexpr int T = 9;
   constexpr int KW = 4 / PT;  // K-slices handled inside the block (one wave each per pixel tile)
   using G = DcGeom<MT, KW>;
@@ -159,9 +167,17 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   if (p.tile_w) {
     const int tpi = p.tiles_y * p.tiles_x;
     const int tl = min(tile, p.ntiles - 1);
-    n = tl / tpi;
-    const int rt = tl - n * tpi;
-    const int ty = rt / p.tiles_x, tx = rt - ty * p.tiles_x;
+    // tile -> (image, tile row, tile column) without integer division: tile counts are far below 2^24, so the
+    // float quotient is off by at most one and a single correction step makes it exact
+    auto divmod = [](int a, int b, float inv_b, int &q, int &r) {
+      q = (int)((float)a * inv_b);
+      r = a - q * b;
+      if (r < 0) { --q; r += b; }
+      if (r >= b) { ++q; r -= b; }
+    };
+    int rt, ty, tx;
+    divmod(tl, tpi, p.inv_tpi, n, rt);
+    divmod(rt, p.tiles_x, p.inv_tiles_x, ty, tx);
     const int sh16 = p.tile_w == 16 ? 4 : 3;
     ho = ty * (32 >> sh16) + (j >> sh16);
     wo = tx * p.tile_w + (j & (p.tile_w - 1));
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
       ay.b[i] = v ? l : 0.f;
     }
     MFN_UNROLL
-    for (int m = 0; m < 4; ++m) ay.idx[m] = min(max(h_in + lo0 + m, 0), H - 1) * W;
+    for (int m = 0; m < 4; ++m) ay.idx[m] = min(max(h_in + lo0 + m, 0), H - 1);
     MFN_UNROLL
     for (int i = 0; i < 3; ++i) {
       bool v; int lo, hi; float l;
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   bool staged;
   {
     const int big = 1 << 28;
-    int rlo = px_valid ? ay.idx[0] / W : big, rhi = px_valid ? ay.idx[3] / W : -big;
+    int rlo = px_valid ? ay.idx[0] : big, rhi = px_valid ? ay.idx[3] : -big;
     int clo = px_valid ? ax.idx[0] : big, chi = px_valid ? ax.idx[3] : -big;
     int nlo = px_valid ? n : big, nhi = px_valid ? n : -big;
     MFN_UNROLL
@@ -272,7 +288,10 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
     }
     wr0 = rlo;
     wc0 = clo & ~3;  // 16-byte aligned window origin
-    staged = fast && p.stage_window && p.tile_w && (W % 4 == 0) && nlo == nhi && (rhi - wr0 < XW_ROWS) && (chi - wc0 < XW_COLS);
+    staged = MFN_UNIFORM((int)(fast && p.stage_window && p.tile_w && (W % 4 == 0) && nlo == nhi && (rhi - wr0 < XW_ROWS) &&
+                               (chi - wc0 < XW_COLS))) != 0;
+    wr0 = MFN_UNIFORM(wr0);
+    wc0 = MFN_UNIFORM(wc0);
 #ifdef MFN_EMU_DEBUG
     if (lane == 0) printf("tile %d wave %d: rows %d..%d cols %d..%d n %d..%d staged %d fast %d\n", tile, wave, rlo, rhi, clo, chi, nlo, nhi, (int)staged, (int)fast);
 #endif
@@ -317,7 +336,7 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   unsigned rowoff[4];
   MFN_UNROLL
   for (int m = 0; m < 4; ++m)
-    rowoff[m] = (unsigned)(n * p.Cin * (int)plane + half * (int)plane + ay.idx[m] + ax.idx[0]);
+    rowoff[m] = (unsigned)(n * p.Cin * (int)plane + half * (int)plane + ay.idx[m] * W + ax.idx[0]);
   auto rowgather_pair = [&](int cp, const float *ap) {
     const float *base = p.x + (size_t)(2 * cp) * plane;  // uniform
     float v[4][4];
@@ -375,8 +394,8 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
     MFN_UNROLL
     for (int i = 0; i < XW_NI; ++i) {
       const int slot = i * 64 + lane;               // float4 slots: [channel 0/1][XW_ROWS][XW_C4 float4]
-      const int chs = slot / (XW_ROWS * XW_C4), rem = slot - chs * (XW_ROWS * XW_C4);
-      const int row = rem / XW_C4, c4 = rem - row * XW_C4;
+      const int chs = slot / 60, rem = slot - chs * 60;  // XW_ROWS * XW_C4 == 60 for both tile shapes
+      const int row = p.tile_w == 16 ? rem / 6 : rem / 5, c4 = rem - row * XW_C4;
       const int r = wr0 + row, c = wc0 + 4 * c4;
       xvoff[i] = (chs < 2 && r <= H - 1 && c <= W - 4)
                      ? (unsigned)(((size_t)nimg * p.Cin * plane + (size_t)chs * plane + (size_t)r * W + c) * 4)
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
     for (int m = 0; m < 4; ++m)
       MFN_UNROLL
       for (int q = 0; q < 4; ++q)
-        loff[m][q] = half * (XW_ROWS * XW_COLS) + (ay.idx[m] / W - wr0) * XW_COLS + (ax.idx[q] - wc0);
+        loff[m][q] = half * (XW_ROWS * XW_COLS) + (ay.idx[m] - wr0) * XW_COLS + (ax.idx[q] - wc0);
   }
   auto issue_x = [&](int cp, int buf) {
     const unsigned soff = (unsigned)((size_t)(2 * cp) * plane * 4);
@@ -401,7 +420,7 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
   // wait below is a count of the newer transfers that may still be outstanding.
   int k_done = 0;  // pairs of this slice already accumulated
   if (staged) {
-    const int nf = max(0, min(nchunks * KC, full_pairs - cp_base));  // uniform
+    const int nf = MFN_UNIFORM(max(0, min(nchunks * KC, full_pairs - cp_base)));
     auto gather = [&](int buf, float (&v)[4][4]) {
       const float *xb = xwin + buf * XW_F;
       MFN_UNROLL
@@ -434,10 +453,13 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
       MFN_UNROLL
       for (int i = 0; i < 3; ++i) interp_col(tr, cv, i);
     }
-    int xb_next = 1, xb_free = 0;  // pair p lives in window buffer p % 3: pair k+1 is read, pair k+3 goes where k was
-    bool w_in_flight = false;      // a weight chunk was issued in the previous iteration
-    MFN_NOUNROLL
-    for (int k = 0; k < nf; ++k) {
+    bool w_in_flight = false;  // a weight chunk was issued in the previous iteration
+    // One pipeline step for pair k.  Pair p lives in window buffer p % 3; the buffer numbers are compile-time
+    // (the loop below is unrolled over the ring) so that the 16 gather addresses are loop-invariant registers
+    // and the buffer is an instruction offset -- fp32 MFMA shares the VALU's ALUs, every saved VALU counts.
+    auto step = [&](int k, auto bn_c) {
+      constexpr int BN = decltype(bn_c)::value;  // buffer of pair k+1 (read now)
+      constexpr int BF = (BN + 2) % 3;           // buffer of pair k = where pair k+3 is streamed to
       const int ch = k / KC, kk = k - ch * KC;
       const bool more3 = k + 3 < nf;
       bool w_now = false;
@@ -448,10 +470,10 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
         MFN_RAW_BARRIER();
         if (k == 0) MFN_STAMP(p.timeline, 1);
         if (ch + 1 < nchunks) { issue(ch + 1); w_now = true; }
-        if (more3) issue_x(cp_base + k + 3, xb_free);
+        if (more3) issue_x(cp_base + k + 3, BF);
       } else {
         if (more3) {
-          issue_x(cp_base + k + 3, xb_free);
+          issue_x(cp_base + k + 3, BF);
           // outstanding, oldest first: window k+1, [weights issued last iteration], window k+2, window k+3
           if (w_in_flight) MFN_WAIT_VM(NI + 2 * XW_NI); else MFN_WAIT_VM(2 * XW_NI);
         } else {
@@ -461,7 +483,7 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
       w_in_flight = w_now;
       const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
       if (k + 1 < nf) {
-        gather(xb_next, v);
+        gather(BN, v);
         mfma_tap(ap, 0, cv[0]); interp_row(v, tr, 0);
         mfma_tap(ap, 1, cv[1]); interp_row(v, tr, 1);
         mfma_tap(ap, 2, cv[2]); interp_row(v, tr, 2);
@@ -477,9 +499,15 @@ __global__ __launch_bounds__(256) void dc_lds_kernel(DeformParams p) {
         MFN_UNROLL
         for (int t = 0; t < T; ++t) mfma_tap(ap, t, cv[t]);
       }
-      xb_free = xb_next;
-      xb_next = xb_next == 2 ? 0 : xb_next + 1;
       MFN_SCHED_BARRIER();
+    };
+    for (int k = 0; k < nf;) {
+      step(k, DcInt<1>{});
+      if (++k >= nf) break;
+      step(k, DcInt<2>{});
+      if (++k >= nf) break;
+      step(k, DcInt<0>{});
+      ++k;
     }
     k_done = nf;
   }

@@ -20,7 +20,7 @@ def ops():
 @pytest.fixture(autouse=True)
 def _reset_tuning():
     yield
-    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
+    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
                        dc_generic=0, dc_tile=0)
 
 
@@ -59,6 +59,27 @@ def test_correlation_channel_slices_and_reduce(ops, oracle, slices, C):
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 16), 2, seed=3)
     emu_ops.set_tuning(corr_variant=9, corr_tw=0)
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 6, 32), 4, seed=4)
+
+
+@pytest.mark.parametrize("shape,md", [((2, 20, 6, 8), 4),      # level-6 like: whole image in one band
+                                      ((1, 37, 12, 16), 4),    # ragged channel groups, several bands
+                                      ((1, 9, 7, 32), 4),      # H not a multiple of the band height
+                                      ((2, 8, 5, 12), 2),      # md=2 (25 channels), one group only
+                                      ((1, 70, 3, 4), 4),      # one quad per row, 16 groups
+                                      ((1, 16, 24, 32), 4)])   # level-4 plane
+def test_correlation_band_kernel(ops, oracle, shape, md):
+    emu_ops.set_tuning(corr_band=1)
+    pc.case_correlation(ops, oracle, ident, ident, shape, md)
+
+
+def test_correlation_band_is_the_default_for_coarse_levels(ops, oracle):
+    pc.case_correlation(ops, oracle, ident, ident, (1, 24, 12, 16), 4)
+    assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) == 0    # level 5: band kernel, no partials
+    assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) == 0     # level 4: band kernel
+    assert ops.ns.correlation_workspace_bytes(8, 64, 48, 64, 4, 1, 1, 1, 4, 1) == 0     # level 3: tiled, unsliced
+    assert ops.ns.correlation_workspace_bytes(8, 196, 6, 8, 4, 1, 1, 1, 4, 1) > 0       # level 6: slices + reduce
+    emu_ops.set_tuning(corr_band=2)
+    assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) > 0      # sliced + reduce path
 
 
 def test_correlation_non_pow2_channels_divide(ops, oracle):
