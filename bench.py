@@ -100,11 +100,13 @@ def roofline_of_dominant_kernel(wl, iters, torch):
         return None
     avg_s = ms.value / cnt.value * 1e-3
     traffic, traffic_src = None, None
-    tf = os.path.join(ROOT, "profiles", "r01_corr_l2_hbm_traffic.json")
-    if os.path.exists(tf) and (wl.N, wl.H, wl.W) == (8, 384, 512):
-        rec = json.load(open(tf))  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very launch shape
+    import glob
+    tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_corr_l2_hbm_traffic.json")))
+    if tfs and (wl.N, wl.H, wl.W) == (8, 384, 512):
+        rec = json.load(open(tfs[-1]))  # newest rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very launch shape
         traffic = rec["traffic_bytes_per_launch"]
-        traffic_src = "profiles/r01_corr_l2_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; %s)" % (
+            os.path.basename(tfs[-1]), rec.get("kernel", ""))
     achieved = nbytes / avg_s / 1e9
     return {"bound": "hbm", "kernel": "%s (level 2: N=%d C=%d %dx%d -> 81 ch)" % (kname, n, c, h, w),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -134,6 +136,35 @@ def per_kernel_breakdown(wl, iters, torch):
     for line in cbuf.value.decode().splitlines():
         name, cnt, ms = line.split()
         out[name] = {"launches_per_pass": int(cnt) // iters, "us_per_pass": round(float(ms) / iters * 1e3, 2)}
+    return out
+
+
+def per_op_graph_cost(wl, torch, reps=20):
+    """What every operator call of the pass costs inside a hipGraph, boundaries included: `reps` dependent
+    repeats of one call captured into a graph, wall clock / reps (sums to ~ms_per_step)."""
+    import ctypes
+    from maskflownet_amd import _lib
+    lib, st = _lib.lib(), wl.stream
+    out = {}
+    for name, fn in wl.calls():
+        with torch.cuda.stream(st):
+            _lib.check(lib.graph_begin_capture(st.cuda_stream))
+            try:
+                for _ in range(reps):
+                    fn()
+            finally:
+                g = ctypes.c_void_p()
+                rc = lib.graph_end_capture(st.cuda_stream, ctypes.byref(g))
+            _lib.check(rc)
+        for _ in range(3):
+            _lib.check(lib.graph_launch(g, st.cuda_stream))
+        st.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            _lib.check(lib.graph_launch(g, st.cuda_stream))
+        st.synchronize()
+        out[name] = round((time.perf_counter() - t0) / (10 * reps) * 1e6, 2)
+        lib.graph_destroy(g)
     return out
 
 
@@ -227,6 +258,7 @@ def main():
     try:
         res["roofline"] = roofline_of_dominant_kernel(wl, args.roofline_iters, torch)
         res["kernels"] = per_kernel_breakdown(wl, 20, torch)
+        res["ops_in_graph_us"] = per_op_graph_cost(wl, torch)
     except Exception as e:  # the headline number must survive a profiler problem
         res["roofline"] = None
         res["roofline_error"] = repr(e)

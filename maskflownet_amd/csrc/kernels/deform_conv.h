@@ -43,6 +43,7 @@ struct DeformParams {
   int allow_fast;  // tuning: 0 forces the per-tap path
   unsigned long long *timeline;  // measurement only (mfn_debug_set_timeline)
   int stage_window;              // tuning: 0 disables the LDS source-window staging
+  int vec_store;                 // out / partial are 16-byte aligned and Wo % 4 == 0: 16-byte epilogue stores
   int ncp_pad, cps_per_slice, ksb, mgroups;  // packed-weight rows per M-group, K-slice length, cross-block K split
   float inv_tpi, inv_tiles_x;                // 1 / (tiles_y * tiles_x), 1 / tiles_x
   int tile_w, tiles_x, tiles_y, ntiles;      // 32-pixel tiles: (32/tile_w) x tile_w output pixels (tile_w 16 or 8), or
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(Defor
   // 2-D pixel tiles keep the source window of a wave small (4x8 px: 7 rows x 11 columns plus the flow's
   // variation, against 4 rows x 35 columns for 32 px of one row) and never span two images.
   int n, ho, wo;
+  int tile_ho0 = 0, tile_wo0 = 0;  // origin of a 2-D tile (uniform)
   bool px_valid;
   if (p.tile_w) {
     const int tpi = p.tiles_y * p.tiles_x;
@@ -179,8 +181,10 @@ __global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(Defor
     divmod(tl, tpi, p.inv_tpi, n, rt);
     divmod(rt, p.tiles_x, p.inv_tiles_x, ty, tx);
     const int sh16 = p.tile_w == 16 ? 4 : 3;
-    ho = ty * (32 >> sh16) + (j >> sh16);
-    wo = tx * p.tile_w + (j & (p.tile_w - 1));
+    tile_ho0 = ty * (32 >> sh16);
+    tile_wo0 = tx * p.tile_w;
+    ho = tile_ho0 + (j >> sh16);
+    wo = tile_wo0 + (j & (p.tile_w - 1));
     px_valid = tile < p.ntiles && ho < Ho && wo < Wo;
     ho = min(ho, Ho - 1);
     wo = min(wo, Wo - 1);
@@ -279,12 +283,13 @@ __global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(Defor
     const int big = 1 << 28;
     int rlo = px_valid ? ay.idx[0] : big, rhi = px_valid ? ay.idx[3] : -big;
     int clo = px_valid ? ax.idx[0] : big, chi = px_valid ? ax.idx[3] : -big;
-    int nlo = px_valid ? n : big, nhi = px_valid ? n : -big;
-    MFN_UNROLL
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-      rlo = min(rlo, __shfl_xor(rlo, sft)); rhi = max(rhi, __shfl_xor(rhi, sft));
-      clo = min(clo, __shfl_xor(clo, sft)); chi = max(chi, __shfl_xor(chi, sft));
-      nlo = min(nlo, __shfl_xor(nlo, sft)); nhi = max(nhi, __shfl_xor(nhi, sft));
+    const int nlo = 0, nhi = 0;  // windows are only staged under 2-D tiles, which never span two images
+    if (p.tile_w && fast) {
+      MFN_UNROLL
+      for (int sft = 32; sft >= 1; sft >>= 1) {
+        rlo = min(rlo, __shfl_xor(rlo, sft)); rhi = max(rhi, __shfl_xor(rhi, sft));
+        clo = min(clo, __shfl_xor(clo, sft)); chi = max(chi, __shfl_xor(chi, sft));
+      }
     }
     wr0 = rlo;
     wc0 = clo & ~3;  // 16-byte aligned window origin
@@ -562,18 +567,56 @@ __global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(Defor
   }
 
   // ---- epilogue.  D reg r of lane (j,half): filter row (r&3)+8*(r>>2)+4*half, pixel j ------------------
-  if (!px_valid) return;
   const bool raw = p.ksb > 1;  // cross-block K split: raw partial sums, bias added by dc_reduce_kernel
-  float *on = (raw ? p.partial + (size_t)blockIdx.y * p.N * p.Cout * oplane : p.out) + (size_t)n * p.Cout * oplane +
-              (size_t)ho * Wo + wo;
-  MFN_UNROLL
-  for (int mt = 0; mt < MT; ++mt)
+  float *obase = (raw ? p.partial + (size_t)blockIdx.y * p.N * p.Cout * oplane : p.out) + (size_t)n * p.Cout * oplane;
+  // 2-D tiles: transpose the 32x32 tile through this wave's (now idle) window ring so that a lane holds 4
+  // adjacent pixels of one filter and writes them with one 16-byte store -- 4 stores per lane instead of 16
+  // dword stores that each touch eight 32-byte segments (the store tail is issue-bound, MI355X_MICROARCH.md).
+  constexpr bool kRingFree = (KW > 1 ? (size_t)PT * (KW - 1) * MT * 16 * 64 * 4 : 0) <= (size_t)2 * STAGE_F * 4;
+  if (kRingFree && p.tile_w && p.vec_store && !(MFN_DC_ABLATE & 8)) {
+    constexpr int TS = 40;  // row stride in floats: 16-byte aligned rows, the two lane halves on disjoint banks
+    float *tr = lds + 2 * STAGE_F + wave * (3 * XW_F);
+    const int quad = lane & 7, orow = lane >> 3;
+    const int px0 = quad * 4;
+    const int prow = p.tile_w == 16 ? px0 >> 4 : px0 >> 3, pcol = px0 & (p.tile_w - 1);
+    const int oy = tile_ho0 + prow, ox = tile_wo0 + pcol;
+    const bool tile_ok = tile < p.ntiles;
     MFN_UNROLL
-    for (int r = 0; r < 16; ++r) {
-      const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (o < p.Cout && !((MFN_DC_ABLATE & 8) && acc[mt][r] != 123.f))
-        on[(size_t)o * oplane] = acc[mt][r] + ((p.bias && !raw) ? p.bias[o] : 0.f);
+    for (int mt = 0; mt < MT; ++mt) {
+      MFN_WAIT_LGKM0();  // the previous tile's reads are done (wave-private buffer: no barrier needed)
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + j] = acc[mt][r];
+      MFN_WAIT_LGKM0();
+      MFN_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        const int ol = i * 8 + orow;
+        const int o = m0 + mt * 32 + ol;
+        float4 v = *reinterpret_cast<const float4 *>(tr + ol * TS + px0);
+        if (tile_ok && o < p.Cout && oy < Ho) {
+          const float b = (p.bias && !raw) ? p.bias[o] : 0.f;
+          float *dst = obase + (size_t)o * oplane + (size_t)oy * Wo + ox;
+          if (ox + 3 < Wo) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(v.x + b, v.y + b, v.z + b, v.w + b);
+          } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            MFN_UNROLL
+            for (int q = 0; q < 4; ++q)
+              if (ox + q < Wo) dst[q] = e[q] + b;
+          }
+        }
+      }
     }
+  } else if (px_valid) {
+    float *on = obase + (size_t)ho * Wo + wo;
+    MFN_UNROLL
+    for (int mt = 0; mt < MT; ++mt)
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < p.Cout && !((MFN_DC_ABLATE & 8) && acc[mt][r] != 123.f))
+          on[(size_t)o * oplane] = acc[mt][r] + ((p.bias && !raw) ? p.bias[o] : 0.f);
+      }
+  }
   MFN_STAMP(p.timeline, 3);
 }
 

@@ -22,6 +22,10 @@ struct WarpParams {
 struct Taps {
   int i00, i01, i10, i11;  // element offsets inside one channel plane (clamped when masked)
   float w00, w01, w10, w11;
+  // paired form: the two taps of a row are adjacent in memory, so one 8-byte load at column
+  // pb = clamp(tx, 0, W-2) serves both.  sel0 / sel1: the left / right tap is the pair's second / first element
+  int p0, p1;        // element offsets of the two pairs (rows cy0, cy1)
+  bool sel0, sel1;   // left tap = pair.y (tx == W-1);  right tap = pair.x (tx == -1)
 };
 
 // grid value -> taps, exactly the BilinearSamplerForward arithmetic (fp32 round trip included)
@@ -47,6 +51,11 @@ __device__ __forceinline__ Taps sampler_taps(float gx, float gy, int iH, int iW)
   t.i01 = cy0 * iW + cx1;
   t.i10 = cy1 * iW + cx0;
   t.i11 = cy1 * iW + cx1;
+  const int pb = min(max(tx, 0), max(iW - 2, 0));
+  t.p0 = cy0 * iW + pb;
+  t.p1 = cy1 * iW + pb;
+  t.sel0 = tx != pb;      // left tap sits in the pair's second slot (only when tx == W-1; masked otherwise)
+  t.sel1 = tx + 1 == pb;  // right tap sits in the pair's first slot (only when tx == -1; masked otherwise)
   return t;
 }
 
@@ -57,6 +66,18 @@ __device__ __forceinline__ float sample(const float *plane, const Taps &t) {
   const float v01 = t.w01 != 0.f ? plane[t.i01] : 0.f;
   const float v10 = t.w10 != 0.f ? plane[t.i10] : 0.f;
   const float v11 = t.w11 != 0.f ? plane[t.i11] : 0.f;
+  return v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
+}
+
+// same result from two 8-byte loads (dword aligned, allowed on gfx950) instead of four 4-byte gathers: half the
+// texture-addresser work of the gather-bound warp.  Needs W >= 2.
+__device__ __forceinline__ float sample_pairs(const float *plane, const Taps &t) {
+  const f2u a = mfn_load2u(plane + t.p0);
+  const f2u b = mfn_load2u(plane + t.p1);
+  const float v00 = t.w00 != 0.f ? (t.sel0 ? a.y : a.x) : 0.f;
+  const float v01 = t.w01 != 0.f ? (t.sel1 ? a.x : a.y) : 0.f;
+  const float v10 = t.w10 != 0.f ? (t.sel0 ? b.y : b.x) : 0.f;
+  const float v11 = t.w11 != 0.f ? (t.sel1 ? b.x : b.y) : 0.f;
   return v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
 }
 
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpParams p) {
     const float *pl = xin + (size_t)c * plane;
     float r[VEC];
     MFN_UNROLL
-    for (int k = 0; k < VEC; ++k) r[k] = sample(pl, t[k]);
+    for (int k = 0; k < VEC; ++k) r[k] = (VEC == 1 && W >= 2) ? sample_pairs(pl, t[k]) : sample(pl, t[k]);
     if (VEC == 4) {
       *reinterpret_cast<float4 *>(o + (size_t)c * plane) = make_float4(r[0], r[1 % VEC], r[2 % VEC], r[3 % VEC]);
     } else {

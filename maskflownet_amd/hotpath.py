@@ -147,22 +147,29 @@ class HotPathWorkload:
                 self.packed[l] = self.ops.pack_deform_weights(self.t["w_%d" % l], shp[l], kernel=(3, 3), pad=(1, 1))
         torch.cuda.synchronize(self.device)
 
-    # the operator sequence of one forward
-    def _enqueue(self):
+    # the operator sequence of one forward, as (name, thunk) pairs
+    def calls(self):
         ops, t, o = self.ops, self.t, self.o
-        ops.Correlation(t["c1_6"], t["c2_6"], 1, MD, 1, 1, MD, True, out=o["corr6"])
+        seq = [("corr6", lambda: ops.Correlation(t["c1_6"], t["c2_6"], 1, MD, 1, 1, MD, True, out=o["corr6"]))]
         for l in (5, 4, 3, 2):
             if self.mode == "dropin":
-                ops.offsets_from_flow(t["flow_%d" % l], SCALE, STRIDES[l], out=o["offset%d" % l])
-                ops.DeformableConvolution(t["c2_%d" % l], o["offset%d" % l], t["w_%d" % l], t["b_%d" % l],
-                                          kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(1, 1),
-                                          num_filter=CHANNELS[l], out=o["deform%d" % l], packed=self.packed.get(l))
+                seq.append(("offsets%d" % l, lambda l=l: ops.offsets_from_flow(t["flow_%d" % l], SCALE, STRIDES[l],
+                                                                               out=o["offset%d" % l])))
+                seq.append(("deform%d" % l, lambda l=l: ops.DeformableConvolution(
+                    t["c2_%d" % l], o["offset%d" % l], t["w_%d" % l], t["b_%d" % l], kernel=(3, 3), stride=(1, 1),
+                    dilate=(1, 1), pad=(1, 1), num_filter=CHANNELS[l], out=o["deform%d" % l], packed=self.packed.get(l))))
             else:
-                ops.deformable_convolution_shared(t["c2_%d" % l], t["flow_%d" % l], SCALE, STRIDES[l],
-                                                  t["w_%d" % l], t["b_%d" % l], out=o["deform%d" % l],
-                                                  packed=self.packed.get(l))
-            ops.Correlation(t["c1_%d" % l], o["deform%d" % l], 1, MD, 1, 1, MD, True, out=o["corr%d" % l])
-        ops.warp(t["img2"], t["flow_full"], clip_grid=False, out=o["warp"])
+                seq.append(("deform%d" % l, lambda l=l: ops.deformable_convolution_shared(
+                    t["c2_%d" % l], t["flow_%d" % l], SCALE, STRIDES[l], t["w_%d" % l], t["b_%d" % l],
+                    out=o["deform%d" % l], packed=self.packed.get(l))))
+            seq.append(("corr%d" % l, lambda l=l: ops.Correlation(t["c1_%d" % l], o["deform%d" % l], 1, MD, 1, 1, MD, True,
+                                                                  out=o["corr%d" % l])))
+        seq.append(("warp", lambda: ops.warp(t["img2"], t["flow_full"], clip_grid=False, out=o["warp"])))
+        return seq
+
+    def _enqueue(self):
+        for _, fn in self.calls():
+            fn()
 
     def run_eager(self):
         with self.torch.cuda.stream(self.stream):

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs merged back under gpurun_out/ into the tracked summaries under profiles/.
+
+    gpurun_out/prof_bench/bench_results.db      rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline
+    gpurun_out/pmc_FETCH_SIZE/r_results.db      rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/prof_one.py corr 2
+    gpurun_out/pmc_WRITE_SIZE/r_results.db      rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python tools/prof_one.py corr 2
+usage: make_profiles.py <tag>      (e.g. r01b)"""
+import json, os, sqlite3, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+
+db = os.path.join(G, "prof_bench", "bench_results.db")
+if os.path.exists(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    with open(os.path.join(P, "%s_bench_kernel_stats.md" % tag), "w") as f:
+        f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline`\n\n" % tag)
+        f.write("MI355X (gfx950), ROCm 7.2.  Source: gpurun_out/prof_bench/bench_results.db (top_kernels view); durations in "
+                "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (level 6: sliced pair "
+                "+ reduce; levels 5/4: band kernel; levels 3/2: LDS-DMA tile kernel), 4 x (offsets + deformable conv), 1 warp.\n"
+                "Only `mfn::` kernels belong to the pass; the `at::native` rows are bench.py's checksum.\n\n")
+        f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
+        for name, calls, tot, avg, pct in rows:
+            short = name.replace("void ", "").replace("mfn::", "")
+            if len(short) > 90:
+                short = short[:87] + "..."
+            f.write("| `%s` | %d | %.1f | %.3f | %.2f |\n" % (short, calls, tot, avg, pct))
+    print("wrote", "%s_bench_kernel_stats.md" % tag)
+
+
+def pmc(counter):
+    db = os.path.join(G, "pmc_%s" % counter, "r_results.db")
+    if not os.path.exists(db):
+        return None
+    cur = sqlite3.connect(db).cursor()
+    vals, dur, kname = [], [], None
+    for name, cnt, val in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+        if "corr_" in name and cnt == counter:
+            vals.append(val); kname = name
+    for name, d in cur.execute("select name, end-start from kernels"):
+        if "corr_" in name:
+            dur.append(d)
+    return kname, sum(vals) / len(vals), len(vals), (sum(dur) / len(dur) if dur else None)
+
+
+fe, wr = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
+if fe and wr:
+    traffic = fe[1] * 1024 * 2 + wr[1] * 1024
+    rec = {"kernel": fe[0].split("(")[0] + " on level 2 (N=8, C=32, 96x128, md=4)",
+           "FETCH_SIZE_KB": fe[1], "WRITE_SIZE_KB": wr[1],
+           "fetch_correction": "x2 (gfx950 rocprofv3 FETCH_SIZE reports half of a wide coalesced stream, MI355X_MICROARCH.md section HBM)",
+           "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 4 * 8 * 96 * 128 * (64 + 81),
+           "launches": fe[2], "avg_kernel_ns_in_pmc_pass": fe[3],
+           "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/prof_one.py corr 2",
+                        "rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python tools/prof_one.py corr 2"]}
+    json.dump(rec, open(os.path.join(P, "%s_corr_l2_hbm_traffic.json" % tag), "w"), indent=1)
+    print("wrote", "%s_corr_l2_hbm_traffic.json" % tag, "traffic %.2f MB" % (traffic / 1e6))
+for name in ("bench", "bench_fused", "bench_cfg3", "bench_repack"):
+    src = os.path.join(G, name + ".log")
+    if os.path.exists(src):
+        line = open(src).read().strip().splitlines()[-1]
+        try:
+            json.loads(line)
+        except Exception:
+            continue
+        open(os.path.join(P, "%s_%s.json.log" % (tag, name)), "w").write(line + "\n")
+        print("wrote", "%s_%s.json.log" % (tag, name))

@@ -49,10 +49,11 @@ for l, cfgs in (((2, [(1, 4), (1, 2)]), (3, [(2, 2), (2, 1), (1, 4)]), (4, [(3, 
         lib.debug_set_timeline(tl.data_ptr()); fn(); torch.cuda.synchronize(); lib.debug_set_timeline(None)
         t = tl.cpu().numpy().reshape(nblk, 4).astype(np.float64) * 0.01
         t -= t[:, 0].min()
+
+        print("deform L%d mt=%d pt=%d blocks %d" % (l, mt, pt, nblk))
         print("  shader cycles : setup %.0f  main loop %.0f  epilogue %.0f  (median per block) -> %.2f GHz in the loop"
               % (np.median(cyc[:,1]-cyc[:,0]), np.median(cyc[:,2]-cyc[:,1]), np.median(cyc[:,3]-cyc[:,2]),
                  np.median(cyc[:,2]-cyc[:,1]) / np.median(t[:,2]-t[:,1]) / 1e3))
-        print("deform L%d mt=%d pt=%d blocks %d" % (l, mt, pt, nblk))
         print("  block start   : median %.2f  p90 %.2f  max %.2f us" % (np.median(t[:,0]), np.percentile(t[:,0],90), t[:,0].max()))
         print("  setup+1st DMA : median %.2f  p90 %.2f us" % (np.median(t[:,1]-t[:,0]), np.percentile(t[:,1]-t[:,0],90)))
         print("  main loop     : median %.2f  p90 %.2f us" % (np.median(t[:,2]-t[:,1]), np.percentile(t[:,2]-t[:,1],90)))
