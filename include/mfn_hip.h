@@ -76,6 +76,16 @@ int mfn_correlation_fwd_ws(const float *data1, const float *data2, float *out, i
                            int W, int max_displacement, int kernel_size, int stride1, int stride2,
                            int pad_size, int is_multiply, void *workspace, size_t workspace_bytes,
                            void *stream);
+/* Fused epilogue: the reference applies LeakyReLU(0.1) to every cost volume right
+ * away (/root/reference/network/MaskFlownet.py:217,231,249,267,285: self.leakyRELU(self.corr(...))).
+ * activation: MFN_ACT_NONE or MFN_ACT_LEAKY_0_1 (max(v, 0.1 v), applied after the 1/C normalisation,
+ * bit-identical to the separate elementwise op).  Otherwise identical to mfn_correlation_fwd_ws. */
+#define MFN_ACT_NONE 0
+#define MFN_ACT_LEAKY_0_1 1
+int mfn_correlation_fwd_act(const float *data1, const float *data2, float *out, int N, int C, int H,
+                            int W, int max_displacement, int kernel_size, int stride1, int stride2,
+                            int pad_size, int is_multiply, int activation, void *workspace,
+                            size_t workspace_bytes, void *stream);
 /* Backward of the same call site (training, /root/reference/network/pipeline.py:112-113).
  * g1/g2: (N,C,H,W); req1/req2 in {MFN_REQ_NULL, MFN_REQ_WRITE, MFN_REQ_ADD}. */
 int mfn_correlation_bwd(const float *gout, const float *data1, const float *data2, float *g1,
@@ -181,6 +191,11 @@ int mfn_deform_conv_bwd(const float *gout, const float *x, const float *offset, 
                         int dh, int dw, int groups, int deform_groups, int req_x, int req_offset,
                         int req_w, int req_bias, void *workspace, size_t workspace_bytes,
                         void *stream);
+/* Upsample(factor) of flow / mask between pyramid levels -- replaces the Gluon block
+ * /root/reference/network/MaskFlownet.py:35-62 (edge pad + Deconvolution with the triangle kernel
+ * 1-|f-1-a|/f, kernel 2f-1, stride f, pad f-1, last row/column dropped; call sites :228-229 ... :311).
+ * x: (N,C,H,W) -> out: (N,C,H*factor,W*factor); factor 1 copies.  Bit-identical to the fp32 oracle. */
+int mfn_upsample_fwd(const float *x, float *out, int N, int C, int H, int W, int factor, void *stream);
 /* Offset builder of /root/reference/network/MaskFlownet.py:230:
  *   offset[n, 2k+t, y, x] = flow_yx[n, t, y, x] * scale / stride   for k < taps. */
 int mfn_offsets_from_flow(const float *flow_yx, float *offset, int N, int H, int W, int taps,

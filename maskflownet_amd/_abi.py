@@ -19,6 +19,7 @@ SIGNATURES = {
     "correlation_fwd": (_i, [_f, _f, _f] + [_i] * 10 + [_s]),
     "correlation_workspace_bytes": (C.c_size_t, [_i] * 10),
     "correlation_fwd_ws": (_i, [_f, _f, _f] + [_i] * 10 + [C.c_void_p, C.c_size_t, _s]),
+    "correlation_fwd_act": (_i, [_f, _f, _f] + [_i] * 11 + [C.c_void_p, C.c_size_t, _s]),
     "warp_fwd": (_i, [_f, _f, _f] + [_i] * 5 + [_s]),
     "grid_generator_warp": (_i, [_f, _f, _i, _i, _i, _s]),
     "grid_generator_affine": (_i, [_f, _f, _i, _i, _i, _s]),
@@ -35,6 +36,7 @@ SIGNATURES = {
     "deform_conv_pack_weights": (_i, [_f] + [_i] * 15 + [C.c_void_p, C.c_size_t, C.POINTER(C.c_ulonglong), _s]),
     "deform_conv_fwd_packed": (_i, [_f, _f, C.c_void_p, C.c_size_t, C.c_ulonglong, _f, _f] + [_i] * 15 + [C.c_void_p, C.c_size_t, _s]),
     "deform_conv_shared_fwd_packed": (_i, [_f, _f, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_ulonglong, _f, _f] + [_i] * 12 + [C.c_void_p, C.c_size_t, _s]),
+    "upsample_fwd": (_i, [_f, _f] + [_i] * 5 + [_s]),
     "deform_conv_bwd_workspace_bytes": (C.c_size_t, [_i] * 15),
     "deform_conv_bwd": (_i, [_f] * 8 + [_i] * 19 + [C.c_void_p, C.c_size_t, _s]),
     "set_tuning": (_i, [C.c_char_p, _i]),

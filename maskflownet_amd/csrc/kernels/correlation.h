@@ -824,6 +824,7 @@ struct CorrGenericParams {
   int N, C, H, W;
   int md, kernel, stride1, stride2, pad, is_multiply;
   int top_c, top_h, top_w, radius, gw;
+  int leaky;  // fused LeakyReLU(0.1)
 };
 
 __global__ __launch_bounds__(256) void corr_generic_kernel(CorrGenericParams p) {
@@ -860,7 +861,8 @@ __global__ __launch_bounds__(256) void corr_generic_kernel(CorrGenericParams p) 
         }
       }
     }
-  p.out[idx] = s / (float)(p.kernel * p.kernel * p.C);
+  const float r = s / (float)(p.kernel * p.kernel * p.C);
+  p.out[idx] = p.leaky ? fmaxf(r, 0.1f * r) : r;
 }
 
 inline int corr_generic_launch(CorrGenericParams p, hipStream_t stream) {

@@ -231,9 +231,27 @@ class DeformableConv2D(nn.Module):
         return s.format(name=self.__class__.__name__, mapping="{0} -> {1}".format(cin, self._channels), **kw)
 
 
-def correlation(im1, im2, md, stride1=1, stride2=1):
-    """Body of MaskFlownet_S.corr / MaskFlownet.corr (MaskFlownet.py:193-195, :440-441)."""
+def correlation(im1, im2, md, stride1=1, stride2=1, leaky=False):
+    """Body of MaskFlownet_S.corr / MaskFlownet.corr (MaskFlownet.py:193-195, :440-441).  leaky=True also applies the
+    LeakyReLU(0.1) the network wraps around every call (:217) -- fused into the kernel epilogue at inference."""
     if _any_grad(im1, im2):
-        return _CorrelationFn.apply(im1, im2, md, stride1, stride2)
+        out = _CorrelationFn.apply(im1, im2, md, stride1, stride2)
+        return torch.nn.functional.leaky_relu(out, 0.1) if leaky else out
     return ops.Correlation(im1, im2, pad_size=md, kernel_size=1, max_displacement=md, stride1=stride1,
-                           stride2=stride2, is_multiply=1)
+                           stride2=stride2, is_multiply=1, activation="leaky" if leaky else None)
+
+
+class Upsample(nn.Module):
+    """Upsample(factor) of flow / mask between pyramid levels (MaskFlownet.py:35-62); forward only -- the network
+    back-propagates through it in training, which is not on the a7 rows and raises here."""
+
+    def __init__(self, factor, **kwargs):
+        super().__init__()
+        self.factor = int(factor)
+
+    def forward(self, img):
+        if self.factor == 1:
+            return img
+        if _any_grad(img):
+            raise NotImplementedError("Upsample: backward is not implemented (forward / inference only)")
+        return ops.Upsample(img, self.factor)

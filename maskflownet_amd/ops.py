@@ -50,7 +50,11 @@ class OpSet:
         return c.value, h.value, w.value
 
     def Correlation(self, data1, data2, kernel_size=1, max_displacement=1, stride1=1, stride2=1, pad_size=0,
-                    is_multiply=True, out=None):
+                    is_multiply=True, out=None, activation=None):
+        """activation="leaky": LeakyReLU(0.1) fused into the epilogue (the reference applies it to every cost
+        volume, MaskFlownet.py:217); bit-identical to the separate elementwise op."""
+        if activation not in (None, "leaky"):
+            raise ValueError("Correlation: activation must be None or 'leaky'")
         d1, d2 = self._in(data1, data2)
         if self.ad.ndim(d1) != 4 or self.ad.shape(d1) != self.ad.shape(d2):
             raise ValueError("Correlation: data1 and data2 must be 4-D with identical shapes, got %s and %s"
@@ -65,9 +69,10 @@ class OpSet:
                 int(bool(is_multiply)))
         nbytes = self.ns.correlation_workspace_bytes(*args)
         ws = self._workspace(d1, nbytes) if nbytes else None
-        self.check(self.ns.correlation_fwd_ws(self.ad.ptr(d1), self.ad.ptr(d2), self.ad.ptr(out), *args,
-                                              self.ad.ptr(ws) if ws is not None else None,
-                                              self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(d1)))
+        self.check(self.ns.correlation_fwd_act(self.ad.ptr(d1), self.ad.ptr(d2), self.ad.ptr(out), *args,
+                                               1 if activation == "leaky" else 0,
+                                               self.ad.ptr(ws) if ws is not None else None,
+                                               self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(d1)))
         return out
 
     def Correlation_backward(self, out_grad, data1, data2, kernel_size=1, max_displacement=1, stride1=1, stride2=1,
@@ -294,6 +299,20 @@ class OpSet:
                                                   self.ad.nbytes(ws), self.ad.stream(x)))
         return out
 
+    def Upsample(self, img, factor, out=None):
+        """MaskFlownet.py:35-62 Upsample(factor): (N,C,H,W) -> (N,C,H*factor,W*factor)."""
+        (x,) = self._in(img)
+        if self.ad.ndim(x) != 4:
+            raise ValueError("Upsample: data must be 4-D")
+        N, C, H, W = self.ad.shape(x)
+        factor = int(factor)
+        if factor < 1:
+            raise ValueError("Upsample: factor must be >= 1")
+        if out is None:
+            out = self.ad.empty(x, (N, C, H * factor, W * factor))
+        self.check(self.ns.upsample_fwd(self.ad.ptr(x), self.ad.ptr(out), N, C, H, W, factor, self.ad.stream(x)))
+        return out
+
     def offsets_from_flow(self, flow, scale, stride, taps=9, out=None):
         (fl,) = self._in(flow)
         N, two, H, W = self.ad.shape(fl)
@@ -398,3 +417,7 @@ def deformable_convolution_shared(*a, **k):
 
 def offsets_from_flow(*a, **k):
     return default_ops().offsets_from_flow(*a, **k)
+
+
+def Upsample(*a, **k):
+    return default_ops().Upsample(*a, **k)

@@ -48,6 +48,19 @@ def case_correlation(ops, oracle, to_dev, to_host, shape, md, seed=0, **tuning):
     return check_close(got, want, what="correlation %s md=%d" % (shape, md))
 
 
+def case_correlation_leaky(ops, oracle, to_dev, to_host, shape, md, seed=0, **kw):
+    """Fused LeakyReLU(0.1) epilogue == the separate elementwise op on the unfused output, bit for bit."""
+    rng = np.random.default_rng(99 + seed)
+    f1, f2 = feat(rng, shape), feat(rng, shape)
+    okw = dict(kernel_size=1, max_displacement=md, stride1=1, stride2=1, pad_size=md, is_multiply=True)
+    okw.update(kw)
+    plain = to_host(ops.Correlation(to_dev(f1), to_dev(f2), **okw))
+    fused = to_host(ops.Correlation(to_dev(f1), to_dev(f2), activation="leaky", **okw))
+    np.testing.assert_array_equal(fused, np.where(plain > 0, plain, np.float32(0.1) * plain))
+    want = oracle.correlation(f1, f2, **okw)
+    return check_close(fused, np.where(want > 0, want, np.float32(0.1) * want), what="correlation leaky %s" % (shape,))
+
+
 def case_correlation_generic(ops, oracle, to_dev, to_host, shape, seed=0, **kw):
     rng = np.random.default_rng(77 + seed)
     f1, f2 = feat(rng, shape), feat(rng, shape)
@@ -64,6 +77,16 @@ def case_warp(ops, oracle, to_dev, to_host, shape, clip, seed=0):
     got = to_host(ops.warp(to_dev(x), to_dev(fl), clip_grid=clip))
     want = oracle.warp(x, fl, clip_grid=clip)
     return check_close(got, want, what="warp %s clip=%s" % (shape, clip))
+
+
+def case_upsample(ops, oracle, to_dev, to_host, shape, factor, seed=0):
+    """Upsample(factor) (MaskFlownet.py:35-62): bit-identical to the fp32 oracle (same products, same order)."""
+    rng = np.random.default_rng(606 + seed)
+    x = rng.standard_normal(shape).astype(np.float32)
+    got = to_host(ops.Upsample(to_dev(x), factor))
+    want = oracle.upsample(x, factor)
+    np.testing.assert_array_equal(got, want)
+    return got
 
 
 def msra_weight(rng, cout, cin, k=3, slope=0.1):

@@ -82,6 +82,16 @@ def test_correlation_band_is_the_default_for_coarse_levels(ops, oracle):
     assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) > 0      # sliced + reduce path
 
 
+@pytest.mark.parametrize("tune,shape", [(dict(corr_variant=6, corr_tw=16), (1, 6, 7, 16)),          # tiled kernel
+                                        (dict(corr_variant=15), (1, 8, 6, 36)),                     # LDS-DMA tile kernel
+                                        (dict(corr_variant=6, corr_tw=16, corr_slices=2), (1, 16, 5, 16)),  # reduce kernel
+                                        (dict(corr_band=1), (2, 20, 6, 8)),                         # band kernel
+                                        (dict(corr_generic=1), (1, 3, 6, 7))])                      # generic kernel
+def test_correlation_fused_leaky_relu(ops, oracle, tune, shape):
+    emu_ops.set_tuning(**tune)
+    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, 4)
+
+
 def test_correlation_non_pow2_channels_divide(ops, oracle):
     pc.case_correlation(ops, oracle, ident, ident, (1, 12, 6, 8), 4)
 
@@ -103,6 +113,11 @@ def test_correlation_odd_width_uses_generic(ops, oracle):
 @pytest.mark.parametrize("clip", [False, True])
 def test_warp(ops, oracle, shape, clip):
     pc.case_warp(ops, oracle, ident, ident, shape, clip)
+
+
+@pytest.mark.parametrize("shape,factor", [((2, 2, 6, 8), 2), ((1, 3, 5, 7), 2), ((1, 2, 4, 6), 4), ((1, 1, 3, 5), 3), ((1, 2, 4, 4), 1)])
+def test_upsample(ops, oracle, shape, factor):
+    pc.case_upsample(ops, oracle, ident, ident, shape, factor)
 
 
 def test_grid_generator_and_sampler(ops, oracle):

@@ -328,6 +328,18 @@ def test_layer_packed_weight_cache_follows_the_parameter(oracle, T):
                                                      kernel=(3, 3), pad=(1, 1)), what="new input shape")
 
 
+@pytest.mark.parametrize("shape", CFG2)
+def test_correlation_fused_leaky_relu_all_levels(ops, oracle, dev, shape):
+    pc.case_correlation_leaky(ops, oracle, dev, host, shape, 4)
+
+
+@pytest.mark.parametrize("shape,factor", [((8, 2, 6, 8), 2), ((8, 2, 48, 64), 2), ((8, 2, 96, 128), 4), ((4, 1, 112, 256), 4),
+                                          ((2, 3, 7, 9), 2), ((1, 2, 5, 6), 3)])
+def test_upsample_flow_and_mask(ops, oracle, dev, shape, factor):
+    # Upsample(2) between levels and Upsample(4) of the final flow (MaskFlownet.py:228-229, :311): bit-exact
+    pc.case_upsample(ops, oracle, dev, host, shape, factor)
+
+
 def test_hot_path_prepacked_equals_stateless(T):
     from maskflownet_amd import hotpath
     a = hotpath.HotPathWorkload("tiny", device="cuda", prepack=True).run_eager()
