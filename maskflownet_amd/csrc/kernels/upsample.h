@@ -5,7 +5,8 @@
 // kernel k[a] = 1 - |f-1-a|/f (kernel 2f-1, stride f, pad f-1), drop the last row/column.  Semantics as
 // oracle/mfn_ref_body.inc upsample.  Written as a gather: output (oy,ox) has at most 2x2 contributing inputs,
 //   iy0 = oy / f with weight 1 - r/f  and  iy0 + 1 (clamped to H-1: the edge pad) with weight r/f,   r = oy % f,
-// accumulated in the oracle's raster order with separately rounded multiplies and adds, so results are bit-identical.
+// accumulated in the oracle's raster order with separately rounded multiplies and adds (fp contraction off), so
+// results are bit-identical.
 // HBM-bound: 4*N*C*H*W*(1 + f*f) bytes; one thread writes 4 adjacent outputs with one 16-byte store.
 #pragma once
 #include "../mfn_rt.h"
@@ -18,12 +19,16 @@ struct UpsampleParams {
   int N, C, H, W, f;
 };
 
+// hipcc contracts a*b+c into FMAs by default (and HIP's __fmul_rn / __fadd_rn are plain operators, not barriers);
+// the oracle (gcc -ffp-contract=off) rounds every product and sum separately, so contraction is switched off here.
 __device__ __forceinline__ float upsample_tri(int cc, int a) {
+#pragma clang fp contract(off)
   return 1.f - fabsf((float)(cc - a)) / (float)(cc + 1);  // the reference's _kernel2d entry, same rounding
 }
 
 template <int VEC>
 __global__ __launch_bounds__(256) void upsample_kernel(UpsampleParams p) {
+#pragma clang fp contract(off)
   const int f = p.f, cc = f - 1;
   const int Hout = p.H * f, Wout = p.W * f;
   const int wv = Wout / VEC;
@@ -48,11 +53,11 @@ __global__ __launch_bounds__(256) void upsample_kernel(UpsampleParams p) {
     const float kb0 = upsample_tri(cc, rx + f - 1);
     const float kb1 = rx ? upsample_tri(cc, rx - 1) : 0.f;
     // dst += v * (ka * kb) in raster order of the contributing inputs; no contraction into FMAs
-    float acc = __fmul_rn(r0[ix0], __fmul_rn(ka0, kb0));
-    if (rx) acc = __fadd_rn(acc, __fmul_rn(r0[ix1], __fmul_rn(ka0, kb1)));
+    float acc = r0[ix0] * (ka0 * kb0);
+    if (rx) acc = acc + r0[ix1] * (ka0 * kb1);
     if (ry) {
-      acc = __fadd_rn(acc, __fmul_rn(r1[ix0], __fmul_rn(ka1, kb0)));
-      if (rx) acc = __fadd_rn(acc, __fmul_rn(r1[ix1], __fmul_rn(ka1, kb1)));
+      acc = acc + r1[ix0] * (ka1 * kb0);
+      if (rx) acc = acc + r1[ix1] * (ka1 * kb1);
     }
     o[k] = acc;
   }

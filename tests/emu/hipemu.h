@@ -169,10 +169,6 @@ static inline int __syncthreads_and(int pred) {
   return ok;
 }
 
-// separately rounded fp32 multiply / add (the host build has no FMA contraction: no -mfma, see build_emu.py)
-static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
-static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
-
 static inline float atomicAdd(float *p, float v) { return std::atomic_ref<float>(*p).fetch_add(v, std::memory_order_relaxed); }
 
 // v_mfma_f32_32x32x2_f32: A lane l = A[i=l&31][k=l>>5], B lane l = B[k=l>>5][j=l&31],
