@@ -285,11 +285,8 @@ __global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(Defor
     int clo = px_valid ? ax.idx[0] : big, chi = px_valid ? ax.idx[3] : -big;
     const int nlo = 0, nhi = 0;  // windows are only staged under 2-D tiles, which never span two images
     if (p.tile_w && fast) {
-      MFN_UNROLL
-      for (int sft = 32; sft >= 1; sft >>= 1) {
-        rlo = min(rlo, __shfl_xor(rlo, sft)); rhi = max(rhi, __shfl_xor(rhi, sft));
-        clo = min(clo, __shfl_xor(clo, sft)); chi = max(chi, __shfl_xor(chi, sft));
-      }
+      rlo = mfn_wave_min_i32(rlo); rhi = mfn_wave_max_i32(rhi);
+      clo = mfn_wave_min_i32(clo); chi = mfn_wave_max_i32(chi);
     }
     wr0 = rlo;
     wc0 = clo & ~3;  // 16-byte aligned window origin

@@ -28,6 +28,14 @@ static inline f32x2 mfn_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x,
 #define MFN_OPAQUE(x) ((void)(x))
 #define MFN_SCHED_BARRIER() ((void)0)
 #define MFN_UNIFORM(x) (x)
+// wave-wide integer min / max, same value in every lane
+#define MFN_WAVE_REDUCE_EMU(name, op)                                  \
+  static inline int name(int v) {                                     \
+    for (int s = 32; s >= 1; s >>= 1) v = op(v, __shfl_xor(v, s));     \
+    return v;                                                          \
+  }
+MFN_WAVE_REDUCE_EMU(mfn_wave_min_i32, std::min)
+MFN_WAVE_REDUCE_EMU(mfn_wave_max_i32, std::max)
 // LDS-DMA emulation: synchronous copy (ordering of the real asynchronous engine is checked on the GPU)
 struct mfn_rsrc_t { const char *base; unsigned nrec; };
 static inline mfn_rsrc_t mfn_make_rsrc(const void *p, unsigned nbytes) { return mfn_rsrc_t{(const char *)p, nbytes}; }
@@ -72,6 +80,28 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
 #define MFN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MFN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define MFN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// wave-wide integer min / max as a DPP scan (row_shr 1,2,4,8, row_bcast 15/31: six v_min/max_i32_dpp, no LDS
+// round trips as ds_bpermute shuffles would need); the result comes back wave-uniform from lane 63
+__device__ __forceinline__ int mfn_wave_min_i32(int v) {
+  const int id = 0x7fffffff;
+  v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x111, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x112, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x114, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x118, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x142, 0xa, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int mfn_wave_max_i32(int v) {
+  const int id = (int)0x80000000;
+  v = max(v, __builtin_amdgcn_update_dpp(id, v, 0x111, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(id, v, 0x112, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(id, v, 0x114, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(id, v, 0x118, 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(id, v, 0x142, 0xa, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false));
+  return __builtin_amdgcn_readlane(v, 63);
+}
 // ---- LDS-DMA (buffer_load_dwordx4 ... lds): global -> LDS without a VGPR round trip ------------------
 // Issued through inline asm on purpose: hipcc waits vmcnt(0) before any ds_read that follows a DMA it
 // knows about, which would serialise the staging ring.  Counting is therefore ours: MFN_WAIT_VM(n).
