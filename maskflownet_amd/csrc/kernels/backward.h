@@ -13,6 +13,7 @@
 // req semantics (MXNet OpReqType): 0 = skip, 1 = write, 3 = add to the existing contents.
 #pragma once
 #include "../mfn_rt.h"
+#include "correlation.h"
 #include "deform_conv.h"
 #include "warp.h"
 
@@ -62,6 +63,115 @@ __global__ __launch_bounds__(256) void corr_bwd_gather_kernel(CorrBwdParams p) {
   }
   if (p.req1) p.g1[idx] = (p.req1 == 3 ? p.g1[idx] : 0.f) + s1;
   if (p.req2) p.g2[idx] = (p.req2 == 3 ? p.g2[idx] : 0.f) + s2;
+}
+
+// Register-blocked form for W % 4 == 0: a thread owns 4 adjacent pixels x 4 channels.  Per displacement row it
+// loads the nine gout quads once for all four channels and, per channel, one 12-wide window of the other feature
+// map (three aligned 16-byte loads, whole quads outside the image read as zero) that serves all nine dx --
+// 0.15 sixteen-byte loads per FMA instead of 2 scalar loads, and one multiply by 1/C at the end instead of a
+// division per term.  For g2 the roles swap: the window slides over gout's displaced row.
+__global__ __launch_bounds__(256) void corr_bwd_block_kernel(CorrBwdParams p) {
+  constexpr int CB = 4;
+  const int W = p.W, H = p.H, C = p.C, D = p.D, md = p.md;
+  const int QW = W >> 2, CG = (C + CB - 1) / CB;
+  const size_t plane = (size_t)H * W;
+  const size_t total = (size_t)p.N * CG * H * QW;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int qx = (int)(idx % QW), y = (int)((idx / QW) % H);
+  const int cg = (int)((idx / ((size_t)QW * H)) % CG), n = (int)(idx / ((size_t)QW * H * CG));
+  const int x = 4 * qx, c0 = cg * CB;
+  const float *go = p.gout + (size_t)n * D * D * plane;
+  const float *f1n = p.f1 + ((size_t)n * C) * plane, *f2n = p.f2 + ((size_t)n * C) * plane;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // 12-wide window [x-4, x+8) of one row; quads outside [0, W) are zero (W % 4 == 0: a quad is in or out as a whole)
+  // every load is unconditional (clamped address) and zeroed by a select afterwards: a branch per load would make
+  // hipcc wait for each one before issuing the next (cdna_hip_programming.md section 5, trap c)
+  const int xl = max(x - 4, 0), xr = min(x + 4, W - 4);
+  const bool okl = x >= 4, okr = x + 4 < W;
+  auto window = [&](const float *row, bool row_ok, float (&v)[12]) {
+    const float4 a = zero_unless(row_ok && okl, *reinterpret_cast<const float4 *>(row + xl));
+    const float4 b = zero_unless(row_ok, *reinterpret_cast<const float4 *>(row + x));
+    const float4 c = zero_unless(row_ok && okr, *reinterpret_cast<const float4 *>(row + xr));
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+  };
+  float s1[CB][4], s2[CB][4];
+  MFN_UNROLL
+  for (int k = 0; k < CB; ++k)
+    MFN_UNROLL
+    for (int q = 0; q < 4; ++q) { s1[k][q] = 0.f; s2[k][q] = 0.f; }
+
+  if (p.req1) {  // g1[c,y,x+q] = sum_d gout[d,y,x+q] * f2[c,y+dy,x+q+dx]
+    for (int iy = 0; iy < D; ++iy) {
+      const int y2u = y + iy - md;
+      const bool rok = y2u >= 0 && y2u < H;
+      const int y2 = min(max(y2u, 0), H - 1);
+      float4 g[9];
+      MFN_UNROLL
+      for (int ix = 0; ix < 9; ++ix)
+        g[ix] = zero_unless(ix < D, *reinterpret_cast<const float4 *>(go + (size_t)(iy * D + min(ix, D - 1)) * plane +
+                                                                      (size_t)y * W + x));
+      MFN_UNROLL
+      for (int k = 0; k < CB; ++k) {
+        float bv[12];
+        window(f2n + (size_t)min(c0 + k, C - 1) * plane + (size_t)y2 * W, rok && c0 + k < C, bv);
+        // window index of pixel q displaced by dx = ix - md: q + dx + 4.  D == 9 and D == 5 (md = 4, 2) are the two
+        // compile-time shapes; entries ix >= D carry zero gout
+        MFN_UNROLL
+        for (int ix = 0; ix < 9; ++ix) {
+          const int o9 = ix, o5 = min(ix + 2, 8);
+          const float b0 = D == 9 ? bv[o9 + 0] : bv[o5 + 0], b1 = D == 9 ? bv[o9 + 1] : bv[o5 + 1];
+          const float b2 = D == 9 ? bv[o9 + 2] : bv[o5 + 2], b3 = D == 9 ? bv[o9 + 3] : bv[o5 + 3];
+          s1[k][0] = fmaf(g[ix].x, b0, s1[k][0]);
+          s1[k][1] = fmaf(g[ix].y, b1, s1[k][1]);
+          s1[k][2] = fmaf(g[ix].z, b2, s1[k][2]);
+          s1[k][3] = fmaf(g[ix].w, b3, s1[k][3]);
+        }
+      }
+    }
+  }
+  if (p.req2) {  // g2[c,y,x+q] = sum_d gout[d,y-dy,x+q-dx] * f1[c,y-dy,x+q-dx]
+    for (int iy = 0; iy < D; ++iy) {
+      const int ysu = y - (iy - md);
+      const bool rok = ysu >= 0 && ysu < H;
+      const int ys = min(max(ysu, 0), H - 1);
+      float av[CB][12];
+      MFN_UNROLL
+      for (int k = 0; k < CB; ++k)
+        window(f1n + (size_t)min(c0 + k, C - 1) * plane + (size_t)ys * W, rok && c0 + k < C, av[k]);
+      MFN_UNROLL
+      for (int ix = 0; ix < 9; ++ix) {
+        float gv[12];
+        window(go + (size_t)(iy * D + min(ix, D - 1)) * plane + (size_t)ys * W, rok && ix < D, gv);
+        // window index of source pixel q - dx = q + 4 - (ix - md): 8 - ix for md = 4, 6 - ix for md = 2
+        const int o9 = 8 - ix, o5 = max(6 - ix, 0);
+        MFN_UNROLL
+        for (int k = 0; k < CB; ++k)
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q) {
+            const float gq = D == 9 ? gv[o9 + q] : gv[o5 + q], aq = D == 9 ? av[k][o9 + q] : av[k][o5 + q];
+            s2[k][q] = fmaf(gq, aq, s2[k][q]);
+          }
+      }
+    }
+  }
+  const float inv = 1.0f / (float)C;
+  MFN_UNROLL
+  for (int k = 0; k < CB; ++k) {
+    if (c0 + k >= C) break;
+    const size_t o = ((size_t)n * C + c0 + k) * plane + (size_t)y * W + x;
+    if (p.req1) {
+      float4 r = make_float4(s1[k][0] * inv, s1[k][1] * inv, s1[k][2] * inv, s1[k][3] * inv);
+      if (p.req1 == 3) { const float4 old = *reinterpret_cast<const float4 *>(p.g1 + o); r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+      *reinterpret_cast<float4 *>(p.g1 + o) = r;
+    }
+    if (p.req2) {
+      float4 r = make_float4(s2[k][0] * inv, s2[k][1] * inv, s2[k][2] * inv, s2[k][3] * inv);
+      if (p.req2 == 3) { const float4 old = *reinterpret_cast<const float4 *>(p.g2 + o); r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+      *reinterpret_cast<float4 *>(p.g2 + o) = r;
+    }
+  }
 }
 
 struct CorrBwdGenericParams {
@@ -126,16 +236,20 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpBwdParams p) {
   const bool y0 = ty >= 0 && ty <= p.H - 1, y1 = ty + 1 >= 0 && ty + 1 <= p.H - 1;
   const bool x0 = tx >= 0 && tx <= p.W - 1, x1 = tx + 1 >= 0 && tx + 1 <= p.W - 1;
   float gwy = 0.f, gwx = 0.f;
+  const int cy0 = min(max(ty, 0), p.H - 1), cy1 = min(max(ty + 1, 0), p.H - 1);
+  const int cx0 = min(max(tx, 0), p.W - 1), cx1 = min(max(tx + 1, 0), p.W - 1);
+  const int i00 = cy0 * p.W + cx0, i01 = cy0 * p.W + cx1, i10 = cy1 * p.W + cx0, i11 = cy1 * p.W + cx1;
   for (int c = 0; c < p.C; ++c) {
     const size_t cb = (n * p.C + c) * plane;
     const float g = p.gout[cb + pix];
     const float *pl = p.x + cb;
-    const size_t i00 = (size_t)min(max(ty, 0), p.H - 1) * p.W + min(max(tx, 0), p.W - 1);
-    const float tl = (y0 && x0) ? pl[(size_t)ty * p.W + tx] : 0.f;
-    const float tr = (y0 && x1) ? pl[(size_t)ty * p.W + tx + 1] : 0.f;
-    const float bl = (y1 && x0) ? pl[(size_t)(ty + 1) * p.W + tx] : 0.f;
-    const float br = (y1 && x1) ? pl[(size_t)(ty + 1) * p.W + tx + 1] : 0.f;
-    (void)i00;
+    // unconditional loads at clamped addresses, masked by a select afterwards: a branch per load would make the
+    // compiler wait for each before issuing the next
+    const float vtl = pl[i00], vtr = pl[i01], vbl = pl[i10], vbr = pl[i11];
+    const float tl = (y0 && x0) ? vtl : 0.f;
+    const float tr = (y0 && x1) ? vtr : 0.f;
+    const float bl = (y1 && x0) ? vbl : 0.f;
+    const float br = (y1 && x1) ? vbr : 0.f;
     if (p.req_x) {
       float *gp = p.gx + cb;
       if (y0 && x0) atomicAdd(gp + (size_t)ty * p.W + tx, g * wy * wx);

@@ -212,6 +212,13 @@ def test_correlation_backward(ops, oracle, kw):
     pc.case_correlation_bwd(ops, oracle, ident, ident, (2, 5, 9, 10), **kw)
 
 
+@pytest.mark.parametrize("shape,kw", [((2, 5, 9, 12), dict()), ((1, 8, 6, 16), dict(max_displacement=2, pad_size=2)),
+                                      ((1, 3, 5, 4), dict())])
+def test_correlation_backward_register_blocked(ops, oracle, shape, kw):
+    # W % 4 == 0: 4 px x 4 channels per thread (ragged channel group, image narrower than the window)
+    pc.case_correlation_bwd(ops, oracle, ident, ident, shape, **kw)
+
+
 @pytest.mark.parametrize("clip", [False, True])
 def test_warp_backward(ops, oracle, clip):
     pc.case_warp_bwd(ops, oracle, ident, ident, (2, 3, 8, 11), clip)
