@@ -159,6 +159,42 @@ def case_deform_packed(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0,
     return pk
 
 
+def case_edge_inputs(ops, oracle, to_dev, to_host):
+    """Edge cases of the domain: empty batch, one-pixel-wide planes, flows / offsets far outside the image and
+    non-finite flow values (must not fault; finite inputs elsewhere give the oracle's values)."""
+    rng = np.random.default_rng(5150)
+    # empty batch: every op returns an empty tensor of the right shape without launching
+    z = np.zeros((0, 4, 6, 8), np.float32)
+    assert tuple(to_host(ops.Correlation(to_dev(z), to_dev(z), 1, 4, 1, 1, 4, True)).shape) == (0, 81, 6, 8)
+    assert tuple(to_host(ops.warp(to_dev(z), to_dev(np.zeros((0, 2, 6, 8), np.float32)))).shape) == (0, 4, 6, 8)
+    w = msra_weight(rng, 4, 4)
+    assert tuple(to_host(ops.DeformableConvolution(to_dev(z), to_dev(np.zeros((0, 18, 6, 8), np.float32)), to_dev(w), None,
+                                                   kernel=(3, 3), pad=(1, 1), no_bias=True)).shape) == (0, 4, 6, 8)
+    # 1x1 and 1xW planes
+    for shape in ((2, 3, 1, 1), (1, 2, 1, 8), (1, 2, 5, 1)):
+        f1, f2 = feat(rng, shape), feat(rng, shape)
+        check_close(to_host(ops.Correlation(to_dev(f1), to_dev(f2), 1, 4, 1, 1, 4, True)),
+                    oracle.correlation(f1, f2, max_displacement=4, pad_size=4), what="corr %s" % (shape,))
+        # (warp on a size-1 axis is undefined in MXNet itself -- GridGenerator divides by (size-1)/2 = 0 and the sampler
+        # casts the NaN coordinate to int -- so it is not part of the contract; the kernel returns zeros there)
+    # flows of +-1e9 px and +-inf: everything lands outside (zeros) or on the border (clip); no NaN from the index math
+    x = rng.standard_normal((1, 2, 6, 8)).astype(np.float32)
+    fl = np.zeros((1, 2, 6, 8), np.float32)
+    fl[0, 0, 0, 0], fl[0, 1, 0, 1], fl[0, 0, 1, 0], fl[0, 1, 1, 1] = 1e9, -1e9, 1e15, -1e15
+    for clip in (False, True):
+        got, want = to_host(ops.warp(to_dev(x), to_dev(fl), clip_grid=clip)), oracle.warp(x, fl, clip_grid=clip)
+        assert np.isfinite(got).all()
+        check_close(got, want, what="warp huge flow clip=%s" % clip)
+    fl[0, 0, 2, 0], fl[0, 1, 2, 1] = np.inf, -np.inf   # non-finite flow: MXNet yields NaN there; here it must not fault
+    got = to_host(ops.warp(to_dev(x), to_dev(fl), clip_grid=False))
+    assert np.isfinite(np.delete(got.reshape(2, -1), [16, 17], axis=1)).all()
+    # deformable conv with every offset far outside: output = bias
+    xs = feat(rng, (1, 4, 5, 8)); b = (rng.standard_normal(4) * 0.1).astype(np.float32)
+    off = np.full((1, 18, 5, 8), 1.0e6, np.float32)
+    got = to_host(ops.DeformableConvolution(to_dev(xs), to_dev(off), to_dev(w), to_dev(b), kernel=(3, 3), pad=(1, 1)))
+    np.testing.assert_array_equal(got, np.broadcast_to(b[None, :, None, None], got.shape))
+
+
 # ---- backward (SURVEY.md section 8 row a7) ------------------------------------------------------------------
 def case_correlation_bwd(ops, oracle, to_dev, to_host, shape, seed=0, **kw):
     rng = np.random.default_rng(31 + seed)

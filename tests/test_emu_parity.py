@@ -242,6 +242,10 @@ def test_backward_req_add_and_null(ops, oracle):
     pc.check_close(g1, w1 + 1.0, what="req add")
 
 
+def test_edge_inputs(ops, oracle):
+    pc.case_edge_inputs(ops, oracle, ident, ident)
+
+
 def test_errors_read_like_mxnet(ops):
     x = np.zeros((1, 2, 4, 4), np.float32)
     with pytest.raises(RuntimeError, match="odd"):

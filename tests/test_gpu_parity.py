@@ -340,6 +340,10 @@ def test_upsample_flow_and_mask(ops, oracle, dev, shape, factor):
     pc.case_upsample(ops, oracle, dev, host, shape, factor)
 
 
+def test_edge_inputs(ops, oracle, dev):
+    pc.case_edge_inputs(ops, oracle, dev, host)
+
+
 def test_hot_path_prepacked_equals_stateless(T):
     from maskflownet_amd import hotpath
     a = hotpath.HotPathWorkload("tiny", device="cuda", prepack=True).run_eager()
