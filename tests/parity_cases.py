@@ -170,6 +170,9 @@ def case_edge_inputs(ops, oracle, to_dev, to_host):
     w = msra_weight(rng, 4, 4)
     assert tuple(to_host(ops.DeformableConvolution(to_dev(z), to_dev(np.zeros((0, 18, 6, 8), np.float32)), to_dev(w), None,
                                                    kernel=(3, 3), pad=(1, 1), no_bias=True)).shape) == (0, 4, 6, 8)
+    gx, goff, gw, gb = ops.DeformableConvolution_backward(to_dev(z), to_dev(z), to_dev(np.zeros((0, 18, 6, 8), np.float32)),
+                                                          to_dev(w), kernel=(3, 3), pad=(1, 1))
+    assert not to_host(gw).any() and not to_host(gb).any() and tuple(to_host(gx).shape) == (0, 4, 6, 8)
     # 1x1 and 1xW planes
     for shape in ((2, 3, 1, 1), (1, 2, 1, 8), (1, 2, 5, 1)):
         f1, f2 = feat(rng, shape), feat(rng, shape)
