@@ -451,6 +451,119 @@ __global__ __launch_bounds__(256) void dc_bwd_weight_kernel(DcBwdParams p) {
   }
 }
 
+// ---- weight gradient on the fp32 MFMA (groups == 1, one deformable group) -----------------------------------
+// gw[o, k] (+)= sum_p gout[o, p] * col[k, p],  k = c*T + t  (the layout of gw itself),  p over all (n, ho, wo).
+// v_mfma_f32_32x32x2_f32 with the PIXELS as the reduction dimension: A[i=o][k=p] comes from an LDS tile of gout,
+// B[k=p][j=combo] is the deformable-im2col value of combo j at pixel p, which lane (j, p&1) forms itself from a
+// per-tile geometry table in LDS (4 bilinear weights + base index per (pixel, tap): any per-tap offsets) and 4
+// gathers.  A block = 4 waves = 4 x 32 combos x MTO filter tiles over one slice of the pixels; slices and combo
+// groups are spread over the grid and the partial sums meet in gw through fp32 atomics (as goffset / gx do).
+struct DcBwdWParams {
+  const float *gout, *x, *offset;
+  float *gw;
+  float *gbias;            // or NULL: the bias gradient (row sums of gout) rides along in the combo-group-0 blocks
+  int N, Cin, H, W, Cout, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
+  int P, K2, T;            // N*Ho*Wo, Cin*T, kh*kw
+  int tiles_per_block;     // 32-pixel tiles each block walks
+};
+template <int MTO>
+__global__ __launch_bounds__(256) void dc_bwd_weight_mfma_kernel(DcBwdWParams p) {
+  constexpr int GW = 8;   // words per (pixel, tap) geometry entry: w1..w4, base, dhW|dwi, image offset, pad
+  constexpr int GS = 33;  // gout tile row stride (32 pixels + 1: the 32 filter rows of an A operand on distinct banks)
+  MFN_DYN_SHARED(float, lds);
+  float *geom = lds;                              // [32][T][GW]
+  float *gs = lds + 32 * p.T * GW;                // [MTO*32][GS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = MFN_UNIFORM(tid >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  const int T = p.T;
+  const size_t oplane = (size_t)p.Ho * p.Wo, plane = (size_t)p.H * p.W;
+  const int o0 = blockIdx.z * (MTO * 32);
+  const int k = (blockIdx.y * 4 + wave) * 32 + j;  // this lane's combo
+  const bool k_ok = k < p.K2;
+  const int kc = k_ok ? k : 0;
+  const int c = kc / T, t = kc - c * T;
+  f32x16 acc[MTO];
+  MFN_UNROLL
+  for (int m = 0; m < MTO; ++m)
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  float bsum = 0.f;  // thread tid < MTO*32 of a combo-group-0 block: sum of gout row o0 + tid over this block's pixels
+  const int tile0 = blockIdx.x * p.tiles_per_block;
+  for (int tl = 0; tl < p.tiles_per_block; ++tl) {
+    const int pbase = (tile0 + tl) * 32;
+    if (pbase >= p.P) break;  // uniform
+    __syncthreads();          // the previous tile's readers are done
+    // geometry table: one entry per (pixel, tap)
+    for (int e = tid; e < 32 * T; e += 256) {
+      const int pp = e / T, tt = e - pp * T;
+      const int pl = pbase + pp;
+      const bool ok = pl < p.P;
+      const int pc = ok ? pl : 0;
+      const int n = pc / (int)oplane, rem = pc - n * (int)oplane;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      const float *op = p.offset + (size_t)n * 2 * T * oplane + rem;
+      const int ti = tt / p.kw, tj = tt - ti * p.kw;
+      const DcTap tp = dc_make_tap(op[(size_t)(2 * tt) * oplane], op[(size_t)(2 * tt + 1) * oplane], ho * p.sh - p.ph,
+                                   wo * p.sw - p.pw, ti * p.dh, tj * p.dw, p.H, p.W, ok);
+      float *g = geom + (size_t)e * GW;
+      g[0] = tp.w1; g[1] = tp.w2; g[2] = tp.w3; g[3] = tp.w4;
+      reinterpret_cast<int *>(g)[4] = tp.base;                       // bit 30 = dwi
+      reinterpret_cast<int *>(g)[5] = tp.dhW;
+      reinterpret_cast<int *>(g)[6] = n * p.Cin * (int)plane;        // element offset of image n (checked < 2^31)
+    }
+    // gout tile [filter][pixel]
+    for (int e = tid; e < MTO * 32 * 32; e += 256) {
+      const int ol = e >> 5, pp = e & 31;
+      const int pl = pbase + pp, o = o0 + ol;
+      float v = 0.f;
+      if (pl < p.P && o < p.Cout) {
+        const int n = pl / (int)oplane, rem = pl - n * (int)oplane;
+        v = p.gout[((size_t)n * p.Cout + o) * oplane + rem];
+      }
+      gs[ol * GS + pp] = v;
+    }
+    __syncthreads();
+    if (p.gbias && blockIdx.y == 0 && tid < MTO * 32) {
+      MFN_UNROLL
+      for (int pp = 0; pp < 32; ++pp) bsum += gs[tid * GS + pp];
+    }
+    MFN_UNROLL
+    for (int s = 0; s < 16; ++s) {
+      const int pp = 2 * s + half;
+      const float *g = geom + (size_t)(pp * T + t) * GW;
+      const int base = reinterpret_cast<const int *>(g)[4], dhW = reinterpret_cast<const int *>(g)[5];
+      const int ioff = reinterpret_cast<const int *>(g)[6];
+      const int bb = base & 0x3FFFFFFF, dwi = (base >> 30) & 1;
+      const float *pl = p.x + (size_t)ioff + (size_t)c * plane;
+      const float v1 = pl[bb], v2 = pl[bb + dwi], v3 = pl[bb + dhW], v4 = pl[bb + dhW + dwi];
+      float col = g[0] * v1 + g[1] * v2 + g[2] * v3 + g[3] * v4;
+      col = k_ok ? col : 0.f;
+      MFN_UNROLL
+      for (int m = 0; m < MTO; ++m) acc[m] = MFN_MFMA_32x32x2(gs[(m * 32 + j) * GS + pp], col, acc[m]);
+    }
+  }
+  if (p.gbias && blockIdx.y == 0 && tid < MTO * 32 && o0 + tid < p.Cout) atomicAdd(p.gbias + o0 + tid, bsum);
+  // D reg r of lane (j, half): filter row (r&3)+8*(r>>2)+4*half, combo j
+  if (!k_ok) return;
+  MFN_UNROLL
+  for (int m = 0; m < MTO; ++m)
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (o < p.Cout) atomicAdd(p.gw + (size_t)o * p.K2 + k, acc[m][r]);
+    }
+}
+template <int MTO>
+inline int dc_bwd_weight_mfma_launch(DcBwdWParams p, int pixel_slices, hipStream_t stream) {
+  const int tiles = cdiv(p.P, 32);
+  p.tiles_per_block = cdiv(tiles, pixel_slices);
+  const dim3 grid(cdiv(tiles, p.tiles_per_block), cdiv(cdiv(p.K2, 32), 4), cdiv(p.Cout, MTO * 32));
+  const size_t lds = ((size_t)32 * p.T * 8 + (size_t)MTO * 32 * 33) * sizeof(float);
+  return launch("dc_bwd_weight_mfma", dc_bwd_weight_mfma_kernel<MTO>, grid, dim3(256), lds, stream, p);
+}
+
 // bias gradient: block per filter, sum over (n, pixel)
 __global__ __launch_bounds__(256) void dc_bwd_bias_kernel(DcBwdParams p) {
   MFN_DYN_SHARED(float, red);
