@@ -564,6 +564,168 @@ inline int dc_bwd_weight_mfma_launch(DcBwdWParams p, int pixel_slices, hipStream
   return launch("dc_bwd_weight_mfma", dc_bwd_weight_mfma_kernel<MTO>, grid, dim3(256), lds, stream, p);
 }
 
+// ---- input + offset gradients on the fp32 MFMA with LDS-privatised scatter (groups == 1, dg == 1, stride 1) -----
+// cg[(c,t), p] = sum_o W[o,c,t] * gout[o,p] is a GEMM: D[channel][pixel] per tap with K = Cout, A = W (read in place),
+// B = gout (coalesced).  The scatter of cg into gx (deformable_col2im) is what bounds MXNet's kernel and the simple
+// one here: 36 global fp32 atomics per (pixel, channel), ~57 G/s on this chip.  Here a block owns an 8x16 pixel tile
+// of one image and 32 input channels and accumulates gx in an LDS window (16 rows x 24 columns per channel, placed by
+// the offset of the tile's centre pixel) with LDS atomics; only contributions that fall outside the window (rough
+// flows) go to global memory directly, and the window is flushed once -- about 3 global atomics per (pixel, channel).
+// goffset is summed over the block's channels in registers and LDS the same way.  The bilinear corner weights are
+// the forward's (dc_make_tap): for every tap MXNet's get_gradient_weight equals them (oracle-checked).
+struct DcBwdIParams {
+  const float *gout, *x, *offset, *w;
+  float *gx, *goffset;
+  int N, Cin, H, W, Cout, kh, kw, ph, pw, dh, dw;  // stride 1: Ho == H, Wo == W
+  int T, tiles_x, tiles_y;
+  int req_x, req_offset;
+};
+constexpr int DCI_TH = 8, DCI_TW = 16, DCI_WR = 16, DCI_WC = 24, DCI_GW = 8;
+__global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) {
+  constexpr int TH = DCI_TH, TW = DCI_TW, WR = DCI_WR, WC = DCI_WC, GW = DCI_GW;
+  MFN_DYN_SHARED(float, lds);
+  float *win = lds;                                // [32 channels][WR][WC]
+  float *gof = win + 32 * WR * WC;                 // [TH*TW pixels][2*T]
+  float *geom = gof + TH * TW * 2 * p.T;           // [32 pixels][T][GW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = MFN_UNIFORM(tid >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  const int T = p.T, H = p.H, W = p.W;
+  const size_t plane = (size_t)H * W;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int n = blockIdx.x / tpi, rt = blockIdx.x - n * tpi;
+  const int ty0 = (rt / p.tiles_x) * TH, tx0 = (rt % p.tiles_x) * TW;
+  const int cb = blockIdx.y * 32;
+  // window origin: follows the offset of the tile's centre pixel (centre tap)
+  int wy0, wx0;
+  {
+    const int cy = min(ty0 + TH / 2, H - 1), cx = min(tx0 + TW / 2, W - 1);
+    const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
+    const float oh = op[(size_t)(2 * (T / 2)) * plane], ow = op[(size_t)(2 * (T / 2) + 1) * plane];
+    const float fh = fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), fw = fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
+    wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - (WR - (TH + p.dh * (p.kh - 1) + 1)) / 2);
+    wx0 = MFN_UNIFORM(tx0 - p.pw + (int)fw - (WC - (TW + p.dw * (p.kw - 1) + 1)) / 2);
+  }
+  for (int e = tid; e < 32 * WR * WC + TH * TW * 2 * T; e += 256) lds[e] = 0.f;
+
+  for (int sub = 0; sub < 4; ++sub) {  // 2 x 16 pixels at a time share one geometry table
+    __syncthreads();
+    for (int e = tid; e < 32 * T; e += 256) {
+      const int pp = e / T, tt = e - pp * T;
+      const int y = ty0 + sub * 2 + (pp >> 4), x = tx0 + (pp & 15);
+      const bool ok = y < H && x < W;
+      const int yc = min(y, H - 1), xc = min(x, W - 1);
+      const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)yc * W + xc;
+      const float oh = op[(size_t)(2 * tt) * plane], ow = op[(size_t)(2 * tt + 1) * plane];
+      const int ti = tt / p.kw, tj = tt - ti * p.kw;
+      const int h_in = yc - p.ph, w_in = xc - p.pw;
+      bool vh, vw;
+      int hl, hh, wl, wh;
+      float lh, lw;
+      dc_axis(oh, h_in, ti * p.dh, H, vh, hl, hh, lh);
+      dc_axis(ow, w_in, tj * p.dw, W, vw, wl, wh, lw);
+      const bool valid = vh && vw && ok;
+      float *g = geom + (size_t)e * GW;
+      g[0] = valid ? (1.f - lh) * (1.f - lw) : 0.f;
+      g[1] = valid ? (1.f - lh) * lw : 0.f;
+      g[2] = valid ? lh * (1.f - lw) : 0.f;
+      g[3] = valid ? lh * lw : 0.f;
+      int *gi = reinterpret_cast<int *>(g);
+      gi[4] = valid ? (((h_in + hl) & 0xFFFF) << 16) | ((w_in + wl) & 0xFFFF) : 0;  // top-left corner (row, column)
+      gi[5] = valid ? ((hh - hl) << 1) | (wh - wl) : 0;                              // corner steps
+      g[6] = valid ? (float)(h_in + ti * p.dh) + oh : -1.f;                          // sampling position (inv_h, inv_w),
+      g[7] = valid ? (float)(w_in + tj * p.dw) + ow : -1.f;                          // -1: outside -> no offset gradient
+    }
+    __syncthreads();
+    const int py = ty0 + sub * 2 + (j >> 4), px = tx0 + (j & 15);
+    const bool pix_ok = py < H && px < W;
+    const size_t pix = (size_t)min(py, H - 1) * W + min(px, W - 1);
+    for (int t = wave; t < T; t += 4) {
+      f32x16 acc;
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // D[channel][pixel] += W[o][channel][t] * gout[o][pixel]
+      const int ca = cb + j;  // A row = channel
+      const float *wa = p.w + ((size_t)(ca < p.Cin ? ca : 0) * T + t);
+      const float *gb = p.gout + (size_t)n * p.Cout * plane + pix;
+      for (int s2 = 0; s2 < p.Cout; s2 += 2) {
+        const int o = s2 + half;
+        const bool ook = o < p.Cout;
+        const float a = (ook && ca < p.Cin) ? wa[(size_t)(ook ? o : 0) * p.Cin * T] : 0.f;
+        const float b = (ook && pix_ok) ? gb[(size_t)(ook ? o : 0) * plane] : 0.f;
+        acc = MFN_MFMA_32x32x2(a, b, acc);
+      }
+      const float *g = geom + (size_t)(j * T + t) * GW;
+      const int *gi = reinterpret_cast<const int *>(g);
+      const float w1 = g[0], w2 = g[1], w3 = g[2], w4 = g[3];
+      const int cy = gi[4] >> 16, cx = gi[4] & 0xFFFF, dyi = (gi[5] >> 1) & 1, dxi = gi[5] & 1;
+      const float ah0 = g[6], aw0 = g[7];
+      // deformable_col2im_coord: 4 samples around (ah, aw) with MXNet's clamping, weights for d/dh and d/dw
+      const bool cin_ok = ah0 >= 0.f && aw0 >= 0.f && ah0 < (float)H && aw0 < (float)W;
+      float ah = cin_ok ? ah0 : 0.f, aw = cin_ok ? aw0 : 0.f;
+      int hl = (int)ah, wl = (int)aw, hh, wh;
+      if (hl >= H - 1) { hh = hl = H - 1; ah = (float)hl; } else hh = hl + 1;
+      if (wl >= W - 1) { wh = wl = W - 1; aw = (float)wl; } else wh = wl + 1;
+      const int i11 = hl * W + wl, i12 = hl * W + wh, i21 = hh * W + wl, i22 = hh * W + wh;
+      const float fw0 = (float)(wl + 1) - aw, fw1 = aw - (float)wl, fh0 = (float)(hl + 1) - ah, fh1 = ah - (float)hl;
+      float acc_h = 0.f, acc_w = 0.f;
+      const int ry = cy - wy0, rx = cx - wx0;  // corner (0,0) inside the window?
+      const bool in00 = ry >= 0 && ry < WR && rx >= 0 && rx < WC;
+      const bool in01 = ry >= 0 && ry < WR && rx + dxi >= 0 && rx + dxi < WC;
+      const bool in10 = ry + dyi >= 0 && ry + dyi < WR && rx >= 0 && rx < WC;
+      const bool in11 = ry + dyi >= 0 && ry + dyi < WR && rx + dxi >= 0 && rx + dxi < WC;
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;  // D reg r of lane (j, half): channel row
+        const int c = cb + cl;
+        if (c >= p.Cin) continue;
+        const float cg = acc[r];
+        if (p.req_offset) {
+          const float *im = p.x + ((size_t)n * p.Cin + c) * plane;
+          const float v11 = im[i11], v12 = im[i12], v21 = im[i21], v22 = im[i22];
+          if (cin_ok) {
+            acc_h += (-fw0 * v11 - fw1 * v12 + fw0 * v21 + fw1 * v22) * cg;
+            acc_w += (-fh0 * v11 + fh0 * v12 - fh1 * v21 + fh1 * v22) * cg;
+          }
+        }
+        if (p.req_x) {
+          float *wc_ = win + (size_t)cl * WR * WC;
+          float *gim = p.gx + ((size_t)n * p.Cin + c) * plane;
+          const float c1 = w1 * cg, c2 = w2 * cg, c3 = w3 * cg, c4 = w4 * cg;
+          if (c1 != 0.f) { if (in00) atomicAdd(wc_ + ry * WC + rx, c1); else atomicAdd(gim + (size_t)cy * W + cx, c1); }
+          if (c2 != 0.f) { if (in01) atomicAdd(wc_ + ry * WC + rx + dxi, c2); else atomicAdd(gim + (size_t)cy * W + cx + dxi, c2); }
+          if (c3 != 0.f) { if (in10) atomicAdd(wc_ + (ry + dyi) * WC + rx, c3); else atomicAdd(gim + (size_t)(cy + dyi) * W + cx, c3); }
+          if (c4 != 0.f) { if (in11) atomicAdd(wc_ + (ry + dyi) * WC + rx + dxi, c4); else atomicAdd(gim + (size_t)(cy + dyi) * W + cx + dxi, c4); }
+        }
+      }
+      if (p.req_offset && pix_ok) {
+        float *go_ = gof + (size_t)(sub * 32 + j) * 2 * T;
+        atomicAdd(go_ + 2 * t, acc_h);
+        atomicAdd(go_ + 2 * t + 1, acc_w);
+      }
+    }
+  }
+  __syncthreads();
+  // flush: one global atomic per touched window cell / offset-gradient entry
+  if (p.req_x)
+    for (int e = tid; e < 32 * WR * WC; e += 256) {
+      const float v = win[e];
+      if (v == 0.f) continue;
+      const int cl = e / (WR * WC), rem = e - cl * (WR * WC);
+      const int yy = wy0 + rem / WC, xx = wx0 + rem % WC;
+      if (cb + cl < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        atomicAdd(p.gx + ((size_t)n * p.Cin + cb + cl) * plane + (size_t)yy * W + xx, v);
+    }
+  if (p.req_offset)
+    for (int e = tid; e < TH * TW * 2 * T; e += 256) {
+      const float v = gof[e];
+      if (v == 0.f) continue;
+      const int pp = e / (2 * T), ch = e - pp * 2 * T;
+      const int y = ty0 + (pp >> 5) * 2 + ((pp & 31) >> 4), x = tx0 + (pp & 15);
+      if (y < H && x < W) atomicAdd(p.goffset + ((size_t)n * 2 * T + ch) * plane + (size_t)y * W + x, v);
+    }
+}
+
 // bias gradient: block per filter, sum over (n, pixel)
 __global__ __launch_bounds__(256) void dc_bwd_bias_kernel(DcBwdParams p) {
   MFN_DYN_SHARED(float, red);

@@ -231,6 +231,13 @@ def test_deform_conv_backward(ops, oracle, kw):
     pc.case_deform_bwd(ops, oracle, ident, ident, 2, 4, 6, 6, 7, **kw)
 
 
+@pytest.mark.parametrize("shape", [(1, 40, 36, 10, 20),   # two channel blocks (ragged), partial 8x16 tiles, 2 filter tiles
+                                   (2, 5, 70, 17, 33)])   # three filter tiles, odd sizes
+def test_deform_conv_backward_mfma_paths(ops, oracle, shape):
+    # tile kernel (LDS window + out-of-window fallback: offsets of sigma 1.5 px around 0) and MFMA weight gradient
+    pc.case_deform_bwd(ops, oracle, ident, ident, *shape, kernel=(3, 3), pad=(1, 1))
+
+
 def test_backward_req_add_and_null(ops, oracle):
     rng = np.random.default_rng(2)
     f1, f2 = pc.feat(rng, (1, 3, 6, 8)), pc.feat(rng, (1, 3, 6, 8))
