@@ -648,12 +648,21 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
       const int ca = cb + j;  // A row = channel
       const float *wa = p.w + ((size_t)(ca < p.Cin ? ca : 0) * T + t);
       const float *gb = p.gout + (size_t)n * p.Cout * plane + pix;
-      for (int s2 = 0; s2 < p.Cout; s2 += 2) {
-        const int o = s2 + half;
-        const bool ook = o < p.Cout;
-        const float a = (ook && ca < p.Cin) ? wa[(size_t)(ook ? o : 0) * p.Cin * T] : 0.f;
-        const float b = (ook && pix_ok) ? gb[(size_t)(ook ? o : 0) * plane] : 0.f;
-        acc = MFN_MFMA_32x32x2(a, b, acc);
+      // four k-steps per trip: eight unconditional loads in flight (clamped rows, zeroed by selects) before the MFMAs
+      for (int s2 = 0; s2 < p.Cout; s2 += 8) {
+        float a[4], b[4];
+        MFN_UNROLL
+        for (int u = 0; u < 4; ++u) {
+          const int o = s2 + 2 * u + half;
+          const int oc = min(o, p.Cout - 1);
+          a[u] = wa[(size_t)oc * p.Cin * T];
+          b[u] = gb[(size_t)oc * plane];
+        }
+        MFN_UNROLL
+        for (int u = 0; u < 4; ++u) {
+          const bool ook = s2 + 2 * u + half < p.Cout;
+          acc = MFN_MFMA_32x32x2((ook && ca < p.Cin) ? a[u] : 0.f, (ook && pix_ok) ? b[u] : 0.f, acc);
+        }
       }
       const float *g = geom + (size_t)(j * T + t) * GW;
       const int *gi = reinterpret_cast<const int *>(g);
