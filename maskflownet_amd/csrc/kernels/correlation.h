@@ -353,7 +353,7 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
 //   5: 2 dy/wave, 1 chunk,  CK=4, prefetch,    >=3 waves/SIMD   (5-wave blocks)
 //   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=4 waves/SIMD
 //   7: 3 dy/wave, 1 chunk,  CK=4, no prefetch, >=2 waves/SIMD
-constexpr int kCorrVariants = 20;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-19: corr_dma_kernel
+constexpr int kCorrVariants = 24;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-23: corr_dma_kernel (20-23: channel groups)
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
@@ -626,8 +626,11 @@ inline int corr_hw_variant(const CorrParams &p, int variant, hipStream_t s) {
 //     missing tail channels are items whose byte offset is out of the descriptor's range -> the
 //     hardware writes zeros;
 //   * per stage: counted s_waitcnt vmcnt, ONE raw s_barrier, issue stage ch+NS-1, consume stage ch.
-template <int D, int CK, int NS, int WPE, bool DBUF>
-__global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrParams p) {
+//   * G > 1: G channel groups inside the block (each its own ring over 1/G of the channels), accumulators added
+//     through LDS at the end -- for levels whose tile count leaves CUs idle (level 3: 192 tiles), no workspace and
+//     no second launch.
+template <int D, int CK, int NS, int WPE, bool DBUF, int G = 1>
+__global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(CorrParams p) {
   constexpr int MD = (D - 1) / 2;
   constexpr int NW = (D + 1) / 2;
   constexpr int NT = NW * 64;
@@ -642,10 +645,13 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrP
   constexpr int OFF = 4 - MD;
   static_assert(CK % 4 == 0 && (ITEMS1 % 64) == 0, "f1/f2 split must fall on a wave boundary");
 
-  MFN_DYN_SHARED(float, lds);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = MFN_UNIFORM(tid >> 6);
+  MFN_DYN_SHARED(float, lds_all);
+  const int lane = threadIdx.x & 63;
+  const int wave_all = MFN_UNIFORM(threadIdx.x >> 6);
+  const int grp = G > 1 ? wave_all / NW : 0;       // channel group of this wave
+  const int wave = wave_all - grp * NW;            // wave inside the group
+  const int tid = wave * 64 + lane;                // thread inside the group
+  float *lds = lds_all + (size_t)grp * NS * STAGE_F;
   MFN_STAMP(p.timeline, 0);
   const int dyi = wave * 2 + (lane >> 5);
   const bool live = dyi < D;
@@ -661,8 +667,12 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrP
   const int y0 = ty * TH, x0 = tx * 32;
   const int H = p.H, W = p.W, C = p.C;
   const size_t plane = (size_t)H * W;
-  const int c_begin = blockIdx.y * p.slice_channels;
-  const int c_end = min(C, c_begin + p.slice_channels);
+  const int s_begin = blockIdx.y * p.slice_channels;
+  const int s_end = min(C, s_begin + p.slice_channels);
+  // every group walks the same number of CK-channel stages (block-wide barriers); a short last group reads zeros
+  const int gch = G > 1 ? ((s_end - s_begin + G * CK - 1) / (G * CK)) * CK : s_end - s_begin;
+  const int c_begin = s_begin + grp * gch;
+  const int c_end = min(s_end, c_begin + gch);
   const float *f1n = p.f1 + (size_t)n * C * plane;
   const float *f2n = p.f2 + (size_t)n * C * plane;
 
@@ -703,10 +713,11 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrP
 
   auto issue = [&](int ch) {  // stage ch -> ring slot ch % NS
     const int c0 = c_begin + ch * CK;
-    const int cleft = min(CK, c_end - c0);
+    const int cleft = max(0, min(CK, c_end - c0));
     const unsigned nrec = (unsigned)((size_t)cleft * plane * 4);
-    const mfn_rsrc_t r1 = mfn_make_rsrc(f1n + (size_t)c0 * plane, nrec);
-    const mfn_rsrc_t r2 = mfn_make_rsrc(f2n + (size_t)c0 * plane, nrec);
+    const int cb = cleft ? c0 : 0;  // an empty stage (short last group) reads nothing: every lane out of range
+    const mfn_rsrc_t r1 = mfn_make_rsrc(f1n + (size_t)cb * plane, nrec);
+    const mfn_rsrc_t r2 = mfn_make_rsrc(f2n + (size_t)cb * plane, nrec);
     float *slot = lds + (ch % NS) * STAGE_F;
     MFN_UNROLL
     for (int i = 0; i < NI; ++i) {
@@ -719,7 +730,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrP
     corr_hw_consume<D, CK, F1_PER_C, F2_PER_C, DBUF>(slot + f1_off, slot + f2_off, accp, accs);
   };
 
-  const int nchunks = (c_end - c_begin + CK - 1) / CK;
+  const int nchunks = G > 1 ? gch / CK : (c_end - c_begin + CK - 1) / CK;
   MFN_UNROLL
   for (int s0 = 0; s0 < NS - 1; ++s0)
     if (s0 < nchunks) issue(s0);
@@ -736,6 +747,32 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrP
     consume(ch);
   }
   MFN_STAMP(p.timeline, 2);
+  if (G > 1) {  // add the groups' accumulators in index order (deterministic); group 0 owns the epilogue
+    constexpr int NACC = 4 * (D - 1) + 4;
+    float *red = lds_all;  // [G-1][NACC][NT]
+    MFN_WAIT_LGKM0();
+    __syncthreads();       // every ring is dead
+    if (grp > 0) {
+      float *dst = red + (size_t)(grp - 1) * NACC * NT + tid;
+      MFN_UNROLL
+      for (int d = 0; d < D - 1; ++d)
+        MFN_UNROLL
+        for (int h = 0; h < 2; ++h) { dst[(d * 4 + h * 2) * NT] = accp[d][h].x; dst[(d * 4 + h * 2 + 1) * NT] = accp[d][h].y; }
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) dst[(4 * (D - 1) + q) * NT] = accs[q];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+    for (int g2 = 1; g2 < G; ++g2) {
+      const float *src = red + (size_t)(g2 - 1) * NACC * NT + tid;
+      MFN_UNROLL
+      for (int d = 0; d < D - 1; ++d)
+        MFN_UNROLL
+        for (int h = 0; h < 2; ++h) { accp[d][h].x += src[(d * 4 + h * 2) * NT]; accp[d][h].y += src[(d * 4 + h * 2 + 1) * NT]; }
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) accs[q] += src[(4 * (D - 1) + q) * NT];
+    }
+  }
 
 #define ACC1(d, q)                                                                        \
   (((q) & 1) ? ((d) < D - 1 ? accp[(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[2 + ((q) - 1) / 2]) \
@@ -764,7 +801,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_dma_kernel(CorrP
 #undef ACC1
 }
 
-template <int D, int CK, int NS, int WPE, bool DBUF>
+template <int D, int CK, int NS, int WPE, bool DBUF, int G = 1>
 inline int corr_dma_launch(CorrParams p, hipStream_t stream, const char *name) {
   constexpr int MD = (D - 1) / 2;
   constexpr int NT = ((D + 1) / 2) * 64;
@@ -774,8 +811,10 @@ inline int corr_dma_launch(CorrParams p, hipStream_t stream, const char *name) {
   p.tiles_y = cdiv(p.H, 4);
   const int nblk = p.N * p.tiles_x * p.tiles_y;
   if (nblk <= 0) return 0;
-  const size_t lds = (size_t)NS * NI * NT * 16;
-  return launch(name, corr_dma_kernel<D, CK, NS, WPE, DBUF>, dim3(nblk, p.nslices), dim3(NT), lds, stream, p);
+  const size_t ring = (size_t)G * NS * NI * NT * 16;
+  const size_t red = (size_t)(G - 1) * (4 * (D - 1) + 4) * NT * sizeof(float);
+  return launch(name, corr_dma_kernel<D, CK, NS, WPE, DBUF, G>, dim3(nblk, p.nslices), dim3(NT * G), ring > red ? ring : red,
+                stream, p);
 }
 // variants 12..19 of corr.variant: (CK, ring stages, min waves/SIMD, double-buffered operands)
 template <int D>
@@ -788,7 +827,11 @@ inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
     case 16: return corr_dma_launch<D, 4, 2, 5, false>(p, s, "corr_dma_v16");
     case 17: return corr_dma_launch<D, 8, 2, 5, false>(p, s, "corr_dma_v17");
     case 18: return corr_dma_launch<D, 4, 3, 5, false>(p, s, "corr_dma_v18");
-    default: return corr_dma_launch<D, 4, 4, 5, false>(p, s, "corr_dma_v19");
+    case 19: return corr_dma_launch<D, 4, 4, 5, false>(p, s, "corr_dma_v19");
+    case 20: return corr_dma_launch<D, 8, 2, 2, true, 2>(p, s, "corr_dma_v20");   // 15 with two channel groups
+    case 21: return corr_dma_launch<D, 8, 2, 2, false, 2>(p, s, "corr_dma_v21");  // 17 with two channel groups
+    case 22: return corr_dma_launch<D, 8, 2, 1, true, 3>(p, s, "corr_dma_v22");   // 15 with three channel groups
+    default: return corr_dma_launch<D, 4, 2, 1, false, 3>(p, s, "corr_dma_v23");  // 16 with three channel groups
   }
 }
 

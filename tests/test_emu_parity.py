@@ -24,11 +24,20 @@ def _reset_tuning():
                        dc_generic=0, dc_tile=0)
 
 
-@pytest.mark.parametrize("variant", range(20))
+@pytest.mark.parametrize("variant", range(24))
 def test_correlation_variants_md4(ops, oracle, variant):
     emu_ops.set_tuning(corr_variant=variant)
     # ragged tiles in both directions: H=10 is not a multiple of any tile height, W=72 > TW=64
     pc.case_correlation(ops, oracle, ident, ident, (1, 6, 10, 72), 4)
+
+
+@pytest.mark.parametrize("variant", [20, 21, 22, 23])
+@pytest.mark.parametrize("C", [20, 48])
+def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
+    # two / three channel groups per block, ragged last group (20 = 16+4 or 8+8+4), added through LDS in index order
+    emu_ops.set_tuning(corr_variant=variant)
+    pc.case_correlation(ops, oracle, ident, ident, (1, C, 6, 40), 4)
+    pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 32), 2, seed=2)
 
 
 @pytest.mark.parametrize("tw,shape", [(32, (2, 5, 9, 36)), (16, (1, 9, 18, 20)), (8, (1, 3, 6, 8)), (64, (1, 4, 5, 64))])
@@ -75,11 +84,11 @@ def test_correlation_band_kernel(ops, oracle, shape, md):
 def test_correlation_band_is_the_default_for_coarse_levels(ops, oracle):
     pc.case_correlation(ops, oracle, ident, ident, (1, 24, 12, 16), 4)
     assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) == 0    # level 5: band kernel, no partials
-    assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) == 0     # level 4: band kernel
-    assert ops.ns.correlation_workspace_bytes(8, 64, 48, 64, 4, 1, 1, 1, 4, 1) == 0     # level 3: tiled, unsliced
+    assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) == 0     # level 4: in-block channel groups
+    assert ops.ns.correlation_workspace_bytes(8, 64, 48, 64, 4, 1, 1, 1, 4, 1) == 0     # level 3: in-block channel groups
     assert ops.ns.correlation_workspace_bytes(8, 196, 6, 8, 4, 1, 1, 1, 4, 1) > 0       # level 6: slices + reduce
     emu_ops.set_tuning(corr_band=2)
-    assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) > 0      # sliced + reduce path
+    assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) > 0     # sliced + reduce path
 
 
 @pytest.mark.parametrize("tune,shape", [(dict(corr_variant=6, corr_tw=16), (1, 6, 7, 16)),          # tiled kernel

@@ -53,7 +53,7 @@ def test_correlation_md2_cascade_levels(ops, oracle, dev, shape):
     pc.case_correlation(ops, oracle, dev, host, shape, 2)  # full MaskFlownet, MaskFlownet.py:322
 
 
-@pytest.mark.parametrize("variant", range(20))
+@pytest.mark.parametrize("variant", range(24))
 def test_correlation_every_variant(ops, oracle, dev, variant):
     from maskflownet_amd import _lib
     _lib.set_tuning(corr_variant=variant)

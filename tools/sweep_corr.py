@@ -46,17 +46,17 @@ def event_us(fn, iters=30):
 
 for cfg in ("cfg2", "cfg3"):
     N, H, W = hotpath.CONFIGS[cfg]
-    for l in (2, 3):
+    for l in (2, 3, 4):
         n, c, h, w = hotpath.level_shapes(N, H, W)[l]
         f1 = torch.randn(n, c, h, w, device="cuda"); f2 = torch.randn(n, c, h, w, device="cuda")
         out = torch.empty(n, 81, h, w, device="cuda")
         fn = lambda: ops.Correlation(f1, f2, 1, 4, 1, 1, 4, True, out=out)
         rows = []
-        for v in list(range(8, 20)) + [-1]:
-            _lib.set_tuning(corr_variant=v, corr_slices=1 if v >= 0 else 0)
+        for v in list(range(12, 24)) + [-1]:
+            _lib.set_tuning(corr_variant=v, corr_slices=1 if v >= 0 else 0, corr_band=2 if v >= 0 else 0)
             rows.append((graph_us(fn), event_us(fn), v))
         rows.sort()
         nb = 4 * n * h * w * (2 * c + 81)
         print("%s L%d (%d MB): " % (cfg, l, nb // 1000000) + "  ".join("v%d %.1f/%.1f" % (v, g, e) for g, e, v in rows[:6])
               + "   [in-graph us / event us]", flush=True)
-_lib.set_tuning(corr_variant=-1, corr_slices=0)
+_lib.set_tuning(corr_variant=-1, corr_slices=0, corr_band=0)
