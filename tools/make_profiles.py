@@ -19,7 +19,8 @@ if os.path.exists(db):
         f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline`\n\n" % tag)
         f.write("MI355X (gfx950), ROCm 7.2.  Source: gpurun_out/prof_bench/bench_results.db (top_kernels view); durations in "
                 "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (level 6: sliced pair "
-                "+ reduce; levels 5/4: band kernel; levels 3/2: LDS-DMA tile kernel), 4 x (offsets + deformable conv), 1 warp.\n"
+                "+ reduce; level 5: band kernel; levels 4/3: LDS-DMA tile kernel with in-block channel groups; level 2: "
+                "LDS-DMA tile kernel), 4 x (offsets + deformable conv), 1 warp.\n"
                 "Only `mfn::` kernels belong to the pass; the `at::native` rows are bench.py's checksum.\n\n")
         f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows:
