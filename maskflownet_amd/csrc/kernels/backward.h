@@ -565,14 +565,16 @@ inline int dc_bwd_weight_mfma_launch(DcBwdWParams p, int pixel_slices, hipStream
 }
 
 // ---- input + offset gradients on the fp32 MFMA with LDS-privatised scatter (groups == 1, dg == 1, stride 1) -----
-// cg[(c,t), p] = sum_o W[o,c,t] * gout[o,p] is a GEMM: D[channel][pixel] per tap with K = Cout, A = W (read in place),
-// B = gout (coalesced).  The scatter of cg into gx (deformable_col2im) is what bounds MXNet's kernel and the simple
-// one here: 36 global fp32 atomics per (pixel, channel), ~57 G/s on this chip.  Here a block owns an 8x16 pixel tile
-// of one image and 32 input channels and accumulates gx in an LDS window (16 rows x 24 columns per channel, placed by
-// the offset of the tile's centre pixel) with LDS atomics; only contributions that fall outside the window (rough
-// flows) go to global memory directly, and the window is flushed once -- about 3 global atomics per (pixel, channel).
-// goffset is summed over the block's channels in registers and LDS the same way.  The bilinear corner weights are
-// the forward's (dc_make_tap): for every tap MXNet's get_gradient_weight equals them (oracle-checked).
+// cg[(c,t), p] = sum_o W[o,c,t] * gout[o,p] is a GEMM: D[pixel][channel] per tap with K = Cout, A = gout (coalesced),
+// B = W (read in place).  The scatter of cg into gx (deformable_col2im) is what bounds MXNet's kernel and the simple
+// one here: 36 global fp32 atomics per (pixel, channel) at ~57 G/s.  LDS float atomics are no way out either (measured
+// ~3 cycles per lane).  So the scatter is arranged to need NO atomics: a wave owns a 2x16 pixel strip and 32 channels,
+// lane j owns channel j (D column), walks the strip's pixels (D rows) and adds cg * bilinear weight into ITS OWN
+// channel plane of a wave-private LDS window (8 rows x 24 columns, placed by the offset of the block's centre pixel)
+// with plain read-add-write; the two half-waves hold different pixels of the same channel and take turns.  The four
+// strips of a block (8x16 pixels) are merged and flushed once with ~3 global atomics per (pixel, channel); only
+// contributions outside a window (rough flows) go to global memory directly.  goffset is reduced over the 32 channels
+// with a DPP scan.  The bilinear corner weights are the forward's (dc_axis): MXNet's get_gradient_weight equals them.
 struct DcBwdIParams {
   const float *gout, *x, *offset, *w;
   float *gx, *goffset;
@@ -580,15 +582,17 @@ struct DcBwdIParams {
   int T, tiles_x, tiles_y;
   int req_x, req_offset;
 };
-constexpr int DCI_TH = 8, DCI_TW = 16, DCI_WR = 16, DCI_WC = 24, DCI_GW = 8;
+constexpr int DCI_TH = 8, DCI_TW = 16, DCI_WR = 8, DCI_WC = 24, DCI_GW = 16;
+constexpr int DCI_PLANE = DCI_WR * DCI_WC + 1;  // odd channel-plane stride: the 32 lanes (channels) hit distinct banks
+constexpr size_t dc_bwd_input_lds_bytes() { return ((size_t)4 * 32 * DCI_PLANE + (size_t)4 * 32 * DCI_GW) * sizeof(float); }
+
 __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) {
-  constexpr int TH = DCI_TH, TW = DCI_TW, WR = DCI_WR, WC = DCI_WC, GW = DCI_GW;
+  constexpr int TH = DCI_TH, TW = DCI_TW, WR = DCI_WR, WC = DCI_WC, GW = DCI_GW, PL = DCI_PLANE;
   MFN_DYN_SHARED(float, lds);
-  float *win = lds;                                // [32 channels][WR][WC]
-  float *gof = win + 32 * WR * WC;                 // [TH*TW pixels][2*T]
-  float *geom = gof + TH * TW * 2 * p.T;           // [32 pixels][T][GW]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = MFN_UNIFORM(tid >> 6);
+  float *win = lds + (size_t)wave * 32 * PL;                      // [32 channels][WR][WC] (+1), this wave's strip
+  float *geom = lds + (size_t)4 * 32 * PL + (size_t)wave * 32 * GW;  // [32 pixels][GW], rebuilt for every tap
   const int j = lane & 31, half = lane >> 5;
   const int T = p.T, H = p.H, W = p.W;
   const size_t plane = (size_t)H * W;
@@ -596,143 +600,162 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   const int n = blockIdx.x / tpi, rt = blockIdx.x - n * tpi;
   const int ty0 = (rt / p.tiles_x) * TH, tx0 = (rt % p.tiles_x) * TW;
   const int cb = blockIdx.y * 32;
-  // window origin: follows the offset of the tile's centre pixel (centre tap)
+  // window origin of the block: follows the offset of the tile's centre pixel (centre tap); strip w sits 2w rows lower
   int wy0, wx0;
   {
     const int cy = min(ty0 + TH / 2, H - 1), cx = min(tx0 + TW / 2, W - 1);
     const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
     const float oh = op[(size_t)(2 * (T / 2)) * plane], ow = op[(size_t)(2 * (T / 2) + 1) * plane];
     const float fh = fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), fw = fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
-    wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - (WR - (TH + p.dh * (p.kh - 1) + 1)) / 2);
+    wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - 2 + 2 * wave);  // strip rows: 2 + dh*(kh-1) + 1 = 5 of the 8, 2 above
     wx0 = MFN_UNIFORM(tx0 - p.pw + (int)fw - (WC - (TW + p.dw * (p.kw - 1) + 1)) / 2);
   }
-  for (int e = tid; e < 32 * WR * WC + TH * TW * 2 * T; e += 256) lds[e] = 0.f;
+  for (int e = lane; e < 32 * PL; e += 64) win[e] = 0.f;
 
-  for (int sub = 0; sub < 4; ++sub) {  // 2 x 16 pixels at a time share one geometry table
-    __syncthreads();
-    for (int e = tid; e < 32 * T; e += 256) {
-      const int pp = e / T, tt = e - pp * T;
-      const int y = ty0 + sub * 2 + (pp >> 4), x = tx0 + (pp & 15);
-      const bool ok = y < H && x < W;
-      const int yc = min(y, H - 1), xc = min(x, W - 1);
-      const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)yc * W + xc;
-      const float oh = op[(size_t)(2 * tt) * plane], ow = op[(size_t)(2 * tt + 1) * plane];
-      const int ti = tt / p.kw, tj = tt - ti * p.kw;
-      const int h_in = yc - p.ph, w_in = xc - p.pw;
+  // this lane as a PIXEL of the strip (geometry build, MFMA A operand) ...
+  const int py = ty0 + 2 * wave + (j >> 4), px = tx0 + (j & 15);
+  const bool pix_ok = py < H && px < W;
+  const int pyc = min(py, H - 1), pxc = min(px, W - 1);
+  const size_t pix = (size_t)pyc * W + pxc;
+  // ... and as a CHANNEL (MFMA B operand, D column, owner of one window plane)
+  const int c = cb + j;
+  const bool c_ok = c < p.Cin;
+  float *wpl = win + (size_t)j * PL;
+  int half_o = half;
+  MFN_OPAQUE(half_o);
+  float *gim = p.gx + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
+  const float *im = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
+
+  for (int t = 0; t < T; ++t) {
+    // ---- geometry of the strip's 32 pixels for tap t (lanes 0..31 write, everyone reads it back as broadcasts)
+    MFN_WAIT_LGKM0();  // the previous tap's readers are done (wave-private table: no block barrier)
+    if (half == 0) {
+      const float *op = p.offset + (size_t)n * 2 * T * plane + pix;
+      const float oh = op[(size_t)(2 * t) * plane], ow = op[(size_t)(2 * t + 1) * plane];
+      const int ti = t / p.kw, tj = t - ti * p.kw;
+      const int h_in = pyc - p.ph, w_in = pxc - p.pw;
       bool vh, vw;
       int hl, hh, wl, wh;
       float lh, lw;
       dc_axis(oh, h_in, ti * p.dh, H, vh, hl, hh, lh);
       dc_axis(ow, w_in, tj * p.dw, W, vw, wl, wh, lw);
-      const bool valid = vh && vw && ok;
-      float *g = geom + (size_t)e * GW;
+      const bool valid = vh && vw && pix_ok;
+      const int cy = h_in + hl, cx = w_in + wl, dyi = hh - hl, dxi = wh - wl;
+      const int ry = cy - wy0, rx = cx - wx0;
+      const bool iny0 = ry >= 0 && ry < WR, iny1 = ry + dyi >= 0 && ry + dyi < WR;
+      const bool inx0 = rx >= 0 && rx < WC, inx1 = rx + dxi >= 0 && rx + dxi < WC;
+      float *g = geom + (size_t)j * GW;
+      int *gi = reinterpret_cast<int *>(g);
       g[0] = valid ? (1.f - lh) * (1.f - lw) : 0.f;
       g[1] = valid ? (1.f - lh) * lw : 0.f;
       g[2] = valid ? lh * (1.f - lw) : 0.f;
       g[3] = valid ? lh * lw : 0.f;
-      int *gi = reinterpret_cast<int *>(g);
-      gi[4] = valid ? (((h_in + hl) & 0xFFFF) << 16) | ((w_in + wl) & 0xFFFF) : 0;  // top-left corner (row, column)
-      gi[5] = valid ? ((hh - hl) << 1) | (wh - wl) : 0;                              // corner steps
-      g[6] = valid ? (float)(h_in + ti * p.dh) + oh : -1.f;                          // sampling position (inv_h, inv_w),
-      g[7] = valid ? (float)(w_in + tj * p.dw) + ow : -1.f;                          // -1: outside -> no offset gradient
+      gi[4] = valid ? ry * WC + rx : 0;                                        // cell of corner (0,0) in the window
+      gi[5] = valid ? (dyi << 5) | (dxi << 4) | ((iny0 && inx0) ? 1 : 0) | ((iny0 && inx1) ? 2 : 0) |
+                          ((iny1 && inx0) ? 4 : 0) | ((iny1 && inx1) ? 8 : 0) : 0;  // corner steps, in-window bits
+      gi[6] = valid ? cy * W + cx : 0;                                         // the same corner in the image plane
+      // deformable_col2im_coord at (inv_h, inv_w): 4 samples with MXNet's clamping, weights of d/dh and d/dw
+      float ah = valid ? (float)(h_in + ti * p.dh) + oh : 0.f, aw = valid ? (float)(w_in + tj * p.dw) + ow : 0.f;
+      int chl = (int)ah, cwl = (int)aw, chh, cwh;
+      if (chl >= H - 1) { chh = chl = H - 1; ah = (float)chl; } else chh = chl + 1;
+      if (cwl >= W - 1) { cwh = cwl = W - 1; aw = (float)cwl; } else cwh = cwl + 1;
+      gi[7] = chl * W + cwl;
+      gi[8] = ((chh - chl) << 1) | (cwh - cwl) | (valid ? 4 : 0);
+      g[9] = (float)(cwl + 1) - aw;   // fw0
+      g[10] = aw - (float)cwl;        // fw1
+      g[11] = (float)(chl + 1) - ah;  // fh0
+      g[12] = ah - (float)chl;        // fh1
     }
-    __syncthreads();
-    const int py = ty0 + sub * 2 + (j >> 4), px = tx0 + (j & 15);
-    const bool pix_ok = py < H && px < W;
-    const size_t pix = (size_t)min(py, H - 1) * W + min(px, W - 1);
-    for (int t = wave; t < T; t += 4) {
-      f32x16 acc;
+    MFN_WAIT_LGKM0();
+    // ---- D[pixel][channel] = sum_o gout[o][pixel] * W[o][channel][t]
+    f32x16 acc;
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float *ga = p.gout + (size_t)n * p.Cout * plane + pix;
+    const float *wb = p.w + ((size_t)(c_ok ? c : 0) * T + t);
+    for (int s2 = 0; s2 < p.Cout; s2 += 8) {  // four k-steps per trip: eight unconditional loads in flight
+      float a[4], b[4];
       MFN_UNROLL
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      // D[channel][pixel] += W[o][channel][t] * gout[o][pixel]
-      const int ca = cb + j;  // A row = channel
-      const float *wa = p.w + ((size_t)(ca < p.Cin ? ca : 0) * T + t);
-      const float *gb = p.gout + (size_t)n * p.Cout * plane + pix;
-      // four k-steps per trip: eight unconditional loads in flight (clamped rows, zeroed by selects) before the MFMAs
-      for (int s2 = 0; s2 < p.Cout; s2 += 8) {
-        float a[4], b[4];
-        MFN_UNROLL
-        for (int u = 0; u < 4; ++u) {
-          const int o = s2 + 2 * u + half;
-          const int oc = min(o, p.Cout - 1);
-          a[u] = wa[(size_t)oc * p.Cin * T];
-          b[u] = gb[(size_t)oc * plane];
-        }
-        MFN_UNROLL
-        for (int u = 0; u < 4; ++u) {
-          const bool ook = s2 + 2 * u + half < p.Cout;
-          acc = MFN_MFMA_32x32x2((ook && ca < p.Cin) ? a[u] : 0.f, (ook && pix_ok) ? b[u] : 0.f, acc);
-        }
+      for (int u = 0; u < 4; ++u) {
+        const int oc = min(s2 + 2 * u + half, p.Cout - 1);
+        a[u] = ga[(size_t)oc * plane];
+        b[u] = wb[(size_t)oc * p.Cin * T];
       }
-      const float *g = geom + (size_t)(j * T + t) * GW;
+      MFN_UNROLL
+      for (int u = 0; u < 4; ++u) {
+        const bool ook = s2 + 2 * u + half < p.Cout;
+        acc = MFN_MFMA_32x32x2((ook && pix_ok) ? a[u] : 0.f, (ook && c_ok) ? b[u] : 0.f, acc);
+      }
+    }
+    // ---- scatter: D reg r of lane (j, half) = pixel (r&3)+8*(r>>2)+4*half of the strip, channel j
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float *g = geom + (size_t)pp * GW;
       const int *gi = reinterpret_cast<const int *>(g);
-      const float w1 = g[0], w2 = g[1], w3 = g[2], w4 = g[3];
-      const int cy = gi[4] >> 16, cx = gi[4] & 0xFFFF, dyi = (gi[5] >> 1) & 1, dxi = gi[5] & 1;
-      const float ah0 = g[6], aw0 = g[7];
-      // deformable_col2im_coord: 4 samples around (ah, aw) with MXNet's clamping, weights for d/dh and d/dw
-      const bool cin_ok = ah0 >= 0.f && aw0 >= 0.f && ah0 < (float)H && aw0 < (float)W;
-      float ah = cin_ok ? ah0 : 0.f, aw = cin_ok ? aw0 : 0.f;
-      int hl = (int)ah, wl = (int)aw, hh, wh;
-      if (hl >= H - 1) { hh = hl = H - 1; ah = (float)hl; } else hh = hl + 1;
-      if (wl >= W - 1) { wh = wl = W - 1; aw = (float)wl; } else wh = wl + 1;
-      const int i11 = hl * W + wl, i12 = hl * W + wh, i21 = hh * W + wl, i22 = hh * W + wh;
-      const float fw0 = (float)(wl + 1) - aw, fw1 = aw - (float)wl, fh0 = (float)(hl + 1) - ah, fh1 = ah - (float)hl;
-      float acc_h = 0.f, acc_w = 0.f;
-      const int ry = cy - wy0, rx = cx - wx0;  // corner (0,0) inside the window?
-      const bool in00 = ry >= 0 && ry < WR && rx >= 0 && rx < WC;
-      const bool in01 = ry >= 0 && ry < WR && rx + dxi >= 0 && rx + dxi < WC;
-      const bool in10 = ry + dyi >= 0 && ry + dyi < WR && rx >= 0 && rx < WC;
-      const bool in11 = ry + dyi >= 0 && ry + dyi < WR && rx + dxi >= 0 && rx + dxi < WC;
-      MFN_UNROLL
-      for (int r = 0; r < 16; ++r) {
-        const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;  // D reg r of lane (j, half): channel row
-        const int c = cb + cl;
-        if (c >= p.Cin) continue;
-        const float cg = acc[r];
-        if (p.req_offset) {
-          const float *im = p.x + ((size_t)n * p.Cin + c) * plane;
-          const float v11 = im[i11], v12 = im[i12], v21 = im[i21], v22 = im[i22];
-          if (cin_ok) {
-            acc_h += (-fw0 * v11 - fw1 * v12 + fw0 * v21 + fw1 * v22) * cg;
-            acc_w += (-fh0 * v11 + fh0 * v12 - fh1 * v21 + fh1 * v22) * cg;
-          }
-        }
-        if (p.req_x) {
-          float *wc_ = win + (size_t)cl * WR * WC;
-          float *gim = p.gx + ((size_t)n * p.Cin + c) * plane;
-          const float c1 = w1 * cg, c2 = w2 * cg, c3 = w3 * cg, c4 = w4 * cg;
-          if (c1 != 0.f) { if (in00) atomicAdd(wc_ + ry * WC + rx, c1); else atomicAdd(gim + (size_t)cy * W + cx, c1); }
-          if (c2 != 0.f) { if (in01) atomicAdd(wc_ + ry * WC + rx + dxi, c2); else atomicAdd(gim + (size_t)cy * W + cx + dxi, c2); }
-          if (c3 != 0.f) { if (in10) atomicAdd(wc_ + (ry + dyi) * WC + rx, c3); else atomicAdd(gim + (size_t)(cy + dyi) * W + cx, c3); }
-          if (c4 != 0.f) { if (in11) atomicAdd(wc_ + (ry + dyi) * WC + rx + dxi, c4); else atomicAdd(gim + (size_t)(cy + dyi) * W + cx + dxi, c4); }
+      const float cg = c_ok ? acc[r] : 0.f;
+      if (p.req_offset) {
+        const int i11 = gi[7], st = gi[8];
+        const int dh_ = (st >> 1) & 1 ? W : 0, dw_ = st & 1;
+        const float v11 = im[i11], v12 = im[i11 + dw_], v21 = im[i11 + dh_], v22 = im[i11 + dh_ + dw_];
+        const float on = (st & 4) ? cg : 0.f;
+        float ch_ = (-g[9] * v11 - g[10] * v12 + g[9] * v21 + g[10] * v22) * on;
+        float cw_ = (-g[11] * v11 + g[11] * v12 - g[12] * v21 + g[12] * v22) * on;
+        ch_ = mfn_half_sum_top(ch_);
+        cw_ = mfn_half_sum_top(cw_);
+        if (j == 31 && (st & 4)) {  // the half-wave's top lane holds the sum; other channel blocks add to the same entry
+          const int y = ty0 + 2 * wave + (pp >> 4), x = tx0 + (pp & 15);
+          float *gof = p.goffset + ((size_t)n * 2 * T + 2 * t) * plane + (size_t)y * W + x;
+          atomicAdd(gof, ch_);
+          atomicAdd(gof + plane, cw_);
         }
       }
-      if (p.req_offset && pix_ok) {
-        float *go_ = gof + (size_t)(sub * 32 + j) * 2 * T;
-        atomicAdd(go_ + 2 * t, acc_h);
-        atomicAdd(go_ + 2 * t + 1, acc_w);
+      if (p.req_x) {
+        const int cell = gi[4], fl = gi[5], gb_ = gi[6];
+        const int dyc = (fl >> 5) & 1 ? WC : 0, dxc = (fl >> 4) & 1;
+        const int dyg = (fl >> 5) & 1 ? W : 0;
+        const float c1 = g[0] * cg, c2 = g[1] * cg, c3 = g[2] * cg, c4 = g[3] * cg;
+        // The two half-waves hold different pixels of the SAME channel plane: they take turns; the LDS pipe executes
+        // a wave's accesses in order, so the second turn (and the next pixel) sees the first one's writes without a
+        // wait.  half_o is opaque so that the compiler cannot fold the two turns into one unordered pass.  Within a
+        // turn the four cells are distinct (clamped corners have dxc / dyc == 0 and zero weight -> folded below), so
+        // the four reads go out together: one LDS round trip per turn.
+        const bool all_in = (fl & 15) == 15 && dxc && dyc;
+        MFN_UNROLL
+        for (int hs = 0; hs < 2; ++hs) {
+          if (half_o == hs) {
+            if (all_in) {
+              const float o1 = wpl[cell], o2 = wpl[cell + 1], o3 = wpl[cell + WC], o4 = wpl[cell + WC + 1];
+              wpl[cell] = o1 + c1; wpl[cell + 1] = o2 + c2; wpl[cell + WC] = o3 + c3; wpl[cell + WC + 1] = o4 + c4;
+            } else {
+              if (fl & 1) wpl[cell] += c1; else if (c1 != 0.f) atomicAdd(gim + gb_, c1);
+              if (fl & 2) wpl[cell + dxc] += c2; else if (c2 != 0.f) atomicAdd(gim + gb_ + dxc, c2);
+              if (fl & 4) wpl[cell + dyc] += c3; else if (c3 != 0.f) atomicAdd(gim + gb_ + dyg, c3);
+              if (fl & 8) wpl[cell + dyc + dxc] += c4; else if (c4 != 0.f) atomicAdd(gim + gb_ + dyg + dxc, c4);
+            }
+          }
+          MFN_WAVE_SYNC_EMU();
+        }
       }
     }
   }
+  if (!p.req_x) return;
   __syncthreads();
-  // flush: one global atomic per touched window cell / offset-gradient entry
-  if (p.req_x)
-    for (int e = tid; e < 32 * WR * WC; e += 256) {
-      const float v = win[e];
-      if (v == 0.f) continue;
-      const int cl = e / (WR * WC), rem = e - cl * (WR * WC);
-      const int yy = wy0 + rem / WC, xx = wx0 + rem % WC;
-      if (cb + cl < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        atomicAdd(p.gx + ((size_t)n * p.Cin + cb + cl) * plane + (size_t)yy * W + xx, v);
+  // ---- merge the four strips' windows (strip w covers block-window rows 2w .. 2w+7) and flush once
+  const int bwy0 = wy0 - 2 * wave;  // the block window's first row (uniform across the block)
+  for (int e = tid; e < 32 * (WR + 6) * WC; e += 256) {
+    const int cl = e / ((WR + 6) * WC), rem = e - cl * ((WR + 6) * WC);
+    const int R = rem / WC, cc = rem - R * WC;
+    float v = 0.f;
+    MFN_UNROLL
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int rr = R - 2 * w2;
+      if (rr >= 0 && rr < WR) v += lds[(size_t)w2 * 32 * PL + (size_t)cl * PL + rr * WC + cc];
     }
-  if (p.req_offset)
-    for (int e = tid; e < TH * TW * 2 * T; e += 256) {
-      const float v = gof[e];
-      if (v == 0.f) continue;
-      const int pp = e / (2 * T), ch = e - pp * 2 * T;
-      const int y = ty0 + (pp >> 5) * 2 + ((pp & 31) >> 4), x = tx0 + (pp & 15);
-      if (y < H && x < W) atomicAdd(p.goffset + ((size_t)n * 2 * T + ch) * plane + (size_t)y * W + x, v);
-    }
+    const int yy = bwy0 + R, xx = wx0 + cc;
+    if (v != 0.f && cb + cl < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
+      atomicAdd(p.gx + ((size_t)n * p.Cin + cb + cl) * plane + (size_t)yy * W + xx, v);
+  }
 }
 
 // bias gradient: block per filter, sum over (n, pixel)

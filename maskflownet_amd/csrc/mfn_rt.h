@@ -34,6 +34,14 @@ static inline f32x2 mfn_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x,
     for (int s = 32; s >= 1; s >>= 1) v = op(v, __shfl_xor(v, s));     \
     return v;                                                          \
   }
+// sum over the 32 lanes of each half-wave; valid in the top lane (31 / 63) of the half
+static inline float mfn_half_sum_top(float v) {
+  for (int s = 16; s >= 1; s >>= 1) v += __shfl_xor(v, s, 32);
+  return v;
+}
+// emulated lanes are free-running threads: where the hardware's in-order LDS pipe orders two lanes' accesses, the
+// emulation needs a wave barrier
+#define MFN_WAVE_SYNC_EMU() (hipemu::wave().bar.arrive_and_wait())
 MFN_WAVE_REDUCE_EMU(mfn_wave_min_i32, std::min)
 MFN_WAVE_REDUCE_EMU(mfn_wave_max_i32, std::max)
 // LDS-DMA emulation: synchronous copy (ordering of the real asynchronous engine is checked on the GPU)
@@ -91,6 +99,18 @@ __device__ __forceinline__ int mfn_wave_min_i32(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x142, 0xa, 0xf, false));
   v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false));
   return __builtin_amdgcn_readlane(v, 63);
+}
+#define MFN_WAVE_SYNC_EMU() ((void)0)
+// sum over the 32 lanes of each half-wave as a DPP scan (no LDS); valid in the top lane (31 / 63) of the half
+__device__ __forceinline__ float mfn_half_sum_top(float v) {
+#define MFN_DPP_ADD_(ctrl, rmask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  MFN_DPP_ADD_(0x111, 0xf);  // row_shr:1
+  MFN_DPP_ADD_(0x112, 0xf);  // row_shr:2
+  MFN_DPP_ADD_(0x114, 0xf);  // row_shr:4
+  MFN_DPP_ADD_(0x118, 0xf);  // row_shr:8  -> lane 15 of every 16-lane row holds the row's sum
+  MFN_DPP_ADD_(0x142, 0xa);  // row_bcast:15 into rows 1 and 3 -> lanes 31 and 63 hold the half-wave sums
+#undef MFN_DPP_ADD_
+  return v;
 }
 __device__ __forceinline__ int mfn_wave_max_i32(int v) {
   const int id = (int)0x80000000;
