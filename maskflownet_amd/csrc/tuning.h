@@ -5,6 +5,7 @@
 //   corr.slices  channel slices per tile (partial sums + reduce kernel); 0 = heuristic
 //   corr.lanemap 0: ds_read_b128 service-group lane order, 1: natural lane order
 //   corr.band    one-launch row-band kernel of the coarse levels: 0 auto (<= 2048 px images), 1 always, 2 never
+//   corr.direct  LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   corr.xcd     1: XCD-aware block remap (neighbouring tiles share an L2)
 //   corr.generic 1: force the generic one-thread-per-output kernel
 //   corr.ablate  measurement only: 1 no stores, 2 no global loads
@@ -20,7 +21,7 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0;
+  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0;
   int warp_vec = 0;
   int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0;
   int *slot(const char *key) {
@@ -32,6 +33,7 @@ struct Tuning {
     if (!strcmp(key, "corr.slices")) return &corr_slices;
     if (!strcmp(key, "corr.lanemap")) return &corr_lanemap;
     if (!strcmp(key, "corr.band")) return &corr_band;
+    if (!strcmp(key, "corr.direct")) return &corr_direct;
     if (!strcmp(key, "warp.vec")) return &warp_vec;
     if (!strcmp(key, "dc.mt")) return &dc_mt;
     if (!strcmp(key, "dc.pt")) return &dc_pt;

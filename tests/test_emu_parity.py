@@ -20,7 +20,7 @@ def ops():
 @pytest.fixture(autouse=True)
 def _reset_tuning():
     yield
-    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
+    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
                        dc_generic=0, dc_tile=0)
 
 
@@ -81,12 +81,23 @@ def test_correlation_band_kernel(ops, oracle, shape, md):
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
 
 
+@pytest.mark.parametrize("shape,md", [((2, 30, 6, 8), 4),      # level-6 like, several channel slices
+                                      ((1, 7, 7, 16), 4),      # ragged channel tail, cfg3 level 6 plane
+                                      ((2, 9, 5, 12), 2),      # md=2
+                                      ((1, 200, 3, 4), 4),     # one quad per row, 196+ channels
+                                      ((1, 5, 12, 16), 4)])    # taller plane: several row bands
+def test_correlation_direct_kernel(ops, oracle, shape, md):
+    emu_ops.set_tuning(corr_direct=1)
+    pc.case_correlation(ops, oracle, ident, ident, shape, md)
+    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
+
+
 def test_correlation_band_is_the_default_for_coarse_levels(ops, oracle):
     pc.case_correlation(ops, oracle, ident, ident, (1, 24, 12, 16), 4)
     assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) == 0    # level 5: band kernel, no partials
     assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) == 0     # level 4: in-block channel groups
     assert ops.ns.correlation_workspace_bytes(8, 64, 48, 64, 4, 1, 1, 1, 4, 1) == 0     # level 3: in-block channel groups
-    assert ops.ns.correlation_workspace_bytes(8, 196, 6, 8, 4, 1, 1, 1, 4, 1) > 0       # level 6: slices + reduce
+    assert ops.ns.correlation_workspace_bytes(8, 196, 6, 8, 4, 1, 1, 1, 4, 1) == 0      # level 6: direct kernel
     emu_ops.set_tuning(corr_band=2)
     assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) > 0     # sliced + reduce path
 

@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, warp_vec=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0)
+    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -64,11 +64,15 @@ def test_correlation_every_variant(ops, oracle, dev, variant):
 
 @pytest.mark.parametrize("shape", [(8, 196, 6, 8), (8, 128, 12, 16), (8, 96, 24, 32), (8, 64, 48, 64), (4, 196, 7, 16),
                                    (4, 128, 14, 32), (2, 33, 9, 20)])
-@pytest.mark.parametrize("band", [1, 2])
+@pytest.mark.parametrize("band", [1, 2, 3])
 def test_correlation_band_kernel_and_sliced_path(ops, oracle, dev, shape, band):
-    # coarse levels: 1 = the one-launch row-band kernel, 2 = channel slices + reduce launch (both against the oracle)
+    # coarse levels: 1 = the one-launch row-band kernel, 2 = channel slices + reduce launch, 3 = the direct kernel of the
+    # tiniest levels (all against the oracle)
     from maskflownet_amd import _lib
-    _lib.set_tuning(corr_band=band)
+    if band == 3:
+        _lib.set_tuning(corr_direct=1)
+    else:
+        _lib.set_tuning(corr_band=band, corr_direct=2)
     pc.case_correlation(ops, oracle, dev, host, shape, 4)
     pc.case_correlation(ops, oracle, dev, host, shape[:1] + (shape[1] // 2,) + shape[2:], 2, seed=5)
 

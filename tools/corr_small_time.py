@@ -8,8 +8,8 @@ from maskflownet_amd import _lib, hotpath
 from maskflownet_amd.ops import default_ops
 lib = _lib.lib(); ops = default_ops()
 st = torch.cuda.Stream()
-for band in (1, 2):
-    _lib.set_tuning(corr_band=band)
+for band in (1, 2, 3):
+    _lib.set_tuning(corr_band=band if band < 3 else 0, corr_direct=1 if band == 3 else 2)
     row = []
     for cfg in ("cfg2", "cfg3"):
         N, H, W = hotpath.CONFIGS[cfg]
@@ -32,4 +32,4 @@ for band in (1, 2):
                 _lib.check(lib.graph_launch(g, st.cuda_stream))
             st.synchronize()
             row.append("%s.L%d %.1f" % (cfg, l, (time.perf_counter() - t0) / 200 * 1e6))
-    print("band=%d : %s" % (band, "  ".join(row)), flush=True)
+    print("band=%d (1 band kernel, 2 slices+reduce, 3 direct) : %s" % (band, "  ".join(row)), flush=True)
