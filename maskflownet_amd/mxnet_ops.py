@@ -36,23 +36,26 @@ if mx is not None:  # pragma: no cover
         _hip.hipDeviceSynchronize()
 
     class _Correlation(mx.operator.CustomOp):
-        def __init__(self, md, kernel, s1, s2, pad, mult):
+        def __init__(self, md, kernel, s1, s2, pad, mult, act=0):
             self.a = (md, kernel, s1, s2, pad, mult)
+            self.act = act
 
         def forward(self, is_train, req, in_data, out_data, aux):
             n, c, h, w = in_data[0].shape
             out = mx.nd.empty(out_data[0].shape, ctx=in_data[0].context)
             md, kernel, s1, s2, pad, mult = self.a
-            _lib.check(_lib.lib().correlation_fwd(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out), n, c, h, w, md,
-                                                  kernel, s1, s2, pad, mult, None))
+            # no workspace: levels that would want channel slices run their single-launch kernels
+            _lib.check(_lib.lib().correlation_fwd_act(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out), n, c, h, w, md,
+                                                      kernel, s1, s2, pad, mult, self.act, None, 0, None))
             _sync()
             self.assign(out_data[0], req[0], out)
 
     @mx.operator.register("mfn_correlation")
     class _CorrelationProp(mx.operator.CustomOpProp):
         def __init__(self, max_displacement="1", kernel_size="1", stride1="1", stride2="1", pad_size=None,
-                     is_multiply="1"):
+                     is_multiply="1", activation="none"):
             super().__init__(need_top_grad=True)
+            self.act = 1 if activation == "leaky" else 0  # fused LeakyReLU(0.1), MaskFlownet.py:217 (inference)
             self.md, self.k = int(max_displacement), int(kernel_size)
             self.s1, self.s2 = int(stride1), int(stride2)
             self.pad = int(pad_size) if pad_size is not None else self.md
@@ -72,7 +75,7 @@ if mx is not None:  # pragma: no cover
             return in_shape, [(n, tc.value, th.value, tw.value)], []
 
         def create_operator(self, ctx, shapes, dtypes):
-            return _Correlation(self.md, self.k, self.s1, self.s2, self.pad, self.mult)
+            return _Correlation(self.md, self.k, self.s1, self.s2, self.pad, self.mult, self.act)
 
     class _Warp(mx.operator.CustomOp):
         def __init__(self, clip):
@@ -159,3 +162,33 @@ if mx is not None:  # pragma: no cover
 
         def create_operator(self, ctx, shapes, dtypes):
             return _DeformConv(self.p)
+
+    class _Upsample(mx.operator.CustomOp):
+        def __init__(self, factor):
+            self.factor = factor
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            n, c, h, w = in_data[0].shape
+            out = mx.nd.empty(out_data[0].shape, ctx=in_data[0].context)
+            _lib.check(_lib.lib().upsample_fwd(_ptr(in_data[0]), _ptr(out), n, c, h, w, self.factor, None))
+            _sync()
+            self.assign(out_data[0], req[0], out)
+
+    @mx.operator.register("mfn_upsample")
+    class _UpsampleProp(mx.operator.CustomOpProp):  # network/MaskFlownet.py:35-62 (forward / inference)
+        def __init__(self, factor="2"):
+            super().__init__(need_top_grad=False)
+            self.factor = int(factor)
+
+        def list_arguments(self):
+            return ["data"]
+
+        def list_outputs(self):
+            return ["output"]
+
+        def infer_shape(self, in_shape):
+            n, c, h, w = in_shape[0]
+            return in_shape, [(n, c, h * self.factor, w * self.factor)], []
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return _Upsample(self.factor)
