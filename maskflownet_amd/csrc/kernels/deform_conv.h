@@ -128,18 +128,20 @@ template <int MT, int KW> struct DcGeom {
 
 // waves per SIMD the register allocator is held to (three for one or two filter tiles per wave: LDS allows
 // three blocks per CU, and a level-2 or level-3 launch is then resident in one round)
-constexpr int dc_min_waves(int mt, int pt) {
-  return mt <= 2 ? 3 : (mt == 3 ? 2 : (pt >= 2 ? 2 : 1));
+constexpr int dc_min_waves(int mt, int pt, int nw = 4) {
+  return nw == 8 ? 2 : (mt <= 2 ? 3 : (mt == 3 ? 2 : (pt >= 2 ? 2 : 1)));
 }
 
-template <int MT, int PT>
-__global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(DeformParams p) {
+// NW = waves per block (4, or 8 for the coarsest level: twice the in-block K slices, half the channel-pair chain per wave)
+template <int MT, int PT, int NW = 4>
+__global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kernel(DeformParams p) {
   constexpr int T = 9;
-  constexpr int KW = 4 / PT;  // K-slices handled inside the block (one wave each per pixel tile)
+  constexpr int NTH = NW * 64;
+  constexpr int KW = NW / PT;  // K-slices handled inside the block (one wave each per pixel tile)
   using G = DcGeom<MT, KW>;
   constexpr int RL = G::RL, KC = G::KC, CH4 = G::CH4;
-  constexpr int NI = (KW * CH4 + 255) / 256;  // DMA instructions per thread per stage
-  constexpr int STAGE_F = NI * 256 * 4;       // floats per stage buffer
+  constexpr int NI = (KW * CH4 + NTH - 1) / NTH;  // DMA instructions per thread per stage
+  constexpr int STAGE_F = NI * NTH * 4;           // floats per stage buffer
   MFN_DYN_SHARED(float, lds);                 // 2 weight stage buffers + x windows (all reused for the K-slice reduction)
   // staged source window per wave and channel: 10 rows x 24 floats under a 2x16 pixel tile, 12 rows x 20 floats
   // under a 4x8 tile -- 60 float4 slots per channel, one channel pair = 2 wave DMA instructions (120 of 128 lanes)
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(Defor
   unsigned voff[NI];
   MFN_UNROLL
   for (int i = 0; i < NI; ++i) {
-    const int it = (i * 4 + wave) * 64 + lane;
+    const int it = (i * NW + wave) * 64 + lane;
     const int k = it / CH4, idx = it - k * CH4;
     voff[i] = k < KW ? (unsigned)(((size_t)(blockIdx.y * KW + k) * p.cps_per_slice * 18 * RL + (size_t)idx * 4) * 4)
                      : 0xFFFFFF00u;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(Defor
     float *buf = lds + (ch & 1) * STAGE_F;
     const unsigned soff = (unsigned)((size_t)ch * G::CHUNK_F * 4);
     MFN_UNROLL
-    for (int i = 0; i < NI; ++i) mfn_dma16_so(wrsrc, buf + (i * 4 + wave) * 256, voff[i], soff);
+    for (int i = 0; i < NI; ++i) mfn_dma16_so(wrsrc, buf + (i * NW + wave) * 256, voff[i], soff);
   };
 
   issue(0);  // the first weight chunk lands while the tap geometry below is computed
@@ -617,22 +619,23 @@ __global__ __launch_bounds__(256, dc_min_waves(MT, PT)) void dc_lds_kernel(Defor
   MFN_STAMP(p.timeline, 3);
 }
 
-template <int MT, int PT>
+template <int MT, int PT, int NW = 4>
 inline size_t dc_lds_bytes() {
-  constexpr int KW = 4 / PT;
-  constexpr int NI = (KW * DcGeom<MT, KW>::CH4 + 255) / 256;
-  const size_t stage = (size_t)2 * NI * 256 * 16;
+  constexpr int KW = NW / PT;
+  constexpr int NI = (KW * DcGeom<MT, KW>::CH4 + NW * 64 - 1) / (NW * 64);
+  const size_t stage = (size_t)2 * NI * NW * 64 * 16;
   const size_t red = KW > 1 ? (size_t)PT * (KW - 1) * MT * 16 * 64 * 4 : 0;
-  const size_t xwin = (size_t)4 * 3 * (2 * 256) * 4;  // 4 waves x 3 buffers x one channel-pair window (XW_F floats)
+  const size_t xwin = (size_t)NW * 3 * (2 * 256) * 4;  // NW waves x 3 buffers x one channel-pair window (XW_F floats)
   return stage + xwin > red ? stage + xwin : red;
 }
 
-template <int MT, int PT>
+template <int MT, int PT, int NW = 4>
 inline int dc_lds_launch(const DeformParams &p, hipStream_t stream, const char *name) {
   const int tiles = p.tile_w ? p.ntiles : cdiv(p.P, 32);
   const int bx = cdiv(tiles, PT);
   if (bx <= 0) return 0;
-  return launch(name, dc_lds_kernel<MT, PT>, dim3(bx, p.ksb, p.mgroups), dim3(256), dc_lds_bytes<MT, PT>(), stream, p);
+  return launch(name, dc_lds_kernel<MT, PT, NW>, dim3(bx, p.ksb, p.mgroups), dim3(NW * 64), dc_lds_bytes<MT, PT, NW>(),
+                stream, p);
 }
 
 // cross-block K-split reduction: out = bias + sum_s partial[s], slices in index order (deterministic)

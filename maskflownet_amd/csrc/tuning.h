@@ -13,6 +13,7 @@
 //   dc.mt        32-filter MFMA tiles per wave: 1 | 2 | 3 | 4
 //   dc.pt        pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
 //   dc.ksb       K split across blocks (partial sums + reduce kernel); 0 = heuristic
+//   dc.nw        waves per block: 0 auto, 4, 8 (8 only with mt = pt = 1)
 //   dc.tile      pixel-tile shape: 0 auto (4x8), 16 force 2x16, 1 force 32 flattened pixels
 //   dc.stage     0: disable the LDS source-window staging of the shared-offset path
 //   dc.fast      0: disable the shared-offset 4x4-neighbourhood gather
@@ -23,7 +24,7 @@ namespace mfn {
 struct Tuning {
   int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0;
   int warp_vec = 0;
-  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0;
+  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
@@ -41,6 +42,7 @@ struct Tuning {
     if (!strcmp(key, "dc.fast")) return &dc_fast;
     if (!strcmp(key, "dc.stage")) return &dc_stage;
     if (!strcmp(key, "dc.tile")) return &dc_tile;
+    if (!strcmp(key, "dc.nw")) return &dc_nw;
     if (!strcmp(key, "dc.generic")) return &dc_generic;
     return nullptr;
   }

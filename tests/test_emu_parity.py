@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0)
+                       dc_generic=0, dc_tile=0, dc_nw=0)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -159,6 +159,14 @@ def test_deform_shared_offsets(ops, oracle, mt, pt, ksb, fused):
     # pt pixel tiles per block, 4/pt in-block K slices, ksb cross-block K slices (partials + reduce)
     emu_ops.set_tuning(dc_mt=mt, dc_pt=pt, dc_ksb=ksb)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 64 if mt == 2 else 32, 6, 7, fused=fused)
+
+
+def test_deform_eight_wave_blocks(ops, oracle):
+    # 8 waves = 8 in-block K slices of one pixel tile (the coarsest-level plan), even and ragged channel counts
+    emu_ops.set_tuning(dc_nw=8, dc_mt=1, dc_pt=1)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 64, 4, 8)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 40, 5, 8, seed=2, fused=False)
+    pc.case_deform_pertap(ops, oracle, ident, ident, 1, 36, 33, 4, 8, kernel=(3, 3), pad=(1, 1))
 
 
 def test_deform_three_filter_tiles_and_two_mgroups(ops, oracle):
