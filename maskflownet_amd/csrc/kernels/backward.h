@@ -570,7 +570,7 @@ inline int dc_bwd_weight_mfma_launch(DcBwdWParams p, int pixel_slices, hipStream
 // one here: 36 global fp32 atomics per (pixel, channel) at ~57 G/s.  LDS float atomics are no way out either (measured
 // ~3 cycles per lane).  So the scatter is arranged to need NO atomics: a wave owns a 2x16 pixel strip and 32 channels,
 // lane j owns channel j (D column), walks the strip's pixels (D rows) and adds cg * bilinear weight into ITS OWN
-// channel plane of a wave-private LDS window (8 rows x 24 columns, placed by the offset of the block's centre pixel)
+// channel plane of a wave-private LDS window (10 rows x 28 columns, placed by the offset of the block's centre pixel)
 // with plain read-add-write; the two half-waves hold different pixels of the same channel and take turns.  The four
 // strips of a block (8x16 pixels) are merged and flushed once with ~3 global atomics per (pixel, channel); only
 // contributions outside a window (rough flows) go to global memory directly.  goffset is reduced over the 32 channels
@@ -581,8 +581,9 @@ struct DcBwdIParams {
   int N, Cin, H, W, Cout, kh, kw, ph, pw, dh, dw;  // stride 1: Ho == H, Wo == W
   int T, tiles_x, tiles_y;
   int req_x, req_offset;
+  unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, scatter, total} shader cycles
 };
-constexpr int DCI_TH = 8, DCI_TW = 16, DCI_WR = 8, DCI_WC = 24, DCI_GW = 16;
+constexpr int DCI_TH = 8, DCI_TW = 16, DCI_WR = 10, DCI_WC = 28, DCI_GW = 16;
 constexpr int DCI_PLANE = DCI_WR * DCI_WC + 1;  // odd channel-plane stride: the 32 lanes (channels) hit distinct banks
 constexpr size_t dc_bwd_input_lds_bytes() { return ((size_t)4 * 32 * DCI_PLANE + (size_t)4 * 32 * DCI_GW) * sizeof(float); }
 
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
     const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
     const float oh = op[(size_t)(2 * (T / 2)) * plane], ow = op[(size_t)(2 * (T / 2) + 1) * plane];
     const float fh = fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), fw = fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
-    wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - 2 + 2 * wave);  // strip rows: 2 + dh*(kh-1) + 1 = 5 of the 8, 2 above
+    wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - (WR - 5) / 2 + 2 * wave);  // a strip needs 2 + dh*(kh-1) + 1 = 5 rows: centred
     wx0 = MFN_UNIFORM(tx0 - p.pw + (int)fw - (WC - (TW + p.dw * (p.kw - 1) + 1)) / 2);
   }
   for (int e = lane; e < 32 * PL; e += 64) win[e] = 0.f;
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   float *gim = p.gx + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
   const float *im = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
 
+  unsigned long long tk0 = MFN_CYCLES(), tk_geo = 0, tk_mma = 0, tk_sc = 0, tka = tk0;
   for (int t = 0; t < T; ++t) {
     // ---- geometry of the strip's 32 pixels for tap t (lanes 0..31 write, everyone reads it back as broadcasts)
     MFN_WAIT_LGKM0();  // the previous tap's readers are done (wave-private table: no block barrier)
@@ -667,50 +669,67 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
       g[12] = ah - (float)chl;        // fh1
     }
     MFN_WAIT_LGKM0();
+    if (p.timeline) { const unsigned long long n_ = MFN_CYCLES(); tk_geo += n_ - tka; tka = n_; }
     // ---- D[pixel][channel] = sum_o gout[o][pixel] * W[o][channel][t]
     f32x16 acc;
     MFN_UNROLL
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const float *ga = p.gout + (size_t)n * p.Cout * plane + pix;
     const float *wb = p.w + ((size_t)(c_ok ? c : 0) * T + t);
-    for (int s2 = 0; s2 < p.Cout; s2 += 8) {  // four k-steps per trip: eight unconditional loads in flight
-      float a[4], b[4];
+    for (int s2 = 0; s2 < p.Cout; s2 += 16) {  // eight k-steps per trip: sixteen unconditional loads in flight
+      float a[8], b[8];
       MFN_UNROLL
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int oc = min(s2 + 2 * u + half, p.Cout - 1);
         a[u] = ga[(size_t)oc * plane];
         b[u] = wb[(size_t)oc * p.Cin * T];
       }
       MFN_UNROLL
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const bool ook = s2 + 2 * u + half < p.Cout;
         acc = MFN_MFMA_32x32x2((ook && pix_ok) ? a[u] : 0.f, (ook && c_ok) ? b[u] : 0.f, acc);
       }
     }
-    // ---- scatter: D reg r of lane (j, half) = pixel (r&3)+8*(r>>2)+4*half of the strip, channel j
-    MFN_UNROLL
-    for (int r = 0; r < 16; ++r) {
-      const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float *g = geom + (size_t)pp * GW;
-      const int *gi = reinterpret_cast<const int *>(g);
-      const float cg = c_ok ? acc[r] : 0.f;
-      if (p.req_offset) {
+    if (p.timeline) { MFN_OPAQUE(acc[0]); const unsigned long long n_ = MFN_CYCLES(); tk_mma += n_ - tka; tka = n_; }
+    // ---- scatter: D reg r of lane (j, half) = pixel (r&3)+8*(r>>2)+4*half of the strip, channel j.
+    // Two passes so that nothing that stores sits between the loads of different pixels (the compiler may then keep
+    // all 16 pixels' geometry reads and x loads in flight): first the offset gradient (loads only; its atomics are
+    // deferred to the end of the pass), then the gx read-add-write pass.
+    if (p.req_offset) {
+      float sh_[16], sw_[16];
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float *g = geom + (size_t)pp * GW;
+        const int *gi = reinterpret_cast<const int *>(g);
+        const float cg = c_ok ? acc[r] : 0.f;
         const int i11 = gi[7], st = gi[8];
         const int dh_ = (st >> 1) & 1 ? W : 0, dw_ = st & 1;
         const float v11 = im[i11], v12 = im[i11 + dw_], v21 = im[i11 + dh_], v22 = im[i11 + dh_ + dw_];
         const float on = (st & 4) ? cg : 0.f;
-        float ch_ = (-g[9] * v11 - g[10] * v12 + g[9] * v21 + g[10] * v22) * on;
-        float cw_ = (-g[11] * v11 + g[11] * v12 - g[12] * v21 + g[12] * v22) * on;
-        ch_ = mfn_half_sum_top(ch_);
-        cw_ = mfn_half_sum_top(cw_);
-        if (j == 31 && (st & 4)) {  // the half-wave's top lane holds the sum; other channel blocks add to the same entry
+        sh_[r] = mfn_half_sum_top((-g[9] * v11 - g[10] * v12 + g[9] * v21 + g[10] * v22) * on);
+        sw_[r] = mfn_half_sum_top((-g[11] * v11 + g[11] * v12 - g[12] * v21 + g[12] * v22) * on);
+      }
+      if (j == 31) {  // the half-wave's top lane holds the sums; other channel blocks add to the same entries
+        MFN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
           const int y = ty0 + 2 * wave + (pp >> 4), x = tx0 + (pp & 15);
-          float *gof = p.goffset + ((size_t)n * 2 * T + 2 * t) * plane + (size_t)y * W + x;
-          atomicAdd(gof, ch_);
-          atomicAdd(gof + plane, cw_);
+          if (y < H && x < W && (sh_[r] != 0.f || sw_[r] != 0.f)) {
+            float *gof = p.goffset + ((size_t)n * 2 * T + 2 * t) * plane + (size_t)y * W + x;
+            atomicAdd(gof, sh_[r]);
+            atomicAdd(gof + plane, sw_[r]);
+          }
         }
       }
-      if (p.req_x) {
+    }
+    if (p.req_x) {
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float *g = geom + (size_t)pp * GW;
+        const int *gi = reinterpret_cast<const int *>(g);
+        const float cg = c_ok ? acc[r] : 0.f;
         const int cell = gi[4], fl = gi[5], gb_ = gi[6];
         const int dyc = (fl >> 5) & 1 ? WC : 0, dxc = (fl >> 4) & 1;
         const int dyg = (fl >> 5) & 1 ? W : 0;
@@ -737,6 +756,15 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
           MFN_WAVE_SYNC_EMU();
         }
       }
+    }
+    if (p.timeline) { MFN_WAIT_LGKM0(); const unsigned long long n_ = MFN_CYCLES(); tk_sc += n_ - tka; tka = n_; }
+  }
+  if (p.timeline) {
+    MFN_WAIT_LGKM0();
+    const unsigned long long n_ = MFN_CYCLES();
+    if (tid == 0) {
+      unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+      b_[0] = tk_geo; b_[1] = tk_mma; b_[2] = tk_sc; b_[3] = n_ - tk0;
     }
   }
   if (!p.req_x) return;

@@ -61,6 +61,7 @@ static inline void mfn_dma16_so(mfn_rsrc_t r, float *lds_wave_base, unsigned vof
 #define MFN_WAIT_LGKM0() (hipemu::wave().bar.arrive_and_wait())
 #define MFN_RAW_BARRIER() __syncthreads()
 #define MFN_STAMP(buf, k) ((void)0)
+#define MFN_CYCLES() 0ull
 #else
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -153,6 +154,7 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
 // measurement only: constant-rate (100 MHz) wall clock stamps, one writer per block
+#define MFN_CYCLES() ((unsigned long long)clock64())
 // measurement only: bit 0 of the buffer address selects the shader-cycle counter instead of the 100 MHz wall clock
 #define MFN_STAMP(buf, k)                                                                                   \
   do {                                                                                                      \

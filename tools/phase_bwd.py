@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Measurement: per-block shader cycles of dc_bwd_input_tile_kernel by phase (geometry / MFMA / scatter)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from maskflownet_amd import _lib, hotpath
+from maskflownet_amd.ops import default_ops
+lib = _lib.lib(); ops = default_ops()
+wl = hotpath.HotPathWorkload("cfg2", mode="dropin")
+for l in (2, 4):
+    n, c, h, w = hotpath.level_shapes(8, 384, 512)[l]
+    off = wl.o["offset%d" % l]; ops.offsets_from_flow(wl.t["flow_%d" % l], hotpath.SCALE, hotpath.STRIDES[l], out=off)
+    go = torch.randn(n, c, h, w, device="cuda")
+    nblk = n * ((h + 7) // 8) * ((w + 15) // 16) * ((c + 31) // 32)
+    for req in (("write", "write"), ("write", "null"), ("null", "write")):
+        tl = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+        fn = lambda: ops.DeformableConvolution_backward(go, wl.t["c2_%d" % l], off, wl.t["w_%d" % l], kernel=(3, 3), pad=(1, 1), req=req + ("null", "null"))
+        fn(); torch.cuda.synchronize()
+        lib.debug_set_timeline(tl.data_ptr()); fn(); torch.cuda.synchronize(); lib.debug_set_timeline(None)
+        t = tl.cpu().numpy().reshape(nblk, 4).astype(np.float64)
+        print("L%d gx=%s goffset=%s blocks %d: median cycles geometry %.0f  mfma %.0f  scatter %.0f  total %.0f"
+              % (l, req[0], req[1], nblk, *np.median(t, axis=0)))
