@@ -356,6 +356,20 @@ def test_hot_path_prepacked_equals_stateless(T):
         assert T.equal(u, v)
 
 
+@pytest.mark.parametrize("cfg", [(1, 128, 192), (3, 192, 256), (2, 256, 448), (5, 64, 64)])
+@pytest.mark.parametrize("mode", ["dropin", "fused"])
+def test_hot_path_pass_other_batch_and_image_sizes(T, cfg, mode):
+    """The launch plans (tile kernels, channel groups, band / direct kernels, pixel tiles per block, 8-wave blocks) are
+    functions of the shape: the whole pass at other batch sizes and resolutions, every output against the oracle."""
+    from maskflownet_amd import hotpath
+    from oracle import hotpath_ref
+    wl = hotpath.HotPathWorkload(cfg, device="cuda", mode=mode, seed=7)
+    outs = wl.run_eager()
+    want = hotpath_ref.oracle_pass(wl.host, wl.N)
+    for name, got in zip(wl.output_names(), outs):
+        pc.check_close(host(got), want[name], tol=2e-5, what="%s %s %s" % (cfg, mode, name))
+
+
 def test_hot_path_pass_graph_replay_matches_eager(T):
     from maskflownet_amd import hotpath
     wl = hotpath.HotPathWorkload("cfg2", device="cuda")
