@@ -177,6 +177,19 @@ int mfn_deform_conv_shared_fwd_packed(const float *x, const float *flow_yx, floa
                                       int W, int Cout, int kh, int kw, int ph, int pw, int dh,
                                       int dw, int groups, void *workspace, size_t workspace_bytes,
                                       void *stream);
+/* The whole warp step of the matching module in one launch, for
+ * /root/reference/network/MaskFlownet.py:230-233 (and :248-251, :266-269, :284-287):
+ *   warp = deform(c2, repeat9(flow*scale/stride)); warp = warp * sigmoid(mask) + tradeoff; warp = LeakyReLU(0.1)(warp)
+ * mask: (N,1,H,W) or NULL; tradeoff: (N,Cout,H,W) (the conv5f(feat) term) or NULL; activation: MFN_ACT_*.
+ * Give either `w` (re-packed on every call into workspace) or `packed` + layout tag (see above).
+ * Elementwise results equal the separate ops' (sigmoid = 1/(1+expf(-m)) in fp32). */
+int mfn_deform_conv_matching_fwd(const float *x, const float *flow_yx, float flow_scale, float flow_stride,
+                                 const float *w_or_null, const void *packed_or_null, size_t packed_bytes,
+                                 unsigned long long layout_tag, const float *bias_or_null,
+                                 const float *mask_or_null, const float *tradeoff_or_null, int activation,
+                                 float *out, int N, int Cin, int H, int W, int Cout, int kh, int kw, int ph,
+                                 int pw, int dh, int dw, int groups, void *workspace, size_t workspace_bytes,
+                                 void *stream);
 /* Backward (training).  gx,goffset,gw,gbias as the forward's x,offset,w,bias; req_* per output
  * (MFN_REQ_NULL skips it and the pointer may be NULL).  The column gradient is formed on the fly,
  * so mfn_deform_conv_bwd_workspace_bytes currently returns 0 and workspace may be NULL.  gx and

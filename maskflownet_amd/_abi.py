@@ -37,6 +37,8 @@ SIGNATURES = {
     "deform_conv_fwd_packed": (_i, [_f, _f, C.c_void_p, C.c_size_t, C.c_ulonglong, _f, _f] + [_i] * 15 + [C.c_void_p, C.c_size_t, _s]),
     "deform_conv_shared_fwd_packed": (_i, [_f, _f, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_ulonglong, _f, _f] + [_i] * 12 + [C.c_void_p, C.c_size_t, _s]),
     "upsample_fwd": (_i, [_f, _f] + [_i] * 5 + [_s]),
+    "deform_conv_matching_fwd": (_i, [_f, _f, C.c_float, C.c_float, _f, C.c_void_p, C.c_size_t, C.c_ulonglong, _f, _f, _f, _i, _f]
+                                 + [_i] * 12 + [C.c_void_p, C.c_size_t, _s]),
     "deform_conv_bwd_workspace_bytes": (C.c_size_t, [_i] * 15),
     "deform_conv_bwd": (_i, [_f] * 8 + [_i] * 19 + [C.c_void_p, C.c_size_t, _s]),
     "set_tuning": (_i, [C.c_char_p, _i]),

@@ -44,6 +44,10 @@ struct DeformParams {
   unsigned long long *timeline;  // measurement only (mfn_debug_set_timeline)
   int stage_window;              // tuning: 0 disables the LDS source-window staging
   int vec_store;                 // out / partial are 16-byte aligned and Wo % 4 == 0: 16-byte epilogue stores
+  // fused epilogue of the matching module (MaskFlownet.py:232-233): out = act(out * sigmoid(mask) + add)
+  const float *ep_mask;          // (N,1,Ho,Wo) or NULL
+  const float *ep_add;           // (N,Cout,Ho,Wo) or NULL
+  int ep_leaky;                  // LeakyReLU(0.1)
   int ncp_pad, cps_per_slice, ksb, mgroups;  // packed-weight rows per M-group, K-slice length, cross-block K split
   float inv_tpi, inv_tiles_x;                // 1 / (tiles_y * tiles_x), 1 / tiles_x
   int tile_w, tiles_x, tiles_y, ntiles;      // 32-pixel tiles: (32/tile_w) x tile_w output pixels (tile_w 16 or 8), or
@@ -66,6 +70,14 @@ __global__ __launch_bounds__(256) void dc_pack_weights_kernel(PackParams p) {
   const int mg = (int)(idx / ((size_t)2 * p.RL * p.T * p.ncp_pad));
   const int c = 2 * cp + half, o = mg * p.RL + r;
   p.wt[idx] = (c < p.Cin && o < p.Cout) ? p.w[((size_t)o * p.Cin + c) * p.T + t] : 0.f;
+}
+
+// the matching module's epilogue on one output value (bias already added): v * sigmoid(mask) + add, LeakyReLU(0.1)
+__device__ __forceinline__ float dc_epilogue(float v, const float *mask, const float *add, int leaky, size_t mask_idx,
+                                             size_t out_idx) {
+  if (mask) v = v * (1.f / (1.f + expf(-mask[mask_idx])));
+  if (add) v = v + add[out_idx];
+  return leaky ? fmaxf(v, 0.1f * v) : v;
 }
 
 // One tap of deformable_im2col: validity on h_im/w_im, bilinear on the (h_in,w_in)-relative map_h,
@@ -567,6 +579,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
 
   // ---- epilogue.  D reg r of lane (j,half): filter row (r&3)+8*(r>>2)+4*half, pixel j ------------------
   const bool raw = p.ksb > 1;  // cross-block K split: raw partial sums, bias added by dc_reduce_kernel
+  const bool ep = p.ep_mask || p.ep_add || p.ep_leaky;
   float *obase = (raw ? p.partial + (size_t)blockIdx.y * p.N * p.Cout * oplane : p.out) + (size_t)n * p.Cout * oplane;
   // 2-D tiles: transpose the 32x32 tile through this wave's (now idle) window ring so that a lane holds 4
   // adjacent pixels of one filter and writes them with one 16-byte store -- 4 stores per lane instead of 16
@@ -593,14 +606,22 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         float4 v = *reinterpret_cast<const float4 *>(tr + ol * TS + px0);
         if (tile_ok && o < p.Cout && oy < Ho) {
           const float b = (p.bias && !raw) ? p.bias[o] : 0.f;
-          float *dst = obase + (size_t)o * oplane + (size_t)oy * Wo + ox;
-          if (ox + 3 < Wo) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(v.x + b, v.y + b, v.z + b, v.w + b);
-          } else {
-            const float e[4] = {v.x, v.y, v.z, v.w};
+          const size_t oidx = (size_t)o * oplane + (size_t)oy * Wo + ox;
+          float *dst = obase + oidx;
+          float e[4] = {v.x + b, v.y + b, v.z + b, v.w + b};
+          if (ep && !raw) {
             MFN_UNROLL
             for (int q = 0; q < 4; ++q)
-              if (ox + q < Wo) dst[q] = e[q] + b;
+              if (ox + q < Wo)
+                e[q] = dc_epilogue(e[q], p.ep_mask, p.ep_add, p.ep_leaky, (size_t)n * oplane + (size_t)oy * Wo + ox + q,
+                                   (size_t)n * p.Cout * oplane + oidx + q);
+          }
+          if (ox + 3 < Wo) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(e[0], e[1], e[2], e[3]);
+          } else {
+            MFN_UNROLL
+            for (int q = 0; q < 4; ++q)
+              if (ox + q < Wo) dst[q] = e[q];
           }
         }
       }
@@ -612,8 +633,13 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       MFN_UNROLL
       for (int r = 0; r < 16; ++r) {
         const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (o < p.Cout && !((MFN_DC_ABLATE & 8) && acc[mt][r] != 123.f))
-          on[(size_t)o * oplane] = acc[mt][r] + ((p.bias && !raw) ? p.bias[o] : 0.f);
+        if (o < p.Cout && !((MFN_DC_ABLATE & 8) && acc[mt][r] != 123.f)) {
+          float v = acc[mt][r] + ((p.bias && !raw) ? p.bias[o] : 0.f);
+          if (ep && !raw)
+            v = dc_epilogue(v, p.ep_mask, p.ep_add, p.ep_leaky, (size_t)n * oplane + (size_t)ho * Wo + wo,
+                            ((size_t)n * p.Cout + o) * oplane + (size_t)ho * Wo + wo);
+          on[(size_t)o * oplane] = v;
+        }
       }
   }
   MFN_STAMP(p.timeline, 3);
@@ -639,14 +665,18 @@ inline int dc_lds_launch(const DeformParams &p, hipStream_t stream, const char *
 }
 
 // cross-block K-split reduction: out = bias + sum_s partial[s], slices in index order (deterministic)
-struct DcReduceParams { const float *partial; const float *bias; float *out; size_t total; int ksb, Cout; size_t oplane; };
+struct DcReduceParams {
+  const float *partial; const float *bias; float *out; size_t total; int ksb, Cout; size_t oplane;
+  const float *ep_mask, *ep_add; int ep_leaky;
+};
 __global__ __launch_bounds__(256) void dc_reduce_kernel(DcReduceParams p) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.total) return;
   float s = p.partial[i];
   for (int k = 1; k < p.ksb; ++k) s += p.partial[(size_t)k * p.total + i];
   const int o = (int)((i / p.oplane) % p.Cout);
-  p.out[i] = s + (p.bias ? p.bias[o] : 0.f);
+  const size_t n_ = i / (p.oplane * p.Cout);
+  p.out[i] = dc_epilogue(s + (p.bias ? p.bias[o] : 0.f), p.ep_mask, p.ep_add, p.ep_leaky, n_ * p.oplane + i % p.oplane, i);
 }
 inline int dc_reduce_launch(DcReduceParams rp, hipStream_t stream) {
   if (!rp.total) return 0;
@@ -706,7 +736,8 @@ __global__ __launch_bounds__(256) void dc_generic_kernel(DeformParams p) {
       s = fmaf(p.w[((size_t)o * cpg + cl) * T + t], val, s);
     }
   }
-  p.out[idx] = s + (p.bias ? p.bias[o] : 0.f);
+  p.out[idx] = dc_epilogue(s + (p.bias ? p.bias[o] : 0.f), p.ep_mask, p.ep_add, p.ep_leaky,
+                           (size_t)n * oplane + (size_t)ho * p.Wo + wo, idx);
 }
 
 inline int dc_generic_launch(const DeformParams &p, hipStream_t stream) {

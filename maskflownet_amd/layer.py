@@ -211,6 +211,20 @@ class DeformableConv2D(nn.Module):
                                                 num_group=kw["num_group"], packed=self._packed(x))
         return self.act(out) if self.act is not None else out
 
+    def forward_matching(self, x, flow, flow_scale, flow_stride, mask=None, tradeoff=None, leaky=True):
+        """The warp step of the matching module in one launch (MaskFlownet.py:230-233):
+        LeakyReLU(0.1)(self(x, repeat9(flow*scale/stride)) * sigmoid(mask) + tradeoff).  Inference only."""
+        if self.weight is None:
+            self._materialize(x.shape[1], x.device)
+        kw = self._kwargs
+        if kw["stride"] != (1, 1) or kw["num_deformable_group"] != 1:
+            raise ValueError("forward_matching needs stride 1 and one deformable group")
+        if _any_grad(x, flow, mask, tradeoff, self.weight, self.bias):
+            raise NotImplementedError("forward_matching is the fused inference path; train through forward()")
+        return ops.default_ops().deformable_matching(x, flow, flow_scale, flow_stride, self.weight, self.bias, mask,
+                                                     tradeoff, leaky=leaky, kernel=kw["kernel"], dilate=kw["dilate"],
+                                                     pad=kw["pad"], num_group=kw["num_group"], packed=self._packed(x))
+
     def _alias(self):
         return "deformable_conv"
 

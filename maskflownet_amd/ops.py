@@ -313,6 +313,39 @@ class OpSet:
         self.check(self.ns.upsample_fwd(self.ad.ptr(x), self.ad.ptr(out), N, C, H, W, factor, self.ad.stream(x)))
         return out
 
+    def deformable_matching(self, data, flow, flow_scale, flow_stride, weight, bias=None, mask=None, tradeoff=None,
+                            leaky=True, kernel=(3, 3), dilate=(1, 1), pad=(1, 1), num_group=1, out=None, packed=None):
+        """MaskFlownet.py:230-233 in one launch: LeakyReLU(0.1)(deform(data, repeat9(flow*scale/stride)) *
+        sigmoid(mask) + tradeoff); mask (N,1,H,W), tradeoff (N,Cout,H,W), both optional."""
+        x, fl, w = self._in(data, flow, weight)
+        b = self._in(bias)[0] if bias is not None else None
+        m = self._in(mask)[0] if mask is not None else None
+        tr = self._in(tradeoff)[0] if tradeoff is not None else None
+        (kh, kw), (ph, pw), (dh, dw) = map(self._pair, (kernel, pad, dilate))
+        N, Cin, H, W = self.ad.shape(x)
+        Cout = self.ad.shape(w)[0]
+        if self.ad.shape(w) != (Cout, Cin // num_group, kh, kw):
+            raise ValueError("deformable_matching: bad weight shape %s" % (self.ad.shape(w),))
+        if self.ad.shape(fl) != (N, 2, H, W):
+            raise ValueError("deformable_matching: flow must be %s" % ((N, 2, H, W),))
+        if m is not None and self.ad.shape(m) != (N, 1, H, W):
+            raise ValueError("deformable_matching: mask must be %s" % ((N, 1, H, W),))
+        if tr is not None and self.ad.shape(tr) != (N, Cout, H, W):
+            raise ValueError("deformable_matching: tradeoff must be %s" % ((N, Cout, H, W),))
+        if out is None:
+            out = self.ad.empty(x, (N, Cout, H, W))
+        nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, 1, 1, ph, pw, dh, dw, num_group, 1)
+        ws = self._workspace(x, nbytes)
+        if packed is not None:
+            packed.require((N, Cin, H, W, Cout, kh, kw, 1, 1, ph, pw, dh, dw, num_group, 1))
+        p = lambda a: self.ad.ptr(a) if a is not None else None
+        self.check(self.ns.deform_conv_matching_fwd(
+            self.ad.ptr(x), self.ad.ptr(fl), float(flow_scale), float(flow_stride), self.ad.ptr(w),
+            self.ad.ptr(packed.buf) if packed is not None else None, packed.nbytes if packed is not None else 0,
+            packed.tag if packed is not None else 0, p(b), p(m), p(tr), 1 if leaky else 0, self.ad.ptr(out), N, Cin, H, W,
+            Cout, kh, kw, ph, pw, dh, dw, num_group, self.ad.ptr(ws), self.ad.nbytes(ws), self.ad.stream(x)))
+        return out
+
     def offsets_from_flow(self, flow, scale, stride, taps=9, out=None):
         (fl,) = self._in(flow)
         N, two, H, W = self.ad.shape(fl)

@@ -116,6 +116,28 @@ def case_deform_shared(ops, oracle, to_dev, to_host, N, C, H, W, scale=20.0, str
     return check_close(to_host(got), want, what="deform shared N%d C%d %dx%d fused=%s" % (N, C, H, W, fused))
 
 
+def case_deform_matching(ops, oracle, to_dev, to_host, N, C, H, W, scale=20.0, stride=8.0, seed=0, **opt):
+    """The matching module's warp step in one launch (MaskFlownet.py:230-233) against the separate oracle ops."""
+    rng = np.random.default_rng(4100 + seed)
+    x = feat(rng, (N, C, H, W))
+    w = msra_weight(rng, C, C)
+    b = (rng.standard_normal((C,)) * 0.1).astype(np.float32)
+    fl = (flow_field(rng, N, H, W, sigma=2.0) * np.float32(stride / scale)).astype(np.float32)
+    mask = rng.standard_normal((N, 1, H, W)).astype(np.float32) * 2 if opt.get("mask", True) else None
+    tr = rng.standard_normal((N, C, H, W)).astype(np.float32) if opt.get("tradeoff", True) else None
+    leaky = opt.get("leaky", True)
+    want = oracle.deformable_convolution(x, oracle.offsets_from_flow(fl, scale, stride), w, b, kernel=(3, 3), pad=(1, 1))
+    if mask is not None:
+        want = want * (np.float32(1) / (np.float32(1) + np.exp(-mask, dtype=np.float32)))
+    if tr is not None:
+        want = want + tr
+    if leaky:
+        want = np.where(want > 0, want, np.float32(0.1) * want)
+    d = lambda a: to_dev(a) if a is not None else None
+    got = to_host(ops.deformable_matching(to_dev(x), to_dev(fl), scale, stride, to_dev(w), to_dev(b), d(mask), d(tr), leaky=leaky))
+    return check_close(got, want.astype(np.float32), what="deform matching %s" % (opt,))
+
+
 def case_deform_pertap(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, **kw):
     rng = np.random.default_rng(555 + seed)
     ng, ndg = kw.get("num_group", 1), kw.get("num_deformable_group", 1)

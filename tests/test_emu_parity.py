@@ -161,6 +161,16 @@ def test_deform_shared_offsets(ops, oracle, mt, pt, ksb, fused):
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 64 if mt == 2 else 32, 6, 7, fused=fused)
 
 
+@pytest.mark.parametrize("opt", [dict(), dict(mask=False), dict(tradeoff=False, leaky=False), dict(mask=False, tradeoff=False)])
+def test_deform_matching_epilogue(ops, oracle, opt):
+    pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 6, 8, **opt)      # 16-byte transposed stores
+    pc.case_deform_matching(ops, oracle, ident, ident, 1, 8, 5, 7, seed=1, **opt)  # scalar stores (W % 4 != 0)
+    emu_ops.set_tuning(dc_ksb=2)
+    pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 4, 8, seed=2, **opt)  # split K: epilogue in the reduce kernel
+    emu_ops.set_tuning(dc_ksb=0, dc_generic=1)
+    pc.case_deform_matching(ops, oracle, ident, ident, 1, 8, 4, 6, seed=3, **opt)   # generic kernel
+
+
 def test_deform_eight_wave_blocks(ops, oracle):
     # 8 waves = 8 in-block K slices of one pixel tile (the coarsest-level plan), even and ragged channel counts
     emu_ops.set_tuning(dc_nw=8, dc_mt=1, dc_pt=1)

@@ -344,6 +344,11 @@ def test_upsample_flow_and_mask(ops, oracle, dev, shape, factor):
     pc.case_upsample(ops, oracle, dev, host, shape, factor)
 
 
+@pytest.mark.parametrize("C,H,W", [(128, 12, 16), (96, 24, 32), (64, 48, 64), (32, 96, 128)])
+def test_deform_matching_epilogue_network_levels(ops, oracle, dev, C, H, W):
+    pc.case_deform_matching(ops, oracle, dev, host, 2, C, H, W)
+
+
 def test_edge_inputs(ops, oracle, dev):
     pc.case_edge_inputs(ops, oracle, dev, host)
 
