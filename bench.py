@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--mode", default="dropin", choices=["dropin", "fused"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -217,6 +217,13 @@ def main():
     else:
         wl.run_eager()
 
+    # untimed spin-up: an idle MI355X sits at ~100 MHz sclk and needs a few hundred ms of work to reach its
+    # sustained clocks; W warm-up steps of 0.2 ms each are not enough on their own
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.5:
+        for _ in range(50):
+            wl.replay()
+        wl.synchronize()
     for _ in range(args.warmup):
         wl.replay()
     wl.synchronize()
