@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void corr_bwd_block_kernel(CorrBwdParams p) {
   const int QW = W >> 2, CG = (C + CB - 1) / CB;
   const size_t plane = (size_t)H * W;
   const size_t total = (size_t)p.N * CG * H * QW;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // blocks of neighbouring rows read the same 9 rows of gout / f2: one XCD per contiguous range (mfn_xcd_remap)
+  const size_t idx = (size_t)mfn_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   if (idx >= total) return;
   const int qx = (int)(idx % QW), y = (int)((idx / QW) % H);
   const int cg = (int)((idx / ((size_t)QW * H)) % CG), n = (int)(idx / ((size_t)QW * H * CG));
@@ -598,7 +599,8 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   const int T = p.T, H = p.H, W = p.W;
   const size_t plane = (size_t)H * W;
   const int tpi = p.tiles_x * p.tiles_y;
-  const int n = blockIdx.x / tpi, rt = blockIdx.x - n * tpi;
+  const int bx = gridDim.y == 1 ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // neighbours share an L2
+  const int n = bx / tpi, rt = bx - n * tpi;
   const int ty0 = (rt / p.tiles_x) * TH, tx0 = (rt % p.tiles_x) * TW;
   const int cb = blockIdx.y * 32;
   // window origin of the block: follows the offset of the tile's centre pixel (centre tap); strip w sits 2w rows lower

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
   // ---- which tile ---------------------------------------------------------------------------
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
-  if (p.xcd_swizzle && (nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)nblk);
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int n = bid / tiles_per_img;
   const int t = bid - n * tiles_per_img;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_hw_kernel(CorrPa
 
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
-  if (p.xcd_swizzle && (nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)nblk);
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int n = bid / tiles_per_img;
   const int t = bid - n * tiles_per_img;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
 
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
-  if (p.xcd_swizzle && (nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)nblk);
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int n = bid / tiles_per_img;
   const int t = bid - n * tiles_per_img;

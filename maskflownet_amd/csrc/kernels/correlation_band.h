@@ -82,8 +82,8 @@ __global__ __launch_bounds__(1024) void corr_band_kernel(CorrBandParams p) {
   int g = 0, wg = wave;                            // group = WG whole waves (at most 16 waves: a short loop)
   while (wg >= p.WG) { wg -= p.WG; ++g; }
   const int t = tid - g * NTG;                     // thread / task index inside the group
-  int n = 0, band = blockIdx.x;
-  corr_band_divmod((int)blockIdx.x, p.bands, p.inv_bands, n, band);
+  int n = 0, band = 0;
+  corr_band_divmod((int)mfn_xcd_remap(blockIdx.x, gridDim.x), p.bands, p.inv_bands, n, band);
   const int y0 = band * p.R;
   const int H = p.H, W = p.W, C = p.C, R = p.R;
   const int QW = W >> 2;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(1024) void corr_direct_kernel(CorrDirectParams p) {
   const int H = p.H, W = p.W, C = p.C, QW = W >> 2;
   const size_t plane = (size_t)H * W;
   // block -> (image, displacement row, band)
-  int b = blockIdx.x, n, rem, dyi, band;
+  int b = (int)mfn_xcd_remap(blockIdx.x, gridDim.x), n, rem, dyi, band;  // the 9 rows of an image on one XCD
   corr_band_divmod(b, D * p.bands, 1.0f / (float)(D * p.bands), n, rem);
   corr_band_divmod(rem, p.bands, p.inv_bands, dyi, band);
   // thread -> (slice, dx, row, quad)

@@ -43,6 +43,7 @@ struct DeformParams {
   int allow_fast;  // tuning: 0 forces the per-tap path
   unsigned long long *timeline;  // measurement only (mfn_debug_set_timeline)
   int stage_window;              // tuning: 0 disables the LDS source-window staging
+  int xcd;                       // 1: blockIdx.x -> tile range remapped per XCD (1-D grids only)
   int vec_store;                 // out / partial are 16-byte aligned and Wo % 4 == 0: 16-byte epilogue stores
   // fused epilogue of the matching module (MaskFlownet.py:232-233): out = act(out * sigmoid(mask) + add)
   const float *ep_mask;          // (N,1,Ho,Wo) or NULL
@@ -167,7 +168,9 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   const int half = lane >> 5, j = lane & 31;
   MFN_STAMP(p.timeline, 0);
   const int pt = wave / KW, kw = wave % KW;
-  const int tile = blockIdx.x * PT + pt;
+  // neighbouring tiles stage overlapping source windows: keep them on one XCD's L2
+  const int bx = p.xcd ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tile = bx * PT + pt;
   const int gs = blockIdx.y * KW + kw;        // global K-slice of this wave
   const int mg = blockIdx.z;                  // M-group: filters [mg*RL, mg*RL + RL)
   const int m0 = mg * RL;

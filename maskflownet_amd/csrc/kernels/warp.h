@@ -3,9 +3,9 @@
 //
 // Replaces /root/reference/network/layer.py:14-18 (Reconstruction2D) and :26-30
 // (Reconstruction2DSmooth); semantics as oracle/mfn_ref_body.inc warp_fwd / bilinear_sampler_fwd.
-// Gather-bound (4*N*H*W*(2C+2) bytes): one thread owns VEC adjacent pixels, reads
-// the flow and writes the output with 16-byte vectors, computes the 4 tap addresses/weights once
-// and reuses them for every channel.  The grid never exists in memory.
+// Gather-bound (4*N*H*W*(2C+2) bytes): one thread owns a pixel, computes the 4 tap
+// addresses/weights once and reuses them for every channel.  The grid never exists in memory.
+// warp_fwd_fast_kernel is what the pass runs; warp_fwd_kernel<1> is the general form (any size, W = 1).
 #pragma once
 #include "../mfn_rt.h"
 
@@ -71,14 +71,15 @@ __device__ __forceinline__ float sample(const float *plane, const Taps &t) {
 
 // same result from two 8-byte loads (dword aligned, allowed on gfx950) instead of four 4-byte gathers: half the
 // texture-addresser work of the gather-bound warp.  Needs W >= 2.
-__device__ __forceinline__ float sample_pairs(const float *plane, const Taps &t) {
-  const f2u a = mfn_load2u(plane + t.p0);
-  const f2u b = mfn_load2u(plane + t.p1);
+__device__ __forceinline__ float combine_pairs(const f2u a, const f2u b, const Taps &t) {
   const float v00 = t.w00 != 0.f ? (t.sel0 ? a.y : a.x) : 0.f;
   const float v01 = t.w01 != 0.f ? (t.sel1 ? a.x : a.y) : 0.f;
   const float v10 = t.w10 != 0.f ? (t.sel0 ? b.y : b.x) : 0.f;
   const float v11 = t.w11 != 0.f ? (t.sel1 ? b.x : b.y) : 0.f;
   return v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
+}
+__device__ __forceinline__ float sample_pairs(const float *plane, const Taps &t) {
+  return combine_pairs(mfn_load2u(plane + t.p0), mfn_load2u(plane + t.p1), t);
 }
 
 // GridGenerator kWarp for one pixel: (flow + index) / ((size-1)/2) - 1
@@ -139,6 +140,93 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpParams p) {
   }
 }
 
+// The kernel of the pass (W >= 2, N*H*W < 2^32).  One pixel per thread, a block = 256 consecutive pixels, and
+//  * blocks XCD-remapped: the source rows a block gathers are also gathered by the blocks of the output rows above
+//    and below; in dispatch order those sit on other XCDs and every L2 fetched its own copy over the fabric
+//    (8x3x384x512: 15.2 us; 11.6 us with the remap; a plain 4-byte-per-lane copy of the same bytes takes 9.3);
+//  * 32-bit index arithmetic;
+//  * the channel loop in groups of G with every tap load of a group issued before the first use, so a pixel costs
+//    two memory round trips (flow, taps) per group instead of one per channel.
+template <int G>
+__global__ __launch_bounds__(256) void warp_fwd_fast_kernel(WarpParams p, unsigned total) {
+  const unsigned idx = mfn_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned W = (unsigned)p.W, H = (unsigned)p.H;
+  const unsigned row = idx / W, x = idx - row * W;
+  const unsigned n = row / H, y = row - n * H;
+  const size_t plane = (size_t)H * W;
+  const unsigned pix = y * W + x;
+  const float *fl = p.flow + (size_t)n * 2 * plane + pix;
+  const float fy = fl[0], fx = fl[plane];
+  float gx, gy;
+  warp_grid(fx, fy, (int)x, (int)y, p.H, p.W, p.clip, gx, gy);
+  const Taps t = sampler_taps(gx, gy, p.H, p.W);
+  const float *xin = p.x + (size_t)n * p.C * plane;
+  float *o = p.out + (size_t)n * p.C * plane + pix;
+  int c = 0;
+  for (; c + G <= p.C; c += G) {
+    f2u a[G], b[G];
+    MFN_UNROLL
+    for (int k = 0; k < G; ++k) {
+      const float *pl = xin + (size_t)(c + k) * plane;
+      a[k] = mfn_load2u(pl + t.p0);
+      b[k] = mfn_load2u(pl + t.p1);
+    }
+    MFN_UNROLL
+    for (int k = 0; k < G; ++k) o[(size_t)(c + k) * plane] = combine_pairs(a[k], b[k], t);
+  }
+  for (; c < p.C; ++c) o[(size_t)c * plane] = sample_pairs(xin + (size_t)c * plane, t);
+}
+
+// PX pixels per thread, `stride` pixels apart (every load / store of a wave still covers 64 adjacent pixels): more
+// bytes in flight per thread in both round trips.  Measured no faster than one pixel per thread on MI355X (the
+// grid of the fast kernel already keeps every CU full), kept behind warp.vec = 2 | 8 for experiments.
+template <int PX>
+__global__ __launch_bounds__(256) void warp_fwd_ilp_kernel(WarpParams p, unsigned total, unsigned stride) {
+  const unsigned W = (unsigned)p.W, H = (unsigned)p.H;
+  const size_t plane = (size_t)H * W;
+  const unsigned idx0 = blockIdx.x * 256u + threadIdx.x;
+  if (idx0 >= stride) return;
+  size_t base[PX];
+  unsigned pix[PX];
+  float fy[PX], fx[PX];
+  bool ok[PX];
+  unsigned xs[PX], ys[PX];
+  MFN_UNROLL
+  for (int k = 0; k < PX; ++k) {
+    const unsigned idx = idx0 + (unsigned)k * stride;
+    ok[k] = idx < total;
+    const unsigned id = ok[k] ? idx : idx0;  // clamped: loads stay unconditional, the store is predicated
+    const unsigned row = id / W, n = row / H;
+    xs[k] = id - row * W;
+    ys[k] = row - n * H;
+    pix[k] = ys[k] * W + xs[k];
+    base[k] = (size_t)n * p.C * plane;
+    const float *fl = p.flow + (size_t)n * 2 * plane + pix[k];
+    fy[k] = fl[0];
+    fx[k] = fl[plane];
+  }
+  Taps t[PX];
+  MFN_UNROLL
+  for (int k = 0; k < PX; ++k) {
+    float gx, gy;
+    warp_grid(fx[k], fy[k], (int)xs[k], (int)ys[k], p.H, p.W, p.clip, gx, gy);
+    t[k] = sampler_taps(gx, gy, p.H, p.W);
+  }
+  for (int c = 0; c < p.C; ++c) {
+    f2u a[PX], b[PX];
+    MFN_UNROLL
+    for (int k = 0; k < PX; ++k) {
+      const float *pl = p.x + base[k] + (size_t)c * plane;
+      a[k] = mfn_load2u(pl + t[k].p0);
+      b[k] = mfn_load2u(pl + t[k].p1);
+    }
+    MFN_UNROLL
+    for (int k = 0; k < PX; ++k)
+      if (ok[k]) p.out[base[k] + (size_t)c * plane + pix[k]] = combine_pairs(a[k], b[k], t[k]);
+  }
+}
+
 inline int warp_fwd_launch(WarpParams p, hipStream_t stream, int vec_pref = 0) {
   // one pixel per thread keeps the 4 gathers of a wave on adjacent addresses (measured 28 us vs 46 us
   // for 4 px/thread on 8x3x384x512 with noisy flow); the 4-px form is kept behind warp.vec=4
@@ -147,6 +235,20 @@ inline int warp_fwd_launch(WarpParams p, hipStream_t stream, int vec_pref = 0) {
   if (total == 0) return 0;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (vec4) return launch("warp_fwd_v4", warp_fwd_kernel<4>, grid, dim3(256), 0, stream, p);
+  // warp.vec: 0 = auto (the fast kernel when its 32-bit indices and 8-byte tap pairs apply), 1 = the general
+  // kernel, 2 | 8 = 2 | 4 strided pixels per thread
+  const bool small = total < ((size_t)1 << 32) - 256 && p.W >= 2;
+  if (small && (vec_pref == 2 || vec_pref == 8)) {
+    const int px = vec_pref == 2 ? 2 : 4;
+    const unsigned stride = (unsigned)((((total + px - 1) / px) + 63) / 64 * 64);
+    const dim3 g((stride + 255) / 256);
+    if (px == 2) return launch("warp_fwd_p2", warp_fwd_ilp_kernel<2>, g, dim3(256), 0, stream, p, (unsigned)total, stride);
+    return launch("warp_fwd_p4", warp_fwd_ilp_kernel<4>, g, dim3(256), 0, stream, p, (unsigned)total, stride);
+  }
+  if (small && vec_pref != 1) {
+    if (p.C % 4 != 0 && p.C % 3 == 0) return launch("warp_fwd_fast", warp_fwd_fast_kernel<3>, grid, dim3(256), 0, stream, p, (unsigned)total);
+    return launch("warp_fwd_fast", warp_fwd_fast_kernel<4>, grid, dim3(256), 0, stream, p, (unsigned)total);
+  }
   return launch("warp_fwd_v1", warp_fwd_kernel<1>, grid, dim3(256), 0, stream, p);
 }
 

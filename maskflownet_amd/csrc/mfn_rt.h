@@ -172,6 +172,15 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 
 namespace mfn {
 
+// Workgroup b of a 1-D grid runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2.  Kernels whose
+// neighbouring tiles read overlapping data remap their block id with this so that XCD k works on one contiguous
+// range of tiles, [k*q + min(k, r), ...) with q = nb / 8, r = nb % 8: the overlap is then served by one L2
+// instead of being fetched over the fabric by several (full-resolution warp: 15.2 -> 11.6 us).
+__host__ __device__ __forceinline__ unsigned mfn_xcd_remap(unsigned b, unsigned nb) {
+  const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, i = b >> 3;
+  return xcd * q + (xcd < r ? xcd : r) + i;
+}
+
 // ---- launch plumbing -------------------------------------------------------------------------
 #if defined(MFN_EMU)
 template <class K, class... Args>

@@ -9,11 +9,12 @@
 //   corr.xcd     1: XCD-aware block remap (neighbouring tiles share an L2)
 //   corr.generic 1: force the generic one-thread-per-output kernel
 //   corr.ablate  measurement only: 1 no stores, 2 no global loads
-//   warp.vec     pixels per thread of the warp kernel: 1 | 4
+//   warp.vec     pixels per thread of the warp kernel: 0 auto (fast kernel) | 1 general | 4 adjacent px, 16-byte stores | 2, 8: 2 / 4 strided px
 //   dc.mt        32-filter MFMA tiles per wave: 1 | 2 | 3 | 4
 //   dc.pt        pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
 //   dc.ksb       K split across blocks (partial sums + reduce kernel); 0 = heuristic
 //   dc.nw        waves per block: 0 auto, 4, 8 (8 only with mt = pt = 1)
+//   dc.xcd       1: every XCD works on one contiguous range of pixel tiles (mfn_xcd_remap), 0: dispatch order
 //   dc.tile      pixel-tile shape: 0 auto (4x8), 16 force 2x16, 1 force 32 flattened pixels
 //   dc.stage     0: disable the LDS source-window staging of the shared-offset path
 //   dc.fast      0: disable the shared-offset 4x4-neighbourhood gather
@@ -24,7 +25,7 @@ namespace mfn {
 struct Tuning {
   int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0;
   int warp_vec = 0;
-  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0;
+  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
@@ -43,6 +44,7 @@ struct Tuning {
     if (!strcmp(key, "dc.stage")) return &dc_stage;
     if (!strcmp(key, "dc.tile")) return &dc_tile;
     if (!strcmp(key, "dc.nw")) return &dc_nw;
+    if (!strcmp(key, "dc.xcd")) return &dc_xcd;
     if (!strcmp(key, "dc.generic")) return &dc_generic;
     return nullptr;
   }

@@ -20,7 +20,7 @@ def ops():
 @pytest.fixture(autouse=True)
 def _reset_tuning():
     yield
-    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
+    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
                        dc_generic=0, dc_tile=0, dc_nw=0)
 
 
@@ -133,6 +133,17 @@ def test_correlation_odd_width_uses_generic(ops, oracle):
 @pytest.mark.parametrize("clip", [False, True])
 def test_warp(ops, oracle, shape, clip):
     pc.case_warp(ops, oracle, ident, ident, shape, clip)
+
+
+@pytest.mark.parametrize("vec", [1, 2, 4, 8])
+def test_warp_kernel_forms(ops, oracle, vec):
+    """warp.vec: 1 = general kernel (64-bit indices), 2 / 8 = strided pixels per thread, 4 = 4 adjacent pixels; the
+    default (0) is the fast kernel of test_warp.  1x2x5x7 has a ragged last stride, 3x6x8x12 crosses batch items
+    inside one thread and has a ragged channel group."""
+    emu_ops.set_tuning(warp_vec=vec)
+    for shape in ((1, 2, 5, 7), (3, 6, 8, 12)):
+        pc.case_warp(ops, oracle, ident, ident, shape, False)
+        pc.case_warp(ops, oracle, ident, ident, shape, True)
 
 
 @pytest.mark.parametrize("shape,factor", [((2, 2, 6, 8), 2), ((1, 3, 5, 7), 2), ((1, 2, 4, 6), 4), ((1, 1, 3, 5), 3), ((1, 2, 4, 4), 1)])

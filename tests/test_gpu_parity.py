@@ -125,7 +125,7 @@ def test_correlation_properties_at_full_size(ops, T):
 
 @pytest.mark.parametrize("shape", [(8, 3, 384, 512), (4, 3, 448, 1024), (2, 16, 40, 52), (1, 3, 37, 53)])
 @pytest.mark.parametrize("clip", [False, True])
-@pytest.mark.parametrize("vec", [0, 4])
+@pytest.mark.parametrize("vec", [0, 1, 2, 4, 8])
 def test_warp(ops, oracle, dev, shape, clip, vec):
     from maskflownet_amd import _lib
     _lib.set_tuning(warp_vec=vec)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measurement: cost of every operator call of the hot-path pass when replayed back to back inside a hipGraph
 (K dependent repeats of one call, wall clock / K) -- what each call contributes to the bench's ms_per_step,
-boundaries included.  usage: op_cost.py [cfg2|cfg3] [dropin|fused]"""
+boundaries included.  usage: op_cost.py [cfg2|cfg3] [dropin|fused] [key=value,...]"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +11,8 @@ from maskflownet_amd.hotpath import MD, SCALE, STRIDES, CHANNELS
 lib = _lib.lib()
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 mode = sys.argv[2] if len(sys.argv) > 2 else "dropin"
+if len(sys.argv) > 3:  # tuning overrides, e.g. dc_xcd=0,corr_xcd=0
+    _lib.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in sys.argv[3].split(","))})
 wl = hotpath.HotPathWorkload(cfg, mode=mode)
 ops, t, o, st = wl.ops, wl.t, wl.o, wl.stream
 K = 20
