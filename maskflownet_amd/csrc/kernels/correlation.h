@@ -689,26 +689,33 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
   MFN_UNROLL
   for (int q = 0; q < 4; ++q) accs[q] = 0.f;
 
-  // per-thread byte offsets of its NI items inside a stage's channel group (stage-invariant)
+  // per-thread byte offsets of its NI items inside a stage's channel group (stage-invariant).  A wave instruction
+  // lies entirely in the f1 or the f2 part (ITEMS1 % 64 == 0), so that choice is a scalar branch and the rest is
+  // straight-line select code (the prologue runs on all 15 waves of a CU at once: every 100 VALU instructions
+  // here cost ~0.6 us of kernel time).
   constexpr unsigned INVALID = 0xFFFFFF00u;
   unsigned voff[NI];
   MFN_UNROLL
   for (int i = 0; i < NI; ++i) {
-    const int it = tid + i * NT;
-    unsigned v = INVALID;
-    if (it < ITEMS1) {
-      const int c = it / (TH * R4), rem = it - c * (TH * R4);
-      const int r = rem / R4, q = rem - r * R4;
-      const int y = y0 + r, x = x0 + 4 * q;
-      if (q < 8 && y < H && x < W) v = (unsigned)(c * (int)plane + y * W + x) * 4u;
-    } else if (it < ITEMS) {
+    const int first = (i * NW + wave) * 64;  // uniform
+    const int it = first + lane;
+    int c, r, q, ybase, xbase, qmax;
+    if (first < ITEMS1) {
+      c = it / (TH * R4);
+      const int rem = it - c * (TH * R4);
+      r = rem / R4; q = rem - r * R4;
+      ybase = y0; xbase = x0; qmax = 8;
+    } else {
       const int it2 = it - ITEMS1;
-      const int c = it2 / (ROWS2 * R4), rem = it2 - c * (ROWS2 * R4);
-      const int r = rem / R4, q = rem - r * R4;
-      const int y = y0 - MD + r, x = x0 - 4 + 4 * q;
-      if (q < 10 && y >= 0 && y < H && x >= 0 && x < W) v = (unsigned)(c * (int)plane + y * W + x) * 4u;
+      c = it2 / (ROWS2 * R4);
+      const int rem = it2 - c * (ROWS2 * R4);
+      r = rem / R4; q = rem - r * R4;
+      ybase = y0 - MD; xbase = x0 - 4; qmax = 10;
     }
-    voff[i] = (p.ablate == 2) ? INVALID : v;
+    const int y = ybase + r, x = xbase + 4 * q;
+    const bool ok = first < ITEMS && q < qmax && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const unsigned v = (unsigned)(c * (int)plane + y * W + x) * 4u;
+    voff[i] = (ok && !(p.ablate & 2)) ? v : INVALID;
   }
 
   auto issue = [&](int ch) {  // stage ch -> ring slot ch % NS
@@ -744,7 +751,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
     MFN_RAW_BARRIER();     // stage ch landed for every wave; slot (ch-1)%NS is free
     if (ch == 0) MFN_STAMP(p.timeline, 1);
     if (ch + NS - 1 < nchunks) issue(ch + NS - 1);
-    consume(ch);
+    if (!(p.ablate & 4)) consume(ch);
   }
   MFN_STAMP(p.timeline, 2);
   if (G > 1) {  // add the groups' accumulators in index order (deterministic); group 0 owns the epilogue
@@ -780,22 +787,37 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
   const bool raw = p.nslices > 1;
   float *outn = (raw ? p.partial + (size_t)blockIdx.y * p.N * (D * D) * plane : p.out) + (size_t)n * (D * D) * plane;
   const bool use_div = p.exact_div && !raw;
+  const bool leaky = p.leaky && !raw;
   const float scale = raw ? 1.f : p.inv_sumelems;
-  const float slope = (p.leaky && !raw) ? 0.1f : 1.f;
   const int y = y0 + row, x = x0 + 4 * gx;
-  if (live && y < H && x < W) {
+  // the normalisation / activation choice is uniform: one straight-line copy of the 9 stores per case instead of
+  // a branch per element (the epilogue, like the prologue, runs on every wave of the CU at the same time)
+  if (live && y < H && x < W && !(p.ablate & 1)) {
     float *dst = outn + (size_t)(dyi * D) * plane + (size_t)y * W + x;
-    MFN_UNROLL
-    for (int d = 0; d < D; ++d) {
-      float v[4];
-      MFN_UNROLL
-      for (int q = 0; q < 4; ++q) {
-        const float r = use_div ? ACC1(d, q) / p.sumelems : ACC1(d, q) * scale;
-        v[q] = fmaxf(r, slope * r);
+    auto emit = [&](auto div_c, auto leaky_c) {
+      constexpr bool DIV = decltype(div_c)::value, LEAKY = decltype(leaky_c)::value;
+      if (!DIV) {  // packed multiplies on the accumulator pairs
+        const f32x2 s2 = mfn_f2(scale, scale);
+        MFN_UNROLL
+        for (int d = 0; d < D - 1; ++d) { accp[d][0] = mfn_mul2(accp[d][0], s2); accp[d][1] = mfn_mul2(accp[d][1], s2); }
+        MFN_UNROLL
+        for (int q = 0; q < 4; ++q) accs[q] *= scale;
       }
-      if (p.ablate != 1 || v[0] != v[0])
+      MFN_UNROLL
+      for (int d = 0; d < D; ++d) {
+        float v[4];
+        MFN_UNROLL
+        for (int q = 0; q < 4; ++q) {
+          const float r = DIV ? ACC1(d, q) / p.sumelems : ACC1(d, q);
+          v[q] = LEAKY ? fmaxf(r, 0.1f * r) : r;
+        }
         *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
-    }
+      }
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    if (use_div) { if (leaky) emit(T_{}, T_{}); else emit(T_{}, F_{}); }
+    else { if (leaky) emit(F_{}, T_{}); else emit(F_{}, F_{}); }
   }
   MFN_STAMP(p.timeline, 3);
 #undef ACC1

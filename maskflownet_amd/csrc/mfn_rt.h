@@ -19,6 +19,7 @@ static inline f2u mfn_load2u(const float *p) { f2u v; memcpy(&v, p, 8); return v
 struct f32x2 { float x, y; };
 static inline f32x2 mfn_f2(float x, float y) { return f32x2{x, y}; }
 static inline f32x2 mfn_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+static inline f32x2 mfn_mul2(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
 #define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_shared())
 #define MFN_MFMA_32x32x2(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
 #define MFN_MFMA_16x16x4(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
@@ -78,6 +79,7 @@ __device__ __forceinline__ f2u mfn_load2u(const float *p) { return *reinterpret_
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 mfn_f2(float x, float y) { return (f32x2){x, y}; }
 #define mfn_fma2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+#define mfn_mul2(a, b) ((a) * (b))
 // all dynamic LDS hangs off ONE 16-byte aligned symbol (cdna_hip_programming.md G17)
 extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
 #define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(mfn_lds_raw)
@@ -169,6 +171,7 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 
 #include <stddef.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mfn {
 

@@ -8,7 +8,7 @@
 //   corr.direct  LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   corr.xcd     1: XCD-aware block remap (neighbouring tiles share an L2)
 //   corr.generic 1: force the generic one-thread-per-output kernel
-//   corr.ablate  measurement only: 1 no stores, 2 no global loads
+//   corr.ablate  measurement only, bit mask (LDS-DMA kernel): 1 no stores, 2 no global loads, 4 no LDS reads / FMAs
 //   warp.vec     pixels per thread of the warp kernel: 0 auto (fast kernel) | 1 general | 4 adjacent px, 16-byte stores | 2, 8: 2 / 4 strided px
 //   dc.mt        32-filter MFMA tiles per wave: 1 | 2 | 3 | 4
 //   dc.pt        pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
