@@ -369,6 +369,9 @@ inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
 }
 inline int corr_variant_tile_h(int tw, int variant) { return variant >= 8 ? 4 : (256 / tw) * (variant == 2 ? 2 : 1); }
 
+#ifndef MFN_CORR_ABLATE
+#define MFN_CORR_ABLATE 0  // tools/corr_ablate_build.py: 1 no LDS operand reads, 2 no FMAs (single-buffered consume only)
+#endif
 // One stage of the half-wave kernels: CK channels, operands double-buffered in registers so the
 // ds_read_b128 of channel c+1 are in flight while channel c's 16 v_pk_fma_f32 + 4 v_fma_f32 issue
 // (measured: without this a lone wave spends ~300 cycles per channel, 80 of them issuing VALU).
@@ -379,10 +382,20 @@ __device__ __forceinline__ void corr_hw_consume(const float *f1p, const float *f
   if (!DBUF) {  // single operand set: ~16 fewer VGPRs (one more resident block per CU); LDS latency is hidden by TLP
     MFN_UNROLL
     for (int c = 0; c < CK; ++c) {
+#if MFN_CORR_ABLATE & 1  // measurement build: operands without LDS traffic (loop-carried, so nothing folds)
+      const float4 a = make_float4(accs[0], accs[1], accs[2], accs[3]), b0 = a, b1 = a, b2 = a;
+#else
       const float4 a = *reinterpret_cast<const float4 *>(f1p + c * F1_PER_C);
       const float4 b0 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C);
       const float4 b1 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C + 4);
       const float4 b2 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C + 8);
+#endif
+#if MFN_CORR_ABLATE & 2  // measurement build: the four reads stay live, the 36 FMAs are gone
+      accs[0] += a.x + b0.x;
+      accs[1] += b1.y + b2.z;
+      MFN_SCHED_BARRIER();
+      continue;
+#endif
       const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
       const f32x2 asw[2] = {mfn_f2(a.y, a.x), mfn_f2(a.w, a.z)};
       MFN_UNROLL
@@ -843,13 +856,13 @@ template <int D>
 inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
     case 12: return corr_dma_launch<D, 4, 3, 4, true>(p, s, "corr_dma_v12");
-    case 13: return corr_dma_launch<D, 4, 4, 4, true>(p, s, "corr_dma_v13");
+    case 13: return corr_dma_launch<D, 4, 2, 5, true>(p, s, "corr_dma_v13");
     case 14: return corr_dma_launch<D, 8, 3, 4, true>(p, s, "corr_dma_v14");
     case 15: return corr_dma_launch<D, 8, 2, 4, true>(p, s, "corr_dma_v15");
     case 16: return corr_dma_launch<D, 4, 2, 5, false>(p, s, "corr_dma_v16");
     case 17: return corr_dma_launch<D, 8, 2, 5, false>(p, s, "corr_dma_v17");
     case 18: return corr_dma_launch<D, 4, 3, 5, false>(p, s, "corr_dma_v18");
-    case 19: return corr_dma_launch<D, 4, 4, 5, false>(p, s, "corr_dma_v19");
+    case 19: return corr_dma_launch<D, 4, 3, 5, true>(p, s, "corr_dma_v19");
     case 20: return corr_dma_launch<D, 8, 2, 2, true, 2>(p, s, "corr_dma_v20");   // 15 with two channel groups
     case 21: return corr_dma_launch<D, 8, 2, 2, false, 2>(p, s, "corr_dma_v21");  // 17 with two channel groups
     case 22: return corr_dma_launch<D, 8, 2, 1, true, 3>(p, s, "corr_dma_v22");   // 15 with three channel groups
