@@ -43,21 +43,26 @@ def parse():
     ap.add_argument("--repack", action="store_true",
                     help="re-lay-out the deformable-conv weights inside every call (stateless operator) instead of "
                          "once per weight version as layer.DeformableConv2D does")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent batches in flight per GPU: step i replays on stream i %% S (each stream has its own "
+                         "outputs); 1 = every pass strictly after the previous one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the oracle baseline")
     ap.add_argument("--roofline-iters", type=int, default=200)
     return ap.parse_args()
 
 
-def timed_steps(wl, steps, dist, torch):
+def timed_steps(wls, steps, dist, torch):
     """barrier + sync | K steps | barrier + sync; returns the MAX over ranks in seconds."""
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        wl.replay()
-    wl.synchronize()
+    ns = len(wls)
+    for i in range(steps):
+        wls[i % ns].replay()
+    for w in wls:
+        w.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -210,24 +215,28 @@ def main():
     from maskflownet_amd import hotpath
     from maskflownet_amd.dist import allreduce_checksum
 
-    wl = hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
-                                 prepack=not args.repack)
-    if not args.no_graph:
-        wl.capture()
-    else:
-        wl.run_eager()
+    wls = [hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
+                                   prepack=not args.repack) for _ in range(max(1, args.streams))]
+    for w in wls:
+        if not args.no_graph:
+            w.capture()
+        else:
+            w.run_eager()
+    wl = wls[0]
 
     # untimed spin-up: an idle MI355X sits at ~100 MHz sclk and needs a few hundred ms of work to reach its
     # sustained clocks; W warm-up steps of 0.2 ms each are not enough on their own
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.5:
-        for _ in range(50):
-            wl.replay()
-        wl.synchronize()
-    for _ in range(args.warmup):
-        wl.replay()
-    wl.synchronize()
-    dt = timed_steps(wl, args.steps, dist, torch)
+        for i in range(50):
+            wls[i % len(wls)].replay()
+        for w in wls:
+            w.synchronize()
+    for i in range(args.warmup):
+        wls[i % len(wls)].replay()
+    for w in wls:
+        w.synchronize()
+    dt = timed_steps(wls, args.steps, dist, torch)
 
     # 2-float record all-reduced over RCCL (the only collective: SURVEY.md 8e)
     local_ck = wl.checksum()
@@ -256,12 +265,28 @@ def main():
                                "configs[%d])" % (wl.N, wl.H, wl.W, 1 if args.config == "cfg2" else 2),
                    "per_gpu_batch": wl.N, "global_batch": pairs_per_step, "mode": args.mode,
                    "deform_weights": "re-packed every call" if args.repack else "packed once per weight version",
-                   "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "batch shard x%d" % world},
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "streams": len(wls), "parallelism": "batch shard x%d" % world},
         "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
         "algorithmic_GFLOP_per_step_per_gpu": round(sum(af.values()) / 1e9, 3),
         "aggregate_GBps_per_gpu": round(sum(ab.values()) / (dt / args.steps) / 1e9, 1),
         "checksum_allreduce_ok": ck_ok,
     }
+    if len(wls) == 1 and world == 1 and not args.no_graph:
+        try:  # informational: the same pass with 3 independent batches in flight (3 streams, own outputs each)
+            extra = [hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
+                                             prepack=not args.repack).capture() for _ in range(2)]
+            pw = [wl] + extra
+            for i in range(60):
+                pw[i % 3].replay()
+            for w in pw:
+                w.synchronize()
+            dt3 = timed_steps(pw, args.steps, None, torch)
+            res["pipelined"] = {"streams": 3, "value": round(wl.N * args.steps / dt3, 2), "unit": "image-pairs/s",
+                                "ms_per_step": round(dt3 / args.steps * 1e3, 4),
+                                "note": "not the headline: `value` above runs every pass strictly after the previous one"}
+            del extra, pw
+        except Exception as e:
+            res["pipelined"] = {"error": repr(e)}
     try:
         res["roofline"] = roofline_of_dominant_kernel(wl, args.roofline_iters, torch)
         res["kernels"] = per_kernel_breakdown(wl, 20, torch)
