@@ -45,7 +45,7 @@ def one():
 
     wl = hotpath.HotPathWorkload("cfg2", mode="fused", prepack=False)
     out = []
-    for l, plans in ((2, [(1, 4)]), (3, [(1, 2), (2, 2)]), (4, [(1, 1), (3, 1)])):
+    for l, plans in ((2, [(1, 4)]), (3, [(1, 2)]), (4, [(1, 1)]), (5, [(1, 1)])):
         fn = lambda: ops.deformable_convolution_shared(wl.t["c2_%d" % l], wl.t["flow_%d" % l], 20.0,
                                                        hotpath.STRIDES[l], wl.t["w_%d" % l], wl.t["b_%d" % l],
                                                        out=wl.o["deform%d" % l])
