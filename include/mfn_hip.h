@@ -86,6 +86,15 @@ int mfn_correlation_fwd_act(const float *data1, const float *data2, float *out, 
                             int W, int max_displacement, int kernel_size, int stride1, int stride2,
                             int pad_size, int is_multiply, int activation, void *workspace,
                             size_t workspace_bytes, void *stream);
+/* Rest of f-1: the cost volume written straight into its channel slice of the decoder's concat buffer
+ * (/root/reference/network/MaskFlownet.py:235,253,271,289: x = concat(corr, c1, feat, flow)) -- no concat copy.
+ * out points at channel c0 of image 0 of a contiguous (N, Ctot, h, w) buffer; out_batch_stride = Ctot*h*w elements
+ * (0 = dense, i.e. D*D*h*w).  Must be >= one output image; the 16-byte-store kernels need out 16-byte aligned and
+ * the stride a multiple of 4 (otherwise the generic kernel runs).  Otherwise identical to mfn_correlation_fwd_act. */
+int mfn_correlation_fwd_into(const float *data1, const float *data2, float *out, long long out_batch_stride,
+                             int N, int C, int H, int W, int max_displacement, int kernel_size, int stride1,
+                             int stride2, int pad_size, int is_multiply, int activation, void *workspace,
+                             size_t workspace_bytes, void *stream);
 /* Backward of the same call site (training, /root/reference/network/pipeline.py:112-113).
  * g1/g2: (N,C,H,W); req1/req2 in {MFN_REQ_NULL, MFN_REQ_WRITE, MFN_REQ_ADD}. */
 int mfn_correlation_bwd(const float *gout, const float *data1, const float *data2, float *g1,

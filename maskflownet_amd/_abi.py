@@ -20,6 +20,7 @@ SIGNATURES = {
     "correlation_workspace_bytes": (C.c_size_t, [_i] * 10),
     "correlation_fwd_ws": (_i, [_f, _f, _f] + [_i] * 10 + [C.c_void_p, C.c_size_t, _s]),
     "correlation_fwd_act": (_i, [_f, _f, _f] + [_i] * 11 + [C.c_void_p, C.c_size_t, _s]),
+    "correlation_fwd_into": (_i, [_f, _f, _f, C.c_longlong] + [_i] * 11 + [C.c_void_p, C.c_size_t, _s]),
     "warp_fwd": (_i, [_f, _f, _f] + [_i] * 5 + [_s]),
     "grid_generator_warp": (_i, [_f, _f, _i, _i, _i, _s]),
     "grid_generator_affine": (_i, [_f, _f, _i, _i, _i, _s]),

@@ -66,6 +66,8 @@ struct CorrParams {
   float inv_sumelems;  // 1/C
   float sumelems;      // C
   int exact_div;       // 1: divide (C not a power of two), 0: multiply by the exact reciprocal
+  size_t out_nstride;  // elements between consecutive images of `out` (D*D*H*W when dense; larger = a channel slice
+                       // of the decoder's concat buffer, MaskFlownet.py:235)
   int xcd_swizzle;     // 1: remap blockIdx so that neighbouring tiles share an XCD's L2
   int leaky;           // fused epilogue (f-1): LeakyReLU(0.1) on the output (MaskFlownet.py:217)
   int ablate;          // measurement only: 1 = drop the output stores, 2 = drop the global loads
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
   (((q) & 1) ? ((d) < D - 1 ? accp[e][k][(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[e][k][2 + ((q) - 1) / 2]) \
              : ((d) > 0 ? accp[e][k][(d) > 0 ? (d) - 1 : 0][(q) / 2].y : accs[e][k][(q) / 2]))
   const bool raw = p.nslices > 1;
-  float *outn = (raw ? p.partial + (size_t)blockIdx.y * p.N * (D * D) * plane : p.out) + (size_t)n * (D * D) * plane;
+  float *outn = raw ? p.partial + ((size_t)blockIdx.y * p.N + n) * (D * D) * plane : p.out + (size_t)n * p.out_nstride;
   const bool use_div = p.exact_div && !raw;
   const float scale = raw ? 1.f : p.inv_sumelems;
   const float slope = (p.leaky && !raw) ? 0.1f : 1.f;  // LeakyReLU(0.1)(r) == max(r, 0.1 r)
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_hw_kernel(CorrPa
   (((q) & 1) ? ((d) < D - 1 ? accp[(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[2 + ((q) - 1) / 2]) \
              : ((d) > 0 ? accp[(d) > 0 ? (d) - 1 : 0][(q) / 2].y : accs[(q) / 2]))
   const bool raw = p.nslices > 1;
-  float *outn = (raw ? p.partial + (size_t)blockIdx.y * p.N * (D * D) * plane : p.out) + (size_t)n * (D * D) * plane;
+  float *outn = raw ? p.partial + ((size_t)blockIdx.y * p.N + n) * (D * D) * plane : p.out + (size_t)n * p.out_nstride;
   const bool use_div = p.exact_div && !raw;
   const float scale = raw ? 1.f : p.inv_sumelems;
   const float slope = (p.leaky && !raw) ? 0.1f : 1.f;
@@ -798,7 +800,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
   (((q) & 1) ? ((d) < D - 1 ? accp[(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[2 + ((q) - 1) / 2]) \
              : ((d) > 0 ? accp[(d) > 0 ? (d) - 1 : 0][(q) / 2].y : accs[(q) / 2]))
   const bool raw = p.nslices > 1;
-  float *outn = (raw ? p.partial + (size_t)blockIdx.y * p.N * (D * D) * plane : p.out) + (size_t)n * (D * D) * plane;
+  float *outn = raw ? p.partial + ((size_t)blockIdx.y * p.N + n) * (D * D) * plane : p.out + (size_t)n * p.out_nstride;
   const bool use_div = p.exact_div && !raw;
   const bool leaky = p.leaky && !raw;
   const float scale = raw ? 1.f : p.inv_sumelems;
@@ -871,7 +873,8 @@ inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
 }
 
 // ---- slice reduction: out = (sum_s partial[s]) / C, slices summed in index order ------------------
-struct CorrReduceParams { const float *partial; float *out; size_t n4; int nslices; float inv, sumelems; int exact_div, leaky; };
+struct CorrReduceParams { const float *partial; float *out; size_t n4; int nslices; float inv, sumelems; int exact_div, leaky;
+                          size_t img4, out_nstride4; };  // float4 per image in the partials / between images of `out`
 __global__ __launch_bounds__(256) void corr_reduce_kernel(CorrReduceParams p) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.n4) return;
@@ -887,7 +890,9 @@ __global__ __launch_bounds__(256) void corr_reduce_kernel(CorrReduceParams p) {
     r[q] = p.exact_div ? r[q] / p.sumelems : r[q] * p.inv;
     if (p.leaky) r[q] = r[q] > 0.f ? r[q] : 0.1f * r[q];
   }
-  reinterpret_cast<float4 *>(p.out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+  size_t o = i;
+  if (p.out_nstride4 != p.img4) { const size_t n = i / p.img4; o = n * p.out_nstride4 + (i - n * p.img4); }
+  reinterpret_cast<float4 *>(p.out)[o] = make_float4(r[0], r[1], r[2], r[3]);
 }
 inline int corr_reduce_launch(CorrReduceParams p, hipStream_t stream) {
   if (!p.n4) return 0;
@@ -903,6 +908,7 @@ struct CorrGenericParams {
   int md, kernel, stride1, stride2, pad, is_multiply;
   int top_c, top_h, top_w, radius, gw;
   int leaky;  // fused LeakyReLU(0.1)
+  size_t out_nstride;
 };
 
 __global__ __launch_bounds__(256) void corr_generic_kernel(CorrGenericParams p) {
@@ -940,7 +946,7 @@ __global__ __launch_bounds__(256) void corr_generic_kernel(CorrGenericParams p) 
       }
     }
   const float r = s / (float)(p.kernel * p.kernel * p.C);
-  p.out[idx] = p.leaky ? fmaxf(r, 0.1f * r) : r;
+  p.out[(size_t)n * p.out_nstride + ((size_t)tc * p.top_h + i) * p.top_w + j] = p.leaky ? fmaxf(r, 0.1f * r) : r;
 }
 
 inline int corr_generic_launch(CorrGenericParams p, hipStream_t stream) {

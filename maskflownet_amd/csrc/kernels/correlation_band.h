@@ -23,6 +23,7 @@ struct CorrBandParams {
   const float *f1;
   const float *f2;
   float *out;
+  size_t out_nstride;  // elements between consecutive images of `out`
   int N, C, H, W;
   int R, bands;      // output rows per workgroup, ceil(H / R)
   int G, WG;         // channel groups per workgroup, waves per group (blockDim = G * WG * 64)
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(1024) void corr_band_kernel(CorrBandParams p) {
 #define ACCB(d, q)                                                                                  \
   (((q) & 1) ? ((d) < D - 1 ? accp[(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[2 + ((q) - 1) / 2]) \
              : ((d) > 0 ? accp[(d) > 0 ? (d) - 1 : 0][(q) / 2].y : accs[(q) / 2]))
-  float *dst = p.out + ((size_t)n * (D * D) + (size_t)dyi * D) * plane + (size_t)y * W + 4 * qx;
+  float *dst = p.out + (size_t)n * p.out_nstride + (size_t)(dyi * D) * plane + (size_t)y * W + 4 * qx;
   const float slope = p.leaky ? 0.1f : 1.f;  // LeakyReLU(0.1)(v) == max(v, 0.1 v)
   MFN_UNROLL
   for (int d = 0; d < D; ++d) {
@@ -341,6 +342,7 @@ namespace mfn {
 struct CorrDirectParams {
   const float *f1, *f2;
   float *out;
+  size_t out_nstride;
   int N, C, H, W;
   int R, bands, S, Q;   // rows per band, bands per image, channel slices, outputs (quad, dx, row) per slice
   int cps;              // channels per slice
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(1024) void corr_direct_kernel(CorrDirectParams p) {
     const float rr = p.exact_div ? acc[e] / p.sumelems : acc[e] * p.inv_sumelems;
     v[e] = fmaxf(rr, slope * rr);
   }
-  *reinterpret_cast<float4 *>(p.out + ((size_t)n * D * D + (size_t)dyi * D + dxi) * plane + (size_t)y * W + x) =
+  *reinterpret_cast<float4 *>(p.out + (size_t)n * p.out_nstride + (size_t)(dyi * D + dxi) * plane + (size_t)y * W + x) =
       make_float4(v[0], v[1], v[2], v[3]);
 }
 

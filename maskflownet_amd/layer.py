@@ -245,14 +245,18 @@ class DeformableConv2D(nn.Module):
         return s.format(name=self.__class__.__name__, mapping="{0} -> {1}".format(cin, self._channels), **kw)
 
 
-def correlation(im1, im2, md, stride1=1, stride2=1, leaky=False):
+def correlation(im1, im2, md, stride1=1, stride2=1, leaky=False, out=None):
     """Body of MaskFlownet_S.corr / MaskFlownet.corr (MaskFlownet.py:193-195, :440-441).  leaky=True also applies the
-    LeakyReLU(0.1) the network wraps around every call (:217) -- fused into the kernel epilogue at inference."""
+    LeakyReLU(0.1) the network wraps around every call (:217) -- fused into the kernel epilogue at inference.
+    out: optional destination, e.g. the cost volume's channel slice x[:, :81] of the decoder's pre-allocated concat
+    buffer (x = concat(corr, c1, feat, flow), :235) -- inference only."""
     if _any_grad(im1, im2):
-        out = _CorrelationFn.apply(im1, im2, md, stride1, stride2)
-        return torch.nn.functional.leaky_relu(out, 0.1) if leaky else out
+        if out is not None:
+            raise RuntimeError("correlation(out=...) is an inference-time fusion; autograd needs its own output")
+        res = _CorrelationFn.apply(im1, im2, md, stride1, stride2)
+        return torch.nn.functional.leaky_relu(res, 0.1) if leaky else res
     return ops.Correlation(im1, im2, pad_size=md, kernel_size=1, max_displacement=md, stride1=stride1,
-                           stride2=stride2, is_multiply=1, activation="leaky" if leaky else None)
+                           stride2=stride2, is_multiply=1, activation="leaky" if leaky else None, out=out)
 
 
 class Upsample(nn.Module):

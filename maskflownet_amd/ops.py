@@ -65,14 +65,23 @@ class OpSet:
             out = self.ad.empty(d1, (N, tc, th, tw))
         elif self.ad.shape(out) != (N, tc, th, tw):
             raise ValueError("Correlation: out has shape %s, expected %s" % (self.ad.shape(out), (N, tc, th, tw)))
+        # `out` may be a channel slice of the decoder's concat buffer (x = concat(corr, c1, feat, flow),
+        # MaskFlownet.py:235): dense per image, images a whole (Ctot, h, w) apart
+        st = self.ad.elem_strides(out)
+        dims, want = (tc, th, tw), (th * tw, tw, 1)
+        dense_img = all(d <= 1 or a == b for d, a, b in zip(dims, st[1:], want))  # size-1 dims: any stride
+        if N * tc * th * tw != 0 and (not dense_img or (N > 1 and st[0] < tc * th * tw)):
+            raise ValueError("Correlation: out must be contiguous or a channel slice buf[:, c0:c0+%d] of a contiguous "
+                             "NCHW buffer (strides %s)" % (tc, st))
         args = (N, C, H, W, int(max_displacement), int(kernel_size), int(stride1), int(stride2), int(pad_size),
                 int(bool(is_multiply)))
         nbytes = self.ns.correlation_workspace_bytes(*args)
         ws = self._workspace(d1, nbytes) if nbytes else None
-        self.check(self.ns.correlation_fwd_act(self.ad.ptr(d1), self.ad.ptr(d2), self.ad.ptr(out), *args,
-                                               1 if activation == "leaky" else 0,
-                                               self.ad.ptr(ws) if ws is not None else None,
-                                               self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(d1)))
+        self.check(self.ns.correlation_fwd_into(self.ad.ptr(d1), self.ad.ptr(d2), self.ad.ptr(out),
+                                                int(st[0]) if N > 1 else 0, *args,
+                                                1 if activation == "leaky" else 0,
+                                                self.ad.ptr(ws) if ws is not None else None,
+                                                self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(d1)))
         return out
 
     def Correlation_backward(self, out_grad, data1, data2, kernel_size=1, max_displacement=1, stride1=1, stride2=1,
@@ -396,6 +405,9 @@ class TorchAdapter:
 
     def ndim(self, a):
         return a.dim()
+
+    def elem_strides(self, a):
+        return tuple(a.stride())
 
     def empty(self, like, shape):
         return self.torch.empty(shape, dtype=self.torch.float32, device=like.device)

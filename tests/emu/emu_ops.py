@@ -27,6 +27,9 @@ class NumpyAdapter:
     def ndim(self, a):
         return a.ndim
 
+    def elem_strides(self, a):
+        return tuple(int(v) // a.itemsize for v in a.strides)
+
     def empty(self, like, shape):
         return np.full(shape, np.nan, dtype=np.float32)  # NaN-poisoned: unwritten outputs are caught
 

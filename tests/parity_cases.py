@@ -61,6 +61,25 @@ def case_correlation_leaky(ops, oracle, to_dev, to_host, shape, md, seed=0, **kw
     return check_close(fused, np.where(want > 0, want, np.float32(0.1) * want), what="correlation leaky %s" % (shape,))
 
 
+def case_correlation_into(ops, oracle, to_dev, to_host, shape, md, c0=3, extra=7, seed=0):
+    """The cost volume written into its channel slice of a wider concat buffer (MaskFlownet.py:235):
+    bit-identical to the dense call, neighbouring channels untouched."""
+    rng = np.random.default_rng(555 + seed)
+    f1, f2 = feat(rng, shape), feat(rng, shape)
+    okw = dict(kernel_size=1, max_displacement=md, stride1=1, stride2=1, pad_size=md, is_multiply=True)
+    N, C, H, W = shape
+    D2 = (2 * md + 1) ** 2
+    dense = to_host(ops.Correlation(to_dev(f1), to_dev(f2), activation="leaky", **okw))
+    sentinel = np.float32(-12345.5)
+    buf = to_dev(np.full((N, c0 + D2 + extra, H, W), sentinel, np.float32))
+    ops.Correlation(to_dev(f1), to_dev(f2), activation="leaky", out=buf[:, c0:c0 + D2], **okw)
+    got = to_host(buf)
+    np.testing.assert_array_equal(got[:, c0:c0 + D2], dense)
+    assert (got[:, :c0] == sentinel).all() and (got[:, c0 + D2:] == sentinel).all(), "wrote outside the slice"
+    want = oracle.correlation(f1, f2, **okw)
+    return check_close(dense, np.where(want > 0, want, np.float32(0.1) * want), what="correlation into %s" % (shape,))
+
+
 def case_correlation_generic(ops, oracle, to_dev, to_host, shape, seed=0, **kw):
     rng = np.random.default_rng(77 + seed)
     f1, f2 = feat(rng, shape), feat(rng, shape)

@@ -112,6 +112,28 @@ def test_correlation_fused_leaky_relu(ops, oracle, tune, shape):
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, 4)
 
 
+@pytest.mark.parametrize("tune,shape,c0", [(dict(corr_variant=6, corr_tw=16), (2, 6, 7, 16), 4),          # tiled kernel
+                                           (dict(corr_variant=15), (2, 8, 6, 36), 4),                     # LDS-DMA tile kernel
+                                           (dict(corr_variant=22), (2, 12, 6, 32), 8),                    # ... with channel groups
+                                           (dict(corr_variant=6, corr_tw=16, corr_slices=2), (3, 16, 5, 16), 4),  # reduce kernel
+                                           (dict(corr_band=1), (2, 20, 6, 8), 4),                         # band kernel
+                                           (dict(corr_direct=1), (2, 30, 6, 8), 4),                       # direct kernel
+                                           (dict(), (2, 5, 6, 8), 3),                                     # slice not 16-byte aligned -> generic
+                                           (dict(corr_generic=1), (2, 3, 6, 7), 3)])                      # generic kernel
+def test_correlation_into_concat_slice(ops, oracle, tune, shape, c0):
+    emu_ops.set_tuning(**tune)
+    pc.case_correlation_into(ops, oracle, ident, ident, shape, 4, c0=c0)
+
+
+def test_correlation_into_rejects_bad_views(ops):
+    f = np.zeros((2, 4, 6, 8), np.float32)
+    buf = np.zeros((2, 100, 6, 8), np.float32)
+    with pytest.raises(ValueError):
+        ops.Correlation(f, f, 1, 4, 1, 1, 4, True, out=buf[:, 0:162:2])            # strided channels
+    with pytest.raises(ValueError):
+        ops.Correlation(f, f, 1, 4, 1, 1, 4, True, out=np.zeros((2, 81, 6, 16), np.float32)[:, :, :, :8])  # strided rows
+
+
 def test_correlation_non_pow2_channels_divide(ops, oracle):
     pc.case_correlation(ops, oracle, ident, ident, (1, 12, 6, 8), 4)
 

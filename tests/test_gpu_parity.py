@@ -337,6 +337,13 @@ def test_correlation_fused_leaky_relu_all_levels(ops, oracle, dev, shape):
     pc.case_correlation_leaky(ops, oracle, dev, host, shape, 4)
 
 
+@pytest.mark.parametrize("shape", CFG2 + [(2, 5, 6, 7)])
+@pytest.mark.parametrize("c0", [0, 4, 3])
+def test_correlation_into_concat_slice(ops, oracle, dev, shape, c0):
+    """f-1: the cost volume lands in its slice of the decoder's concat buffer (c0 = 3 with an odd plane count is not 16-byte aligned)."""
+    pc.case_correlation_into(ops, oracle, dev, host, shape, 4, c0=c0)
+
+
 @pytest.mark.parametrize("shape,factor", [((8, 2, 6, 8), 2), ((8, 2, 48, 64), 2), ((8, 2, 96, 128), 4), ((4, 1, 112, 256), 4),
                                           ((2, 3, 7, 9), 2), ((1, 2, 5, 6), 3)])
 def test_upsample_flow_and_mask(ops, oracle, dev, shape, factor):
