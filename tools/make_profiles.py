@@ -18,9 +18,10 @@ if os.path.exists(db):
     with open(os.path.join(P, "%s_bench_kernel_stats.md" % tag), "w") as f:
         f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline`\n\n" % tag)
         f.write("MI355X (gfx950), ROCm 7.2.  Source: gpurun_out/prof_bench/bench_results.db (top_kernels view); durations in "
-                "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (level 6: sliced pair "
-                "+ reduce; level 5: band kernel; levels 4/3: LDS-DMA tile kernel with in-block channel groups; level 2: "
-                "LDS-DMA tile kernel), 4 x (offsets + deformable conv), 1 warp.\n"
+                "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (level 6: direct "
+                "kernel; level 5: band kernel; levels 4/3: LDS-DMA tile kernel with in-block channel groups; level 2: "
+                "LDS-DMA tile kernel), 4 x (offsets + deformable conv), 1 warp.  bench.py also runs the pass on two more "
+                "streams for its informational `pipelined` figure, and the level-2 correlation 200 more times for `roofline`.\n"
                 "Only `mfn::` kernels belong to the pass; the `at::native` rows are bench.py's checksum.\n\n")
         f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows:
@@ -58,7 +59,7 @@ if fe and wr:
                         "rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python tools/prof_one.py corr 2"]}
     json.dump(rec, open(os.path.join(P, "%s_corr_l2_hbm_traffic.json" % tag), "w"), indent=1)
     print("wrote", "%s_corr_l2_hbm_traffic.json" % tag, "traffic %.2f MB" % (traffic / 1e6))
-for name in ("bench", "bench_fused", "bench_cfg3", "bench_repack"):
+for name in ("bench", "bench_fused", "bench_cfg3", "bench_repack", "bench_streams3"):
     src = os.path.join(G, name + ".log")
     if os.path.exists(src):
         line = open(src).read().strip().splitlines()[-1]
