@@ -391,3 +391,22 @@ def test_hot_path_pass_graph_replay_matches_eager(T):
     T.cuda.synchronize()
     for a, b in zip(outs_eager, wl.outputs()):
         assert T.equal(a, b)
+
+
+def test_hot_path_three_batches_in_flight_match_single_stream(T):
+    """bench.py --streams 3: graphs replayed concurrently on three streams (own outputs, per-stream workspaces) give
+    exactly the single-stream results."""
+    from maskflownet_amd import hotpath
+    ref = [o.clone() for o in hotpath.HotPathWorkload("cfg2", device="cuda", prepack=False).run_eager()]
+    wls = [hotpath.HotPathWorkload("cfg2", device="cuda", prepack=(i != 1)).capture() for i in range(3)]
+    for w in wls:
+        for o in w.outputs():
+            o.fill_(float("nan"))
+    T.cuda.synchronize()
+    for i in range(30):
+        wls[i % 3].replay()
+    for w in wls:
+        w.synchronize()
+    for w in wls:
+        for a, b in zip(ref, w.outputs()):
+            assert T.equal(a, b)
