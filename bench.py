@@ -294,7 +294,7 @@ def main():
     except Exception as e:  # the headline number must survive a profiler problem
         res["roofline"] = None
         res["roofline_error"] = repr(e)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: other ranks would idle in the barrier meanwhile
         res["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)
     print(json.dumps(res))
