@@ -68,6 +68,7 @@ struct CorrParams {
   int exact_div;       // 1: divide (C not a power of two), 0: multiply by the exact reciprocal
   size_t out_nstride;  // elements between consecutive images of `out` (D*D*H*W when dense; larger = a channel slice
                        // of the decoder's concat buffer, MaskFlownet.py:235)
+  int nt_store;        // cache policy of the output stores (mfn_store4_stream; LDS-DMA kernel)
   int xcd_swizzle;     // 1: remap blockIdx so that neighbouring tiles share an XCD's L2
   int leaky;           // fused epilogue (f-1): LeakyReLU(0.1) on the output (MaskFlownet.py:217)
   int ablate;          // measurement only: 1 = drop the output stores, 2 = drop the global loads
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
           const float r = DIV ? ACC1(d, q) / p.sumelems : ACC1(d, q);
           v[q] = LEAKY ? fmaxf(r, 0.1f * r) : r;
         }
-        *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
+        mfn_store4_stream(dst + (size_t)d * plane, v[0], v[1], v[2], v[3], p.nt_store);
       }
     };
     using T_ = std::integral_constant<bool, true>;

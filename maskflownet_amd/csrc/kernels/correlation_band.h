@@ -24,6 +24,7 @@ struct CorrBandParams {
   const float *f2;
   float *out;
   size_t out_nstride;  // elements between consecutive images of `out`
+  int st_policy;       // mfn_store4_stream
   int N, C, H, W;
   int R, bands;      // output rows per workgroup, ceil(H / R)
   int G, WG;         // channel groups per workgroup, waves per group (blockDim = G * WG * 64)
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(1024) void corr_band_kernel(CorrBandParams p) {
       const float rr = p.exact_div ? s / p.sumelems : s * p.inv_sumelems;
       v[q] = fmaxf(rr, slope * rr);
     }
-    *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
+    mfn_store4_stream(dst + (size_t)d * plane, v[0], v[1], v[2], v[3], p.st_policy);
   }
 #undef ACCB
 }
@@ -343,6 +344,7 @@ struct CorrDirectParams {
   const float *f1, *f2;
   float *out;
   size_t out_nstride;
+  int st_policy;
   int N, C, H, W;
   int R, bands, S, Q;   // rows per band, bands per image, channel slices, outputs (quad, dx, row) per slice
   int cps;              // channels per slice
@@ -423,8 +425,8 @@ __global__ __launch_bounds__(1024) void corr_direct_kernel(CorrDirectParams p) {
     const float rr = p.exact_div ? acc[e] / p.sumelems : acc[e] * p.inv_sumelems;
     v[e] = fmaxf(rr, slope * rr);
   }
-  *reinterpret_cast<float4 *>(p.out + (size_t)n * p.out_nstride + (size_t)(dyi * D + dxi) * plane + (size_t)y * W + x) =
-      make_float4(v[0], v[1], v[2], v[3]);
+  mfn_store4_stream(p.out + (size_t)n * p.out_nstride + (size_t)(dyi * D + dxi) * plane + (size_t)y * W + x, v[0], v[1], v[2],
+                    v[3], p.st_policy);
 }
 
 // plan: the band height R that gives the most channel slices within 1024 threads (latency is what counts here)

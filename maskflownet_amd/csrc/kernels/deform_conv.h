@@ -44,6 +44,7 @@ struct DeformParams {
   unsigned long long *timeline;  // measurement only (mfn_debug_set_timeline)
   int stage_window;              // tuning: 0 disables the LDS source-window staging
   int xcd;                       // 1: blockIdx.x -> tile range remapped per XCD (1-D grids only)
+  int st_policy;                 // cache policy of the output stores (mfn_store4_stream)
   int vec_store;                 // out / partial are 16-byte aligned and Wo % 4 == 0: 16-byte epilogue stores
   // fused epilogue of the matching module (MaskFlownet.py:232-233): out = act(out * sigmoid(mask) + add)
   const float *ep_mask;          // (N,1,Ho,Wo) or NULL
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
                                    (size_t)n * p.Cout * oplane + oidx + q);
           }
           if (ox + 3 < Wo) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(e[0], e[1], e[2], e[3]);
+            mfn_store4_stream(dst, e[0], e[1], e[2], e[3], raw ? 0 : p.st_policy);  // partial sums are re-read: plain
           } else {
             MFN_UNROLL
             for (int q = 0; q < 4; ++q)
@@ -750,7 +751,7 @@ inline int dc_generic_launch(const DeformParams &p, hipStream_t stream) {
 }
 
 // ---- offset builder (MaskFlownet.py:230) ----------------------------------------------------------------
-struct OffsetsParams { const float *flow; float *offset; int N, H, W, taps; float scale, stride; };
+struct OffsetsParams { const float *flow; float *offset; int N, H, W, taps; float scale, stride; int st_policy; };
 __global__ __launch_bounds__(256) void offsets_from_flow_kernel(OffsetsParams p) {
   const size_t plane = (size_t)p.H * p.W;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over N*2*plane
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(256) void offsets_from_flow_kernel(OffsetsParams p)
   const size_t t = r / plane, pix = r - t * plane;
   const float v = p.flow[idx] * p.scale / p.stride;
   float *o = p.offset + n * 2 * p.taps * plane + t * plane + pix;
-  for (int k = 0; k < p.taps; ++k) o[(size_t)2 * k * plane] = v;
+  for (int k = 0; k < p.taps; ++k) mfn_store1_stream(o + (size_t)2 * k * plane, v, p.st_policy);
 }
 inline int offsets_from_flow_launch(OffsetsParams p, hipStream_t stream) {
   const size_t total = (size_t)p.N * 2 * p.H * p.W;

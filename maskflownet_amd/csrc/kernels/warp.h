@@ -17,6 +17,7 @@ struct WarpParams {
   float *out;
   int N, C, H, W;
   int clip;
+  int st_policy;  // cache policy of the output stores (mfn_store1_stream; fast kernel)
 };
 
 struct Taps {
@@ -173,9 +174,9 @@ __global__ __launch_bounds__(256) void warp_fwd_fast_kernel(WarpParams p, unsign
       b[k] = mfn_load2u(pl + t.p1);
     }
     MFN_UNROLL
-    for (int k = 0; k < G; ++k) o[(size_t)(c + k) * plane] = combine_pairs(a[k], b[k], t);
+    for (int k = 0; k < G; ++k) mfn_store1_stream(o + (size_t)(c + k) * plane, combine_pairs(a[k], b[k], t), p.st_policy);
   }
-  for (; c < p.C; ++c) o[(size_t)c * plane] = sample_pairs(xin + (size_t)c * plane, t);
+  for (; c < p.C; ++c) mfn_store1_stream(o + (size_t)c * plane, sample_pairs(xin + (size_t)c * plane, t), p.st_policy);
 }
 
 // PX pixels per thread, `stride` pixels apart (every load / store of a wave still covers 64 adjacent pixels): more

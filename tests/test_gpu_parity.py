@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0)
+    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -410,3 +410,17 @@ def test_hot_path_three_batches_in_flight_match_single_stream(T):
     for w in wls:
         for a, b in zip(ref, w.outputs()):
             assert T.equal(a, b)
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2, 3])
+def test_output_store_cache_policies_are_bit_identical(T, policy):
+    """store.policy only changes how the output lines travel (plain / nt / sc0 sc1 / sc0 sc1 nt), never the values."""
+    from maskflownet_amd import _lib, hotpath
+    ref = [o.clone() for o in hotpath.HotPathWorkload("tiny", device="cuda").run_eager()]
+    _lib.set_tuning(store_policy=policy)
+    try:
+        got = hotpath.HotPathWorkload("tiny", device="cuda").run_eager()
+        for a, b in zip(ref, got):
+            assert T.equal(a, b)
+    finally:
+        _lib.set_tuning(store_policy=-1)

@@ -115,7 +115,7 @@ int main() {
   (void)hipMalloc(&x, hx.size() * 4); (void)hipMalloc(&f, hf.size() * 4); (void)hipMalloc(&o, hx.size() * 4);
   (void)hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(f, hf.data(), hf.size() * 4, hipMemcpyHostToDevice);
-  WarpParams p{x, f, o, N, C, H, W, 0};
+  WarpParams p{x, f, o, N, C, H, W, 0, 0};
   const unsigned total = (unsigned)(N * plane);
   const dim3 g((total + 255) / 256);
   printf("full                 %7.2f us\n", timeit(s, [&] { k<0><<<g, 256, 0, s>>>(p, total); }, 20));
