@@ -35,6 +35,7 @@ struct CorrBwdParams {
   float *g1, *g2;
   int N, C, H, W, md, D;  // D = 2*md+1 (kernel 1, strides 1, pad == md: top_h = H, top_w = W)
   int req1, req2;
+  int st_policy;  // cache policy of the gradient stores (mfn_store4_stream; block kernel)
 };
 // g1[n,c,y,x] = 1/C sum_d gout[n,d,y,x]       * f2[n,c,y+dy,x+dx]
 // g2[n,c,y,x] = 1/C sum_d gout[n,d,y-dy,x-dx] * f1[n,c,y-dy,x-dx]      (terms outside the image vanish)
@@ -165,12 +166,12 @@ __global__ __launch_bounds__(256) void corr_bwd_block_kernel(CorrBwdParams p) {
     if (p.req1) {
       float4 r = make_float4(s1[k][0] * inv, s1[k][1] * inv, s1[k][2] * inv, s1[k][3] * inv);
       if (p.req1 == 3) { const float4 old = *reinterpret_cast<const float4 *>(p.g1 + o); r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
-      *reinterpret_cast<float4 *>(p.g1 + o) = r;
+      mfn_store4_stream(p.g1 + o, r.x, r.y, r.z, r.w, p.st_policy);
     }
     if (p.req2) {
       float4 r = make_float4(s2[k][0] * inv, s2[k][1] * inv, s2[k][2] * inv, s2[k][3] * inv);
       if (p.req2 == 3) { const float4 old = *reinterpret_cast<const float4 *>(p.g2 + o); r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
-      *reinterpret_cast<float4 *>(p.g2 + o) = r;
+      mfn_store4_stream(p.g2 + o, r.x, r.y, r.z, r.w, p.st_policy);
     }
   }
 }

@@ -17,6 +17,7 @@ struct UpsampleParams {
   const float *x;
   float *out;
   int N, C, H, W, f;
+  int st_policy;  // cache policy of the output stores (mfn_store4_stream)
 };
 
 // hipcc contracts a*b+c into FMAs by default (and HIP's __fmul_rn / __fadd_rn are plain operators, not barriers);
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(UpsampleParams p) {
   }
   float *dst = p.out + nc * (size_t)Hout * Wout + (size_t)oy * Wout + (size_t)xv * VEC;
   if (VEC == 4) {
-    *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+    mfn_store4_stream(dst, o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC], p.st_policy);
   } else {
     MFN_UNROLL
     for (int k = 0; k < VEC; ++k) dst[k] = o[k];
