@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="independent batches in flight per GPU: step i replays on stream i %% S (each stream has its own "
                          "outputs); 1 = every pass strictly after the previous one")
+    ap.add_argument("--tuning", default="", help="library tuning overrides for A/B measurements, e.g. store_policy=0,dc_xcd=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the oracle baseline")
     ap.add_argument("--roofline-iters", type=int, default=200)
@@ -83,26 +84,50 @@ def roofline_of_dominant_kernel(wl, iters, torch):
     n, c, h, w = hotpath.level_shapes(wl.N, wl.H, wl.W)[2]
     nbytes = 4 * n * h * w * (2 * c + 81)
     nflops = 2 * n * h * w * c * 81
+    def query(tag=b""):
+        c_, m_ = ctypes.c_int(0), ctypes.c_double(0.0)
+        buf = ctypes.create_string_buffer(8192)
+        lib.profile_dump(buf, 8192)
+        for line in buf.value.decode().splitlines():  # whichever correlation kernel the library dispatched
+            nm = line.split()[0]
+            if nm.startswith("corr_") and nm.endswith(tag.decode()) and "reduce" not in nm:
+                lib.profile_query(nm.encode(), ctypes.byref(c_), ctypes.byref(m_))
+                return nm.split("@")[0], c_.value, m_.value
+        return None, 0, 0.0
+
+    corr2 = lambda: wl.ops.Correlation(t["c1_2"], o["deform2"], 1, 4, 1, 1, 4, True, out=o["corr2"])
     with torch.cuda.stream(wl.stream):
+        # (a) back to back on hot caches: the kernel alone
         for _ in range(10):
-            wl.ops.Correlation(t["c1_2"], o["deform2"], 1, 4, 1, 1, 4, True, out=o["corr2"])
+            corr2()
         wl.stream.synchronize()
         lib.profile_reset()
         lib.profile_enable(1)
         for _ in range(iters):
-            wl.ops.Correlation(t["c1_2"], o["deform2"], 1, 4, 1, 1, 4, True, out=o["corr2"])
+            corr2()
         lib.profile_enable(0)
         wl.stream.synchronize()
-    cnt, ms = ctypes.c_int(0), ctypes.c_double(0.0)
-    kname = None
-    for cand in (b"corr_dma", b"corr_hw", b"corr_tiled"):  # whichever variant the library dispatched
-        lib.profile_query(cand, ctypes.byref(cnt), ctypes.byref(ms))
-        if cnt.value:
-            kname = cand.decode()
-            break
+        _, hot_cnt, hot_ms = query()
+        # (b) where it runs in the pass: the whole operator sequence with every kernel timed (as rocprofv3 does), the
+        # level-2 correlation's launches tagged (its inputs were just written by the level-2 deformable conv and the
+        # caches hold other kernels' data)
+        lib.profile_reset()
+        lib.profile_enable(1)
+        for _ in range(iters):
+            for name, fn in wl.calls():
+                if name == "corr2":
+                    lib.profile_tag(b"L2")
+                    fn()
+                    lib.profile_tag(None)
+                else:
+                    fn()
+        lib.profile_enable(0)
+        wl.stream.synchronize()
+    kname, cnt_v, ms_v = query(b"@L2")
     lib.profile_reset()
-    if cnt.value == 0:
+    if cnt_v == 0:
         return None
+    cnt, ms = ctypes.c_int(cnt_v), ctypes.c_double(ms_v)
     avg_s = ms.value / cnt.value * 1e-3
     traffic, traffic_src = None, None
     import glob
@@ -117,7 +142,9 @@ def roofline_of_dominant_kernel(wl, iters, torch):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg_s * 1e6, 3),
-            "launches_timed": cnt.value, "fp32_tflops": round(nflops / avg_s / 1e12, 2),
+            "launches_timed": cnt.value, "timed_where": "inside the operator sequence of the pass (eager, HIP events around every kernel on the launch stream)",
+            "hot_loop_avg_launch_us": round(hot_ms / max(hot_cnt, 1) * 1e3, 3),
+            "fp32_tflops": round(nflops / avg_s / 1e12, 2),
             "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)}
 
 
@@ -214,6 +241,9 @@ def main():
 
     from maskflownet_amd import hotpath
     from maskflownet_amd.dist import allreduce_checksum
+    if args.tuning:
+        from maskflownet_amd import _lib
+        _lib.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))})
 
     wls = [hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
                                    prepack=not args.repack) for _ in range(max(1, args.streams))]
@@ -265,7 +295,8 @@ def main():
                                "configs[%d])" % (wl.N, wl.H, wl.W, 1 if args.config == "cfg2" else 2),
                    "per_gpu_batch": wl.N, "global_batch": pairs_per_step, "mode": args.mode,
                    "deform_weights": "re-packed every call" if args.repack else "packed once per weight version",
-                   "launch": "eager" if args.no_graph else "hipGraph replay", "streams": len(wls), "parallelism": "batch shard x%d" % world},
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "streams": len(wls),
+                   **({"tuning_overrides": args.tuning} if args.tuning else {}), "parallelism": "batch shard x%d" % world},
         "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
         "algorithmic_GFLOP_per_step_per_gpu": round(sum(af.values()) / 1e9, 3),
         "aggregate_GBps_per_gpu": round(sum(ab.values()) / (dt / args.steps) / 1e9, 1),

@@ -238,6 +238,9 @@ int mfn_graph_destroy(void *graph_exec);
  * accumulated per kernel name.  Used by bench.py for the roofline line. */
 int mfn_profile_enable(int on);
 int mfn_profile_reset(void);
+/* Records taken until the next call carry the suffix "@tag" (NULL / "" clears it): tells the launches of one operator
+ * call apart inside a fully profiled pass. */
+int mfn_profile_tag(const char *tag);
 /* Synchronises the recorded events, then reports launches and summed milliseconds of every
  * kernel whose name contains `name_substr`.  Returns the number of matching launches. */
 int mfn_profile_query(const char *name_substr, int *launches, double *total_ms);

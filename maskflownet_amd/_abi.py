@@ -56,6 +56,7 @@ PRODUCT_ONLY = {
     "graph_destroy": (_i, [C.c_void_p]),
     "profile_enable": (_i, [_i]),
     "profile_reset": (_i, []),
+    "profile_tag": (_i, [C.c_char_p]),
     "profile_query": (_i, [C.c_char_p, _pi, C.POINTER(C.c_double)]),
     "profile_dump": (_i, [C.c_char_p, _i]),
 }

@@ -17,10 +17,11 @@ struct ProfRec { std::string name; hipEvent_t e0, e1; };
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static bool g_prof_on = false;
+static std::string g_prof_tag;  // appended to the names of the records taken while it is set (mfn_profile_tag)
 bool profile_enabled() { return g_prof_on; }
 void profile_record(const char *name, hipEvent_t e0, hipEvent_t e1) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof.push_back(ProfRec{name, e0, e1});
+  g_prof.push_back(ProfRec{g_prof_tag.empty() ? std::string(name) : std::string(name) + "@" + g_prof_tag, e0, e1});
 }
 }  // namespace mfn
 
@@ -58,6 +59,11 @@ int mfn_graph_destroy(void *exec) {
 
 // ---- profiler ------------------------------------------------------------------------------------------
 int mfn_profile_enable(int on) { g_prof_on = on != 0; return 0; }
+int mfn_profile_tag(const char *tag) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_tag = tag ? tag : "";
+  return 0;
+}
 int mfn_profile_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto &r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

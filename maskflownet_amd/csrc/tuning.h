@@ -8,8 +8,9 @@
 //   corr.direct  LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   corr.xcd     1: XCD-aware block remap (neighbouring tiles share an L2)
 //   corr.generic 1: force the generic one-thread-per-output kernel
-//   store.policy cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for correlation and offsets,
-//                nt for warp and deformable conv; smaller outputs plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
+//   store.corr / store.dc / store.warp / store.off   the same per kernel family (override store.policy)
+//   store.policy cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
+//                nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
 //   corr.ablate  measurement only, bit mask (LDS-DMA kernel): 1 no stores, 2 no global loads, 4 no LDS reads / FMAs
 //   warp.vec     pixels per thread of the warp kernel: 0 auto (fast kernel) | 1 general | 4 adjacent px, 16-byte stores | 2, 8: 2 / 4 strided px
 //   dc.mt        32-filter MFMA tiles per wave: 1 | 2 | 3 | 4
@@ -26,7 +27,7 @@
 namespace mfn {
 struct Tuning {
   int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0;
-  int store_policy = -1;
+  int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
   int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1;
   int *slot(const char *key) {
@@ -36,6 +37,10 @@ struct Tuning {
     if (!strcmp(key, "corr.generic")) return &corr_generic;
     if (!strcmp(key, "corr.ablate")) return &corr_ablate;
     if (!strcmp(key, "store.policy")) return &store_policy;
+    if (!strcmp(key, "store.corr")) return &store_corr;
+    if (!strcmp(key, "store.dc")) return &store_dc;
+    if (!strcmp(key, "store.warp")) return &store_warp;
+    if (!strcmp(key, "store.off")) return &store_off;
     if (!strcmp(key, "corr.slices")) return &corr_slices;
     if (!strcmp(key, "corr.lanemap")) return &corr_lanemap;
     if (!strcmp(key, "corr.band")) return &corr_band;
