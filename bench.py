@@ -37,7 +37,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2 (default, the headline) / cfg3: MaskFlownet-S forward; cfg4: full model (S + cascade) forward; "
+                         "cfg5: S forward + backward + gradient all-reduce")
     ap.add_argument("--mode", default="dropin", choices=["dropin", "fused"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--repack", action="store_true",
@@ -60,8 +62,9 @@ def timed_steps(wls, steps, dist, torch):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ns = len(wls)
+    gb = wls[0].N * (dist.get_world_size() if dist is not None else 1)
     for i in range(steps):
-        wls[i % ns].replay()
+        wls[i % ns].step(dist, gb)
     for w in wls:
         w.synchronize()
     torch.cuda.synchronize()
@@ -86,8 +89,8 @@ def roofline_of_dominant_kernel(wl, iters, torch):
     nflops = 2 * n * h * w * c * 81
     def query(tag=b""):
         c_, m_ = ctypes.c_int(0), ctypes.c_double(0.0)
-        buf = ctypes.create_string_buffer(8192)
-        lib.profile_dump(buf, 8192)
+        buf = ctypes.create_string_buffer(32768)
+        lib.profile_dump(buf, 32768)
         for line in buf.value.decode().splitlines():  # whichever correlation kernel the library dispatched
             nm = line.split()[0]
             if nm.startswith("corr_") and nm.endswith(tag.decode()) and "reduce" not in nm:
@@ -161,8 +164,8 @@ def per_kernel_breakdown(wl, iters, torch):
     wl.stream.synchronize()
     buf = (b"\0" * 8192)
     import ctypes
-    cbuf = ctypes.create_string_buffer(8192)
-    lib.profile_dump(cbuf, 8192)
+    cbuf = ctypes.create_string_buffer(32768)
+    lib.profile_dump(cbuf, 32768)
     lib.profile_reset()
     out = {}
     for line in cbuf.value.decode().splitlines():
@@ -204,11 +207,11 @@ def cpu_baseline(wl, seconds):
     """The oracle's pass over the same synthetic batch, 1 thread, repeated until ~`seconds` of CPU work
     have been spent (reported baseline only, never the thing measured or shipped)."""
     from oracle import hotpath_ref
-    hotpath_ref.oracle_pass(wl.host, 1)  # touch the library / page in
+    hotpath_ref.oracle_pass(wl.host, 1, kind=wl.kind, mode=wl.mode)  # touch the library / page in
     t0 = time.perf_counter()
     pairs = 0
     while True:
-        hotpath_ref.oracle_pass(wl.host, wl.N)
+        hotpath_ref.oracle_pass(wl.host, wl.N, kind=wl.kind, mode=wl.mode)
         pairs += wl.N
         dt = time.perf_counter() - t0
         if dt >= seconds or dt >= 30.0:
@@ -263,7 +266,7 @@ def main():
         for w in wls:
             w.synchronize()
     for i in range(args.warmup):
-        wls[i % len(wls)].replay()
+        wls[i % len(wls)].step(dist, wl.N * world)
     for w in wls:
         w.synchronize()
     dt = timed_steps(wls, args.steps, dist, torch)
@@ -282,17 +285,28 @@ def main():
     pairs_per_step = wl.N * world
     value = pairs_per_step * args.steps / dt
     ms_per_step = dt / args.steps * 1e3
-    ab = hotpath.algorithmic_bytes(wl.N, wl.H, wl.W, args.mode)
-    af = hotpath.algorithmic_flops(wl.N, wl.H, wl.W)
+    ab = hotpath.algorithmic_bytes(wl.N, wl.H, wl.W, args.mode, kind=wl.kind)
+    af = hotpath.algorithmic_flops(wl.N, wl.H, wl.W, kind=wl.kind)
+    metric = {"cfg2": "image-pairs/s MaskFlownet-S 384x512 fwd hot path (correlation + deformable conv + warp)",
+              "cfg3": "image-pairs/s MaskFlownet-S 448x1024 fwd hot path",
+              "cfg4": "image-pairs/s full MaskFlownet (S + cascade) 384x512 fwd hot path",
+              "cfg5": "image-pairs/s MaskFlownet-S 384x512 train-step hot path (fwd + bwd of correlation / deformable "
+                      "conv + gradient all-reduce)"}[args.config]
+    workload = {"S": "MaskFlownet-S forward hot path: 5x Correlation(md=4) + 4x DeformableConvolution(3x3, shared 9-tap "
+                     "offsets) + 1x warp",
+                "full": "full MaskFlownet forward hot path: the S pass + cascade (5x DeformableConvolution incl. level 6, "
+                        "10x Correlation(md=2))",
+                "train": "MaskFlownet-S train-step hot path: the S forward pass + 5x Correlation backward + 4x "
+                         "DeformableConvolution backward (data, offset, weight, bias) + 1 all-reduce of the 1.1 MB "
+                         "gradient bucket"}[wl.kind]
+    cfg_index = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}[args.config]
     res = {
-        "metric": "image-pairs/s MaskFlownet-S 384x512 fwd hot path (correlation + deformable conv + warp)"
-                  if args.config == "cfg2" else "image-pairs/s MaskFlownet-S 448x1024 fwd hot path",
+        "metric": metric,
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "MaskFlownet-S forward hot path: 5x Correlation(md=4) + 4x DeformableConvolution"
-                               "(3x3, shared 9-tap offsets) + 1x warp, batch=%d synthetic %dx%d per GPU (BASELINE "
-                               "configs[%d])" % (wl.N, wl.H, wl.W, 1 if args.config == "cfg2" else 2),
+        "config": {"workload": "%s, batch=%d synthetic %dx%d per GPU (BASELINE configs[%d])"
+                               % (workload, wl.N, wl.H, wl.W, cfg_index),
                    "per_gpu_batch": wl.N, "global_batch": pairs_per_step, "mode": args.mode,
                    "deform_weights": "re-packed every call" if args.repack else "packed once per weight version",
                    "launch": "eager" if args.no_graph else "hipGraph replay", "streams": len(wls),
@@ -308,7 +322,7 @@ def main():
                                              prepack=not args.repack).capture() for _ in range(2)]
             pw = [wl] + extra
             for i in range(60):
-                pw[i % 3].replay()
+                pw[i % 3].step()
             for w in pw:
                 w.synchronize()
             dt3 = timed_steps(pw, args.steps, None, torch)

@@ -46,3 +46,17 @@ def global_mean(local_sum, local_count, dist, device=None):
     v = torch.tensor([float(local_sum), float(local_count)], dtype=torch.float64, device=device)
     v = allreduce_checksum(v, dist)
     return float(v[0] / v[1]) if float(v[1]) > 0 else float("nan")
+
+
+def allreduce_bucket(bucket, dist, batch_size=None):
+    """The training step's only exchange (BASELINE.json configs[4]): all-reduce(sum), in place, of the flat bucket that
+    holds every parameter gradient of the hot path (hotpath.grad_bucket_layout: deform5..deform2 weight + bias, 1.1 MB
+    -- one collective instead of the reference's per-parameter kvstore push/pull, pipeline.py:114 trainer.step), then
+    the 1/batch_size of trainer.step(batch_size) when `batch_size` (the GLOBAL batch) is given.  Gradients are sums over
+    samples (A.4: dW accumulated over n), so the reduced bucket equals the single-process gradient of the whole batch
+    up to fp32 summation order.  Identity when not distributed."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+    if batch_size is not None:
+        bucket.mul_(1.0 / float(batch_size))
+    return bucket

@@ -256,8 +256,10 @@ class OpSet:
 
     def DeformableConvolution_backward(self, out_grad, data, offset, weight, kernel=(3, 3), stride=(1, 1),
                                        dilate=(1, 1), pad=(0, 0), num_group=1, num_deformable_group=1, no_bias=False,
-                                       req=("write", "write", "write", "write")):
-        """Gradients w.r.t. (data, offset, weight, bias) -- MXNet DeformableConvolutionOp::Backward."""
+                                       req=("write", "write", "write", "write"), out=None):
+        """Gradients w.r.t. (data, offset, weight, bias) -- MXNet DeformableConvolutionOp::Backward.
+        out: optional (gx, goffset, gweight, gbias) buffers to write/add into (required for req "add"; lets a
+        training step keep its parameter gradients in one flat all-reduce bucket)."""
         go, x, off, w = self._in(out_grad, data, offset, weight)
         (kh, kw), (sh, sw), (ph, pw), (dh, dw) = map(self._pair, (kernel, stride, pad, dilate))
         N, Cin, H, W = self.ad.shape(x)
@@ -265,10 +267,25 @@ class OpSet:
         rq = [_REQ[r] for r in req]
         if no_bias:
             rq[3] = 0
-        gx = self.ad.empty(x, self.ad.shape(x)) if rq[0] else None
-        goff = self.ad.empty(x, self.ad.shape(off)) if rq[1] else None
-        gw = self.ad.empty(x, self.ad.shape(w)) if rq[2] else None
-        gb = self.ad.empty(x, (Cout,)) if rq[3] else None
+        want = (self.ad.shape(x), self.ad.shape(off), self.ad.shape(w), (Cout,))
+        given = tuple(out) if out is not None else (None, None, None, None)
+        if len(given) != 4:
+            raise ValueError("DeformableConvolution_backward: out must be (gx, goffset, gweight, gbias)")
+        grads = []
+        for i, (g, shp) in enumerate(zip(given, want)):
+            if not rq[i]:
+                grads.append(None)
+            elif g is None:
+                if rq[i] == _REQ["add"]:
+                    raise ValueError("DeformableConvolution_backward: req 'add' needs the buffer to add into (out[%d])" % i)
+                grads.append(self.ad.empty(x, shp))
+            else:
+                (g,) = self._in(g)
+                if self.ad.shape(g) != tuple(shp):
+                    raise ValueError("DeformableConvolution_backward: out[%d] has shape %s, expected %s"
+                                     % (i, self.ad.shape(g), tuple(shp)))
+                grads.append(g)
+        gx, goff, gw, gb = grads
         p = lambda a: self.ad.ptr(a) if a is not None else None
         self.check(self.ns.deform_conv_bwd(self.ad.ptr(go), self.ad.ptr(x), self.ad.ptr(off), self.ad.ptr(w), p(gx),
                                            p(goff), p(gw), p(gb), N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw,

@@ -320,6 +320,32 @@ def test_backward_req_add_and_null(ops, oracle):
     pc.check_close(g1, w1 + 1.0, what="req add")
 
 
+def test_deform_conv_backward_into_caller_buffers(ops, oracle):
+    """out=(gx, goffset, gw, gb): the parameter gradients land in views of one flat bucket (the training pass's
+    all-reduce bucket); req 'add' accumulates into them and refuses to run without a buffer."""
+    rng = np.random.default_rng(3)
+    N, C, H, W = 2, 4, 6, 7
+    x, off = pc.feat(rng, (N, C, H, W)), rng.standard_normal((N, 18, H, W)).astype(np.float32)
+    w, go = rng.standard_normal((C, C, 3, 3)).astype(np.float32), rng.standard_normal((N, C, H, W)).astype(np.float32)
+    want = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=(3, 3), pad=(1, 1))
+    bucket = np.full(C * C * 9 + C, np.nan, np.float32)
+    gw_v, gb_v = bucket[:C * C * 9].reshape(C, C, 3, 3), bucket[C * C * 9:]
+    gx, goff = np.empty_like(x), np.empty_like(off)
+    got = ops.DeformableConvolution_backward(go, x, off, w, kernel=(3, 3), pad=(1, 1), out=(gx, goff, gw_v, gb_v))
+    assert got[2] is gw_v and got[3] is gb_v
+    for g, r, nm in zip((gx, goff, bucket[:C * C * 9].reshape(C, C, 3, 3), bucket[C * C * 9:]), want,
+                        ("gx", "goffset", "gw", "gb")):
+        pc.check_close(g, r, tol=2e-5, what="out= " + nm)
+    ops.DeformableConvolution_backward(go, x, off, w, kernel=(3, 3), pad=(1, 1), req=("null", "null", "add", "add"),
+                                       out=(None, None, gw_v, gb_v))
+    pc.check_close(gw_v, 2 * want[2], tol=2e-5, what="add gw")
+    pc.check_close(gb_v, 2 * want[3], tol=2e-5, what="add gb")
+    with pytest.raises(ValueError, match="add"):
+        ops.DeformableConvolution_backward(go, x, off, w, kernel=(3, 3), pad=(1, 1), req=("add", "null", "null", "null"))
+    with pytest.raises(ValueError, match="shape"):
+        ops.DeformableConvolution_backward(go, x, off, w, kernel=(3, 3), pad=(1, 1), out=(gx, goff, gw_v, gw_v))
+
+
 def test_edge_inputs(ops, oracle):
     pc.case_edge_inputs(ops, oracle, ident, ident)
 

@@ -382,6 +382,63 @@ def test_hot_path_pass_other_batch_and_image_sizes(T, cfg, mode):
         pc.check_close(host(got), want[name], tol=2e-5, what="%s %s %s" % (cfg, mode, name))
 
 
+@pytest.mark.parametrize("cfg,mode", [((2, 64, 128, "full"), "dropin"), ((2, 64, 128, "full"), "fused"),
+                                      ((1, 128, 192, "full"), "fused"), ((2, 64, 128, "train"), "dropin"),
+                                      ((1, 128, 192, "train"), "dropin")])
+def test_full_model_and_training_passes_against_the_oracle(T, cfg, mode):
+    """BASELINE configs[3] / configs[4] at sizes the oracle finishes in seconds: the cascade's md=2 cost volumes and
+    its own deformable convs (level 6 included), and the backward chain corr_bwd -> deform_bwd with the parameter
+    gradients written into the flat all-reduce bucket."""
+    from maskflownet_amd import hotpath
+    from oracle import hotpath_ref
+    wl = hotpath.HotPathWorkload(cfg, device="cuda", mode=mode, seed=7)
+    outs = wl.run_eager()
+    want = hotpath_ref.oracle_pass(wl.host, wl.N, kind=wl.kind, mode=mode)
+    assert len(outs) == len(wl.output_names()) > 14
+    for name, got in zip(wl.output_names(), outs):
+        pc.check_close(host(got), want[name], tol=5e-5 if name.startswith("g") else 2e-5,
+                       what="%s %s %s" % (cfg, mode, name))
+    if wl.kind == "train":   # the bucket IS the gradients (views), in layout order
+        lay, n = hotpath.grad_bucket_layout(wl.N, wl.H, wl.W)
+        flat = np.concatenate([want[name].reshape(-1) for name, _, _ in lay])
+        assert wl.grad_bucket.numel() == n
+        pc.check_close(host(wl.grad_bucket), flat, tol=5e-5, what="grad bucket")
+
+
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+def test_full_size_cascade_and_training_graph_replay_matches_eager(T, cfg):
+    """cfg4 / cfg5 at BASELINE size: the hipGraph bench.py replays reproduces the eager pass (the backward's zero-fills
+    and accumulations are inside the graph: two replays must not accumulate), and the size-independent properties hold:
+    corr_v is symmetric under swapping its inputs with the displacement reversed; the bias gradient is the plain sum
+    of the out-gradient."""
+    from maskflownet_amd import hotpath
+    wl = hotpath.HotPathWorkload(cfg, device="cuda")
+    eager = [o.clone() for o in wl.run_eager()]
+    wl.capture()
+    for o in wl.outputs():
+        o.fill_(float("nan"))
+    for _ in range(2):
+        wl.replay()
+    wl.synchronize()
+    T.cuda.synchronize()
+    names = wl.output_names()
+    for nm, a, b in zip(names, eager, wl.outputs()):
+        if nm.startswith(("gw_", "gb_", "g_c2_", "g_offset_")):   # atomics / split reductions: order may differ
+            pc.check_close(host(b), host(a), tol=2e-5, what="replay " + nm)
+        else:
+            assert T.equal(a, b), nm
+    o = dict(zip(names, wl.outputs()))
+    if cfg == "cfg4":
+        v = o["corr_v2"]
+        sw = wl.ops.Correlation(wl.t["c4_2"], wl.t["c3_2"], 1, 2, 1, 1, 2, True)
+        # out[d](p) with (f1,f2) swapped = out[-d](p + d): compare the zero-displacement channel and one shifted pair
+        pc.check_close(host(v[:, 12]), host(sw[:, 12]), tol=1e-6, what="corr_v2 swap, d=0")
+        pc.check_close(host(v[:, 13, :, :-1]), host(sw[:, 11, :, 1:]), tol=1e-6, what="corr_v2 swap, d=(0,1)")
+    else:
+        g = o["g_warp_3"].sum(dim=(0, 2, 3), dtype=T.float64)
+        pc.check_close(host(o["gb_3"]).astype(np.float64), host(g), tol=2e-5, what="gb_3 = sum of gout")
+
+
 def test_hot_path_pass_graph_replay_matches_eager(T):
     from maskflownet_amd import hotpath
     wl = hotpath.HotPathWorkload("cfg2", device="cuda")
