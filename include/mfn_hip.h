@@ -200,8 +200,11 @@ int mfn_deform_conv_matching_fwd(const float *x, const float *flow_yx, float flo
                                  int pw, int dh, int dw, int groups, void *workspace, size_t workspace_bytes,
                                  void *stream);
 /* Backward (training).  gx,goffset,gw,gbias as the forward's x,offset,w,bias; req_* per output
- * (MFN_REQ_NULL skips it and the pointer may be NULL).  The column gradient is formed on the fly,
- * so mfn_deform_conv_bwd_workspace_bytes currently returns 0 and workspace may be NULL.  gx and
+ * (MFN_REQ_NULL skips it and the pointer may be NULL).  The column gradient is formed on the fly;
+ * the only scratch is one int per 2x16-pixel strip (mfn_deform_conv_bwd_workspace_bytes; 0 for
+ * shapes without the shared-offset kernel): with it, strips whose nine taps share one offset
+ * (MaskFlownet.py:230) take all taps in one pass.  workspace may be NULL (tap-by-tap kernel only,
+ * same results up to summation order).  gx and
  * goffset are accumulated with fp32 atomics (as MXNet's GPU kernels do): bit-level results can
  * differ from run to run by summation order. */
 size_t mfn_deform_conv_bwd_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw,

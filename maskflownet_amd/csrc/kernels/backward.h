@@ -584,6 +584,7 @@ struct DcBwdIParams {
   int T, tiles_x, tiles_y;
   int req_x, req_offset;
   unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, scatter, total} shader cycles
+  const int *skip;               // per (tile, strip): non-zero = already done by dc_bwd_input_shared_kernel; may be NULL
 };
 constexpr int DCI_TH = 8, DCI_TW = 16, DCI_WR = 10, DCI_WC = 28, DCI_GW = 16;
 constexpr int DCI_PLANE = DCI_WR * DCI_WC + 1;  // odd channel-plane stride: the 32 lanes (channels) hit distinct banks
@@ -604,6 +605,14 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   const int n = bx / tpi, rt = bx - n * tpi;
   const int ty0 = (rt / p.tiles_x) * TH, tx0 = (rt % p.tiles_x) * TW;
   const int cb = blockIdx.y * 32;
+  // strips the shared-offset kernel has finished: skipped here (a block whose four strips are all done leaves at once)
+  bool skipw = false;
+  if (p.skip) {
+    const int *sk = p.skip + (size_t)bx * 4;
+    const int s0 = sk[0], s1 = sk[1], s2 = sk[2], s3 = sk[3];
+    if (MFN_UNIFORM((int)(s0 && s1 && s2 && s3))) return;
+    skipw = MFN_UNIFORM(sk[wave]) != 0;
+  }
   // window origin of the block: follows the offset of the tile's centre pixel (centre tap); strip w sits 2w rows lower
   int wy0, wx0;
   {
@@ -631,7 +640,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   const float *im = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
 
   unsigned long long tk0 = MFN_CYCLES(), tk_geo = 0, tk_mma = 0, tk_sc = 0, tka = tk0;
-  for (int t = 0; t < T; ++t) {
+  for (int t = 0; t < (skipw ? 0 : T); ++t) {
     // ---- geometry of the strip's 32 pixels for tap t (lanes 0..31 write, everyone reads it back as broadcasts)
     MFN_WAIT_LGKM0();  // the previous tap's readers are done (wave-private table: no block barrier)
     if (half == 0) {
@@ -774,6 +783,277 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   __syncthreads();
   // ---- merge the four strips' windows (strip w covers block-window rows 2w .. 2w+7) and flush once
   const int bwy0 = wy0 - 2 * wave;  // the block window's first row (uniform across the block)
+  for (int e = tid; e < 32 * (WR + 6) * WC; e += 256) {
+    const int cl = e / ((WR + 6) * WC), rem = e - cl * ((WR + 6) * WC);
+    const int R = rem / WC, cc = rem - R * WC;
+    float v = 0.f;
+    MFN_UNROLL
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int rr = R - 2 * w2;
+      if (rr >= 0 && rr < WR) v += lds[(size_t)w2 * 32 * PL + (size_t)cl * PL + rr * WC + cc];
+    }
+    const int yy = bwy0 + R, xx = wx0 + cc;
+    if (v != 0.f && cb + cl < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
+      atomicAdd(p.gx + ((size_t)n * p.Cin + cb + cl) * plane + (size_t)yy * W + xx, v);
+  }
+}
+
+
+// ---- shared-offset fast path of the input / offset gradient (3x3, dilation 1; the only form the reference uses:
+// MaskFlownet.py:230 feeds one (dy,dx) to all nine taps) ----------------------------------------------------------------
+// dc_bwd_input_tile_kernel above walks the nine taps one by one: nine GEMMs that each re-read gout, nine geometry
+// tables, 36 read-add-writes and 36 strided x loads per (pixel, channel) -- 534 us at level 2 where the arithmetic
+// needs ~12.  With ONE offset per pixel the nine taps sample a 4x4 neighbourhood with separable weights (the
+// forward's "regular" fast path, deform_conv.h), so here, per 2x16 strip and 32 channels:
+//   * one pass over gout: the column gradients of all nine taps are accumulated together (nine fp32-MFMA accumulator
+//     tiles, 144 registers; the block runs one wave per SIMD anyway because of its LDS windows), the weights of a lane's
+//     channel are nine consecutive floats;
+//   * cg is folded onto the 4x4 neighbourhood (42 FMAs, row weights then column weights) and added to the lane's
+//     private window plane in ONE round trip of 16 reads + 16 writes per turn instead of nine of 4 + 4;
+//   * the 4x4 x neighbourhood is loaded once (four 16-byte loads) and serves all 18 offset-gradient terms.
+// A strip qualifies when every pixel's nine offsets are bit-identical and the floor pattern is regular on both axes
+// (forward weights and deformable_col2im_coord's absolute-coordinate floors agree with floor(off)+i); otherwise its flag
+// stays 0 and dc_bwd_input_tile_kernel (launched next with the flags as its skip list) does that strip tap by tap.
+constexpr int DCS_WR = 10, DCS_WC = 26, DCS_GS = 40;
+constexpr int DCS_PLANE = DCS_WR * DCS_WC + 1;  // odd plane stride: the 32 lanes (channels) hit distinct banks
+constexpr size_t dc_bwd_shared_lds_bytes() { return ((size_t)4 * 32 * DCS_PLANE + (size_t)4 * 32 * DCS_GS) * sizeof(float); }
+// words of a pixel's geometry record
+enum { DCS_AY = 0, DCS_BY = 3, DCS_AX = 6, DCS_BX = 9, DCS_M9 = 12, DCS_FH0 = 21, DCS_FH1 = 24, DCS_FW0 = 27, DCS_FW1 = 30,
+       DCS_CELL = 33, DCS_LY0 = 34, DCS_LX0 = 35, DCS_FL = 36 };
+struct DcBwdSParams {
+  const float *gout, *x, *offset, *w;
+  float *gx, *goffset;
+  int *flags;  // per (tile, strip): 1 = finished here, 0 = left to dc_bwd_input_tile_kernel
+  int N, Cin, H, W, Cout, ph, pw;
+  int tiles_x, tiles_y;
+  int req_x, req_offset;
+};
+
+// one axis of the record: forward weights of tap row i on lines i / i+1 (dc_axis), validity, and the weights of
+// deformable_col2im_coord's absolute-coordinate interpolation; *ok is cleared when the floors leave the regular pattern
+__device__ __forceinline__ void dcs_axis(float off, int in0, int dim, int lo0, float *g, int a_, int b_, int f0_, int f1_,
+                                         float vf[3], bool &ok) {
+  MFN_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    bool v; int lo, hi; float l;
+    dc_axis(off, in0, i, dim, v, lo, hi, l);
+    if (v && lo != lo0 + i) ok = false;
+    g[a_ + i] = 1.f - l;
+    g[b_ + i] = l;
+    vf[i] = v ? 1.f : 0.f;
+    float a = v ? (float)(in0 + i) + off : 0.f;
+    int cl = (int)a;
+    if (cl >= dim - 1) { cl = dim - 1; a = (float)cl; }
+    if (v && cl != min(max(in0 + lo0 + i, 0), dim - 1)) ok = false;
+    g[f0_ + i] = (float)(cl + 1) - a;
+    g[f1_ + i] = a - (float)cl;
+  }
+}
+
+__global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p) {
+  constexpr int TH = DCI_TH, TW = DCI_TW, WR = DCS_WR, WC = DCS_WC, GS = DCS_GS, PL = DCS_PLANE, T = 9;
+  MFN_DYN_SHARED(float, lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = MFN_UNIFORM(tid >> 6);
+  float *win = lds + (size_t)wave * 32 * PL;                         // [32 channels][WR][WC] (+1), this wave's strip
+  float *geom = lds + (size_t)4 * 32 * PL + (size_t)wave * 32 * GS;  // [32 pixels][GS]
+  const int j = lane & 31, half = lane >> 5;
+  const int H = p.H, W = p.W;
+  const size_t plane = (size_t)H * W;
+  const int tpi = p.tiles_x * p.tiles_y;
+  const int bx = gridDim.y == 1 ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // as the tile kernel
+  const int n = bx / tpi, rt = bx - n * tpi;
+  const int ty0 = (rt / p.tiles_x) * TH, tx0 = (rt % p.tiles_x) * TW;
+  const int cb = blockIdx.y * 32;
+  int wy0, wx0;  // window origin: follows the offset of the tile's centre pixel; strip w sits 2w rows lower
+  {
+    const int cy = min(ty0 + TH / 2, H - 1), cx = min(tx0 + TW / 2, W - 1);
+    const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
+    const float oh = op[(size_t)8 * plane], ow = op[(size_t)9 * plane];
+    const float fh = fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), fw = fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
+    wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - (WR - 5) / 2 + 2 * wave);
+    wx0 = MFN_UNIFORM(tx0 - p.pw + (int)fw - (WC - (TW + 3)) / 2);
+  }
+  for (int e = lane; e < 32 * PL; e += 64) win[e] = 0.f;
+
+  // this lane as a PIXEL of the strip (geometry record, MFMA A operand) ...
+  const int py = ty0 + 2 * wave + (j >> 4), px = tx0 + (j & 15);
+  const bool pix_ok = py < H && px < W;
+  const int pyc = min(py, H - 1), pxc = min(px, W - 1);
+  const size_t pix = (size_t)pyc * W + pxc;
+  // ... and as a CHANNEL (MFMA B operand, D column, owner of one window plane)
+  const int c = cb + j;
+  const bool c_ok = c < p.Cin;
+  float *wpl = win + (size_t)j * PL;
+  int half_o = half;
+  MFN_OPAQUE(half_o);
+  float *gim = p.gx + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
+  const float *im = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
+
+  // ---- geometry records of the strip's 32 pixels (lanes 0..31 write, everyone reads them back as broadcasts)
+  bool ok = true;
+  if (half == 0) {
+    const float *op = p.offset + (size_t)n * 2 * T * plane + pix;
+    const float oh = op[0], ow = op[plane];
+    MFN_UNROLL
+    for (int t = 1; t < T; ++t) ok = ok && (op[(size_t)(2 * t) * plane] == oh) && (op[(size_t)(2 * t + 1) * plane] == ow);
+    const int h_in = pyc - p.ph, w_in = pxc - p.pw;
+    const int lo0y = (int)fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), lo0x = (int)fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
+    float *g = geom + (size_t)j * GS;
+    int *gi = reinterpret_cast<int *>(g);
+    float vyf[3], vxf[3];
+    dcs_axis(oh, h_in, H, lo0y, g, DCS_AY, DCS_BY, DCS_FH0, DCS_FH1, vyf, ok);
+    dcs_axis(ow, w_in, W, lo0x, g, DCS_AX, DCS_BX, DCS_FW0, DCS_FW1, vxf, ok);
+    MFN_UNROLL
+    for (int t = 0; t < T; ++t) g[DCS_M9 + t] = pix_ok ? vyf[t / 3] * vxf[t % 3] : 0.f;
+    const int ly0 = h_in + lo0y, lx0 = w_in + lo0x;
+    const int ry = ly0 - wy0, rx = lx0 - wx0;
+    gi[DCS_CELL] = (ry >= 0 && ry <= WR - 4 && rx >= 0 && rx <= WC - 4) ? ry * WC + rx : -1;
+    gi[DCS_LY0] = ly0;
+    gi[DCS_LX0] = lx0;
+    gi[DCS_FL] = (lx0 >= 0 && lx0 + 3 <= W - 1) ? 1 : 0;  // the neighbourhood's rows are four contiguous in-image floats
+    ok = ok || !pix_ok;
+  }
+  const bool fast = __all(ok) != 0;  // wave-uniform: the whole strip or nothing
+  if (lane == 0) p.flags[(size_t)bx * 4 + wave] = fast ? 1 : 0;  // every channel block writes the same value
+  MFN_WAIT_LGKM0();
+
+  if (fast) {
+    // ---- D_t[pixel][channel] = sum_o gout[o][pixel] * W[o][channel][t], all nine taps in one pass over gout
+    f32x16 acc[T];
+    MFN_UNROLL
+    for (int t = 0; t < T; ++t)
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const float *ga = p.gout + (size_t)n * p.Cout * plane + pix;
+    const float *wb = p.w + (size_t)(c_ok ? c : 0) * T;
+    for (int s2 = 0; s2 < p.Cout; s2 += 8) {  // four k-steps per trip: 40 unconditional loads in flight
+      float a[4], b[4][T];
+      MFN_UNROLL
+      for (int u = 0; u < 4; ++u) {
+        const int oc = min(s2 + 2 * u + half, p.Cout - 1);
+        a[u] = ga[(size_t)oc * plane];
+        const float *wr = wb + (size_t)oc * p.Cin * T;
+        MFN_UNROLL
+        for (int t = 0; t < T; ++t) b[u][t] = wr[t];
+      }
+      MFN_UNROLL
+      for (int u = 0; u < 4; ++u) {
+        const bool ook = s2 + 2 * u + half < p.Cout;
+        const float av = (ook && pix_ok) ? a[u] : 0.f;
+        MFN_UNROLL
+        for (int t = 0; t < T; ++t) acc[t] = MFN_MFMA_32x32x2(av, (ook && c_ok) ? b[u][t] : 0.f, acc[t]);
+      }
+    }
+    // ---- per pixel of the strip: D reg r of lane (j, half) = pixel (r&3)+8*(r>>2)+4*half, channel j
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) {
+      const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float *g = geom + (size_t)pp * GS;
+      const int *gi = reinterpret_cast<const int *>(g);
+      float cg[T];
+      MFN_UNROLL
+      for (int t = 0; t < T; ++t) cg[t] = (c_ok ? acc[t][r] : 0.f) * g[DCS_M9 + t];  // invalid taps contribute nothing
+      const int ly0 = gi[DCS_LY0], lx0 = gi[DCS_LX0];
+      if (p.req_offset) {
+        // the 4x4 x neighbourhood at the clamped lines (clamped duplicates carry zero weight)
+        float X[4][4];
+        int ro[4];
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m) ro[m] = min(max(ly0 + m, 0), H - 1) * W;
+        if (gi[DCS_FL]) {
+          MFN_UNROLL
+          for (int m = 0; m < 4; ++m) {
+            const f4u q = mfn_load4u(im + ro[m] + lx0);
+            X[m][0] = q.x; X[m][1] = q.y; X[m][2] = q.z; X[m][3] = q.w;
+          }
+        } else {
+          int co[4];
+          MFN_UNROLL
+          for (int m = 0; m < 4; ++m) co[m] = min(max(lx0 + m, 0), W - 1);
+          MFN_UNROLL
+          for (int m = 0; m < 4; ++m)
+            MFN_UNROLL
+            for (int v = 0; v < 4; ++v) X[m][v] = im[ro[m] + co[v]];
+        }
+        float sh_[T], sw_[T];
+        MFN_UNROLL
+        for (int i = 0; i < 3; ++i)
+          MFN_UNROLL
+          for (int jj = 0; jj < 3; ++jj) {
+            const int t = 3 * i + jj;
+            // d/dh: fw0*(v21-v11) + fw1*(v22-v12);  d/dw: fh0*(v12-v11) + fh1*(v22-v21)
+            const float th = g[DCS_FW0 + jj] * (X[i + 1][jj] - X[i][jj]) + g[DCS_FW1 + jj] * (X[i + 1][jj + 1] - X[i][jj + 1]);
+            const float tw = g[DCS_FH0 + i] * (X[i][jj + 1] - X[i][jj]) + g[DCS_FH1 + i] * (X[i + 1][jj + 1] - X[i + 1][jj]);
+            sh_[t] = mfn_half_sum_top(th * cg[t]);
+            sw_[t] = mfn_half_sum_top(tw * cg[t]);
+          }
+        if (j == 31) {  // the half-wave's top lane holds the sums over its 32 channels; other channel blocks add too
+          const int y = ty0 + 2 * wave + (pp >> 4), x = tx0 + (pp & 15);
+          if (y < H && x < W) {
+            float *gof = p.goffset + (size_t)n * 2 * T * plane + (size_t)y * W + x;
+            MFN_UNROLL
+            for (int t = 0; t < T; ++t) {
+              if (sh_[t] != 0.f) atomicAdd(gof + (size_t)(2 * t) * plane, sh_[t]);
+              if (sw_[t] != 0.f) atomicAdd(gof + (size_t)(2 * t + 1) * plane, sw_[t]);
+            }
+          }
+        }
+      }
+      if (p.req_x) {
+        // fold the nine taps onto the 4x4 neighbourhood: along x first, then along y
+        float G[4][4];
+        {
+          float R[3][4];
+          MFN_UNROLL
+          for (int i = 0; i < 3; ++i) {
+            R[i][0] = cg[3 * i] * g[DCS_AX];
+            R[i][1] = fmaf(cg[3 * i], g[DCS_BX], cg[3 * i + 1] * g[DCS_AX + 1]);
+            R[i][2] = fmaf(cg[3 * i + 1], g[DCS_BX + 1], cg[3 * i + 2] * g[DCS_AX + 2]);
+            R[i][3] = cg[3 * i + 2] * g[DCS_BX + 2];
+          }
+          MFN_UNROLL
+          for (int v = 0; v < 4; ++v) {
+            G[0][v] = g[DCS_AY] * R[0][v];
+            G[1][v] = fmaf(g[DCS_BY], R[0][v], g[DCS_AY + 1] * R[1][v]);
+            G[2][v] = fmaf(g[DCS_BY + 1], R[1][v], g[DCS_AY + 2] * R[2][v]);
+            G[3][v] = g[DCS_BY + 2] * R[2][v];
+          }
+        }
+        const int cell = gi[DCS_CELL];
+        if (cell < 0) {  // neighbourhood outside the window (rough flow): straight to global memory
+          MFN_UNROLL
+          for (int u = 0; u < 4; ++u)
+            MFN_UNROLL
+            for (int v = 0; v < 4; ++v) {
+              const int yy = ly0 + u, xx = lx0 + v;
+              if (G[u][v] != 0.f && yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(gim + (size_t)yy * W + xx, G[u][v]);
+            }
+        }
+        // The two half-waves hold different pixels of the SAME channel plane and take turns (see the tile kernel): the
+        // 16 cells of a turn are distinct (unclamped lines), so all reads go out together -- one LDS round trip per turn.
+        MFN_UNROLL
+        for (int hs = 0; hs < 2; ++hs) {
+          if (half_o == hs && cell >= 0) {
+            float o[4][4];
+            MFN_UNROLL
+            for (int u = 0; u < 4; ++u)
+              MFN_UNROLL
+              for (int v = 0; v < 4; ++v) o[u][v] = wpl[cell + u * WC + v];
+            MFN_UNROLL
+            for (int u = 0; u < 4; ++u)
+              MFN_UNROLL
+              for (int v = 0; v < 4; ++v) wpl[cell + u * WC + v] = o[u][v] + G[u][v];
+          }
+          MFN_WAVE_SYNC_EMU();
+        }
+      }
+    }
+  }
+  if (!p.req_x) return;
+  __syncthreads();
+  // ---- merge the four strips' windows (strip w covers block-window rows 2w .. 2w+WR-1) and flush once
+  const int bwy0 = wy0 - 2 * wave;
   for (int e = tid; e < 32 * (WR + 6) * WC; e += 256) {
     const int cl = e / ((WR + 6) * WC), rem = e - cl * ((WR + 6) * WC);
     const int R = rem / WC, cc = rem - R * WC;

@@ -287,10 +287,14 @@ class OpSet:
                 grads.append(g)
         gx, goff, gw, gb = grads
         p = lambda a: self.ad.ptr(a) if a is not None else None
+        nbytes = self.ns.deform_conv_bwd_workspace_bytes(N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group,
+                                                         num_deformable_group)
+        ws = self._workspace(x, nbytes) if nbytes else None   # strip flags of the shared-offset kernel
         self.check(self.ns.deform_conv_bwd(self.ad.ptr(go), self.ad.ptr(x), self.ad.ptr(off), self.ad.ptr(w), p(gx),
                                            p(goff), p(gw), p(gb), N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw,
-                                           num_group, num_deformable_group, rq[0], rq[1], rq[2], rq[3], None, 0,
-                                           self.ad.stream(x)))
+                                           num_group, num_deformable_group, rq[0], rq[1], rq[2], rq[3],
+                                           self.ad.ptr(ws) if ws is not None else None,
+                                           self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(x)))
         return gx, goff, gw, gb
 
     def deformable_convolution_shared(self, data, flow, flow_scale, flow_stride, weight, bias=None, kernel=(3, 3),

@@ -264,6 +264,46 @@ def case_warp_bwd(ops, oracle, to_dev, to_host, shape, clip, seed=0):
     return max(check_close(to_host(gx), wx, what="warp gx"), check_close(to_host(gf), wf, tol=5e-5, what="warp gflow"))
 
 
+def shared_offsets(rng, N, H, W, kind):
+    """(N,18,H,W) offsets with ONE (dy,dx) per pixel repeated over the nine taps (MaskFlownet.py:230) -- what the
+    shared-offset backward kernel takes in one pass.  kind: smooth (sub-pixel field + global shift), integer (floors
+    on the lattice: clamp / zero rules at the borders), outside (a quarter of the image points far outside), rough
+    (per-pixel noise: neighbourhoods leave the LDS window), mixed (some rows get per-tap offsets: those strips must
+    be left to the tap-by-tap kernel)."""
+    if kind == "integer":
+        fl = rng.integers(-3, 4, (N, 2, 1, 1)).astype(np.float32) + np.zeros((N, 2, H, W), np.float32)
+        fl[:, :, ::3, ::4] += 1.0
+    else:
+        fl = (rng.standard_normal((N, 2, 1, 1)) * 2.0 + rng.standard_normal((N, 2, H, W)) * (3.0 if kind == "rough" else 0.3)
+              ).astype(np.float32)
+    if kind == "outside":
+        fl[:, :, : H // 2, : W // 2] += np.float32(1.5 * max(H, W))
+        fl[:, 0, H // 2:, : W // 3] -= np.float32(H + 0.5)
+    off = np.repeat(fl[:, None], 9, axis=1).reshape(N, 18, H, W).copy()
+    if kind == "mixed":
+        off[:, :, 1::4, :] += (rng.standard_normal((N, 18, len(range(1, H, 4)), W)) * 0.7).astype(np.float32)
+    return off
+
+
+def case_deform_bwd_shared(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, kind, seed=0, req=("write",) * 4, pad=(1, 1)):
+    rng = np.random.default_rng(77 + seed)
+    x = feat(rng, (N, Cin, H, W))
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * 0.2).astype(np.float32)
+    off = shared_offsets(rng, N, H, W, kind)
+    go = rng.standard_normal((N, Cout, H, W)).astype(np.float32)
+    kw = dict(kernel=(3, 3), pad=pad)
+    got = ops.DeformableConvolution_backward(to_dev(go), to_dev(x), to_dev(off), to_dev(w), req=req, **kw)
+    want = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, **kw)
+    errs = []
+    for g, r, rq, nm in zip(got, want, req, ("gx", "goffset", "gw", "gbias")):
+        if rq in ("null", None):
+            assert g is None
+            continue
+        errs.append(check_close(to_host(g), r, tol=2e-5 if nm == "gx" else 5e-5,
+                                what="shared-offset deform %s %s %s" % (nm, kind, (N, Cin, Cout, H, W))))
+    return max(errs)
+
+
 def case_deform_bwd(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, **kw):
     rng = np.random.default_rng(51 + seed)
     ng, ndg = kw.get("num_group", 1), kw.get("num_deformable_group", 1)

@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0)
+                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -307,6 +307,19 @@ def test_deform_conv_backward(ops, oracle, kw):
 def test_deform_conv_backward_mfma_paths(ops, oracle, shape):
     # tile kernel (LDS window + out-of-window fallback: offsets of sigma 1.5 px around 0) and MFMA weight gradient
     pc.case_deform_bwd(ops, oracle, ident, ident, *shape, kernel=(3, 3), pad=(1, 1))
+
+
+@pytest.mark.parametrize("kind", ["smooth", "integer", "outside", "rough", "mixed"])
+def test_deform_conv_backward_shared_offsets(ops, oracle, kind):
+    # two channel blocks (the second ragged), ragged 8x16 tiles (the GPU test runs more images and filters)
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 34 if kind == "smooth" else 8, 6, 11, 21, kind)
+
+
+def test_deform_conv_backward_shared_offsets_partial_requests_and_switch(ops, oracle):
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 17, "smooth", req=("write", "null", "null", "null"))
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 17, "smooth", req=("null", "write", "write", "write"))
+    emu_ops.set_tuning(dc_bwdshared=0)   # the tap-by-tap kernel alone gives the same gradients
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 17, "smooth", seed=3)
 
 
 def test_backward_req_add_and_null(ops, oracle):

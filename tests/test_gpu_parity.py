@@ -245,6 +245,39 @@ def test_deform_conv_backward_levels(ops, oracle, dev, C, H, W):
     pc.case_deform_bwd(ops, oracle, dev, host, 2, C, C, H, W, kernel=(3, 3), pad=(1, 1))
 
 
+@pytest.mark.parametrize("kind", ["smooth", "integer", "outside", "rough", "mixed"])
+@pytest.mark.parametrize("N,C,H,W", [(2, 128, 12, 16), (2, 96, 24, 32), (1, 64, 48, 64), (1, 32, 96, 128), (2, 40, 11, 21)])
+def test_deform_conv_backward_shared_offsets(ops, oracle, dev, kind, N, C, H, W):
+    """One (dy,dx) per pixel for all nine taps (MaskFlownet.py:230): dc_bwd_input_shared_kernel takes the strips that
+    qualify, the tap-by-tap kernel the rest ('mixed'); borders, far-outside and rough flows included."""
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, N, C, C if C != 40 else 36, H, W, kind)
+
+
+def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracle, dev, T):
+    from maskflownet_amd import _lib
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("write", "null", "null", "null"))
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("null", "write", "write", "write"))
+    _lib.set_tuning(dc_bwdshared=0)
+    try:
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth")
+    finally:
+        _lib.set_tuning(dc_bwdshared=1)
+    # straight through the C ABI with workspace = NULL: tap-by-tap kernel only, same gradients
+    rng = np.random.default_rng(1)
+    N, C, H, W = 1, 8, 16, 16
+    x, w = pc.feat(rng, (N, C, H, W)), (rng.standard_normal((C, C, 3, 3)) * 0.2).astype(np.float32)
+    off, go = pc.shared_offsets(rng, N, H, W, "smooth"), rng.standard_normal((N, C, H, W)).astype(np.float32)
+    tx, toff, tw, tgo = (dev(a) for a in (x, off, w, go))
+    gx, goff = T.empty_like(tx), T.empty_like(toff)
+    lib = _lib.lib()
+    _lib.check(lib.deform_conv_bwd(tgo.data_ptr(), tx.data_ptr(), toff.data_ptr(), tw.data_ptr(), gx.data_ptr(),
+                                   goff.data_ptr(), None, None, N, C, H, W, C, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, None, 0,
+                                   T.cuda.current_stream().cuda_stream))
+    want = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=(3, 3), pad=(1, 1))
+    pc.check_close(host(gx), want[0], tol=2e-5, what="NULL workspace gx")
+    pc.check_close(host(goff), want[1], tol=5e-5, what="NULL workspace goffset")
+
+
 @pytest.mark.parametrize("kw", [dict(kernel=(3, 3), pad=(1, 1), stride=(2, 2)), dict(kernel=(3, 3), pad=(2, 2), dilate=(2, 2)),
                                 dict(kernel=(3, 3), pad=(1, 1), num_group=2), dict(kernel=(3, 3), pad=(1, 1), num_deformable_group=2)])
 def test_deform_conv_backward_parameters(ops, oracle, dev, kw):
