@@ -468,28 +468,40 @@ struct DcBwdWParams {
   int P, K2, T;            // N*Ho*Wo, Cin*T, kh*kw
   int tiles_per_block;     // 32-pixel tiles each block walks
 };
+// LDS floats of the weight-gradient kernel: geometry [T][7][32] + gout tile [MTO*32][33] + column tiles 4 x [32][33]
+constexpr size_t dc_bwd_weight_lds_floats(int T, int mto) { return (size_t)T * 7 * 32 + (size_t)mto * 32 * 33 + (size_t)4 * 32 * 33; }
 template <int MTO>
 __global__ __launch_bounds__(256) void dc_bwd_weight_mfma_kernel(DcBwdWParams p) {
-  constexpr int GW = 8;   // words per (pixel, tap) geometry entry: w1..w4, base, dhW|dwi, image offset, pad
-  constexpr int GS = 33;  // gout tile row stride (32 pixels + 1: the 32 filter rows of an A operand on distinct banks)
+  constexpr int GF = 7;   // fields of a (tap, pixel) geometry entry, stored field-major [T][GF][32 pixels]: w1..w4, base,
+                          // dhW, image offset -- lanes that are neighbouring PIXELS read neighbouring words (no conflicts)
+  constexpr int GS = 33;  // tile row stride (32 pixels + 1: the 32 rows of an MFMA operand on distinct banks)
   MFN_DYN_SHARED(float, lds);
-  float *geom = lds;                              // [32][T][GW]
-  float *gs = lds + 32 * p.T * GW;                // [MTO*32][GS]
+  float *geom = lds;                                   // [T][GF][32]
+  float *gs = lds + p.T * GF * 32;                     // [MTO*32][GS]   gout tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = MFN_UNIFORM(tid >> 6);
+  float *colt = gs + MTO * 32 * GS + wave * 32 * GS;   // [32 combos][GS] this wave's im2col tile
   const int j = lane & 31, half = lane >> 5;
   const int T = p.T;
   const size_t oplane = (size_t)p.Ho * p.Wo, plane = (size_t)p.H * p.W;
   const int o0 = blockIdx.z * (MTO * 32);
-  const int k = (blockIdx.y * 4 + wave) * 32 + j;  // this lane's combo
+  const int k0 = (blockIdx.y * 4 + wave) * 32;     // the wave's first combo
+  const int k = k0 + j;                            // this lane's combo as MFMA column
   const bool k_ok = k < p.K2;
-  const int kc = k_ok ? k : 0;
-  const int c = kc / T, t = kc - c * T;
   f32x16 acc[MTO];
   MFN_UNROLL
   for (int m = 0; m < MTO; ++m)
     MFN_UNROLL
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  // column build: lane (j, half) = PIXEL j of the tile, combos k0 + 2q + half, q < 16 -- for one (channel, tap) the 32
+  // pixels of a tile gather neighbouring addresses (smooth flow), where one lane per combo gathered 64 cache lines
+  int qc[16], qt[16];
+  MFN_UNROLL
+  for (int q = 0; q < 16; ++q) {
+    const int kk = min(k0 + 2 * q + half, p.K2 - 1);
+    qc[q] = kk / T;
+    qt[q] = kk - qc[q] * T;
+  }
 
   float bsum = 0.f;  // thread tid < MTO*32 of a combo-group-0 block: sum of gout row o0 + tid over this block's pixels
   const int tile0 = blockIdx.x * p.tiles_per_block;
@@ -497,9 +509,9 @@ __global__ __launch_bounds__(256) void dc_bwd_weight_mfma_kernel(DcBwdWParams p)
     const int pbase = (tile0 + tl) * 32;
     if (pbase >= p.P) break;  // uniform
     __syncthreads();          // the previous tile's readers are done
-    // geometry table: one entry per (pixel, tap)
+    // geometry table: one entry per (tap, pixel)
     for (int e = tid; e < 32 * T; e += 256) {
-      const int pp = e / T, tt = e - pp * T;
+      const int tt = e >> 5, pp = e & 31;
       const int pl = pbase + pp;
       const bool ok = pl < p.P;
       const int pc = ok ? pl : 0;
@@ -509,11 +521,11 @@ __global__ __launch_bounds__(256) void dc_bwd_weight_mfma_kernel(DcBwdWParams p)
       const int ti = tt / p.kw, tj = tt - ti * p.kw;
       const DcTap tp = dc_make_tap(op[(size_t)(2 * tt) * oplane], op[(size_t)(2 * tt + 1) * oplane], ho * p.sh - p.ph,
                                    wo * p.sw - p.pw, ti * p.dh, tj * p.dw, p.H, p.W, ok);
-      float *g = geom + (size_t)e * GW;
-      g[0] = tp.w1; g[1] = tp.w2; g[2] = tp.w3; g[3] = tp.w4;
-      reinterpret_cast<int *>(g)[4] = tp.base;                       // bit 30 = dwi
-      reinterpret_cast<int *>(g)[5] = tp.dhW;
-      reinterpret_cast<int *>(g)[6] = n * p.Cin * (int)plane;        // element offset of image n (checked < 2^31)
+      float *g = geom + (size_t)tt * GF * 32 + pp;
+      g[0] = tp.w1; g[32] = tp.w2; g[64] = tp.w3; g[96] = tp.w4;
+      reinterpret_cast<int *>(g)[128] = tp.base;                     // bit 30 = dwi
+      reinterpret_cast<int *>(g)[160] = tp.dhW;
+      reinterpret_cast<int *>(g)[192] = n * p.Cin * (int)plane;      // element offset of image n (checked < 2^31)
     }
     // gout tile [filter][pixel]
     for (int e = tid; e < MTO * 32 * 32; e += 256) {
@@ -531,20 +543,32 @@ __global__ __launch_bounds__(256) void dc_bwd_weight_mfma_kernel(DcBwdWParams p)
       MFN_UNROLL
       for (int pp = 0; pp < 32; ++pp) bsum += gs[tid * GS + pp];
     }
+    // the wave's column tile: col[combo][pixel] (zero for combos past K2 and pixels past P: their weights are zero).
+    // All 16 values are formed before the first is stored: a store between them would keep the next combo's table
+    // reads and gathers (possible aliases, for the compiler) from being issued until it retires.
+    float colv[16];
+    MFN_UNROLL
+    for (int q = 0; q < 16; ++q) {
+      const float *g = geom + (size_t)qt[q] * GF * 32 + j;
+      const int base = reinterpret_cast<const int *>(g)[128], dhW = reinterpret_cast<const int *>(g)[160];
+      const int ioff = reinterpret_cast<const int *>(g)[192];
+      const int bb = base & 0x3FFFFFFF, dwi = (base >> 30) & 1;
+      const float *pl = p.x + (size_t)ioff + (size_t)qc[q] * plane;
+      const float v1 = pl[bb], v2 = pl[bb + dwi], v3 = pl[bb + dhW], v4 = pl[bb + dhW + dwi];
+      const float col = g[0] * v1 + g[32] * v2 + g[64] * v3 + g[96] * v4;
+      colv[q] = (k0 + 2 * q + half < p.K2) ? col : 0.f;
+    }
+    MFN_UNROLL
+    for (int q = 0; q < 16; ++q) colt[(2 * q + half) * GS + j] = colv[q];
+    MFN_WAIT_LGKM0();  // the wave's own tile: written above, read below (no block barrier)
     MFN_UNROLL
     for (int s = 0; s < 16; ++s) {
       const int pp = 2 * s + half;
-      const float *g = geom + (size_t)(pp * T + t) * GW;
-      const int base = reinterpret_cast<const int *>(g)[4], dhW = reinterpret_cast<const int *>(g)[5];
-      const int ioff = reinterpret_cast<const int *>(g)[6];
-      const int bb = base & 0x3FFFFFFF, dwi = (base >> 30) & 1;
-      const float *pl = p.x + (size_t)ioff + (size_t)c * plane;
-      const float v1 = pl[bb], v2 = pl[bb + dwi], v3 = pl[bb + dhW], v4 = pl[bb + dhW + dwi];
-      float col = g[0] * v1 + g[1] * v2 + g[2] * v3 + g[3] * v4;
-      col = k_ok ? col : 0.f;
+      const float col = colt[j * GS + pp];
       MFN_UNROLL
       for (int m = 0; m < MTO; ++m) acc[m] = MFN_MFMA_32x32x2(gs[(m * 32 + j) * GS + pp], col, acc[m]);
     }
+    MFN_WAIT_LGKM0();  // ... and all read before the next tile's build overwrites it
   }
   if (p.gbias && blockIdx.y == 0 && tid < MTO * 32 && o0 + tid < p.Cout) atomicAdd(p.gbias + o0 + tid, bsum);
   // D reg r of lane (j, half): filter row (r&3)+8*(r>>2)+4*half, combo j
@@ -562,7 +586,7 @@ inline int dc_bwd_weight_mfma_launch(DcBwdWParams p, int pixel_slices, hipStream
   const int tiles = cdiv(p.P, 32);
   p.tiles_per_block = cdiv(tiles, pixel_slices);
   const dim3 grid(cdiv(tiles, p.tiles_per_block), cdiv(cdiv(p.K2, 32), 4), cdiv(p.Cout, MTO * 32));
-  const size_t lds = ((size_t)32 * p.T * 8 + (size_t)MTO * 32 * 33) * sizeof(float);
+  const size_t lds = dc_bwd_weight_lds_floats(p.T, MTO) * sizeof(float);
   return launch("dc_bwd_weight_mfma", dc_bwd_weight_mfma_kernel<MTO>, grid, dim3(256), lds, stream, p);
 }
 
@@ -816,10 +840,13 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
 // stays 0 and dc_bwd_input_tile_kernel (launched next with the flags as its skip list) does that strip tap by tap.
 constexpr int DCS_WR = 10, DCS_WC = 26, DCS_GS = 40;
 constexpr int DCS_PLANE = DCS_WR * DCS_WC + 1;  // odd plane stride: the 32 lanes (channels) hit distinct banks
-constexpr size_t dc_bwd_shared_lds_bytes() { return ((size_t)4 * 32 * DCS_PLANE + (size_t)4 * 32 * DCS_GS) * sizeof(float); }
+constexpr int DCS_OS = 18;  // offset-gradient sums of a pixel (9 taps x {dh, dw}), staged per strip and flushed coalesced
+constexpr size_t dc_bwd_shared_lds_bytes() {
+  return ((size_t)4 * 32 * DCS_PLANE + (size_t)4 * 32 * DCS_GS + (size_t)4 * 32 * DCS_OS) * sizeof(float);
+}
 // words of a pixel's geometry record
 enum { DCS_AY = 0, DCS_BY = 3, DCS_AX = 6, DCS_BX = 9, DCS_M9 = 12, DCS_FH0 = 21, DCS_FH1 = 24, DCS_FW0 = 27, DCS_FW1 = 30,
-       DCS_CELL = 33, DCS_LY0 = 34, DCS_LX0 = 35, DCS_FL = 36 };
+       DCS_CELL = 36, DCS_LY0 = 37, DCS_LX0 = 38, DCS_FL = 39 };  // the four ints: one 16-byte read
 struct DcBwdSParams {
   const float *gout, *x, *offset, *w;
   float *gx, *goffset;
@@ -827,6 +854,7 @@ struct DcBwdSParams {
   int N, Cin, H, W, Cout, ph, pw;
   int tiles_x, tiles_y;
   int req_x, req_offset;
+  unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, per-pixel phase, total} shader cycles
 };
 
 // one axis of the record: forward weights of tap row i on lines i / i+1 (dc_axis), validity, and the weights of
@@ -857,6 +885,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
   const int wave = MFN_UNIFORM(tid >> 6);
   float *win = lds + (size_t)wave * 32 * PL;                         // [32 channels][WR][WC] (+1), this wave's strip
   float *geom = lds + (size_t)4 * 32 * PL + (size_t)wave * 32 * GS;  // [32 pixels][GS]
+  float *gsum = lds + (size_t)4 * 32 * (PL + GS) + (size_t)wave * 32 * DCS_OS;  // [32 pixels][18]
   const int j = lane & 31, half = lane >> 5;
   const int H = p.H, W = p.W;
   const size_t plane = (size_t)H * W;
@@ -891,6 +920,8 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
   const float *im = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
 
   // ---- geometry records of the strip's 32 pixels (lanes 0..31 write, everyone reads them back as broadcasts)
+  const unsigned long long tk0 = MFN_CYCLES();
+  unsigned long long tk1 = tk0, tk2 = tk0, tk3 = tk0;
   bool ok = true;
   if (half == 0) {
     const float *op = p.offset + (size_t)n * 2 * T * plane + pix;
@@ -917,6 +948,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
   const bool fast = __all(ok) != 0;  // wave-uniform: the whole strip or nothing
   if (lane == 0) p.flags[(size_t)bx * 4 + wave] = fast ? 1 : 0;  // every channel block writes the same value
   MFN_WAIT_LGKM0();
+  if (p.timeline) tk1 = tk2 = tk3 = MFN_CYCLES();
 
   if (fast) {
     // ---- D_t[pixel][channel] = sum_o gout[o][pixel] * W[o][channel][t], all nine taps in one pass over gout
@@ -925,57 +957,101 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
     for (int t = 0; t < T; ++t)
       MFN_UNROLL
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const float *ga = p.gout + (size_t)n * p.Cout * plane + pix;
-    const float *wb = p.w + (size_t)(c_ok ? c : 0) * T;
-    for (int s2 = 0; s2 < p.Cout; s2 += 8) {  // four k-steps per trip: 40 unconditional loads in flight
-      float a[4], b[4][T];
+    // scalar base + 32-bit lane offset (the launch checks that an image's gout and the weights stay below 2^29 floats):
+    // the filter index of a k-step is uniform but for `half`, so its two candidate offsets are scalar
+    const float *ga = p.gout + (size_t)n * p.Cout * plane;
+    const int ga_lane = (int)pix, wb_lane = (c_ok ? c : 0) * T;
+    const int iplane = (int)plane, wstep = p.Cin * T;
+    // four k-steps (eight filters) per trip, 16 unconditional loads; the next trip's loads are issued before this
+    // trip's 36 MFMAs (two register sets), so the matrix pipe does not wait for memory between trips
+    float a[2][4], b[2][4][T];
+    auto ld = [&](const int buf, int s2) {
       MFN_UNROLL
       for (int u = 0; u < 4; ++u) {
-        const int oc = min(s2 + 2 * u + half, p.Cout - 1);
-        a[u] = ga[(size_t)oc * plane];
-        const float *wr = wb + (size_t)oc * p.Cin * T;
-        MFN_UNROLL
-        for (int t = 0; t < T; ++t) b[u][t] = wr[t];
+        const int oc0 = min(s2 + 2 * u, p.Cout - 1), oc1 = min(s2 + 2 * u + 1, p.Cout - 1);
+        const int oc = half ? oc1 : oc0;
+        a[buf][u] = ga[ga_lane + oc * iplane];
+        const float *wr = p.w + (wb_lane + oc * wstep);  // nine consecutive floats at 4-byte alignment
+        const f4u q0 = mfn_load4u(wr), q1 = mfn_load4u(wr + 4);
+        b[buf][u][0] = q0.x; b[buf][u][1] = q0.y; b[buf][u][2] = q0.z; b[buf][u][3] = q0.w;
+        b[buf][u][4] = q1.x; b[buf][u][5] = q1.y; b[buf][u][6] = q1.z; b[buf][u][7] = q1.w;
+        b[buf][u][8] = wr[8];
       }
+    };
+    auto mm = [&](const int buf, int s2) {
       MFN_UNROLL
       for (int u = 0; u < 4; ++u) {
-        const bool ook = s2 + 2 * u + half < p.Cout;
-        const float av = (ook && pix_ok) ? a[u] : 0.f;
+        // only the filter tail needs a zero: rows of pixels outside the image and columns of channels >= Cin hold
+        // finite values from clamped addresses and are dropped below (m9 = 0 / c_ok), so the nine MFMAs of a k-step
+        // issue back to back from the loaded registers
+        const float av = (s2 + 2 * u + half < p.Cout) ? a[buf][u] : 0.f;
         MFN_UNROLL
-        for (int t = 0; t < T; ++t) acc[t] = MFN_MFMA_32x32x2(av, (ook && c_ok) ? b[u][t] : 0.f, acc[t]);
+        for (int t = 0; t < T; ++t) acc[t] = MFN_MFMA_32x32x2(av, b[buf][u][t], acc[t]);
+      }
+    };
+    ld(0, 0);
+    for (int s2 = 0; s2 < p.Cout; s2 += 16) {
+      const bool more = s2 + 8 < p.Cout;
+      if (more) ld(1, s2 + 8);
+      mm(0, s2);
+      if (more) {
+        if (s2 + 16 < p.Cout) ld(0, s2 + 16);
+        mm(1, s2 + 8);
       }
     }
+    if (p.timeline) { MFN_OPAQUE(acc[0][0]); MFN_OPAQUE(acc[8][15]); tk2 = tk3 = MFN_CYCLES(); }
     // ---- per pixel of the strip: D reg r of lane (j, half) = pixel (r&3)+8*(r>>2)+4*half, channel j
+    // the 4x4 x neighbourhood of pixel r at the clamped lines (clamped duplicates carry zero weight)
+    auto loadX = [&](const int r, float (&X)[4][4]) {
+      const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float4 gq = *reinterpret_cast<const float4 *>(geom + (size_t)pp * GS + DCS_CELL);
+      const int ly0 = mfn_f2i(gq.y), lx0 = mfn_f2i(gq.z);
+      int ro[4];
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m) ro[m] = min(max(ly0 + m, 0), H - 1) * W;
+      if (mfn_f2i(gq.w)) {
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m) {
+          const f4u q = mfn_load4u(im + ro[m] + lx0);
+          X[m][0] = q.x; X[m][1] = q.y; X[m][2] = q.z; X[m][3] = q.w;
+        }
+      } else {
+        int co[4];
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m) co[m] = min(max(lx0 + m, 0), W - 1);
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m)
+          MFN_UNROLL
+          for (int v = 0; v < 4; ++v) X[m][v] = im[ro[m] + co[v]];
+      }
+    };
+    auto loadG = [&](const int r, float (&gq)[GS]) {
+      const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float4 *g4 = reinterpret_cast<const float4 *>(geom + (size_t)pp * GS);
+      MFN_UNROLL
+      for (int q = 0; q < GS / 4; ++q) {
+        const float4 v = g4[q];
+        gq[4 * q] = v.x; gq[4 * q + 1] = v.y; gq[4 * q + 2] = v.z; gq[4 * q + 3] = v.w;
+      }
+    };
+    float Xn[4][4];
+    if (p.req_offset) loadX(0, Xn);
     MFN_UNROLL
     for (int r = 0; r < 16; ++r) {
       const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float *g = geom + (size_t)pp * GS;
-      const int *gi = reinterpret_cast<const int *>(g);
+      float g[GS];  // the pixel's record: ten 16-byte broadcast reads issued together, one wait
+      loadG(r, g);
       float cg[T];
       MFN_UNROLL
       for (int t = 0; t < T; ++t) cg[t] = (c_ok ? acc[t][r] : 0.f) * g[DCS_M9 + t];  // invalid taps contribute nothing
-      const int ly0 = gi[DCS_LY0], lx0 = gi[DCS_LX0];
+      const int ly0 = mfn_f2i(g[DCS_LY0]), lx0 = mfn_f2i(g[DCS_LX0]);
       if (p.req_offset) {
-        // the 4x4 x neighbourhood at the clamped lines (clamped duplicates carry zero weight)
         float X[4][4];
-        int ro[4];
         MFN_UNROLL
-        for (int m = 0; m < 4; ++m) ro[m] = min(max(ly0 + m, 0), H - 1) * W;
-        if (gi[DCS_FL]) {
+        for (int m = 0; m < 4; ++m)
           MFN_UNROLL
-          for (int m = 0; m < 4; ++m) {
-            const f4u q = mfn_load4u(im + ro[m] + lx0);
-            X[m][0] = q.x; X[m][1] = q.y; X[m][2] = q.z; X[m][3] = q.w;
-          }
-        } else {
-          int co[4];
-          MFN_UNROLL
-          for (int m = 0; m < 4; ++m) co[m] = min(max(lx0 + m, 0), W - 1);
-          MFN_UNROLL
-          for (int m = 0; m < 4; ++m)
-            MFN_UNROLL
-            for (int v = 0; v < 4; ++v) X[m][v] = im[ro[m] + co[v]];
-        }
+          for (int v = 0; v < 4; ++v) X[m][v] = Xn[m][v];
+        if (r + 1 < 16) loadX(r + 1, Xn);  // the next pixel's neighbourhood travels while this one is reduced
         float sh_[T], sw_[T];
         MFN_UNROLL
         for (int i = 0; i < 3; ++i)
@@ -988,16 +1064,10 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
             sh_[t] = mfn_half_sum_top(th * cg[t]);
             sw_[t] = mfn_half_sum_top(tw * cg[t]);
           }
-        if (j == 31) {  // the half-wave's top lane holds the sums over its 32 channels; other channel blocks add too
-          const int y = ty0 + 2 * wave + (pp >> 4), x = tx0 + (pp & 15);
-          if (y < H && x < W) {
-            float *gof = p.goffset + (size_t)n * 2 * T * plane + (size_t)y * W + x;
-            MFN_UNROLL
-            for (int t = 0; t < T; ++t) {
-              if (sh_[t] != 0.f) atomicAdd(gof + (size_t)(2 * t) * plane, sh_[t]);
-              if (sw_[t] != 0.f) atomicAdd(gof + (size_t)(2 * t + 1) * plane, sw_[t]);
-            }
-          }
+        if (j == 31) {  // the half-wave's top lane holds the sums over its 32 channels
+          float2 *os = reinterpret_cast<float2 *>(gsum + (size_t)pp * DCS_OS);
+          MFN_UNROLL
+          for (int t = 0; t < T; ++t) os[t] = make_float2(sh_[t], sw_[t]);
         }
       }
       if (p.req_x) {
@@ -1020,7 +1090,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
             G[3][v] = g[DCS_BY + 2] * R[2][v];
           }
         }
-        const int cell = gi[DCS_CELL];
+        const int cell = mfn_f2i(g[DCS_CELL]);
         if (cell < 0) {  // neighbourhood outside the window (rough flow): straight to global memory
           MFN_UNROLL
           for (int u = 0; u < 4; ++u)
@@ -1049,23 +1119,57 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
         }
       }
     }
+    if (p.req_offset) {  // the strip's 32 x 18 sums: one coalesced pass of atomics (other channel blocks add to the same)
+      MFN_WAIT_LGKM0();
+      MFN_UNROLL
+      for (int i = 0; i < DCS_OS / 2; ++i) {
+        const int t2 = 2 * i + half;  // lanes 0..31: channel 2i of the record, lanes 32..63: channel 2i+1; lane = pixel
+        const float v = gsum[(size_t)j * DCS_OS + t2];
+        if (pix_ok && v != 0.f)
+          atomicAdd(p.goffset + ((size_t)n * 2 * T + t2) * plane + pix, v);
+      }
+    }
+    if (p.timeline) { MFN_WAIT_LGKM0(); tk3 = MFN_CYCLES(); }
   }
-  if (!p.req_x) return;
-  __syncthreads();
+  if (p.req_x) __syncthreads();
+  const unsigned long long tk4 = p.timeline ? MFN_CYCLES() : 0ull;  // after the block barrier
+  if (p.req_x) {
   // ---- merge the four strips' windows (strip w covers block-window rows 2w .. 2w+WR-1) and flush once
   const int bwy0 = wy0 - 2 * wave;
-  for (int e = tid; e < 32 * (WR + 6) * WC; e += 256) {
-    const int cl = e / ((WR + 6) * WC), rem = e - cl * ((WR + 6) * WC);
-    const int R = rem / WC, cc = rem - R * WC;
-    float v = 0.f;
+  constexpr int CELLS = 32 * (WR + 6) * WC;  // a multiple of 4 * 256
+  static_assert(CELLS % 1024 == 0, "merge loop: four cells per thread per trip");
+  for (int e0 = tid; e0 < CELLS; e0 += 1024) {  // four cells per trip, their 16 LDS reads issued together (no branches)
+    float v[4];
+    int cl[4], R[4], cc[4];
     MFN_UNROLL
-    for (int w2 = 0; w2 < 4; ++w2) {
-      const int rr = R - 2 * w2;
-      if (rr >= 0 && rr < WR) v += lds[(size_t)w2 * 32 * PL + (size_t)cl * PL + rr * WC + cc];
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + 256 * q;
+      cl[q] = e / ((WR + 6) * WC);
+      const int rem = e - cl[q] * ((WR + 6) * WC);
+      R[q] = rem / WC;
+      cc[q] = rem - R[q] * WC;
+      float s_ = 0.f;
+      MFN_UNROLL
+      for (int w2 = 0; w2 < 4; ++w2) {
+        const int rr = R[q] - 2 * w2;
+        const bool in = rr >= 0 && rr < WR;
+        const float val = lds[(size_t)w2 * 32 * PL + (size_t)cl[q] * PL + (in ? rr : 0) * WC + cc[q]];
+        s_ += in ? val : 0.f;
+      }
+      v[q] = s_;
     }
-    const int yy = bwy0 + R, xx = wx0 + cc;
-    if (v != 0.f && cb + cl < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
-      atomicAdd(p.gx + ((size_t)n * p.Cin + cb + cl) * plane + (size_t)yy * W + xx, v);
+    MFN_UNROLL
+    for (int q = 0; q < 4; ++q) {
+      const int yy = bwy0 + R[q], xx = wx0 + cc[q];
+      if (v[q] != 0.f && cb + cl[q] < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        atomicAdd(p.gx + ((size_t)n * p.Cin + cb + cl[q]) * plane + (size_t)yy * W + xx, v[q]);
+    }
+  }
+  }
+  if (p.timeline && tid == 0) {
+    unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    // low halves as the tile kernel's record; high half of [0]: wave 0's wait at the block barrier
+    b_[0] = ((tk1 - tk0) & 0xffffffffull) | ((tk4 - tk3) << 32); b_[1] = tk2 - tk1; b_[2] = tk3 - tk2; b_[3] = MFN_CYCLES() - tk0;
   }
 }
 

@@ -8,7 +8,7 @@ from maskflownet_amd import _lib, hotpath
 from maskflownet_amd.ops import default_ops
 lib = _lib.lib(); ops = default_ops()
 wl = hotpath.HotPathWorkload("cfg2", mode="dropin")
-for l in (2, 4):
+for l in (2, 3, 4, 5):
     n, c, h, w = hotpath.level_shapes(8, 384, 512)[l]
     off = wl.o["offset%d" % l]; ops.offsets_from_flow(wl.t["flow_%d" % l], hotpath.SCALE, hotpath.STRIDES[l], out=off)
     go = torch.randn(n, c, h, w, device="cuda")
@@ -18,6 +18,10 @@ for l in (2, 4):
         fn = lambda: ops.DeformableConvolution_backward(go, wl.t["c2_%d" % l], off, wl.t["w_%d" % l], kernel=(3, 3), pad=(1, 1), req=req + ("null", "null"))
         fn(); torch.cuda.synchronize()
         lib.debug_set_timeline(tl.data_ptr()); fn(); torch.cuda.synchronize(); lib.debug_set_timeline(None)
-        t = tl.cpu().numpy().reshape(nblk, 4).astype(np.float64)
+        raw = tl.cpu().numpy().reshape(nblk, 4)
+        bar = (raw[:, 0] >> 32).astype(np.float64)   # shared-offset kernel: wave 0's wait at the block barrier
+        raw[:, 0] &= 0xffffffff
+        t = raw.astype(np.float64)
+        print("   barrier wait %.0f  merge+flush %.0f" % (np.median(bar), np.median(t[:, 3] - t[:, 0] - t[:, 1] - t[:, 2] - bar)))
         print("L%d gx=%s goffset=%s blocks %d: median cycles geometry %.0f  mfma %.0f  scatter %.0f  total %.0f"
               % (l, req[0], req[1], nblk, *np.median(t, axis=0)))
