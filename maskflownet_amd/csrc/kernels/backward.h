@@ -505,43 +505,75 @@ __global__ __launch_bounds__(256) void dc_bwd_weight_mfma_kernel(DcBwdWParams p)
 
   float bsum = 0.f;  // thread tid < MTO*32 of a combo-group-0 block: sum of gout row o0 + tid over this block's pixels
   const int tile0 = blockIdx.x * p.tiles_per_block;
+  // What a thread stages for a tile -- the offsets of its (tap, pixel) entries and its gout values -- is loaded one tile
+  // ahead: the loads of tile i+1 are issued right after tile i's staging barrier and travel during its column build and
+  // MFMAs.  (One block alone on a CU needed ~15 k cycles per 32-pixel tile: offsets -> table -> gathers -> MFMA, each a
+  // full memory round trip behind the other.)
+  constexpr int NE = 4;  // entries per thread: taps tid/32 + 8 i (T <= 25)
+  struct Stage {
+    float oh[NE], ow[NE], gv[MTO * 4];
+    int n, rem, ho, wo;
+    bool ok;
+  };
+  const int pp = tid & 31, tt0 = tid >> 5;
+  auto prefetch = [&](int pbase, Stage &q) {
+    const int pl = pbase + pp;
+    q.ok = pl < p.P;
+    const int pc = q.ok ? pl : 0;
+    q.n = pc / (int)oplane;
+    q.rem = pc - q.n * (int)oplane;
+    q.ho = q.rem / p.Wo;
+    q.wo = q.rem - q.ho * p.Wo;
+    const float *op = p.offset + (size_t)q.n * 2 * T * oplane + q.rem;
+    MFN_UNROLL
+    for (int i = 0; i < NE; ++i) {
+      const int tt = min(tt0 + 8 * i, T - 1);
+      q.oh[i] = op[(size_t)(2 * tt) * oplane];
+      q.ow[i] = op[(size_t)(2 * tt + 1) * oplane];
+    }
+    const float *gp = p.gout + (size_t)q.n * p.Cout * oplane + q.rem;
+    MFN_UNROLL
+    for (int i = 0; i < MTO * 4; ++i) q.gv[i] = gp[(size_t)min(o0 + tt0 + 8 * i, p.Cout - 1) * oplane];
+  };
+  // one tile ahead only with one filter tile per wave: with two the extra live registers cost a wave per SIMD and more
+  // than the prefetch returns (measured: levels 5..3 +8 / +10 / +25 us with it, level 2 -25 us)
+  constexpr bool AHEAD = MTO == 1;
+  Stage cur;
+  if (AHEAD) prefetch(tile0 * 32 < p.P ? tile0 * 32 : 0, cur);
   for (int tl = 0; tl < p.tiles_per_block; ++tl) {
     const int pbase = (tile0 + tl) * 32;
     if (pbase >= p.P) break;  // uniform
     __syncthreads();          // the previous tile's readers are done
+    if (!AHEAD) prefetch(pbase, cur);
     // geometry table: one entry per (tap, pixel)
-    for (int e = tid; e < 32 * T; e += 256) {
-      const int tt = e >> 5, pp = e & 31;
-      const int pl = pbase + pp;
-      const bool ok = pl < p.P;
-      const int pc = ok ? pl : 0;
-      const int n = pc / (int)oplane, rem = pc - n * (int)oplane;
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      const float *op = p.offset + (size_t)n * 2 * T * oplane + rem;
-      const int ti = tt / p.kw, tj = tt - ti * p.kw;
-      const DcTap tp = dc_make_tap(op[(size_t)(2 * tt) * oplane], op[(size_t)(2 * tt + 1) * oplane], ho * p.sh - p.ph,
-                                   wo * p.sw - p.pw, ti * p.dh, tj * p.dw, p.H, p.W, ok);
-      float *g = geom + (size_t)tt * GF * 32 + pp;
-      g[0] = tp.w1; g[32] = tp.w2; g[64] = tp.w3; g[96] = tp.w4;
-      reinterpret_cast<int *>(g)[128] = tp.base;                     // bit 30 = dwi
-      reinterpret_cast<int *>(g)[160] = tp.dhW;
-      reinterpret_cast<int *>(g)[192] = n * p.Cin * (int)plane;      // element offset of image n (checked < 2^31)
+    MFN_UNROLL
+    for (int i = 0; i < NE; ++i) {
+      const int tt = tt0 + 8 * i;
+      if (tt < T) {
+        const int ti = tt / p.kw, tj = tt - ti * p.kw;
+        const DcTap tp = dc_make_tap(cur.oh[i], cur.ow[i], cur.ho * p.sh - p.ph, cur.wo * p.sw - p.pw, ti * p.dh, tj * p.dw,
+                                     p.H, p.W, cur.ok);
+        float *g = geom + (size_t)tt * GF * 32 + pp;
+        g[0] = tp.w1; g[32] = tp.w2; g[64] = tp.w3; g[96] = tp.w4;
+        reinterpret_cast<int *>(g)[128] = tp.base;                     // bit 30 = dwi
+        reinterpret_cast<int *>(g)[160] = tp.dhW;
+        reinterpret_cast<int *>(g)[192] = cur.n * p.Cin * (int)plane;  // element offset of image n (checked < 2^31)
+      }
     }
     // gout tile [filter][pixel]
-    for (int e = tid; e < MTO * 32 * 32; e += 256) {
-      const int ol = e >> 5, pp = e & 31;
-      const int pl = pbase + pp, o = o0 + ol;
-      float v = 0.f;
-      if (pl < p.P && o < p.Cout) {
-        const int n = pl / (int)oplane, rem = pl - n * (int)oplane;
-        v = p.gout[((size_t)n * p.Cout + o) * oplane + rem];
-      }
-      gs[ol * GS + pp] = v;
+    MFN_UNROLL
+    for (int i = 0; i < MTO * 4; ++i) {
+      const int ol = tt0 + 8 * i;
+      gs[ol * GS + pp] = (cur.ok && o0 + ol < p.Cout) ? cur.gv[i] : 0.f;
     }
     __syncthreads();
+    if (AHEAD) {
+      const int nb = pbase + 32;
+      prefetch((tl + 1 < p.tiles_per_block && nb < p.P) ? nb : pbase, cur);  // the next tile's staging loads, in flight from here
+    }
     if (p.gbias && blockIdx.y == 0 && tid < MTO * 32) {
       MFN_UNROLL
-      for (int pp = 0; pp < 32; ++pp) bsum += gs[tid * GS + pp];
+      for (int q2 = 0; q2 < 32; ++q2) bsum += gs[tid * GS + q2];
     }
     // the wave's column tile: col[combo][pixel] (zero for combos past K2 and pixels past P: their weights are zero).
     // All 16 values are formed before the first is stored: a store between them would keep the next combo's table
@@ -919,6 +951,29 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
   float *gim = p.gx + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
   const float *im = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
 
+  // scalar base + 32-bit lane offset (the launch checks that an image's gout and the weights stay below 2^29 floats):
+  // the filter index of a k-step is uniform but for `half`, so its two candidate offsets are scalar
+  const float *ga = p.gout + (size_t)n * p.Cout * plane;
+  const int ga_lane = (int)pix, wb_lane = (c_ok ? c : 0) * T;
+  const int iplane = (int)plane, wstep = p.Cin * T;
+  // four k-steps (eight filters) per trip, 16 unconditional loads into one of three register sets (see the K loop)
+  float a[3][4], b[3][4][T];
+  auto ld = [&](const int buf, int s2) {
+    MFN_UNROLL
+    for (int u = 0; u < 4; ++u) {
+      const int oc0 = min(s2 + 2 * u, p.Cout - 1), oc1 = min(s2 + 2 * u + 1, p.Cout - 1);
+      const int oc = half ? oc1 : oc0;
+      a[buf][u] = ga[ga_lane + oc * iplane];
+      const float *wr = p.w + (wb_lane + oc * wstep);  // nine consecutive floats at 4-byte alignment
+      const f4u q0 = mfn_load4u(wr), q1 = mfn_load4u(wr + 4);
+      b[buf][u][0] = q0.x; b[buf][u][1] = q0.y; b[buf][u][2] = q0.z; b[buf][u][3] = q0.w;
+      b[buf][u][4] = q1.x; b[buf][u][5] = q1.y; b[buf][u][6] = q1.z; b[buf][u][7] = q1.w;
+      b[buf][u][8] = wr[8];
+    }
+  };
+  ld(0, 0);  // the first two trips travel while the geometry records are built (they do not depend on them)
+  ld(1, 8);
+
   // ---- geometry records of the strip's 32 pixels (lanes 0..31 write, everyone reads them back as broadcasts)
   const unsigned long long tk0 = MFN_CYCLES();
   unsigned long long tk1 = tk0, tk2 = tk0, tk3 = tk0;
@@ -957,27 +1012,6 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
     for (int t = 0; t < T; ++t)
       MFN_UNROLL
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // scalar base + 32-bit lane offset (the launch checks that an image's gout and the weights stay below 2^29 floats):
-    // the filter index of a k-step is uniform but for `half`, so its two candidate offsets are scalar
-    const float *ga = p.gout + (size_t)n * p.Cout * plane;
-    const int ga_lane = (int)pix, wb_lane = (c_ok ? c : 0) * T;
-    const int iplane = (int)plane, wstep = p.Cin * T;
-    // four k-steps (eight filters) per trip, 16 unconditional loads; the next trip's loads are issued before this
-    // trip's 36 MFMAs (two register sets), so the matrix pipe does not wait for memory between trips
-    float a[2][4], b[2][4][T];
-    auto ld = [&](const int buf, int s2) {
-      MFN_UNROLL
-      for (int u = 0; u < 4; ++u) {
-        const int oc0 = min(s2 + 2 * u, p.Cout - 1), oc1 = min(s2 + 2 * u + 1, p.Cout - 1);
-        const int oc = half ? oc1 : oc0;
-        a[buf][u] = ga[ga_lane + oc * iplane];
-        const float *wr = p.w + (wb_lane + oc * wstep);  // nine consecutive floats at 4-byte alignment
-        const f4u q0 = mfn_load4u(wr), q1 = mfn_load4u(wr + 4);
-        b[buf][u][0] = q0.x; b[buf][u][1] = q0.y; b[buf][u][2] = q0.z; b[buf][u][3] = q0.w;
-        b[buf][u][4] = q1.x; b[buf][u][5] = q1.y; b[buf][u][6] = q1.z; b[buf][u][7] = q1.w;
-        b[buf][u][8] = wr[8];
-      }
-    };
     auto mm = [&](const int buf, int s2) {
       MFN_UNROLL
       for (int u = 0; u < 4; ++u) {
@@ -989,15 +1023,16 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
         for (int t = 0; t < T; ++t) acc[t] = MFN_MFMA_32x32x2(av, b[buf][u][t], acc[t]);
       }
     };
-    ld(0, 0);
-    for (int s2 = 0; s2 < p.Cout; s2 += 16) {
-      const bool more = s2 + 8 < p.Cout;
-      if (more) ld(1, s2 + 8);
+    // three register sets: the loads of trip i+2 are issued before the MFMAs of trip i (one wave per SIMD: nobody else
+    // hides the ~1.5 us a strided weight load takes; with two sets a trip cost 3.7 k cycles against 2.3 k of MFMA).
+    // Loads past Cout are clamped and unused; the first two trips' loads were issued before the geometry records.
+    for (int s2 = 0; s2 < p.Cout; s2 += 24) {
+      ld(2, s2 + 16);
       mm(0, s2);
-      if (more) {
-        if (s2 + 16 < p.Cout) ld(0, s2 + 16);
-        mm(1, s2 + 8);
-      }
+      ld(0, s2 + 24);
+      if (s2 + 8 < p.Cout) mm(1, s2 + 8);
+      ld(1, s2 + 32);
+      if (s2 + 16 < p.Cout) mm(2, s2 + 16);
     }
     if (p.timeline) { MFN_OPAQUE(acc[0][0]); MFN_OPAQUE(acc[8][15]); tk2 = tk3 = MFN_CYCLES(); }
     // ---- per pixel of the strip: D reg r of lane (j, half) = pixel (r&3)+8*(r>>2)+4*half, channel j

@@ -22,6 +22,8 @@ for l in (2, 3, 4, 5):
         bar = (raw[:, 0] >> 32).astype(np.float64)   # shared-offset kernel: wave 0's wait at the block barrier
         raw[:, 0] &= 0xffffffff
         t = raw.astype(np.float64)
-        print("   barrier wait %.0f  merge+flush %.0f" % (np.median(bar), np.median(t[:, 3] - t[:, 0] - t[:, 1] - t[:, 2] - bar)))
+        print("   barrier wait %.0f  merge+flush %.0f   block total: mean %.0f p95 %.0f max %.0f; sum over blocks / 256 CUs = %.0f cycles"
+              % (np.median(bar), np.median(t[:, 3] - t[:, 0] - t[:, 1] - t[:, 2] - bar), t[:, 3].mean(), np.percentile(t[:, 3], 95),
+                 t[:, 3].max(), t[:, 3].sum() / 256))
         print("L%d gx=%s goffset=%s blocks %d: median cycles geometry %.0f  mfma %.0f  scatter %.0f  total %.0f"
               % (l, req[0], req[1], nblk, *np.median(t, axis=0)))
