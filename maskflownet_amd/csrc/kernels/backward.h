@@ -870,12 +870,16 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
 // A strip qualifies when every pixel's nine offsets are bit-identical and the floor pattern is regular on both axes
 // (forward weights and deformable_col2im_coord's absolute-coordinate floors agree with floor(off)+i); otherwise its flag
 // stays 0 and dc_bwd_input_tile_kernel (launched next with the flags as its skip list) does that strip tap by tap.
-constexpr int DCS_WR = 10, DCS_WC = 26, DCS_GS = 40;
-constexpr int DCS_PLANE = DCS_WR * DCS_WC + 1;  // odd plane stride: the 32 lanes (channels) hit distinct banks
+// Strips (waves) per block NS: 2 = a 4x16-pixel sub-tile, two blocks per CU (one can flush while the other computes; levels
+// 5 / 4: 76 -> 70, 97 -> 88 us, levels 3 / 2 unchanged); 4 = the tile kernel's 8x16 tile, fewer halo cells to flush (1.63
+// against 2.08 atomics per pixel and channel) but one block per CU.  At level 2 the gx flush is what the launch waits for:
+// gx alone 215 us, goffset alone 107 us, both 242 us, although a block's instructions take 71 k / 59 k cycles (~90 / ~75 us of
+// three rounds) -- 6.5 M fp32 atomics at the device's ~55 G/s.
+constexpr int DCS_WR = 10, DCS_GS = 40;
 constexpr int DCS_OS = 18;  // offset-gradient sums of a pixel (9 taps x {dh, dw}), staged per strip and flushed coalesced
-constexpr size_t dc_bwd_shared_lds_bytes() {
-  return ((size_t)4 * 32 * DCS_PLANE + (size_t)4 * 32 * DCS_GS + (size_t)4 * 32 * DCS_OS) * sizeof(float);
-}
+constexpr int dcs_wc(int ns) { return ns == 4 ? 26 : 24; }
+constexpr int dcs_plane(int ns) { return DCS_WR * dcs_wc(ns) + 1; }  // odd plane stride: the 32 lanes (channels) hit distinct banks
+constexpr size_t dc_bwd_shared_lds_bytes(int ns) { return (size_t)ns * 32 * (dcs_plane(ns) + DCS_GS + DCS_OS) * sizeof(float); }
 // words of a pixel's geometry record
 enum { DCS_AY = 0, DCS_BY = 3, DCS_AX = 6, DCS_BX = 9, DCS_M9 = 12, DCS_FH0 = 21, DCS_FH1 = 24, DCS_FW0 = 27, DCS_FW1 = 30,
        DCS_CELL = 36, DCS_LY0 = 37, DCS_LX0 = 38, DCS_FL = 39 };  // the four ints: one 16-byte read
@@ -910,25 +914,31 @@ __device__ __forceinline__ void dcs_axis(float off, int in0, int dim, int lo0, f
   }
 }
 
-__global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p) {
-  constexpr int TH = DCI_TH, TW = DCI_TW, WR = DCS_WR, WC = DCS_WC, GS = DCS_GS, PL = DCS_PLANE, T = 9;
+template <int NS>
+__global__ __launch_bounds__(64 * NS) void dc_bwd_input_shared_kernel(DcBwdSParams p) {
+  constexpr int SB = 4 / NS, NT = 64 * NS;  // SB sub-tiles of 2*NS rows per 8-row tile of the tile kernel
+  constexpr int TW = DCI_TW, WR = DCS_WR, WC = dcs_wc(NS), GS = DCS_GS, PL = dcs_plane(NS), T = 9;
   MFN_DYN_SHARED(float, lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = MFN_UNIFORM(tid >> 6);
   float *win = lds + (size_t)wave * 32 * PL;                         // [32 channels][WR][WC] (+1), this wave's strip
-  float *geom = lds + (size_t)4 * 32 * PL + (size_t)wave * 32 * GS;  // [32 pixels][GS]
-  float *gsum = lds + (size_t)4 * 32 * (PL + GS) + (size_t)wave * 32 * DCS_OS;  // [32 pixels][18]
+  float *geom = lds + (size_t)NS * 32 * PL + (size_t)wave * 32 * GS;  // [32 pixels][GS]
+  float *gsum = lds + (size_t)NS * 32 * (PL + GS) + (size_t)wave * 32 * DCS_OS;  // [32 pixels][18]
   const int j = lane & 31, half = lane >> 5;
   const int H = p.H, W = p.W;
   const size_t plane = (size_t)H * W;
   const int tpi = p.tiles_x * p.tiles_y;
-  const int bx = gridDim.y == 1 ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // as the tile kernel
-  const int n = bx / tpi, rt = bx - n * tpi;
-  const int ty0 = (rt / p.tiles_x) * TH, tx0 = (rt % p.tiles_x) * TW;
+  const int bx = gridDim.y == 1 ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // neighbours share an L2
+  // block -> (image, 8-row tile row, sub-tile, tile column); the strip's flag sits where the tile kernel looks for it
+  const int n = bx / (tpi * SB), rt = bx - n * (tpi * SB);
+  const int ty8 = rt / (SB * p.tiles_x), r2 = rt - ty8 * (SB * p.tiles_x);
+  const int sb = r2 / p.tiles_x, txi = r2 - sb * p.tiles_x;
+  const int ty0 = ty8 * DCI_TH + sb * 2 * NS, tx0 = txi * TW;
+  const size_t flag_idx = ((size_t)(n * tpi + ty8 * p.tiles_x + txi)) * 4 + sb * NS + wave;
   const int cb = blockIdx.y * 32;
-  int wy0, wx0;  // window origin: follows the offset of the tile's centre pixel; strip w sits 2w rows lower
+  int wy0, wx0;  // window origin: follows the offset of the sub-tile's centre pixel; strip w sits 2w rows lower
   {
-    const int cy = min(ty0 + TH / 2, H - 1), cx = min(tx0 + TW / 2, W - 1);
+    const int cy = min(ty0 + NS, H - 1), cx = min(tx0 + TW / 2, W - 1);
     const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
     const float oh = op[(size_t)8 * plane], ow = op[(size_t)9 * plane];
     const float fh = fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), fw = fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
@@ -1001,7 +1011,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
     ok = ok || !pix_ok;
   }
   const bool fast = __all(ok) != 0;  // wave-uniform: the whole strip or nothing
-  if (lane == 0) p.flags[(size_t)bx * 4 + wave] = fast ? 1 : 0;  // every channel block writes the same value
+  if (lane == 0) p.flags[flag_idx] = fast ? 1 : 0;  // every channel block writes the same value
   MFN_WAIT_LGKM0();
   if (p.timeline) tk1 = tk2 = tk3 = MFN_CYCLES();
 
@@ -1160,8 +1170,12 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
       for (int i = 0; i < DCS_OS / 2; ++i) {
         const int t2 = 2 * i + half;  // lanes 0..31: channel 2i of the record, lanes 32..63: channel 2i+1; lane = pixel
         const float v = gsum[(size_t)j * DCS_OS + t2];
-        if (pix_ok && v != 0.f)
-          atomicAdd(p.goffset + ((size_t)n * 2 * T + t2) * plane + pix, v);
+        float *dst = p.goffset + ((size_t)n * 2 * T + t2) * plane + pix;
+        if (gridDim.y == 1) {  // one channel block: this strip is the only writer of its entries (the tile kernel skips it)
+          if (pix_ok) *dst += v;  // zero-filled (write) or the caller's values (add)
+        } else if (pix_ok && v != 0.f) {
+          atomicAdd(dst, v);    // device-wide fp32 atomics are the scarce resource of this kernel (~57 G/s)
+        }
       }
     }
     if (p.timeline) { MFN_WAIT_LGKM0(); tk3 = MFN_CYCLES(); }
@@ -1169,23 +1183,24 @@ __global__ __launch_bounds__(256) void dc_bwd_input_shared_kernel(DcBwdSParams p
   if (p.req_x) __syncthreads();
   const unsigned long long tk4 = p.timeline ? MFN_CYCLES() : 0ull;  // after the block barrier
   if (p.req_x) {
-  // ---- merge the four strips' windows (strip w covers block-window rows 2w .. 2w+WR-1) and flush once
+  // ---- merge the strips' windows (strip w covers block-window rows 2w .. 2w+WR-1) and flush once
   const int bwy0 = wy0 - 2 * wave;
-  constexpr int CELLS = 32 * (WR + 6) * WC;  // a multiple of 4 * 256
-  static_assert(CELLS % 1024 == 0, "merge loop: four cells per thread per trip");
-  for (int e0 = tid; e0 < CELLS; e0 += 1024) {  // four cells per trip, their 16 LDS reads issued together (no branches)
+  constexpr int BR = WR + 2 * (NS - 1);     // rows of the block window
+  constexpr int CELLS = 32 * BR * WC;
+  static_assert(CELLS % (4 * NT) == 0, "merge loop: four cells per thread per trip");
+  for (int e0 = tid; e0 < CELLS; e0 += 4 * NT) {  // four cells per trip, their LDS reads issued together (no branches)
     float v[4];
     int cl[4], R[4], cc[4];
     MFN_UNROLL
     for (int q = 0; q < 4; ++q) {
-      const int e = e0 + 256 * q;
-      cl[q] = e / ((WR + 6) * WC);
-      const int rem = e - cl[q] * ((WR + 6) * WC);
+      const int e = e0 + NT * q;
+      cl[q] = e / (BR * WC);
+      const int rem = e - cl[q] * (BR * WC);
       R[q] = rem / WC;
       cc[q] = rem - R[q] * WC;
       float s_ = 0.f;
       MFN_UNROLL
-      for (int w2 = 0; w2 < 4; ++w2) {
+      for (int w2 = 0; w2 < NS; ++w2) {
         const int rr = R[q] - 2 * w2;
         const bool in = rr >= 0 && rr < WR;
         const float val = lds[(size_t)w2 * 32 * PL + (size_t)cl[q] * PL + (in ? rr : 0) * WC + cc[q]];

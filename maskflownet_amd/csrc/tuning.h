@@ -23,6 +23,7 @@
 //   dc.fast      0: disable the shared-offset 4x4-neighbourhood gather
 //   dc.generic   1: force the generic one-thread-per-output kernel
 //   dc.bwdshared 0: input/offset gradient tap by tap only (no shared-offset kernel)
+//   dc.bwdstrips 2x16-pixel strips per block of the shared-offset backward kernel: 0 auto, 2, 4
 //   dc.bwdwblocks target number of blocks of the weight-gradient kernel (pixel slices x combo groups x filter groups); 0 auto
 #pragma once
 #include <string.h>
@@ -31,7 +32,7 @@ struct Tuning {
   int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0;
   int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
-  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0;
+  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
@@ -59,6 +60,7 @@ struct Tuning {
     if (!strcmp(key, "dc.generic")) return &dc_generic;
     if (!strcmp(key, "dc.bwdshared")) return &dc_bwdshared;
     if (!strcmp(key, "dc.bwdwblocks")) return &dc_bwdwblocks;
+    if (!strcmp(key, "dc.bwdstrips")) return &dc_bwdstrips;
     return nullptr;
   }
 };

@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1)
+                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -318,6 +318,10 @@ def test_deform_conv_backward_shared_offsets(ops, oracle, kind):
 def test_deform_conv_backward_shared_offsets_partial_requests_and_switch(ops, oracle):
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 17, "smooth", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 17, "smooth", req=("null", "write", "write", "write"))
+    emu_ops.set_tuning(dc_bwdstrips=4)   # four-strip blocks (what large launches use)
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 9, 17, "smooth", seed=4)
+    emu_ops.set_tuning(dc_bwdstrips=2)
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 9, 17, "smooth", seed=4)
     emu_ops.set_tuning(dc_bwdshared=0)   # the tap-by-tap kernel alone gives the same gradients
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 17, "smooth", seed=3)
 

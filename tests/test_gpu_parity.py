@@ -257,11 +257,15 @@ def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracl
     from maskflownet_amd import _lib
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("null", "write", "write", "write"))
-    _lib.set_tuning(dc_bwdshared=0)
     try:
+        for strips in (2, 4):   # both block shapes of the shared-offset kernel, whatever the heuristic would pick
+            _lib.set_tuning(dc_bwdstrips=strips)
+            pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 40, 36, 27, 45, "smooth")
+            pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "mixed")
+        _lib.set_tuning(dc_bwdshared=0)
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth")
     finally:
-        _lib.set_tuning(dc_bwdshared=1)
+        _lib.set_tuning(dc_bwdshared=1, dc_bwdstrips=0)
     # straight through the C ABI with workspace = NULL: tap-by-tap kernel only, same gradients
     rng = np.random.default_rng(1)
     N, C, H, W = 1, 8, 16, 16

@@ -12,7 +12,7 @@ for l in (2, 3, 4, 5):
     n, c, h, w = hotpath.level_shapes(8, 384, 512)[l]
     off = wl.o["offset%d" % l]; ops.offsets_from_flow(wl.t["flow_%d" % l], hotpath.SCALE, hotpath.STRIDES[l], out=off)
     go = torch.randn(n, c, h, w, device="cuda")
-    nblk = n * ((h + 7) // 8) * ((w + 15) // 16) * ((c + 31) // 32)
+    nblk = 2 * n * ((h + 7) // 8) * ((w + 15) // 16) * ((c + 31) // 32)   # shared-offset kernel: two 4-row blocks per 8-row tile
     for req in (("write", "write"), ("write", "null"), ("null", "write")):
         tl = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
         fn = lambda: ops.DeformableConvolution_backward(go, wl.t["c2_%d" % l], off, wl.t["w_%d" % l], kernel=(3, 3), pad=(1, 1), req=req + ("null", "null"))
