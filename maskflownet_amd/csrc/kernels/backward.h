@@ -29,6 +29,40 @@ inline int fill_zero_launch(float *p, size_t n, hipStream_t s) {
   return launch("fill_zero", fill_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, FillParams{p, n});
 }
 
+// up to four buffers in one launch (the write-mode gradients of a deformable-conv backward: gx, goffset, gw, gbias);
+// a thread zeroes four consecutive floats of one buffer
+struct Fill4Params { float *p[4]; size_t n[4]; unsigned qend[4]; };  // qend: running total of 4-float groups
+__global__ __launch_bounds__(256) void fill_zero4_kernel(Fill4Params f) {
+  const unsigned q = blockIdx.x * 256u + threadIdx.x;
+  MFN_UNROLL
+  for (int k = 0; k < 4; ++k) {
+    const unsigned q0 = k ? f.qend[k - 1] : 0u;
+    if (q >= q0 && q < f.qend[k]) {
+      const size_t b = (size_t)(q - q0) * 4;
+      MFN_UNROLL
+      for (int e = 0; e < 4; ++e)
+        if (b + e < f.n[k]) f.p[k][b + e] = 0.f;
+    }
+  }
+}
+inline int fill_zero4_launch(float *const ptr[4], const size_t cnt[4], hipStream_t s) {
+  Fill4Params f;
+  size_t tot = 0;
+  for (int k = 0; k < 4; ++k) {
+    f.p[k] = ptr[k];
+    f.n[k] = ptr[k] ? cnt[k] : 0;
+    tot += (f.n[k] + 3) / 4;
+    f.qend[k] = (unsigned)tot;
+  }
+  if (!tot) return 0;
+  if (tot >= 0xffffff00ull) {  // beyond 32-bit group indices: one launch per buffer
+    for (int k = 0; k < 4; ++k)
+      if (int rc = fill_zero_launch(f.p[k], f.n[k], s)) return rc;
+    return 0;
+  }
+  return launch("fill_zero4", fill_zero4_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, f);
+}
+
 // ---- correlation -----------------------------------------------------------------------------------
 struct CorrBwdParams {
   const float *gout, *f1, *f2;
@@ -104,7 +138,10 @@ __global__ __launch_bounds__(256) void corr_bwd_block_kernel(CorrBwdParams p) {
     MFN_UNROLL
     for (int q = 0; q < 4; ++q) { s1[k][q] = 0.f; s2[k][q] = 0.f; }
 
-  if (p.req1) {  // g1[c,y,x+q] = sum_d gout[d,y,x+q] * f2[c,y+dy,x+q+dx]
+  // gridDim.y == 2: the two gradients go to different blocks (two independent chains of D dependent load rounds; at the
+  // coarse levels the launch is nothing but that latency chain: 27 us for 0.3 MB)
+  const bool do1 = p.req1 && (gridDim.y == 1 || blockIdx.y == 0), do2 = p.req2 && (gridDim.y == 1 || blockIdx.y == 1);
+  if (do1) {  // g1[c,y,x+q] = sum_d gout[d,y,x+q] * f2[c,y+dy,x+q+dx]
     for (int iy = 0; iy < D; ++iy) {
       const int y2u = y + iy - md;
       const bool rok = y2u >= 0 && y2u < H;
@@ -133,7 +170,7 @@ __global__ __launch_bounds__(256) void corr_bwd_block_kernel(CorrBwdParams p) {
       }
     }
   }
-  if (p.req2) {  // g2[c,y,x+q] = sum_d gout[d,y-dy,x+q-dx] * f1[c,y-dy,x+q-dx]
+  if (do2) {  // g2[c,y,x+q] = sum_d gout[d,y-dy,x+q-dx] * f1[c,y-dy,x+q-dx]
     for (int iy = 0; iy < D; ++iy) {
       const int ysu = y - (iy - md);
       const bool rok = ysu >= 0 && ysu < H;
@@ -163,12 +200,12 @@ __global__ __launch_bounds__(256) void corr_bwd_block_kernel(CorrBwdParams p) {
   for (int k = 0; k < CB; ++k) {
     if (c0 + k >= C) break;
     const size_t o = ((size_t)n * C + c0 + k) * plane + (size_t)y * W + x;
-    if (p.req1) {
+    if (do1) {
       float4 r = make_float4(s1[k][0] * inv, s1[k][1] * inv, s1[k][2] * inv, s1[k][3] * inv);
       if (p.req1 == 3) { const float4 old = *reinterpret_cast<const float4 *>(p.g1 + o); r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
       mfn_store4_stream(p.g1 + o, r.x, r.y, r.z, r.w, p.st_policy);
     }
-    if (p.req2) {
+    if (do2) {
       float4 r = make_float4(s2[k][0] * inv, s2[k][1] * inv, s2[k][2] * inv, s2[k][3] * inv);
       if (p.req2 == 3) { const float4 old = *reinterpret_cast<const float4 *>(p.g2 + o); r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
       mfn_store4_stream(p.g2 + o, r.x, r.y, r.z, r.w, p.st_policy);

@@ -8,6 +8,7 @@
 //   corr.direct  LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   corr.xcd     1: XCD-aware block remap (neighbouring tiles share an L2)
 //   corr.generic 1: force the generic one-thread-per-output kernel
+//   corr.bwdsplit 1: the correlation backward computes g1 and g2 in separate blocks, 0: one thread computes both
 //   store.corr / store.dc / store.warp / store.off   the same per kernel family (override store.policy)
 //   store.policy cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
@@ -29,7 +30,7 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0;
+  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0, corr_bwdsplit = 1;
   int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
   int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0;
@@ -48,6 +49,7 @@ struct Tuning {
     if (!strcmp(key, "corr.lanemap")) return &corr_lanemap;
     if (!strcmp(key, "corr.band")) return &corr_band;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
+    if (!strcmp(key, "corr.bwdsplit")) return &corr_bwdsplit;
     if (!strcmp(key, "warp.vec")) return &warp_vec;
     if (!strcmp(key, "dc.mt")) return &dc_mt;
     if (!strcmp(key, "dc.pt")) return &dc_pt;
