@@ -124,7 +124,7 @@ def test_call_lists_of_every_pass_through_the_emulated_kernels(kind, mode, monke
     """The operator sequences bench.py replays (S / full / train, drop-in and fused), run on the emulated kernels
     with numpy buffers: every output of the pass against the oracle's pass, the gradient bucket included.  Narrow
     pyramid (the emulator is slow; the GPU tests run the real channel widths)."""
-    for l, c in {6: 20, 5: 16, 4: 12, 3: 8, 2: 6}.items():
+    for l, c in {6: 12, 5: 8, 4: 8, 3: 6, 2: 4}.items():
         monkeypatch.setitem(hotpath.CHANNELS, l, c)
     cfg = (1, 64, 64) + ((kind,) if kind != "S" else ())
     wl = hotpath.HotPathWorkload(cfg, mode=mode, seed=3, buffers=_EmuBuffers())
