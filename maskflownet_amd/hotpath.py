@@ -239,6 +239,9 @@ class _TorchBuffers:
     def launching(self):
         return self.torch.cuda.stream(self.stream)
 
+    def as_collective_tensor(self, flat):
+        return flat  # torch.distributed reduces the device tensor in place
+
     def synchronize(self):
         self.stream.synchronize()
 
@@ -412,18 +415,22 @@ class HotPathWorkload:
         if self.graph is not None:
             _lib.check(self.lib.graph_launch(self.graph, self.stream.cuda_stream))
         else:
-            with self.torch.cuda.stream(self.stream):
+            with self.bufs.launching():
                 self._enqueue()
 
     def step(self, dist=None, global_batch=None):
-        """One step of the pass: replay(); the training pass then all-reduces its flat gradient bucket over the ranks
-        (RCCL; enqueued behind the pass on the workload's stream, the next replay waits for it) and applies
-        trainer.step's 1/batch (pipeline.py:114).  No host synchronisation."""
+        """One step of the pass: replay(), then the training pass's exchange().  No host synchronisation."""
         self.replay()
+        self.exchange(dist, global_batch)
+
+    def exchange(self, dist=None, global_batch=None):
+        """The training pass's only collective: all-reduce(sum) of the flat gradient bucket over the ranks (RCCL; enqueued
+        behind the pass on the workload's stream, the next replay waits for it) and trainer.step's 1/batch
+        (pipeline.py:114).  Nothing to do for the forward passes or without a process group."""
         if self.kind == "train" and dist is not None:
             from .dist import allreduce_bucket
-            with self.torch.cuda.stream(self.stream):
-                allreduce_bucket(self.grad_bucket, dist, batch_size=global_batch)
+            with self.bufs.launching():
+                allreduce_bucket(self.bufs.as_collective_tensor(self.grad_bucket), dist, batch_size=global_batch)
 
     def synchronize(self):
         self.stream.synchronize()

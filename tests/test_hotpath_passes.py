@@ -114,6 +114,10 @@ class _EmuBuffers:
     def launching(self):
         return self._ctx()
 
+    def as_collective_tensor(self, flat):
+        import torch
+        return torch.from_numpy(flat)  # shares the numpy bucket's memory: the all-reduce lands in it
+
     def synchronize(self):
         pass
 
@@ -149,3 +153,42 @@ def test_train_pass_refuses_fused_mode():
         hotpath.HotPathWorkload((1, 64, 64, "train"), mode="fused", buffers=_EmuBuffers())
     with pytest.raises(ValueError, match="kind"):
         hotpath.HotPathWorkload((1, 64, 64, "half"), buffers=_EmuBuffers())
+
+
+def _train_step_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for l, c in {6: 6, 5: 4, 4: 4, 3: 4, 2: 4}.items():
+            hotpath.CHANNELS[l] = c
+        wl = hotpath.HotPathWorkload((1, 64, 64, "train"), seed=20 + rank, buffers=_EmuBuffers())   # every rank its own shard
+        wl.replay()
+        local = wl.grad_bucket.copy()
+        wl.exchange(dist, global_batch=world * wl.N)    # what step() does after the pass: ONE all-reduce of the bucket + 1/batch
+        q.put((rank, local, wl.grad_bucket.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_step_allreduces_one_flat_bucket():
+    """bench.py --config cfg5 at N > 1, on CPU: two gloo ranks run the training pass on different shards (emulated
+    kernels); after the step's exchange both hold the same bucket = (sum of the ranks' local parameter gradients) / global batch."""
+    import os
+    import torch.multiprocessing as mp
+    world, port = 2, 33000 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, l0, g0), (_, l1, g1) = res
+    assert np.array_equal(g0, g1)
+    assert not np.array_equal(l0, l1)
+    np.testing.assert_allclose(g0, (l0 + l1) / 2.0, rtol=0, atol=1e-6 * np.abs(l0 + l1).max())
