@@ -105,6 +105,9 @@ __global__ __launch_bounds__(256) void corr_bwd_gather_kernel(CorrBwdParams p) {
 // map (three aligned 16-byte loads, whole quads outside the image read as zero) that serves all nine dx --
 // 0.15 sixteen-byte loads per FMA instead of 2 scalar loads, and one multiply by 1/C at the end instead of a
 // division per term.  For g2 the roles swap: the window slides over gout's displaced row.
+// PART 0: both gradients (gridDim.y == 2 hands them to different blocks), 1: g1 only, 2: g2 only -- the single-gradient
+// instances need fewer registers (one set of accumulators, one window buffer) and run more waves per SIMD
+template <int PART>
 __global__ __launch_bounds__(256) void corr_bwd_block_kernel(CorrBwdParams p) {
   constexpr int CB = 4;
   const int W = p.W, H = p.H, C = p.C, D = p.D, md = p.md;
@@ -140,7 +143,8 @@ __global__ __launch_bounds__(256) void corr_bwd_block_kernel(CorrBwdParams p) {
 
   // gridDim.y == 2: the two gradients go to different blocks (two independent chains of D dependent load rounds; at the
   // coarse levels the launch is nothing but that latency chain: 27 us for 0.3 MB)
-  const bool do1 = p.req1 && (gridDim.y == 1 || blockIdx.y == 0), do2 = p.req2 && (gridDim.y == 1 || blockIdx.y == 1);
+  const bool do1 = PART != 2 && p.req1 && (gridDim.y == 1 || blockIdx.y == 0);
+  const bool do2 = PART != 1 && p.req2 && (gridDim.y == 1 || blockIdx.y == 1);
   if (do1) {  // g1[c,y,x+q] = sum_d gout[d,y,x+q] * f2[c,y+dy,x+q+dx]
     for (int iy = 0; iy < D; ++iy) {
       const int y2u = y + iy - md;

@@ -8,7 +8,8 @@
 //   corr.direct  LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   corr.xcd     1: XCD-aware block remap (neighbouring tiles share an L2)
 //   corr.generic 1: force the generic one-thread-per-output kernel
-//   corr.bwdsplit 1: the correlation backward computes g1 and g2 in separate blocks, 0: one thread computes both
+//   corr.bwdsplit 1: the correlation backward computes g1 and g2 in separate blocks of one launch, 2: in separate launches,
+//                 0: one thread computes both
 //   store.corr / store.dc / store.warp / store.off   the same per kernel family (override store.policy)
 //   store.policy cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
