@@ -1,65 +1,183 @@
-"""MXNet side of the drop-in boundary: mx.operator.CustomOp registrations that route
-F.Correlation / GridGenerator+BilinearSampler / contrib.DeformableConvolution call sites of
-/root/reference/network/layer.py and network/MaskFlownet.py:195,441 into libmfn_hip.so.
+"""MXNet side of the drop-in boundary: mx.operator.CustomOp registrations that route the operator call
+sites of /root/reference/network/layer.py:17-18,29-30,119-121 and network/MaskFlownet.py:195,441 into
+libmfn_hip.so, forward AND backward (training goes through MXNet's autograd, network/pipeline.py:112-113).
 
-MXNet has no ROCm build and cannot be installed in this image, so this module is import-guarded
-and UNTESTED here; it documents exactly what a maintainer adds on the reference side
-(INTEGRATION.md).  Usage inside the reference:
+Two ways to use it inside the reference:
 
-    import maskflownet_amd.mxnet_ops            # registers mfn_correlation / mfn_warp / mfn_deform_conv
-    F.Custom(im1, im2, op_type='mfn_correlation', max_displacement=4)          # MaskFlownet.py:195
-    F.Custom(x, flow, op_type='mfn_warp', clip_grid=0)                         # layer.py:17-18
-    F.Custom(x, offset, weight, bias, op_type='mfn_deform_conv', pad=1)        # layer.py:119-121
+  (a) no edit at all --
+        import maskflownet_amd.mxnet_ops as mfn_mx;  mfn_mx.install()
+      replaces F.Correlation, F.GridGenerator, F.BilinearSampler and F.contrib.DeformableConvolution in
+      mx.nd and mx.sym by shims that call F.Custom(..., op_type='mfn_*', **same_kwargs): layer.py's
+      `**self._kwargs` dict (:91-95, including 'layout' and name='fwd') and MaskFlownet_S.corr's keyword
+      list pass through unchanged.
+  (b) the fused forms: F.Custom(x, flow, op_type='mfn_warp', clip_grid=0) in place of the
+      GridGenerator + BilinearSampler pair of layer.py:17-18, activation='leaky' on mfn_correlation,
+      mfn_upsample for MaskFlownet.py:35-62.
 
-CustomOp.forward runs on MXNet's custom-op worker thread and has no access to MXNet's stream, so
-each op waits for its inputs, launches on the NULL stream and synchronises before returning.
+CustomOp protocol notes (MXNet 1.5 python/mxnet/operator.py):
+  * every keyword reaches CustomOpProp.__init__ as a STRING ("(3, 3)", "False", "NCHW");
+  * forward/backward run on MXNet's custom-op worker thread, which has no access to MXNet's stream: each
+    call waits for its inputs (wait_to_read), hipSetDevice()s to the arrays' context (the reference drives
+    several GPUs from one process, pipeline.py:95), launches on the NULL stream and hipDeviceSynchronize()s
+    before returning;
+  * `req` is honoured per output / gradient: 'null' skips, 'write' / 'inplace' let the kernel write straight
+    into the framework's buffer (no temporary, no copy), 'add' uses the library's MFN_REQ_ADD for gradients
+    and a temporary + self.assign for forward outputs;
+  * MXNet's default CustomOp.backward is a silent no-op, so every op here either implements backward or
+    raises from it.
+
+MXNet has no ROCm build and is not installable in this image; the module is exercised against the stub
+under tests/fake_mxnet (same protocol, torch tensors as device memory): tests/test_mxnet_binding.py.
 """
 import ctypes
 
-try:  # pragma: no cover - MXNet is not available in this image
+try:
     import mxnet as mx
-except ImportError:  # the module stays importable so its docs/tests can reference it
+except ImportError:  # the package itself never needs MXNet; only this adapter does
     mx = None
 
 from . import _lib
 
-if mx is not None:  # pragma: no cover
-    _hip = ctypes.CDLL("libamdhip64.so")
+_REQ = {"null": 0, "write": 1, "inplace": 1, "add": 3}  # -> MFN_REQ_* (include/mfn_hip.h)
 
-    def _ptr(nd):
-        nd.wait_to_read()
-        p = ctypes.c_void_p()
-        mx.base.check_call(mx.base._LIB.MXNDArrayGetData(nd.handle, ctypes.byref(p)))
-        return p.value
 
-    def _sync():
-        _hip.hipDeviceSynchronize()
+class _HipRuntime:
+    """hipSetDevice / hipDeviceSynchronize around every operator call (see module docstring)."""
 
-    class _Correlation(mx.operator.CustomOp):
-        def __init__(self, md, kernel, s1, s2, pad, mult, act=0):
-            self.a = (md, kernel, s1, s2, pad, mult)
-            self.act = act
+    def __init__(self):
+        self._hip = ctypes.CDLL("libamdhip64.so")
+
+    def enter(self, ctx):
+        if ctx.device_type != "gpu":
+            raise mx.base.MXNetError("mfn_* operators run on the MI355X only: array lives on %s "
+                                     "(there is no CPU implementation behind them)" % (ctx,))
+        rc = self._hip.hipSetDevice(int(ctx.device_id))
+        if rc != 0:
+            raise mx.base.MXNetError("hipSetDevice(%d) failed: %d" % (ctx.device_id, rc))
+
+    def sync(self):
+        rc = self._hip.hipDeviceSynchronize()
+        if rc != 0:
+            raise mx.base.MXNetError("hipDeviceSynchronize failed: %d" % rc)
+
+
+_rt = None   # tests substitute a host runtime
+_ns = None   # ... and the namespace of the kernel-emulation build; the product binds libmfn_hip.so
+
+
+def _runtime():
+    global _rt
+    if _rt is None:
+        _rt = _HipRuntime()
+    return _rt
+
+
+def _lib_ns():
+    return _ns if _ns is not None else _lib.lib()
+
+
+def _check(status):
+    if status != 0:
+        raise mx.base.MXNetError("mfn status %d: %s" % (status, _lib_ns().last_error().decode(errors="replace")))
+
+
+def _ptr(nd):
+    if nd is None:
+        return None
+    nd.wait_to_read()
+    p = ctypes.c_void_p()
+    mx.base.check_call(mx.base._LIB.MXNDArrayGetData(nd.handle, ctypes.byref(p)))
+    return p.value
+
+
+def _bool(s):
+    return str(s).strip() in ("1", "True", "true")
+
+
+def _tuple(s):
+    """'(3, 3)' / '[1, 1]' / '3' -> (int, int): MXNet's Shape(tuple) parameters, stringified by the bridge."""
+    vals = [int(v) for v in str(s).strip("()[] ").replace(" ", "").split(",") if v]
+    if len(vals) == 1:
+        vals = vals * 2
+    if len(vals) != 2:
+        raise ValueError("2-D kernel / stride / dilate / pad expected, got %r" % (s,))
+    return tuple(vals)
+
+
+_packed = {}   # (weight address, dims, tuning epoch) -> (buffer NDArray, nbytes, tag)
+
+
+def invalidate_packed():
+    """Forget the cached inference-time weight layouts.  The cache is keyed on the weight array's device
+    address, so call this after anything that rewrites parameters in place outside of training
+    (load_parameters / set_data -- /root/reference/network/pipeline.py:56-63)."""
+    _packed.clear()
+
+
+if mx is not None:
+    class _Out:
+        """Where a forward output goes for a given req: straight into MXNet's buffer ('write' / 'inplace'),
+        into a temporary that assign() adds afterwards ('add'), or nowhere ('null')."""
+
+        def __init__(self, op, dst, req):
+            self.op, self.dst, self.req = op, dst, req
+            self.buf = dst if req in ("write", "inplace") else (
+                mx.nd.empty(dst.shape, ctx=dst.context) if req == "add" else None)
+
+        def finish(self):
+            if self.req == "add":
+                self.op.assign(self.dst, "add", self.buf)
+
+    class _Op(mx.operator.CustomOp):
+        def _begin(self, arr):
+            _runtime().enter(arr.context)
+            return _lib_ns()
+
+        def _end(self):
+            _runtime().sync()
+
+    # ---- Correlation (network/MaskFlownet.py:193-195, :440-441) ------------------------------------
+    class _Correlation(_Op):
+        def __init__(self, a, act):
+            self.a, self.act = a, act
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            if req[0] == "null":
+                return
             n, c, h, w = in_data[0].shape
-            out = mx.nd.empty(out_data[0].shape, ctx=in_data[0].context)
-            md, kernel, s1, s2, pad, mult = self.a
+            lib = self._begin(in_data[0])
+            out = _Out(self, out_data[0], req[0])
             # no workspace: levels that would want channel slices run their single-launch kernels
-            _lib.check(_lib.lib().correlation_fwd_act(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out), n, c, h, w, md,
-                                                      kernel, s1, s2, pad, mult, self.act, None, 0, None))
-            _sync()
-            self.assign(out_data[0], req[0], out)
+            _check(lib.correlation_fwd_act(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out.buf), n, c, h, w, *self.a,
+                                           self.act, None, 0, None))
+            self._end()
+            out.finish()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            if self.act:
+                raise NotImplementedError("mfn_correlation(activation='leaky') is the fused inference form; train with "
+                                          "the separate LeakyReLU (MaskFlownet.py:217)")
+            r1, r2 = _REQ[req[0]], _REQ[req[1]]
+            if not (r1 or r2):
+                return
+            n, c, h, w = in_data[0].shape
+            lib = self._begin(in_data[0])
+            _check(lib.correlation_bwd(_ptr(out_grad[0]), _ptr(in_data[0]), _ptr(in_data[1]),
+                                       _ptr(in_grad[0]) if r1 else None, _ptr(in_grad[1]) if r2 else None,
+                                       n, c, h, w, *self.a, r1, r2, None))
+            self._end()
 
     @mx.operator.register("mfn_correlation")
     class _CorrelationProp(mx.operator.CustomOpProp):
-        def __init__(self, max_displacement="1", kernel_size="1", stride1="1", stride2="1", pad_size=None,
+        def __init__(self, kernel_size="1", max_displacement="1", stride1="1", stride2="1", pad_size="0",
                      is_multiply="1", activation="none"):
             super().__init__(need_top_grad=True)
-            self.act = 1 if activation == "leaky" else 0  # fused LeakyReLU(0.1), MaskFlownet.py:217 (inference)
-            self.md, self.k = int(max_displacement), int(kernel_size)
-            self.s1, self.s2 = int(stride1), int(stride2)
-            self.pad = int(pad_size) if pad_size is not None else self.md
-            self.mult = int(is_multiply in ("1", "True", "true"))
+            if activation not in ("none", "None", "leaky"):
+                raise ValueError("mfn_correlation: activation must be 'none' or 'leaky'")
+            self.act = 1 if activation == "leaky" else 0  # fused LeakyReLU(0.1), MaskFlownet.py:217
+            # order of the C ABI: max_displacement, kernel_size, stride1, stride2, pad_size, is_multiply
+            self.a = (int(max_displacement), int(kernel_size), int(stride1), int(stride2), int(pad_size),
+                      int(_bool(is_multiply)))
 
         def list_arguments(self):
             return ["data1", "data2"]
@@ -68,31 +186,52 @@ if mx is not None:  # pragma: no cover
             return ["output"]
 
         def infer_shape(self, in_shape):
+            if len(in_shape[0]) != 4 or list(in_shape[0]) != list(in_shape[1]):
+                raise ValueError("mfn_correlation: data1 and data2 must be 4-D with identical shapes, got %s and %s"
+                                 % (in_shape[0], in_shape[1]))
             n, c, h, w = in_shape[0]
+            md, k, s1, s2, pad, _ = self.a
             tc, th, tw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-            _lib.check(_lib.lib().correlation_out_shape(h, w, self.md, self.k, self.s1, self.s2, self.pad,
-                                                        ctypes.byref(tc), ctypes.byref(th), ctypes.byref(tw)))
+            _check(_lib_ns().correlation_out_shape(h, w, md, k, s1, s2, pad, ctypes.byref(tc), ctypes.byref(th),
+                                                   ctypes.byref(tw)))
             return in_shape, [(n, tc.value, th.value, tw.value)], []
 
-        def create_operator(self, ctx, shapes, dtypes):
-            return _Correlation(self.md, self.k, self.s1, self.s2, self.pad, self.mult, self.act)
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return list(out_grad) + list(in_data)
 
-    class _Warp(mx.operator.CustomOp):
+        def create_operator(self, ctx, shapes, dtypes):
+            return _Correlation(self.a, self.act)
+
+    # ---- fused warp (layer.py:14-18 Reconstruction2D, :26-30 Reconstruction2DSmooth) -----------------
+    class _Warp(_Op):
         def __init__(self, clip):
             self.clip = clip
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            if req[0] == "null":
+                return
             n, c, h, w = in_data[0].shape
-            out = mx.nd.empty(out_data[0].shape, ctx=in_data[0].context)
-            _lib.check(_lib.lib().warp_fwd(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out), n, c, h, w, self.clip, None))
-            _sync()
-            self.assign(out_data[0], req[0], out)
+            lib = self._begin(in_data[0])
+            out = _Out(self, out_data[0], req[0])
+            _check(lib.warp_fwd(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out.buf), n, c, h, w, self.clip, None))
+            self._end()
+            out.finish()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            rx, rf = _REQ[req[0]], _REQ[req[1]]  # F.BlockGrad(flow) (layer.py:15-16) arrives as req 'null'
+            if not (rx or rf):
+                return
+            n, c, h, w = in_data[0].shape
+            lib = self._begin(in_data[0])
+            _check(lib.warp_bwd(_ptr(out_grad[0]), _ptr(in_data[0]), _ptr(in_data[1]), _ptr(in_grad[0]) if rx else None,
+                                _ptr(in_grad[1]) if rf else None, n, c, h, w, self.clip, rx, rf, None))
+            self._end()
 
     @mx.operator.register("mfn_warp")
     class _WarpProp(mx.operator.CustomOpProp):
         def __init__(self, clip_grid="0"):
             super().__init__(need_top_grad=True)
-            self.clip = int(clip_grid)
+            self.clip = int(_bool(clip_grid))
 
         def list_arguments(self):
             return ["data", "flow"]
@@ -101,44 +240,177 @@ if mx is not None:  # pragma: no cover
             return ["output"]
 
         def infer_shape(self, in_shape):
-            return in_shape, [in_shape[0]], []
+            n, c, h, w = in_shape[0]
+            if list(in_shape[1]) != [n, 2, h, w]:
+                raise ValueError("mfn_warp: flow must have shape %s, got %s" % ((n, 2, h, w), tuple(in_shape[1])))
+            return in_shape, [tuple(in_shape[0])], []
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return list(out_grad) + list(in_data)
 
         def create_operator(self, ctx, shapes, dtypes):
             return _Warp(self.clip)
 
-    class _DeformConv(mx.operator.CustomOp):
+    # ---- the two MXNet operators of layer.py:17-18 on their own (install() routes them) ---------------
+    class _GridGenerator(_Op):
+        def __init__(self, kind):
+            self.kind = kind
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            if req[0] == "null":
+                return
+            lib = self._begin(in_data[0])
+            out = _Out(self, out_data[0], req[0])
+            n, _, h, w = out_data[0].shape
+            fn = lib.grid_generator_warp if self.kind == "warp" else lib.grid_generator_affine
+            _check(fn(_ptr(in_data[0]), _ptr(out.buf), n, h, w, None))
+            self._end()
+            out.finish()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            if _REQ[req[0]]:
+                raise NotImplementedError("mfn_grid_generator has no backward: the reference never differentiates its "
+                                          "grids (BlockGrad / image warp, MaskFlownet.py:311); use mfn_warp to train through a warp")
+
+    @mx.operator.register("mfn_grid_generator")
+    class _GridGeneratorProp(mx.operator.CustomOpProp):
+        def __init__(self, transform_type="", target_shape="(0, 0)"):
+            super().__init__(need_top_grad=True)
+            if transform_type not in ("warp", "affine"):
+                raise ValueError("GridGenerator: transform_type must be 'affine' or 'warp'")
+            self.kind, self.target = transform_type, _tuple(target_shape)
+
+        def list_arguments(self):
+            return ["data"]
+
+        def list_outputs(self):
+            return ["output"]
+
+        def infer_shape(self, in_shape):
+            s = list(in_shape[0])
+            if self.kind == "warp":
+                if len(s) != 4 or s[1] != 2:
+                    raise ValueError("GridGenerator(warp): data must be (N,2,H,W)")
+                return in_shape, [tuple(s)], []
+            if len(s) != 2 or s[1] != 6 or min(self.target) <= 0:
+                raise ValueError("GridGenerator(affine): data must be (N,6) and target_shape=(H,W) positive")
+            return in_shape, [(s[0], 2, self.target[0], self.target[1])], []
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return _GridGenerator(self.kind)
+
+    class _BilinearSampler(_Op):
+        def forward(self, is_train, req, in_data, out_data, aux):
+            if req[0] == "null":
+                return
+            n, c, ih, iw = in_data[0].shape
+            _, _, oh, ow = in_data[1].shape
+            lib = self._begin(in_data[0])
+            out = _Out(self, out_data[0], req[0])
+            _check(lib.bilinear_sampler_fwd(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out.buf), n, c, ih, iw, oh, ow, None))
+            self._end()
+            out.finish()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            if _REQ[req[0]] or _REQ[req[1]]:
+                raise NotImplementedError("mfn_bilinear_sampler has no backward; use mfn_warp to train through a warp")
+
+    @mx.operator.register("mfn_bilinear_sampler")
+    class _BilinearSamplerProp(mx.operator.CustomOpProp):
+        def __init__(self, cudnn_off="None"):
+            super().__init__(need_top_grad=True)
+
+        def list_arguments(self):
+            return ["data", "grid"]
+
+        def list_outputs(self):
+            return ["output"]
+
+        def infer_shape(self, in_shape):
+            d, g = list(in_shape[0]), list(in_shape[1])
+            if len(d) != 4 or len(g) != 4 or g[1] != 2 or g[0] != d[0]:
+                raise ValueError("BilinearSampler: data (N,C,H,W) and grid (N,2,H',W') expected")
+            return in_shape, [(d[0], d[1], g[2], g[3])], []
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return _BilinearSampler()
+
+    # ---- DeformableConvolution (layer.py:117-124; kwargs :91-95) --------------------------------------
+    class _DeformConv(_Op):
         def __init__(self, p):
             self.p = p
             self.ws = None
 
+        def _dims(self, in_data):
+            n, cin, h, wd = in_data[0].shape
+            p = self.p
+            return (n, cin, h, wd, in_data[2].shape[0], p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"], p["dh"],
+                    p["dw"], p["g"], p["dg"])
+
+        def _workspace(self, need, ctx):
+            if need and (self.ws is None or self.ws.size * 4 < need or self.ws.context != ctx):
+                self.ws = mx.nd.empty(((need + 3) // 4,), ctx=ctx)
+            return self.ws if need else None
+
+        def _pack(self, lib, w, dims):
+            key = (_ptr(w), dims, _lib.tuning_epoch())
+            hit = _packed.get(key)
+            if hit is None:
+                nbytes = lib.deform_conv_packed_weight_bytes(*dims)
+                buf = mx.nd.empty(((nbytes + 3) // 4,), ctx=w.context)
+                tag = ctypes.c_ulonglong()
+                _check(lib.deform_conv_pack_weights(_ptr(w), *dims, _ptr(buf), nbytes, ctypes.byref(tag), None))
+                hit = _packed[key] = (buf, nbytes, tag.value)
+            return hit
+
         def forward(self, is_train, req, in_data, out_data, aux):
+            if req[0] == "null":
+                return
             x, off, w = in_data[:3]
             b = in_data[3] if len(in_data) > 3 else None
-            n, cin, h, wd = x.shape
-            cout = w.shape[0]
-            p = self.p
-            lib = _lib.lib()
-            need = lib.deform_conv_workspace_bytes(n, cin, h, wd, cout, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"],
-                                                   p["dh"], p["dw"], p["g"], p["dg"])
-            if self.ws is None or self.ws.size * 4 < need:
-                self.ws = mx.nd.empty(((need + 3) // 4,), ctx=x.context)
-            out = mx.nd.empty(out_data[0].shape, ctx=x.context)
-            _lib.check(lib.deform_conv_fwd(_ptr(x), _ptr(off), _ptr(w), _ptr(b) if b is not None else None, _ptr(out),
-                                           n, cin, h, wd, cout, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"],
-                                           p["dh"], p["dw"], p["g"], p["dg"], _ptr(self.ws), self.ws.size * 4, None))
-            _sync()
-            self.assign(out_data[0], req[0], out)
+            dims = self._dims(in_data)
+            lib = self._begin(x)
+            ws = self._workspace(lib.deform_conv_workspace_bytes(*dims), x.context)
+            out = _Out(self, out_data[0], req[0])
+            wsp, wsn = (_ptr(ws), ws.size * 4) if ws is not None else (None, 0)
+            if is_train:
+                # the weights change every step: let the call lay them out in its workspace
+                _check(lib.deform_conv_fwd(_ptr(x), _ptr(off), _ptr(w), _ptr(b), _ptr(out.buf), *dims, wsp, wsn, None))
+            else:
+                # inference: constant parameters, laid out once per (weight buffer, shape, tuning)
+                buf, nbytes, tag = self._pack(lib, w, dims)
+                _check(lib.deform_conv_fwd_packed(_ptr(x), _ptr(off), _ptr(buf), nbytes, tag, _ptr(b), _ptr(out.buf),
+                                                  *dims, wsp, wsn, None))
+            self._end()
+            out.finish()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            rq = [_REQ[r] for r in req] + [0] * (4 - len(req))   # no_bias: three inputs
+            if not any(rq):
+                return
+            x, off, w = in_data[:3]
+            dims = self._dims(in_data)
+            lib = self._begin(x)
+            # one int per 2x16-pixel strip: lets strips whose nine taps share one offset (MaskFlownet.py:230) take
+            # all taps in one pass
+            ws = self._workspace(lib.deform_conv_bwd_workspace_bytes(*dims), x.context)
+            g = [_ptr(in_grad[i]) if i < len(in_grad) and rq[i] else None for i in range(4)]
+            _check(lib.deform_conv_bwd(_ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w), g[0], g[1], g[2], g[3], *dims,
+                                       rq[0], rq[1], rq[2], rq[3], _ptr(ws) if ws is not None else None,
+                                       ws.size * 4 if ws is not None else 0, None))
+            self._end()
 
     @mx.operator.register("mfn_deform_conv")
     class _DeformConvProp(mx.operator.CustomOpProp):
         def __init__(self, kernel="(3, 3)", stride="(1, 1)", dilate="(1, 1)", pad="(0, 0)", num_filter="0",
-                     num_group="1", num_deformable_group="1", no_bias="False"):
+                     num_group="1", num_deformable_group="1", no_bias="False", layout="None", workspace="1024"):
             super().__init__(need_top_grad=True)
-            t = lambda s: tuple(int(v) for v in str(s).strip("()[] ").replace(" ", "").split(",") if v)
-            (kh, kw), (sh, sw), (dh, dw), (ph, pw) = t(kernel), t(stride), t(dilate), t(pad)
+            if str(layout) not in ("None", "NCHW"):
+                raise ValueError("mfn_deform_conv: only layout='NCHW' is supported, got %r" % (layout,))
+            (kh, kw), (sh, sw), (dh, dw), (ph, pw) = _tuple(kernel), _tuple(stride), _tuple(dilate), _tuple(pad)
             self.p = dict(kh=kh, kw=kw, sh=sh, sw=sw, dh=dh, dw=dw, ph=ph, pw=pw, g=int(num_group),
                           dg=int(num_deformable_group))
-            self.no_bias = str(no_bias) in ("1", "True", "true")
+            self.no_bias = _bool(no_bias)
             self.num_filter = int(num_filter)
 
         def list_arguments(self):
@@ -151,34 +423,52 @@ if mx is not None:  # pragma: no cover
             n, cin, h, w = in_shape[0]
             p = self.p
             ho, wo = ctypes.c_int(), ctypes.c_int()
-            _lib.check(_lib.lib().deform_conv_out_shape(h, w, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"],
-                                                        p["dh"], p["dw"], ctypes.byref(ho), ctypes.byref(wo)))
+            _check(_lib_ns().deform_conv_out_shape(h, w, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"], p["dh"],
+                                                   p["dw"], ctypes.byref(ho), ctypes.byref(wo)))
             cout = self.num_filter or in_shape[2][0]
-            shapes = [in_shape[0], (n, 2 * p["kh"] * p["kw"] * p["dg"], ho.value, wo.value),
+            if cin % p["g"] or cout % p["g"] or cin % p["dg"]:
+                raise ValueError("mfn_deform_conv: channels must divide num_group / num_deformable_group")
+            # the weight / bias shapes are OUTPUTS of this pass too: Gluon's deferred initialisation
+            # (DeformableConv2D(in_channels=0), MaskFlownet.py:155-158) learns them here
+            shapes = [tuple(in_shape[0]), (n, 2 * p["kh"] * p["kw"] * p["dg"], ho.value, wo.value),
                       (cout, cin // p["g"], p["kh"], p["kw"])]
             if not self.no_bias:
                 shapes.append((cout,))
             return shapes, [(n, cout, ho.value, wo.value)], []
 
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return list(out_grad) + list(in_data)
+
         def create_operator(self, ctx, shapes, dtypes):
             return _DeformConv(self.p)
 
-    class _Upsample(mx.operator.CustomOp):
+    # ---- Upsample(factor) (MaskFlownet.py:35-62), forward / inference ----------------------------------
+    class _Upsample(_Op):
         def __init__(self, factor):
             self.factor = factor
 
         def forward(self, is_train, req, in_data, out_data, aux):
+            if req[0] == "null":
+                return
             n, c, h, w = in_data[0].shape
-            out = mx.nd.empty(out_data[0].shape, ctx=in_data[0].context)
-            _lib.check(_lib.lib().upsample_fwd(_ptr(in_data[0]), _ptr(out), n, c, h, w, self.factor, None))
-            _sync()
-            self.assign(out_data[0], req[0], out)
+            lib = self._begin(in_data[0])
+            out = _Out(self, out_data[0], req[0])
+            _check(lib.upsample_fwd(_ptr(in_data[0]), _ptr(out.buf), n, c, h, w, self.factor, None))
+            self._end()
+            out.finish()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            if _REQ[req[0]]:
+                raise NotImplementedError("mfn_upsample is forward-only (SURVEY.md 8 f-2); keep the reference's Upsample "
+                                          "block where gradients flow through it")
 
     @mx.operator.register("mfn_upsample")
-    class _UpsampleProp(mx.operator.CustomOpProp):  # network/MaskFlownet.py:35-62 (forward / inference)
+    class _UpsampleProp(mx.operator.CustomOpProp):
         def __init__(self, factor="2"):
-            super().__init__(need_top_grad=False)
+            super().__init__(need_top_grad=True)
             self.factor = int(factor)
+            if self.factor < 1:
+                raise ValueError("mfn_upsample: factor must be >= 1")
 
         def list_arguments(self):
             return ["data"]
@@ -192,3 +482,41 @@ if mx is not None:  # pragma: no cover
 
         def create_operator(self, ctx, shapes, dtypes):
             return _Upsample(self.factor)
+
+    # ---- install(): the reference's operator names, unchanged ------------------------------------------
+    def _route(F, op_type, arg_names):
+        def op(*args, name=None, **kwargs):
+            args = list(args)
+            for n in arg_names[len(args):]:   # MXNet accepts the tensor inputs by keyword (layer.py:17: data=...)
+                if n in kwargs:
+                    args.append(kwargs.pop(n))
+            if name is not None:
+                kwargs["name"] = name         # consumed by the front-end (symbol name), never reaches the Prop
+            return F.Custom(*args, op_type=op_type, **kwargs)
+        op.__name__ = op_type
+        return op
+
+    _ROUTES = (("Correlation", None, "mfn_correlation", ("data1", "data2")),
+               ("GridGenerator", None, "mfn_grid_generator", ("data",)),
+               ("BilinearSampler", None, "mfn_bilinear_sampler", ("data", "grid")),
+               ("DeformableConvolution", "contrib", "mfn_deform_conv", ("data", "offset", "weight", "bias")))
+    _saved = []
+
+    def install(namespaces=None):
+        """Route the four operators of the hot path to libmfn_hip.so in mx.nd and mx.sym (both, so that the model
+        keeps working after hybridize(), pipeline.py:25).  uninstall() restores MXNet's own."""
+        for F in (namespaces if namespaces is not None else (mx.nd, mx.sym)):
+            if not hasattr(F, "Custom"):
+                continue
+            for name, sub, op_type, arg_names in _ROUTES:
+                holder = getattr(F, sub) if sub else F
+                _saved.append((holder, name, getattr(holder, name, None)))
+                setattr(holder, name, _route(F, op_type, arg_names))
+
+    def uninstall():
+        while _saved:
+            holder, name, old = _saved.pop()
+            if old is None:
+                delattr(holder, name)
+            else:
+                setattr(holder, name, old)
