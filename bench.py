@@ -37,9 +37,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "tiny", "tiny_full", "tiny_train"],
                     help="cfg2 (default, the headline) / cfg3: MaskFlownet-S forward; cfg4: full model (S + cascade) forward; "
-                         "cfg5: S forward + backward + gradient all-reduce")
+                         "cfg5: S forward + backward + gradient all-reduce; tiny*: 2 x 64x128 smoke shapes (not a BASELINE config)")
     ap.add_argument("--mode", default="dropin", choices=["dropin", "fused"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--repack", action="store_true",
@@ -52,14 +52,45 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the oracle baseline")
     ap.add_argument("--roofline-iters", type=int, default=200)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1: nccl (= RCCL, the product) or gloo (launcher dry run on CPU, "
+                         "needs --buffers)")
+    ap.add_argument("--buffers", default="",
+                    help="MODULE:FACTORY of a HotPathWorkload buffers object instead of the torch-ROCm device buffers -- "
+                         "the CPU test-suite runs the launcher with numpy buffers over the emulated kernels "
+                         "(tests/test_bench_launcher.py); such a line is marked as a dry run, never a measurement")
     return ap.parse_args()
 
 
-def timed_steps(wls, steps, dist, torch):
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: start the N ranks ourselves -- one process per
+    GPU under torch.distributed.run on 127.0.0.1 -- and hand their output through.  The reference's single process
+    drives its whole device list (/root/reference/main.py:56, network/pipeline.py:95); here that is N RCCL ranks."""
+    import socket
+    import subprocess
+    if not args.buffers:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d but only %d GPU(s) are visible; refusing to run fewer ranks than asked"
+                     % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def timed_steps(wls, steps, dist, torch, gpu=True):
     """barrier + sync | K steps | barrier + sync; returns the MAX over ranks in seconds."""
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     ns = len(wls)
     gb = wls[0].N * (dist.get_world_size() if dist is not None else 1)
@@ -67,12 +98,12 @@ def timed_steps(wls, steps, dist, torch):
         wls[i % ns].step(dist, gb)
     for w in wls:
         w.synchronize()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
@@ -205,13 +236,15 @@ def per_op_graph_cost(wl, torch, reps=20):
 
 def cpu_baseline(wl, seconds):
     """The oracle's pass over the same synthetic batch, 1 thread, repeated until ~`seconds` of CPU work
-    have been spent (reported baseline only, never the thing measured or shipped)."""
+    have been spent (reported baseline only, never the thing measured or shipped).  Returns the baseline record
+    and the outputs of the oracle's last pass over the FULL batch (the parity check of the line compares the
+    GPU's outputs with them)."""
     from oracle import hotpath_ref
     hotpath_ref.oracle_pass(wl.host, 1, kind=wl.kind, mode=wl.mode)  # touch the library / page in
     t0 = time.perf_counter()
     pairs = 0
     while True:
-        hotpath_ref.oracle_pass(wl.host, wl.N, kind=wl.kind, mode=wl.mode)
+        want = hotpath_ref.oracle_pass(wl.host, wl.N, kind=wl.kind, mode=wl.mode)
         pairs += wl.N
         dt = time.perf_counter() - t0
         if dt >= seconds or dt >= 30.0:
@@ -220,27 +253,86 @@ def cpu_baseline(wl, seconds):
             "host_cores_available": os.cpu_count(),
             "sample": "%d pairs (%d passes over the same synthetic batch of %d), full hot-path pass, "
                       "oracle/libmfn_ref.so (loop-faithful C restatement of the MXNet 1.5 CPU operators, gcc -O2, "
-                      "1 thread), %.1f s" % (pairs, pairs // wl.N, wl.N, dt)}
+                      "1 thread), %.1f s" % (pairs, pairs // wl.N, wl.N, dt)}, want
+
+
+def cpu_baseline_threads(wl, seconds, threads):
+    """SURVEY.md 8(d) baseline (ii): the same oracle pass with the batch split over `threads` host threads (one
+    oracle call per sample shard; ctypes releases the GIL) -- a generous multi-core CPU figure."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import hotpath_ref
+    threads = max(1, min(threads, wl.N))
+    bounds = [(wl.N * k // threads, wl.N * (k + 1) // threads) for k in range(threads)]
+
+    def shard(b):
+        lo, hi = b
+        host = {k: (v[lo:hi] if (isinstance(v, np.ndarray) and v.ndim == 4 and v.shape[0] == wl.N and k[0] not in "wb") else v)
+                for k, v in wl.host.items()}
+        return hotpath_ref.oracle_pass(host, hi - lo, kind=wl.kind, mode=wl.mode)
+
+    t0 = time.perf_counter()
+    pairs = 0
+    with ThreadPoolExecutor(threads) as ex:
+        while True:
+            list(ex.map(shard, bounds))
+            pairs += wl.N
+            dt = time.perf_counter() - t0
+            if dt >= seconds or dt >= 30.0:
+                break
+    return {"value": round(pairs / dt, 4), "unit": "image-pairs/s", "cores": threads, "kind": "port",
+            "sample": "%d pairs, batch sharded over %d host threads, %.1f s" % (pairs, threads, dt)}
+
+
+def parity_vs_oracle(wl, want):
+    """max over the pass's outputs of max|gpu - oracle| / max|oracle| at the bench's own size (tolerance of
+    BASELINE.json north_star: 1e-4 relative fp32)."""
+    import numpy as np
+    worst, worst_name, per = 0.0, None, {}
+    for name, got in zip(wl.output_names(), wl.outputs()):
+        ref = np.asarray(want[name], np.float64)
+        g = got.detach().cpu().numpy().astype(np.float64) if hasattr(got, "detach") else np.asarray(got, np.float64)
+        err = float(np.abs(g - ref).max() / max(np.abs(ref).max(), 1e-30)) if np.isfinite(g).all() else float("inf")
+        per[name] = err
+        if err >= worst:
+            worst, worst_name = err, name
+    return {"max_rel_err": worst, "worst_output": worst_name, "tolerance": 1e-4, "ok": bool(worst <= 1e-4),
+            "outputs_checked": len(per), "reference": "oracle pass over the full bench batch (oracle/hotpath_ref.py)"}
+
+
+def make_buffers(spec):
+    import importlib
+    mod, _, fn = spec.partition(":")
+    return getattr(importlib.import_module(mod), fn)()
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)   # never returns
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without torchrun and "
+                 "let bench.py start the ranks)" % (args.gpus, world, args.gpus))
+    gpu = not args.buffers
+    if args.backend == "gloo" and gpu:
+        sys.exit("bench.py: --backend gloo is the CPU dry run of the launcher and needs --buffers")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if gpu:
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group(backend=args.backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend=args.backend)
         dist = dist_mod
-    else:
+    elif gpu:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
 
     from maskflownet_amd import hotpath
     from maskflownet_amd.dist import allreduce_checksum
@@ -248,10 +340,16 @@ def main():
         from maskflownet_amd import _lib
         _lib.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))})
 
-    wls = [hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
-                                   prepack=not args.repack) for _ in range(max(1, args.streams))]
+    def workload():
+        if gpu:
+            return hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
+                                           prepack=not args.repack)
+        return hotpath.HotPathWorkload(args.config, mode=args.mode, prepack=not args.repack, seed=20260925 + rank,
+                                       buffers=make_buffers(args.buffers))
+
+    wls = [workload() for _ in range(max(1, args.streams))]
     for w in wls:
-        if not args.no_graph:
+        if gpu and not args.no_graph:
             w.capture()
         else:
             w.run_eager()
@@ -260,7 +358,7 @@ def main():
     # untimed spin-up: an idle MI355X sits at ~100 MHz sclk and needs a few hundred ms of work to reach its
     # sustained clocks; W warm-up steps of 0.2 ms each are not enough on their own
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.5:
+    while gpu and time.perf_counter() - t_spin < 0.5:
         for i in range(50):
             wls[i % len(wls)].replay()
         for w in wls:
@@ -269,12 +367,18 @@ def main():
         wls[i % len(wls)].step(dist, wl.N * world)
     for w in wls:
         w.synchronize()
-    dt = timed_steps(wls, args.steps, dist, torch)
+    dt = timed_steps(wls, args.steps, dist, torch, gpu)
 
     # 2-float record all-reduced over RCCL (the only collective: SURVEY.md 8e)
     local_ck = wl.checksum()
     global_ck = allreduce_checksum(local_ck, dist)
-    ck_ok = bool(abs(float(global_ck[0]) - world * float(local_ck[0])) <= 1e-9 * abs(float(global_ck[0])))
+    if dist is not None:  # every rank's own record, to check the reduced one against
+        every = [torch.zeros_like(local_ck) for _ in range(world)]
+        dist.all_gather(every, local_ck)
+        expect = torch.stack(every).sum(0)
+    else:
+        expect = local_ck
+    ck_ok = bool(torch.allclose(global_ck, expect, rtol=1e-12, atol=0.0)) and float(global_ck[1]) == world * float(local_ck[1])
 
     if rank != 0:
         if dist is not None:
@@ -291,35 +395,36 @@ def main():
               "cfg3": "image-pairs/s MaskFlownet-S 448x1024 fwd hot path",
               "cfg4": "image-pairs/s full MaskFlownet (S + cascade) 384x512 fwd hot path",
               "cfg5": "image-pairs/s MaskFlownet-S 384x512 train-step hot path (fwd + bwd of correlation / deformable "
-                      "conv + gradient all-reduce)"}[args.config]
-    workload = {"S": "MaskFlownet-S forward hot path: 5x Correlation(md=4) + 4x DeformableConvolution(3x3, shared 9-tap "
-                     "offsets) + 1x warp",
-                "full": "full MaskFlownet forward hot path: the S pass + cascade (5x DeformableConvolution incl. level 6, "
-                        "10x Correlation(md=2))",
-                "train": "MaskFlownet-S train-step hot path: the S forward pass + 5x Correlation backward + 4x "
-                         "DeformableConvolution backward (data, offset, weight, bias) + 1 all-reduce of the 1.1 MB "
-                         "gradient bucket"}[wl.kind]
-    cfg_index = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}[args.config]
+                      "conv + gradient all-reduce)"}.get(args.config, args.config)
+    workload_s = {"S": "MaskFlownet-S forward hot path: 5x Correlation(md=4) + 4x DeformableConvolution(3x3, shared 9-tap "
+                       "offsets) + 1x warp",
+                  "full": "full MaskFlownet forward hot path: the S pass + cascade (5x DeformableConvolution incl. level 6, "
+                          "10x Correlation(md=2))",
+                  "train": "MaskFlownet-S train-step hot path: the S forward pass + 5x Correlation backward + 4x "
+                           "DeformableConvolution backward (data, offset, weight, bias) + 1 all-reduce of the 1.1 MB "
+                           "gradient bucket"}[wl.kind]
+    cfg_index = {"cfg2": 1, "cfg3": 2, "cfg4": 3, "cfg5": 4}.get(args.config, -1)
     res = {
         "metric": metric,
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if gpu else "synthetic -- DRY RUN of the launcher on CPU (emulated kernels, numpy buffers): not a measurement",
         "config": {"workload": "%s, batch=%d synthetic %dx%d per GPU (BASELINE configs[%d])"
-                               % (workload, wl.N, wl.H, wl.W, cfg_index),
+                               % (workload_s, wl.N, wl.H, wl.W, cfg_index),
                    "per_gpu_batch": wl.N, "global_batch": pairs_per_step, "mode": args.mode,
                    "deform_weights": "re-packed every call" if args.repack else "packed once per weight version",
-                   "launch": "eager" if args.no_graph else "hipGraph replay", "streams": len(wls),
+                   "launch": "eager" if (args.no_graph or not gpu) else "hipGraph replay", "streams": len(wls),
+                   "backend": (args.backend if world > 1 else None),
                    **({"tuning_overrides": args.tuning} if args.tuning else {}), "parallelism": "batch shard x%d" % world},
         "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
         "algorithmic_GFLOP_per_step_per_gpu": round(sum(af.values()) / 1e9, 3),
         "aggregate_GBps_per_gpu": round(sum(ab.values()) / (dt / args.steps) / 1e9, 1),
         "checksum_allreduce_ok": ck_ok,
     }
-    if len(wls) == 1 and world == 1 and not args.no_graph:
+    if gpu and len(wls) == 1 and world == 1 and not args.no_graph:
         try:  # informational: the same pass with 3 independent batches in flight (3 streams, own outputs each)
-            extra = [hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
-                                             prepack=not args.repack).capture() for _ in range(2)]
+            extra = [workload().capture() for _ in range(2)]
             pw = [wl] + extra
             for i in range(60):
                 pw[i % 3].step()
@@ -332,16 +437,24 @@ def main():
             del extra, pw
         except Exception as e:
             res["pipelined"] = {"error": repr(e)}
-    try:
-        res["roofline"] = roofline_of_dominant_kernel(wl, args.roofline_iters, torch)
-        res["kernels"] = per_kernel_breakdown(wl, 20, torch)
-        res["ops_in_graph_us"] = per_op_graph_cost(wl, torch)
-    except Exception as e:  # the headline number must survive a profiler problem
-        res["roofline"] = None
-        res["roofline_error"] = repr(e)
-    if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only: other ranks would idle in the barrier meanwhile
-        res["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+    if gpu:
+        try:
+            res["roofline"] = roofline_of_dominant_kernel(wl, args.roofline_iters, torch)
+            res["kernels"] = per_kernel_breakdown(wl, 20, torch)
+            res["ops_in_graph_us"] = per_op_graph_cost(wl, torch)
+        except Exception as e:  # the headline number must survive a profiler problem
+            res["roofline"] = None
+            res["roofline_error"] = repr(e)
+    if not args.no_cpu_baseline and world == 1 and gpu:  # rank 0 at N=1 only: other ranks would idle in the barrier meanwhile
+        res["cpu_baseline"], want = cpu_baseline(wl, args.cpu_seconds)
         res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)
+        wl.replay()
+        wl.synchronize()
+        res["parity"] = parity_vs_oracle(wl, want)
+        try:
+            res["cpu_baseline_multithread"] = cpu_baseline_threads(wl, min(args.cpu_seconds, 8.0), os.cpu_count() or 1)
+        except Exception as e:
+            res["cpu_baseline_multithread"] = {"error": repr(e)}
     print(json.dumps(res))
     sys.stdout.flush()
     if dist is not None:

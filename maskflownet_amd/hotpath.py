@@ -276,7 +276,10 @@ class HotPathWorkload:
             self.host.update(synth_inputs_full(self.N, self.H, self.W, seed))
         if self.kind == "train":
             self.host.update(synth_inputs_train(self.N, self.H, self.W, seed))
-        self.t = {k: bufs.to_device(v) for k, v in self.host.items()}
+        # uploads and the weight packing below run on the workload's own stream (torch streams are non-blocking: work
+        # left on the default stream would not be ordered before the first launch / the captured graph)
+        with bufs.launching():
+            self.t = {k: bufs.to_device(v) for k, v in self.host.items()}
         shp = level_shapes(self.N, self.H, self.W)
         D2 = (2 * MD + 1) ** 2
         self.o = {}
@@ -310,13 +313,16 @@ class HotPathWorkload:
         self.prepack = bool(prepack)
         self.packed = {}
         if self.prepack:
-            for l in (5, 4, 3, 2):
-                self.packed[l] = self.ops.pack_deform_weights(self.t["w_%d" % l], shp[l], kernel=(3, 3), pad=(1, 1))
-            if self.kind == "full":
-                for l in (6, 5, 4, 3, 2):
-                    self.packed["u%d" % l] = self.ops.pack_deform_weights(self.t["wu_%d" % l], shp[l], kernel=(3, 3),
-                                                                          pad=(1, 1))
+            with bufs.launching():
+                for l in (5, 4, 3, 2):
+                    self.packed[l] = self.ops.pack_deform_weights(self.t["w_%d" % l], shp[l], kernel=(3, 3), pad=(1, 1))
+                if self.kind == "full":
+                    for l in (6, 5, 4, 3, 2):
+                        self.packed["u%d" % l] = self.ops.pack_deform_weights(self.t["wu_%d" % l], shp[l],
+                                                                              kernel=(3, 3), pad=(1, 1))
         bufs.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize(self.device)   # allocations / fills made on other streams are complete too
 
     # the operator sequence of one forward, as (name, thunk) pairs
     def calls(self):
@@ -433,7 +439,7 @@ class HotPathWorkload:
                 allreduce_bucket(self.bufs.as_collective_tensor(self.grad_bucket), dist, batch_size=global_batch)
 
     def synchronize(self):
-        self.stream.synchronize()
+        self.bufs.synchronize()
 
     def outputs(self):
         return [self.o[k] for k in self.output_names()]
@@ -443,6 +449,11 @@ class HotPathWorkload:
 
     def checksum(self):
         """[sum |out|, element count] over all outputs -- the 2-float record ranks all-reduce."""
+        if self.torch is None:   # numpy buffers (CPU dry run of the call lists)
+            import torch
+            outs = [np.asarray(x, np.float64) for x in self.outputs()]
+            return torch.tensor([sum(float(np.abs(x).sum()) for x in outs), float(sum(x.size for x in outs))],
+                                dtype=torch.float64)
         tot = self.torch.zeros(2, device=self.device, dtype=self.torch.float64)
         for x in self.outputs():
             tot[0] += x.abs().sum(dtype=self.torch.float64)
