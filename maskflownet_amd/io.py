@@ -9,7 +9,9 @@
   is int32 storage type (0 = dense), shape as uint32 ndim + int64 dims, context (int32 dev_type, int32 dev_id), int32
   dtype flag, raw little-endian data; V1 (0xF993FAC8) has no storage type; older files start with the uint32 ndim and
   carry uint32 dims.  Restated from MXNet 1.x `src/ndarray/ndarray.cc`; MXNet cannot run here and the reference's
-  weights are absent (.MISSING_LARGE_BLOBS), so the reader is pinned only by round trips through the writer below.
+  weights are absent (.MISSING_LARGE_BLOBS), so the reader is pinned by tests/golden/mxnet_v2.params -- assembled byte
+  by byte from that layout by tests/golden/make_params_fixture.py, independently of the writer below -- and by round
+  trips.
 """
 import struct
 
@@ -143,16 +145,33 @@ def save_params(path, params):
 
 def load_into(module, params, strict=True):
     """Copy checkpoint arrays into a torch module that uses the reference's parameter names (layer.DeformableConv2D:
-    '<prefix>weight' / '<prefix>bias')."""
+    '<prefix>weight' / '<prefix>bias').  Blocks built the way the reference builds them -- DeformableConv2D with
+    in_channels=0, MaskFlownet.py:155-158: weight creation deferred to the first forward -- are materialised here from
+    the checkpoint's weight shape first, so that their parameters exist to be loaded (and are seen by an optimizer
+    built afterwards).  strict: every parameter must be in the checkpoint AND every checkpoint key must match a
+    parameter.  Returns (missing, unexpected)."""
     import torch
+    from .layer import DeformableConv2D
+    for name, mod in module.named_modules():
+        if isinstance(mod, DeformableConv2D) and mod.weight is None:
+            key = (name + "." if name else "") + "weight"
+            if key in params:
+                w = params[key]
+                if w.ndim != 4 or w.shape[0] != mod._channels or tuple(w.shape[2:]) != tuple(mod._kwargs["kernel"]):
+                    raise ValueError("%s: checkpoint shape %s does not fit DeformableConv2D(%d, kernel %s)"
+                                     % (key, w.shape, mod._channels, mod._kwargs["kernel"]))
+                mod._materialize(int(w.shape[1]) * mod._kwargs["num_group"], torch.device("cpu"))
     own = dict(module.named_parameters())
     missing = [k for k in own if k not in params]
+    unexpected = [k for k in params if k not in own]
     if strict and missing:
         raise KeyError("checkpoint lacks %s" % missing)
+    if strict and unexpected:
+        raise KeyError("checkpoint keys without a parameter: %s" % unexpected)
     with torch.no_grad():
         for k, p in own.items():
             if k in params:
                 if tuple(p.shape) != tuple(params[k].shape):
                     raise ValueError("%s: checkpoint shape %s, module shape %s" % (k, params[k].shape, tuple(p.shape)))
                 p.copy_(torch.from_numpy(np.ascontiguousarray(params[k])))
-    return missing
+    return missing, unexpected
