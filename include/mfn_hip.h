@@ -14,7 +14,10 @@
  *   - return value: 0 = ok; < 0 = bad argument (MFN_E_*); > 0 = a hipError_t from the
  *     launch.  mfn_last_error() returns a thread-local description of the last failure.
  *     Nothing throws across the boundary.
- *   - the library is re-entrant; it keeps no per-call state.
+ *   - the operator entry points are re-entrant and keep no per-call state: any number of host threads may call
+ *     them concurrently on their own streams.  The process-global MEASUREMENT state is the exception and is not
+ *     part of the drop-in surface: mfn_set_tuning / mfn_profile_* / mfn_debug_set_timeline write plain globals
+ *     that every launch reads -- call them only while no other thread is inside the library.
  *   - flow tensors use the network's channel order: channel 0 = dy (vertical),
  *     channel 1 = dx (horizontal)   (/root/reference/network/pipeline.py:105,
  *     /root/reference/network/layer.py:17).
@@ -250,7 +253,8 @@ int mfn_profile_query(const char *name_substr, int *launches, double *total_ms);
 /* Writes up to `cap` bytes of "name launches total_ms\n" lines into buf; returns bytes needed. */
 int mfn_profile_dump(char *buf, int cap);
 
-/* Kernel-selection knobs for tuning sweeps (process-global, not part of the drop-in surface).
+/* Kernel-selection knobs for tuning sweeps (process-global, NOT thread-safe, not part of the drop-in surface: set
+ * them before the first operator call or while no other thread is inside the library).
  * Unknown keys return MFN_E_PARAM.  Keys: see maskflownet_amd/csrc/tuning.h. */
 /* Measurement only: when non-NULL, instrumented kernels write 4 x uint64 wall-clock stamps (100 MHz)
  * per workgroup into this device buffer (caller sizes it: 32 bytes x workgroups). */

@@ -5,6 +5,7 @@ symbol, importing the ops raises.  (The oracle under oracle/ and the emulation b
 tests/emu/ are test infrastructure and are never imported from here.)
 """
 import ctypes
+import hashlib
 import os
 import subprocess
 
@@ -35,34 +36,78 @@ def _sources():
     for d, _, files in os.walk(CSRC):
         out += [os.path.join(d, f) for f in files if f.endswith((".hip", ".h", ".inc"))]
     out.append(os.path.join(os.path.dirname(_HERE), "include", "mfn_hip.h"))
-    return out
+    return sorted(out)
+
+
+def source_hash():
+    """sha256 over the library's sources (paths relative to the repo root + contents) and the compiler flags."""
+    root = os.path.dirname(_HERE)
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for path in _sources():
+        h.update(os.path.relpath(path, root).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash(so_path=None):
+    """The source hash embedded in a built library (the text of mfn_version_string), or None.  Read from the file's
+    bytes, not through dlopen: a process that has the old library mapped would get the old text back."""
+    so_path = so_path or SO_PATH
+    if not os.path.exists(so_path):
+        return None
+    with open(so_path, "rb") as f:
+        blob = f.read()
+    k = blob.find(b"(gfx950) src=")
+    if k < 0:
+        return None
+    return blob[k + 13:k + 29].decode(errors="replace")
+
+
+last_build = None   # "rebuilt" | "reused": what the last build() call did
 
 
 def build(force=False, verbose=False):
-    """Compile libmfn_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = _sources()
-    if (not force and os.path.exists(SO_PATH)
-            and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(s) for s in srcs)):
+    """Compile libmfn_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).  The library carries a
+    hash of its sources; it is reused only when that hash equals the sources' present one (mtimes play no role)."""
+    global last_build, _lib
+    want = source_hash()
+    if not force and built_hash() == want:
+        last_build = "reused"
+        if verbose:
+            print("libmfn_hip.so reused (src=%s)" % want)
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH, os.path.join(CSRC, "api.hip")]
+    tmp = SO_PATH + ".tmp%d" % os.getpid()   # never dlopen()ed under this name: a fresh inode replaces the old library
+    cmd = [hipcc] + HIPCC_FLAGS + ['-DMFN_SOURCE_HASH="%s"' % want, "-o", tmp, os.path.join(CSRC, "api.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, SO_PATH)
+    _lib = None
+    last_build = "rebuilt"
+    if verbose:
+        print("libmfn_hip.so rebuilt (src=%s)" % want)
     return SO_PATH
 
 
 def lib():
-    """The bound library; raises if it has not been built (no silent fallback)."""
+    """The bound library; raises if it has not been built or was built from other sources (no silent fallback)."""
     global _lib
     if _lib is None:
         if not os.path.exists(SO_PATH):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
         cdll = ctypes.CDLL(SO_PATH)
-        _lib = _abi.bind(cdll, "mfn_", product=True)
-        if _lib.abi_version() != 1:
+        ns = _abi.bind(cdll, "mfn_", product=True)
+        if ns.abi_version() != 1:
             raise ImportError("libmfn_hip.so ABI version mismatch")
+        if not os.environ.get("MFN_HIP_SO"):   # measurement builds (tools/ablate.py) are somebody else's sources
+            have, want = built_hash(), source_hash()
+            if have != want:
+                raise ImportError("%s was built from other sources (library src=%s, tree src=%s): rebuild with "
+                                  "`python -c 'import __graft_entry__ as g; g.build()'`" % (SO_PATH, have, want))
+        _lib = ns
     return _lib
 
 

@@ -30,7 +30,12 @@ void profile_record(const char *name, hipEvent_t e0, hipEvent_t e1) {
 extern "C" {
 
 int mfn_abi_version(void) { return MFN_ABI_VERSION; }
-const char *mfn_version_string(void) { return "mfn_hip 0.1 (gfx950)"; }
+#ifndef MFN_SOURCE_HASH
+#define MFN_SOURCE_HASH "unhashed"
+#endif
+// MFN_SOURCE_HASH: sha256 (first 16 hex digits) over csrc/** and include/mfn_hip.h, put on the compiler command line by
+// maskflownet_amd/_lib.py:build(); _lib.lib() refuses a library whose hash differs from the sources next to it.
+const char *mfn_version_string(void) { return "mfn_hip 0.2 (gfx950) src=" MFN_SOURCE_HASH; }
 
 // ---- hipGraph plumbing -------------------------------------------------------------------------------
 int mfn_graph_begin_capture(void *stream) {

@@ -206,6 +206,11 @@ class DeformableConv2D(nn.Module):
         kw = self._kwargs
         if kw["stride"] != (1, 1) or kw["num_deformable_group"] != 1:
             raise ValueError("forward_shared needs stride 1 and one deformable group")
+        if _any_grad(x, flow, self.weight, self.bias):
+            # no silent gradient cut: the fused kernel has no autograd graph; forward() with the materialised
+            # offsets (ops.offsets_from_flow) is the differentiable form
+            raise NotImplementedError("forward_shared is the fused inference path; train through forward() "
+                                      "(or call it under torch.no_grad())")
         out = ops.deformable_convolution_shared(x, flow, flow_scale, flow_stride, self.weight, self.bias,
                                                 kernel=kw["kernel"], dilate=kw["dilate"], pad=kw["pad"],
                                                 num_group=kw["num_group"], packed=self._packed(x))

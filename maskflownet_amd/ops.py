@@ -29,6 +29,7 @@ class OpSet:
         self.ad = adapter
         self.check = check
         self._ws = {}
+        self._retired = []
 
     # ---- helpers -------------------------------------------------------------------------------
     def _in(self, *arrs):
@@ -38,9 +39,24 @@ class OpSet:
         key = self.ad.device_key(like)
         ws = self._ws.get(key)
         if ws is None or self.ad.nbytes(ws) < nbytes:
+            if ws is not None:
+                # a hipGraph captured earlier (hotpath.capture, or a user's own capture) still holds the old
+                # pointer: the superseded buffer must outlive it, so it is parked instead of freed
+                self._retired.append(ws)
             ws = self.ad.empty_bytes(like, max(int(nbytes), 1 << 20))
             self._ws[key] = ws
         return ws
+
+    def _out(self, out, like, shape, what):
+        """A caller-supplied destination goes to the kernel as it is: it must already be what the kernel writes --
+        float32, contiguous NCHW of exactly `shape`, on the inputs' device (no silent copy, no reshaping)."""
+        shape = tuple(int(v) for v in shape)
+        if out is None:
+            return self.ad.empty(like, shape)
+        if self.ad.shape(out) != shape:
+            raise ValueError("%s: out has shape %s, expected %s" % (what, self.ad.shape(out), shape))
+        self.ad.require_destination(out, like, what)
+        return out
 
     # ---- Correlation ---------------------------------------------------------------------------
     def correlation_out_shape(self, H, W, kernel_size=1, max_displacement=1, stride1=1, stride2=1, pad_size=0):
@@ -113,8 +129,7 @@ class OpSet:
         N, C, H, W = self.ad.shape(xx)
         if self.ad.shape(fl) != (N, 2, H, W):
             raise ValueError("warp: flow must have shape %s, got %s" % ((N, 2, H, W), self.ad.shape(fl)))
-        if out is None:
-            out = self.ad.empty(xx, (N, C, H, W))
+        out = self._out(out, xx, (N, C, H, W), "warp")
         self.check(self.ns.warp_fwd(self.ad.ptr(xx), self.ad.ptr(fl), self.ad.ptr(out), N, C, H, W,
                                     int(bool(clip_grid)), self.ad.stream(xx)))
         return out
@@ -214,8 +229,7 @@ class OpSet:
             raise ValueError("DeformableConvolution: offset shape %s, expected %s" % (self.ad.shape(off), exp_off))
         if b is not None and self.ad.shape(b) != (Cout,):
             raise ValueError("DeformableConvolution: bias shape %s, expected (%d,)" % (self.ad.shape(b), Cout))
-        if out is None:
-            out = self.ad.empty(x, (N, Cout, Ho, Wo))
+        out = self._out(out, x, (N, Cout, Ho, Wo), "DeformableConvolution")
         nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group,
                                                      num_deformable_group)
         ws = self._workspace(x, nbytes)
@@ -310,8 +324,7 @@ class OpSet:
             raise ValueError("deformable_convolution_shared: bad weight shape %s" % (self.ad.shape(w),))
         if self.ad.shape(fl) != (N, 2, H, W):
             raise ValueError("deformable_convolution_shared: flow must be %s" % ((N, 2, H, W),))
-        if out is None:
-            out = self.ad.empty(x, (N, Cout, H, W))
+        out = self._out(out, x, (N, Cout, H, W), "deformable_convolution_shared")
         nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, 1, 1, ph, pw, dh, dw, num_group, 1)
         ws = self._workspace(x, nbytes)
         if packed is not None:
@@ -338,8 +351,7 @@ class OpSet:
         factor = int(factor)
         if factor < 1:
             raise ValueError("Upsample: factor must be >= 1")
-        if out is None:
-            out = self.ad.empty(x, (N, C, H * factor, W * factor))
+        out = self._out(out, x, (N, C, H * factor, W * factor), "Upsample")
         self.check(self.ns.upsample_fwd(self.ad.ptr(x), self.ad.ptr(out), N, C, H, W, factor, self.ad.stream(x)))
         return out
 
@@ -362,8 +374,7 @@ class OpSet:
             raise ValueError("deformable_matching: mask must be %s" % ((N, 1, H, W),))
         if tr is not None and self.ad.shape(tr) != (N, Cout, H, W):
             raise ValueError("deformable_matching: tradeoff must be %s" % ((N, Cout, H, W),))
-        if out is None:
-            out = self.ad.empty(x, (N, Cout, H, W))
+        out = self._out(out, x, (N, Cout, H, W), "deformable_matching")
         nbytes = self.ns.deform_conv_workspace_bytes(N, Cin, H, W, Cout, kh, kw, 1, 1, ph, pw, dh, dw, num_group, 1)
         ws = self._workspace(x, nbytes)
         if packed is not None:
@@ -381,8 +392,7 @@ class OpSet:
         N, two, H, W = self.ad.shape(fl)
         if two != 2:
             raise ValueError("offsets_from_flow: flow must be (N,2,H,W)")
-        if out is None:
-            out = self.ad.empty(fl, (N, 2 * taps, H, W))
+        out = self._out(out, fl, (N, 2 * taps, H, W), "offsets_from_flow")
         self.check(self.ns.offsets_from_flow(self.ad.ptr(fl), self.ad.ptr(out), N, H, W, int(taps), float(scale),
                                              float(stride), self.ad.stream(fl)))
         return out
@@ -417,6 +427,15 @@ class TorchAdapter:
         if a.dtype != t.float32:
             raise TypeError("float32 expected, got %s" % a.dtype)
         return a if a.is_contiguous() else a.contiguous()
+
+    def require_destination(self, out, like, what):
+        t = self.torch
+        if not isinstance(out, t.Tensor) or out.dtype != t.float32:
+            raise TypeError("%s: out must be a float32 torch.Tensor" % what)
+        if out.device != like.device:
+            raise RuntimeError("%s: out lives on %s, the inputs on %s" % (what, out.device, like.device))
+        if not out.is_contiguous():
+            raise ValueError("%s: out must be contiguous (strides %s)" % (what, tuple(out.stride())))
 
     def ptr(self, a):
         return a.data_ptr()

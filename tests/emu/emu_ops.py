@@ -18,6 +18,12 @@ class NumpyAdapter:
             raise TypeError("float32 expected, got %s" % a.dtype)
         return np.ascontiguousarray(a)
 
+    def require_destination(self, out, like, what):
+        if not isinstance(out, np.ndarray) or out.dtype != np.float32:
+            raise TypeError("%s: out must be a float32 ndarray" % what)
+        if not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("%s: out must be contiguous" % what)
+
     def ptr(self, a):
         return a.ctypes.data
 

@@ -90,3 +90,20 @@ def test_ops_refuse_cpu_tensors():
     x = torch.zeros(1, 2, 8, 8)
     with pytest.raises(RuntimeError, match="no CPU"):
         ops.Correlation(x, x, 1, 4, 1, 1, 4)
+
+
+def test_library_carries_the_hash_of_its_sources(lib, tmp_path, monkeypatch):
+    """Build provenance: the .so names the sources it was built from; a library built from other sources is
+    refused, and build() reuses a library only on an equal hash (mtimes play no role)."""
+    want = _lib.source_hash()
+    assert _lib.built_hash() == want
+    assert ("src=" + want).encode() in lib.version_string()
+    assert _lib.build() == _lib.SO_PATH and _lib.last_build == "reused"
+    stale = tmp_path / "libmfn_hip.so"
+    blob = open(_lib.SO_PATH, "rb").read().replace(("src=" + want).encode(), b"src=" + b"0" * 16)
+    stale.write_bytes(blob)
+    monkeypatch.setattr(_lib, "SO_PATH", str(stale))
+    monkeypatch.setattr(_lib, "_lib", None)
+    assert _lib.built_hash() == "0" * 16
+    with pytest.raises(ImportError, match="other sources"):
+        _lib.lib()

@@ -380,3 +380,23 @@ def test_errors_read_like_mxnet(ops):
                                   np.zeros((2,), np.float32), kernel=(3, 3), pad=(1, 1))
     with pytest.raises(RuntimeError, match="fit in blob"):
         ops.Correlation(x, x, kernel_size=1, max_displacement=4, pad_size=0)
+
+
+def test_destination_buffers_are_validated_and_old_workspaces_outlive_a_regrow(ops):
+    """out= goes to the kernel as it is, so it must already be what the kernel writes; a workspace that is replaced
+    by a larger one is parked (a captured hipGraph may still point at it)."""
+    x = np.zeros((1, 2, 4, 8), np.float32)
+    fl = np.zeros((1, 2, 4, 8), np.float32)
+    with pytest.raises(ValueError, match="shape"):
+        ops.warp(x, fl, out=np.zeros((1, 2, 4, 4), np.float32))
+    with pytest.raises(ValueError, match="contiguous"):
+        ops.warp(x, fl, out=np.zeros((1, 2, 4, 16), np.float32)[..., ::2])
+    with pytest.raises(TypeError):
+        ops.Upsample(x, 2, out=np.zeros((1, 2, 8, 16), np.float64))
+    with pytest.raises(ValueError, match="shape"):
+        ops.offsets_from_flow(fl, 20.0, 4.0, out=np.zeros((1, 9, 4, 8), np.float32))
+    ops._ws.clear()
+    small = ops._workspace(x, 16)
+    big = ops._workspace(x, ops.ad.nbytes(small) + 4096)
+    assert big is not small and any(r is small for r in ops._retired)
+    ops._retired.clear()

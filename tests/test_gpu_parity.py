@@ -163,6 +163,48 @@ def test_deform_conv_network_levels(ops, oracle, dev, C, H, W, stride, fused):
     pc.case_deform_shared(ops, oracle, dev, host, 2, C, H, W, stride=stride, fused=fused)
 
 
+@pytest.mark.parametrize("C,H,W,stride", DEFORM_LEVELS)
+def test_deform_conv_cfg2_levels_at_bench_batch(ops, oracle, dev, C, H, W, stride):
+    """BASELINE configs[1]: N=8 at every level, the drop-in operator signature (materialised offsets)."""
+    pc.case_deform_shared(ops, oracle, dev, host, 8, C, H, W, stride=stride, fused=False)
+
+
+# cfg3 (448x1024, N=4): L5 14x32, L4 28x64, L3 56x128, L2 112x256
+@pytest.mark.parametrize("C,H,W,stride", [(128, 14, 32, 32.0), (96, 28, 64, 16.0), (64, 56, 128, 8.0), (32, 112, 256, 4.0)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_deform_conv_cfg3_levels(ops, oracle, dev, C, H, W, stride, fused):
+    pc.case_deform_shared(ops, oracle, dev, host, 4, C, H, W, stride=stride, fused=fused, seed=3)
+
+
+def test_affine_grid_generator_and_sampler_with_other_target_shape(ops, oracle, dev, T):
+    """GeometryAugmentation's use of the pair (/root/reference/augmentation.py:306-321,333; :60-64): an affine grid
+    at target_shape != the data's size, clipped to [-1, 1], sampling a 6-channel image+mask+flow stack."""
+    rng = np.random.default_rng(17)
+    N, iH, iW, oH, oW = 4, 436, 1024, 320, 768           # Sintel frame -> training crop (MaskFlownet_ft_sintel: 320x768)
+    ang = rng.uniform(-0.3, 0.3, N)
+    sc = rng.uniform(0.7, 1.3, N)
+    theta = np.stack([sc * np.cos(ang), -sc * np.sin(ang), rng.uniform(-0.2, 0.2, N),
+                      sc * np.sin(ang), sc * np.cos(ang), rng.uniform(-0.2, 0.2, N)], axis=1).astype(np.float32)
+    data = rng.standard_normal((N, 6, iH, iW)).astype(np.float32)
+    grid = ops.GridGenerator(dev(theta), "affine", target_shape=(oH, oW))
+    want_grid = oracle.grid_generator_affine(theta, (oH, oW))
+    assert tuple(grid.shape) == (N, 2, oH, oW)
+    np.testing.assert_allclose(host(grid), want_grid, rtol=0, atol=2e-6)
+    clipped = grid.clamp(-1, 1)                            # augmentation.py:310
+    got = ops.BilinearSampler(dev(data), clipped)
+    pc.check_close(host(got), oracle.bilinear_sampler(data, np.clip(host(grid), -1, 1)), what="affine sampler (clipped grid)")
+    got = ops.BilinearSampler(dev(data), grid)             # unclipped: taps outside contribute zero (augmentation.py:321)
+    pc.check_close(host(got), oracle.bilinear_sampler(data, host(grid)), what="affine sampler")
+    # identity theta at the data's own size reproduces the data (align-corners mapping)
+    ident = np.tile(np.array([[1, 0, 0, 0, 1, 0]], np.float32), (N, 1))
+    same = ops.BilinearSampler(dev(data), ops.GridGenerator(dev(ident), "affine", target_shape=(iH, iW)))
+    assert (same - dev(data)).abs().max().item() <= 2e-3   # fp32 normalise / denormalise round trip at W=1024
+    import torch.nn.functional as F
+    tg = F.affine_grid(dev(theta).view(N, 2, 3), (N, 6, oH, oW), align_corners=True)
+    want = F.grid_sample(dev(data), tg, mode="bilinear", padding_mode="zeros", align_corners=True)
+    assert (ops.BilinearSampler(dev(data), grid) - want).abs().max().item() <= 3e-4 * want.abs().max().item()
+
+
 def test_deform_conv_sintel_level_and_full_model_l6(ops, oracle, dev):
     pc.case_deform_shared(ops, oracle, dev, host, 1, 32, 112, 256, stride=4.0)
     pc.case_deform_shared(ops, oracle, dev, host, 2, 196, 6, 8, stride=64.0)  # full model deform6, C=196 -> 224 padded
@@ -223,7 +265,8 @@ def test_deform_conv_zero_offset_is_conv2d_at_full_size(ops, T):
 
 
 # ---- backward: the gradients config 5 (train step) needs, at the network's level shapes ---------------------
-@pytest.mark.parametrize("shape", [(2, 196, 6, 8), (2, 128, 12, 16), (2, 64, 48, 64), (2, 32, 96, 128)])
+@pytest.mark.parametrize("shape", [(2, 196, 6, 8), (2, 128, 12, 16), (2, 96, 24, 32), (2, 64, 48, 64), (2, 32, 96, 128),
+                                   (8, 32, 96, 128), (4, 64, 56, 128)])
 def test_correlation_backward_levels(ops, oracle, dev, shape):
     pc.case_correlation_bwd(ops, oracle, dev, host, shape)
 
