@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the oracle baseline")
     ap.add_argument("--roofline-iters", type=int, default=200)
+    ap.add_argument("--no-epe", action="store_true",
+                    help="skip the network-level EPE delta (MaskFlownet-S end to end, HIP hot path vs the CPU reference path)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL, the product) or gloo (launcher dry run on CPU, "
                          "needs --buffers)")
@@ -300,6 +302,27 @@ def parity_vs_oracle(wl, want):
             "outputs_checked": len(per), "reference": "oracle pass over the full bench batch (oracle/hotpath_ref.py)"}
 
 
+def network_epe_delta(H, W, device):
+    """Second half of BASELINE.json's metric, "EPE delta vs CPU ref": MaskFlownet-S end to end on one synthetic pair
+    at the bench resolution, seeded MSRAPrelu weights (oracle/network_ref.py: the reference's dataflow as torch glue).
+    ops_only: both runs share the torch-ROCm convolutions, the hot path comes from libmfn_hip.so vs the CPU oracle;
+    vs_cpu_reference: HIP hot path + torch-ROCm convolutions against oracle hot path + torch CPU convolutions."""
+    from oracle import network_ref as nr
+    t0 = time.perf_counter()
+    im1, im2 = nr.synthetic_pair(1, H, W)
+    hip = nr.Net(nr.Params(seed=7), nr.HipMatching(device), device).forward(im1, im2)
+    ora = nr.Net(nr.Params(seed=7), nr.OracleMatching(), device).forward(im1, im2)
+    cpu = nr.Net(nr.Params(seed=7), nr.OracleMatching(), "cpu").forward(im1, im2)
+    d_ops, d_cpu = nr.epe_delta(hip, ora), nr.epe_delta(hip, cpu)
+    return {"epe_delta_px": d_cpu["epe_delta_px"], "epe_delta_rel": d_cpu["epe_delta_rel"],
+            "mean_flow_px": d_cpu["mean_flow_px"], "tolerance_rel": 1e-4, "ok": bool(d_cpu["epe_delta_rel"] <= 1e-4),
+            "ops_only": {"epe_delta_px": d_ops["epe_delta_px"], "epe_delta_rel": d_ops["epe_delta_rel"]},
+            "setup": "MaskFlownet-S (71 layers, 10 514 256 seeded MSRAPrelu parameters), 1 synthetic pair %dx%d "
+                     "(image2 = image1 shifted by (+3,-5) px), final Upsample(4) flow; reference = oracle operators + "
+                     "torch CPU convolutions" % (H, W),
+            "seconds": round(time.perf_counter() - t0, 1)}
+
+
 def make_buffers(spec):
     import importlib
     mod, _, fn = spec.partition(":")
@@ -455,6 +478,11 @@ def main():
             res["cpu_baseline_multithread"] = cpu_baseline_threads(wl, min(args.cpu_seconds, 8.0), os.cpu_count() or 1)
         except Exception as e:
             res["cpu_baseline_multithread"] = {"error": repr(e)}
+    if gpu and world == 1 and not args.no_epe and wl.kind != "train":
+        try:
+            res["epe"] = network_epe_delta(wl.H, wl.W, "cuda:%d" % torch.cuda.current_device())
+        except Exception as e:
+            res["epe"] = {"error": repr(e)}
     print(json.dumps(res))
     sys.stdout.flush()
     if dist is not None:

@@ -1,0 +1,81 @@
+"""Network-level parity (BASELINE.json metric: "EPE delta vs CPU ref"; north_star: <= 1e-4): MaskFlownet-S end to end
+(oracle/network_ref.py: the reference's dataflow as torch glue) with the matching hot path taken from the HIP library
+vs from the CPU oracle, same seeded MSRAPrelu weights, same synthetic image pair.
+
+CPU run: pins the harness itself against the reference's structure (71 parametrised layers, 10 514 256 parameters --
+SURVEY.md 8d, computed from MaskFlownet.py:79-163; the ten hot-path calls in the reference's order) and runs the
+emulated kernels through it.  GPU run: the EPE delta at the bench resolution."""
+import numpy as np
+import pytest
+
+from oracle import network_ref as nr
+
+
+class _EmuMatching:
+    """The four operators from the kernel-emulation build (numpy in / out), for the CPU run."""
+    name = "emu"
+
+    def __init__(self):
+        from tests.emu import emu_ops
+        self.ops = emu_ops.emu_ops()
+
+    def corr(self, a, b):
+        return self.ops.Correlation(a, b, kernel_size=1, max_displacement=4, stride1=1, stride2=1, pad_size=4)
+
+    def deform(self, x, offset, w, b):
+        return self.ops.DeformableConvolution(x, offset, w, b, kernel=(3, 3), pad=(1, 1), num_filter=w.shape[0])
+
+    def warp(self, x, flow):
+        return self.ops.warp(x, flow, clip_grid=False)
+
+    def upsample(self, x, f):
+        return self.ops.Upsample(x, f)
+
+
+def test_harness_has_the_references_structure():
+    im1, im2 = nr.synthetic_pair(1, 64, 128, seed=3)
+    assert abs(float(np.concatenate([im1, im2], 2).mean())) < 1e-6           # centralize, pipeline.py:85-87
+    np.testing.assert_allclose(im2[0, :, 10:50, 10:100], im1[0, :, 7:47, 15:105], atol=1e-6)   # image2 = image1 moved by (+3, -5)
+    P = nr.Params(seed=0)
+    net = nr.Net(P, nr.OracleMatching(), "cpu")
+    out = net.forward(im1, im2)
+    assert P.count() == 10514256 and len(P.store) == 2 * 71                  # 71 layers, 10 514 256 parameters
+    assert [c[0] for c in net.calls] == ["correlation"] + ["deformable_conv", "correlation"] * 4 + ["warp"]
+    assert [c[1][1] for c in net.calls[:-1]] == [196, 128, 128, 96, 96, 64, 64, 32, 32]
+    assert out["flow_full"].shape == (1, 2, 64, 128) and [p.shape[2] for p in out["predictions"]] == [1, 2, 4, 8, 16]
+    assert out["occlusion"].shape == (1, 1, 16, 32) and out["warped"].shape == (1, 3, 64, 128)
+    assert all(np.isfinite(v).all() for v in [out["flow_full"], out["warped"]] + out["predictions"])
+    # same seed -> same weights regardless of creation order; another seed -> another network
+    again = nr.Net(nr.Params(seed=0), nr.OracleMatching(), "cpu").forward(im1, im2)
+    np.testing.assert_array_equal(again["flow_full"], out["flow_full"])
+    other = nr.Net(nr.Params(seed=1), nr.OracleMatching(), "cpu").forward(im1, im2)
+    assert nr.epe_delta(other, out)["epe_delta_rel"] > 1e-2
+
+
+def test_emulated_kernels_through_the_network():
+    im1, im2 = nr.synthetic_pair(1, 64, 64, seed=4)
+    ref = nr.Net(nr.Params(seed=2), nr.OracleMatching(), "cpu").forward(im1, im2)
+    got = nr.Net(nr.Params(seed=2), _EmuMatching(), "cpu").forward(im1, im2)
+    d = nr.epe_delta(got, ref)
+    assert d["epe_delta_rel"] <= 1e-4, d
+
+
+@pytest.mark.gpu
+def test_gpu_network_epe_delta_vs_cpu_reference():
+    """(i) ops only: both runs use the same torch-ROCm convolutions, the hot path comes from libmfn_hip.so vs the
+    oracle; (ii) vs the CPU reference path: torch CPU convolutions + oracle operators, against torch-ROCm
+    convolutions + HIP operators.  384x512, one pair."""
+    import torch
+    assert torch.cuda.is_available()
+    im1, im2 = nr.synthetic_pair(1, 384, 512)
+    hip = nr.Net(nr.Params(seed=7), nr.HipMatching("cuda:0"), "cuda:0").forward(im1, im2)
+    ora = nr.Net(nr.Params(seed=7), nr.OracleMatching(), "cuda:0").forward(im1, im2)
+    cpu = nr.Net(nr.Params(seed=7), nr.OracleMatching(), "cpu").forward(im1, im2)
+    d_ops, d_cpu = nr.epe_delta(hip, ora), nr.epe_delta(hip, cpu)
+    print("EPE delta ops-only %r; vs CPU reference path %r" % (d_ops, d_cpu))
+    assert d_ops["mean_flow_px"] > 0.1
+    assert d_ops["epe_delta_rel"] <= 1e-4, d_ops
+    assert d_cpu["epe_delta_rel"] <= 1e-4, d_cpu
+    for k in ("warped", "occlusion"):
+        ref = np.abs(cpu[k]).max()
+        assert np.abs(hip[k] - cpu[k]).max() <= 2e-4 * ref, k
