@@ -356,7 +356,7 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
 //   5: 2 dy/wave, 1 chunk,  CK=4, prefetch,    >=3 waves/SIMD   (5-wave blocks)
 //   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=4 waves/SIMD
 //   7: 3 dy/wave, 1 chunk,  CK=4, no prefetch, >=2 waves/SIMD
-constexpr int kCorrVariants = 24;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-23: corr_dma_kernel (20-23: channel groups)
+constexpr int kCorrVariants = 26;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-23: corr_dma_kernel (20-23: channel groups)
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
@@ -869,6 +869,8 @@ inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
     case 20: return corr_dma_launch<D, 8, 2, 2, true, 2>(p, s, "corr_dma_v20");   // 15 with two channel groups
     case 21: return corr_dma_launch<D, 8, 2, 2, false, 2>(p, s, "corr_dma_v21");  // 17 with two channel groups
     case 22: return corr_dma_launch<D, 8, 2, 1, true, 3>(p, s, "corr_dma_v22");   // 15 with three channel groups
+    case 24: return corr_dma_launch<D, 4, 4, 5, false>(p, s, "corr_dma_v24");     // 16 with a 4-stage ring (3 stages in flight)
+    case 25: return corr_dma_launch<D, 8, 3, 5, false>(p, s, "corr_dma_v25");     // 17 with a 3-stage ring
     default: return corr_dma_launch<D, 4, 2, 1, false, 3>(p, s, "corr_dma_v23");  // 16 with three channel groups
   }
 }

@@ -159,7 +159,15 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
 // measurement only: constant-rate (100 MHz) wall clock stamps, one writer per block
 #define MFN_CYCLES() ((unsigned long long)clock64())
-// measurement only: bit 0 of the buffer address selects the shader-cycle counter instead of the 100 MHz wall clock
+// measurement only: bit 0 of the buffer address selects the shader-cycle counter instead of the 100 MHz wall clock.
+// Compiled in only with -DMFN_TIMELINE=1 (tools/timeline*.py build their own library): the stamps cost registers and a
+// branch inside the kernels' main loops.
+#ifndef MFN_TIMELINE
+#define MFN_TIMELINE 0
+#endif
+#if !MFN_TIMELINE
+#define MFN_STAMP(buf, k) ((void)0)
+#else
 #define MFN_STAMP(buf, k)                                                                                   \
   do {                                                                                                      \
     if ((buf) && threadIdx.x == 0) {                                                                        \
@@ -169,6 +177,7 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
           cyc_ ? (unsigned long long)clock64() : (unsigned long long)wall_clock64();                        \
     }                                                                                                       \
   } while (0)
+#endif
 #endif
 
 #include <stddef.h>

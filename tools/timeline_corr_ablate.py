@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
 """In-kernel timeline (wall clock stamps per block) of the level-2 LDS-DMA correlation kernel under corr.ablate."""
+import os as _os
+if not _os.environ.get("MFN_HIP_SO"):
+    raise SystemExit("needs the stamp-enabled build: python tools/timeline_build.py, then MFN_HIP_SO=tools/ablate_build/libmfn_timeline.so")
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
