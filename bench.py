@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the oracle baseline")
     ap.add_argument("--roofline-iters", type=int, default=200)
+    ap.add_argument("--flow", default="smooth", choices=["smooth", "rough"],
+                    help="flow fields of the synthetic batch: smooth = Upsample(2)-recursive fields as inside the network "
+                         "(default); rough = SURVEY.md 8(d)'s i.i.d. N(0, 2 px) + 2%% outliers per pixel")
     ap.add_argument("--no-epe", action="store_true",
                     help="skip the network-level EPE delta (MaskFlownet-S end to end, HIP hot path vs the CPU reference path)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -144,25 +147,66 @@ def roofline_of_dominant_kernel(wl, iters, torch):
         lib.profile_enable(0)
         wl.stream.synchronize()
         _, hot_cnt, hot_ms = query()
-        # (b) where it runs in the pass: the whole operator sequence with every kernel timed (as rocprofv3 does), the
-        # level-2 correlation's launches tagged (its inputs were just written by the level-2 deformable conv and the
-        # caches hold other kernels' data)
+        # (b) where it runs in the pass: the whole operator sequence with every kernel timed (as rocprofv3 does), every
+        # operator call's launches tagged with its name (the level-2 correlation's inputs were just written by the level-2
+        # deformable conv and the caches hold other kernels' data)
         lib.profile_reset()
         lib.profile_enable(1)
         for _ in range(iters):
             for name, fn in wl.calls():
-                if name == "corr2":
-                    lib.profile_tag(b"L2")
-                    fn()
-                    lib.profile_tag(None)
-                else:
-                    fn()
+                lib.profile_tag(name.encode())
+                fn()
+        lib.profile_tag(None)
         lib.profile_enable(0)
         wl.stream.synchronize()
-    kname, cnt_v, ms_v = query(b"@L2")
+        per_op = {}
+        buf = ctypes.create_string_buffer(65536)
+        lib.profile_dump(buf, 65536)
+        for line in buf.value.decode().splitlines():
+            nm, c_, ms_ = line.split()
+            if "@" in nm:
+                kern, op = nm.split("@")
+                per_op.setdefault(op, []).append((kern, int(c_), float(ms_)))
+        # (c) the same launch on buffers rotated through more than the 256 MiB Infinity Cache: an HBM number, no cache help
+        sets, rot = [], None
+        try:
+            need = 320 << 20
+            per_set = nbytes
+            nsets = int(need // per_set) + 1
+            f1s = [torch.empty_like(t["c1_2"]).copy_(t["c1_2"]) for _ in range(nsets)]
+            f2s = [torch.empty_like(o["deform2"]).copy_(o["deform2"]) for _ in range(nsets)]
+            outs = [torch.empty_like(o["corr2"]) for _ in range(nsets)]
+            for i in range(nsets):
+                wl.ops.Correlation(f1s[i], f2s[i], 1, 4, 1, 1, 4, True, out=outs[i])
+            wl.stream.synchronize()
+            lib.profile_reset()
+            lib.profile_enable(1)
+            for it in range(max(iters, 3 * nsets)):
+                i = it % nsets
+                wl.ops.Correlation(f1s[i], f2s[i], 1, 4, 1, 1, 4, True, out=outs[i])
+            lib.profile_enable(0)
+            wl.stream.synchronize()
+            _, rc, rms = query()
+            if rc:
+                ravg = rms / rc * 1e-3
+                rot = {"avg_launch_us": round(ravg * 1e6, 3), "achieved": round(nbytes / ravg / 1e9, 1), "unit": "GB/s",
+                       "frac": round(nbytes / ravg / 1e9 / HBM_PEAK_GBS, 4),
+                       "frac_of_measured_copy_peak_6290": round(nbytes / ravg / 1e9 / 6290.0, 4),
+                       "buffer_sets": nsets, "working_set_MB": round(nsets * per_set / 1e6, 1),
+                       "note": "inputs and outputs rotate through > 256 MiB (Infinity Cache size), back to back launches"}
+            del f1s, f2s, outs
+        except Exception as e:  # informational
+            rot = {"error": repr(e)}
+    def pick(op):
+        best = None
+        for kern, c_, ms_ in per_op.get(op, []):
+            if kern.startswith("corr_") and "reduce" not in kern:
+                best = (kern, c_, ms_)
+        return best or (None, 0, 0.0)
+    kname, cnt_v, ms_v = pick("corr2")
     lib.profile_reset()
     if cnt_v == 0:
-        return None
+        return None, compute_roofline(wl, per_op, hotpath)
     cnt, ms = ctypes.c_int(cnt_v), ctypes.c_double(ms_v)
     avg_s = ms.value / cnt.value * 1e-3
     traffic, traffic_src = None, None
@@ -181,7 +225,37 @@ def roofline_of_dominant_kernel(wl, iters, torch):
             "launches_timed": cnt.value, "timed_where": "inside the operator sequence of the pass (eager, HIP events around every kernel on the launch stream)",
             "hot_loop_avg_launch_us": round(hot_ms / max(hot_cnt, 1) * 1e3, 3),
             "fp32_tflops": round(nflops / avg_s / 1e12, 2),
-            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)}
+            "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4),
+            "hbm_rotated": rot}, compute_roofline(wl, per_op, hotpath)
+
+
+FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+
+
+def compute_roofline(wl, per_op, hotpath):
+    """The kernels that dominate the step are the deformable convolutions (fp32 ALU bound: the exact-fp32 MFMA and the
+    VALU share the ALUs): GEMM flops of each level (2*N*h*w*Cout*Cin*9) / the time of that call's kernels
+    inside the profiled pass, against 157.3 TFLOP/s."""
+    shp = hotpath.level_shapes(wl.N, wl.H, wl.W)
+    levels, tot_f, tot_s = {}, 0.0, 0.0
+    for l in (5, 4, 3, 2):
+        recs = per_op.get("deform%d" % l, [])
+        if not recs:
+            continue
+        n, c, h, w = shp[l]
+        flops = 2.0 * n * h * w * c * c * 9
+        launches = max(r[1] for r in recs)
+        sec = sum(r[2] for r in recs) / launches * 1e-3
+        tot_f += flops
+        tot_s += sec
+        levels["L%d" % l] = {"kernels": [r[0] for r in recs], "us": round(sec * 1e6, 2), "GFLOP": round(flops / 1e9, 3),
+                             "achieved": round(flops / sec / 1e12, 1), "frac": round(flops / sec / 1e12 / FP32_PEAK_TFLOPS, 3)}
+    if not tot_s:
+        return None
+    return {"bound": "mfma", "kernel": "dc_lds_kernel (DeformableConvolution, fused gather + fp32 MFMA GEMM), all four levels",
+            "achieved": round(tot_f / tot_s / 1e12, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tot_f / tot_s / 1e12 / FP32_PEAK_TFLOPS, 3), "us_per_pass": round(tot_s * 1e6, 1), "levels": levels,
+            "note": "fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: bit-exact fmaf chain); interpolation flops not counted"}
 
 
 def per_kernel_breakdown(wl, iters, torch):
@@ -363,12 +437,13 @@ def main():
         from maskflownet_amd import _lib
         _lib.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))})
 
-    def workload():
+    def workload(flow_model=None):
+        fm = flow_model or args.flow
         if gpu:
             return hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
-                                           prepack=not args.repack)
+                                           prepack=not args.repack, flow_model=fm)
         return hotpath.HotPathWorkload(args.config, mode=args.mode, prepack=not args.repack, seed=20260925 + rank,
-                                       buffers=make_buffers(args.buffers))
+                                       buffers=make_buffers(args.buffers), flow_model=fm)
 
     wls = [workload() for _ in range(max(1, args.streams))]
     for w in wls:
@@ -438,6 +513,9 @@ def main():
                    "per_gpu_batch": wl.N, "global_batch": pairs_per_step, "mode": args.mode,
                    "deform_weights": "re-packed every call" if args.repack else "packed once per weight version",
                    "launch": "eager" if (args.no_graph or not gpu) else "hipGraph replay", "streams": len(wls),
+                   "flow_fields": ("smooth: the reference's Upsample(2) applied recursively to a coarse field, as flow_l is inside "
+                                   "the network" if args.flow == "smooth" else
+                                   "rough: SURVEY.md 8(d), i.i.d. N(0, 2 px) per pixel + 2% outliers in [-h, h]"),
                    "backend": (args.backend if world > 1 else None),
                    **({"tuning_overrides": args.tuning} if args.tuning else {}), "parallelism": "batch shard x%d" % world},
         "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
@@ -460,9 +538,27 @@ def main():
             del extra, pw
         except Exception as e:
             res["pipelined"] = {"error": repr(e)}
+    if gpu and len(wls) == 1 and world == 1 and not args.no_graph and args.flow == "smooth":
+        try:  # what SURVEY.md 8(d)'s flow distribution costs: the same pass over a batch with i.i.d. rough flows
+            rw = workload("rough").capture()
+            for _ in range(50):
+                rw.step()
+            rw.synchronize()
+            steps_r = max(50, args.steps // 4)
+            dtr = timed_steps([rw], steps_r, None, torch)
+            res["rough_flow"] = {"value": round(rw.N * steps_r / dtr, 2), "unit": "image-pairs/s",
+                                 "ms_per_step": round(dtr / steps_r * 1e3, 4), "steps": steps_r,
+                                 "flow_fields": "i.i.d. N(0, 2 px) per pixel + 2% outliers in [-h, h] (SURVEY.md 8d): no wave shares "
+                                                "a source window, every tile takes the row-gather / per-pixel tiers",
+                                 "ops_in_graph_us": {k: v for k, v in per_op_graph_cost(rw, torch, reps=10).items()
+                                                     if k.startswith(("deform", "warp"))},
+                                 "note": "not the headline: inside the network flow_l is Upsample(2) of the coarser level's flow"}
+            del rw
+        except Exception as e:
+            res["rough_flow"] = {"error": repr(e)}
     if gpu:
         try:
-            res["roofline"] = roofline_of_dominant_kernel(wl, args.roofline_iters, torch)
+            res["roofline"], res["roofline_compute"] = roofline_of_dominant_kernel(wl, args.roofline_iters, torch)
             res["kernels"] = per_kernel_breakdown(wl, 20, torch)
             res["ops_in_graph_us"] = per_op_graph_cost(wl, torch)
         except Exception as e:  # the headline number must survive a profiler problem

@@ -121,8 +121,23 @@ def upsample2(a):
     return out
 
 
-def synth_inputs(N, H, W, seed=20260925):
-    """Seeded synthetic tensors (numpy) for every level -- SURVEY.md 8(d) 'op level'."""
+FLOW_MODELS = ("smooth", "rough")
+
+
+def rough_flow(rng, n, h, w):
+    """SURVEY.md 8(d)'s op-level flow: N(0, sigma = 2 px) per pixel (level pixels), 2 % of the pixels uniform in
+    [-h, h] (out of range).  No spatial coherence at all: a wave's 4x4 neighbourhoods do not share a window."""
+    fl = rng.standard_normal((n, 2, h, w)) * 2.0
+    out = rng.random((n, 1, h, w)) < 0.02
+    return np.where(out, rng.uniform(-h, h, (n, 2, h, w)), fl).astype(np.float32)
+
+
+def synth_inputs(N, H, W, seed=20260925, flow_model="smooth"):
+    """Seeded synthetic tensors (numpy) for every level -- SURVEY.md 8(d) 'op level'.  flow_model "smooth" (default):
+    flow_l is what it is in the network, the reference's Upsample(2) applied recursively to a coarse field (piecewise
+    linear); "rough": 8(d)'s i.i.d. N(0, 2 px) + 2 % outliers per pixel, the adversarial case for the gather."""
+    if flow_model not in FLOW_MODELS:
+        raise ValueError("flow_model must be one of %s" % (FLOW_MODELS,))
     data = {}
     for l, shp in level_shapes(N, H, W).items():
         rng = np.random.default_rng(seed + l)
@@ -139,6 +154,8 @@ def synth_inputs(N, H, W, seed=20260925):
             for _ in range(3):
                 fl = upsample2(fl)
             fl = fl[:, :, :h, :w].astype(np.float32)
+            if flow_model == "rough":
+                fl = rough_flow(rng, n, h, w)
             # level-pixel offsets = flow * SCALE / stride  ->  store the network-unit flow
             data["flow_%d" % l] = (fl * np.float32(STRIDES[l] / SCALE)).astype(np.float32)
             fan = 9.0 * c
@@ -151,6 +168,8 @@ def synth_inputs(N, H, W, seed=20260925):
     for _ in range(5):
         ff = upsample2(ff)
     data["flow_full"] = (ff[:, :, :H, :W] * 4.0).astype(np.float32)
+    if flow_model == "rough":
+        data["flow_full"] = (rough_flow(rng, N, H, W) * 4.0).astype(np.float32)   # sigma 8 full-resolution px
     return data
 
 
@@ -247,7 +266,8 @@ class _TorchBuffers:
 
 
 class HotPathWorkload:
-    def __init__(self, cfg="cfg2", device="cuda", mode="dropin", seed=20260925, prepack=True, buffers=None):
+    def __init__(self, cfg="cfg2", device="cuda", mode="dropin", seed=20260925, prepack=True, buffers=None,
+                 flow_model="smooth"):
         """prepack=True: the deformable-conv weights are laid out once here, as layer.DeformableConv2D does
         for a block's constant parameters at inference; False re-packs inside every operator call (what a
         stateless MXNet operator sees).  Outputs are bit-identical either way.
@@ -271,7 +291,8 @@ class HotPathWorkload:
         self.ops = bufs.ops
         self.lib = _lib.lib() if buffers is None else None
         self.stream = getattr(bufs, "stream", None)
-        self.host = synth_inputs(self.N, self.H, self.W, seed)
+        self.flow_model = flow_model
+        self.host = synth_inputs(self.N, self.H, self.W, seed, flow_model)
         if self.kind == "full":
             self.host.update(synth_inputs_full(self.N, self.H, self.W, seed))
         if self.kind == "train":
