@@ -356,7 +356,7 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
 //   5: 2 dy/wave, 1 chunk,  CK=4, prefetch,    >=3 waves/SIMD   (5-wave blocks)
 //   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=4 waves/SIMD
 //   7: 3 dy/wave, 1 chunk,  CK=4, no prefetch, >=2 waves/SIMD
-constexpr int kCorrVariants = 26;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-23: corr_dma_kernel (20-23: channel groups)
+constexpr int kCorrVariants = 28;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-23: corr_dma_kernel (20-23: channel groups)
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
@@ -871,6 +871,8 @@ inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
     case 22: return corr_dma_launch<D, 8, 2, 1, true, 3>(p, s, "corr_dma_v22");   // 15 with three channel groups
     case 24: return corr_dma_launch<D, 4, 4, 5, false>(p, s, "corr_dma_v24");     // 16 with a 4-stage ring (3 stages in flight)
     case 25: return corr_dma_launch<D, 8, 3, 5, false>(p, s, "corr_dma_v25");     // 17 with a 3-stage ring
+    case 26: return corr_dma_launch<D, 8, 2, 5, true>(p, s, "corr_dma_v26");      // 15 held to five waves per SIMD
+    case 27: return corr_dma_launch<D, 16, 2, 5, true>(p, s, "corr_dma_v27");     // two 16-channel stages (C = 32: one barrier pair)
     default: return corr_dma_launch<D, 4, 2, 1, false, 3>(p, s, "corr_dma_v23");  // 16 with three channel groups
   }
 }

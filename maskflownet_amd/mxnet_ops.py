@@ -140,6 +140,7 @@ if mx is not None:
     class _Correlation(_Op):
         def __init__(self, a, act):
             self.a, self.act = a, act
+            self.ws = None
 
         def forward(self, is_train, req, in_data, out_data, aux):
             if req[0] == "null":
@@ -147,9 +148,13 @@ if mx is not None:
             n, c, h, w = in_data[0].shape
             lib = self._begin(in_data[0])
             out = _Out(self, out_data[0], req[0])
-            # no workspace: levels that would want channel slices run their single-launch kernels
+            # scratch for the channel-sliced kernels of the coarse levels (0 bytes where the plan does not slice)
+            need = lib.correlation_workspace_bytes(n, c, h, w, *self.a)
+            if need and (self.ws is None or self.ws.size * 4 < need or self.ws.context != in_data[0].context):
+                self.ws = mx.nd.empty(((need + 3) // 4,), ctx=in_data[0].context)
+            wsp, wsn = (_ptr(self.ws), self.ws.size * 4) if need else (None, 0)
             _check(lib.correlation_fwd_act(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out.buf), n, c, h, w, *self.a,
-                                           self.act, None, 0, None))
+                                           self.act, wsp, wsn, None))
             self._end()
             out.finish()
 
