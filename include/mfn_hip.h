@@ -230,6 +230,38 @@ int mfn_offsets_from_flow(const float *flow_yx, float *offset, int N, int H, int
                           float scale, float stride, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Convolution / Deconvolution -- replace the Gluon blocks of
+ * /root/reference/network/MaskFlownet.py:79-163: nn.Conv2D(channels, kernel_size=3, strides, padding, dilation)
+ * [+ LeakyReLU(0.1)] of conv() / predict_flow() / predict_mask() (:165-191) and nn.Conv2DTranspose(channels, 4, 2, 1)
+ * [+ LeakyReLU(0.1)] of deconv() (:175-183), i.e. MXNet's Convolution / Deconvolution operators:
+ *   Convolution:   out[n,o,y,x] = b[o] + sum_{c,i,j} w[o,c,i,j] * x[n,c, y*sh-ph+i*dh, x*sw-pw+j*dw]      (zero outside)
+ *   Deconvolution: out[n,o,y,x] = b[o] + sum_{c,i,j} w[c,o,i,j] * x[n,c,(y+ph-i*dh)/sh,(x+pw-j*dw)/sw]   (exact divisions only)
+ * x: (N,Cin,H,W); w: (Cout,Cin/groups,kh,kw), transposed: (Cin,Cout/groups,kh,kw); out: (N,Cout,Ho,Wo) from
+ * mfn_conv2d_out_shape.  3x3 convolutions and 4x4 transposed convolutions with groups == 1 run fused gather + fp32-MFMA
+ * implicit GEMM kernels (no im2col buffer); every other parameter set runs a generic kernel.
+ * activation: MFN_ACT_NONE | MFN_ACT_LEAKY_0_1 (fused, bit-identical to the separate elementwise op).
+ * out_batch_stride: elements between consecutive output images (0 = dense): lets a layer write straight into its
+ * channel slice of the decoder's concat buffer (x = concat(conv(x), x), MaskFlownet.py:219-223).
+ * Weights: give `w` (re-laid-out into `workspace` on every call, mfn_conv2d_workspace_bytes) or a buffer made once by
+ * mfn_conv2d_pack_weights + its layout tag (mfn_conv2d_packed_weight_bytes; a tag that does not match the plan of the
+ * current shape / tuning is refused, never silently used).
+ * ------------------------------------------------------------------------------------------- */
+int mfn_conv2d_out_shape(int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int transposed,
+                         int adj_h, int adj_w, int *Ho, int *Wo);
+size_t mfn_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                  int pw, int dh, int dw, int groups, int transposed);
+size_t mfn_conv2d_packed_weight_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                      int pw, int dh, int dw, int groups, int transposed);
+int mfn_conv2d_pack_weights(const float *w, int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw,
+                            int ph, int pw, int dh, int dw, int groups, int transposed, void *packed,
+                            size_t packed_bytes, unsigned long long *layout_tag, void *stream);
+int mfn_conv2d_fwd(const float *x, const float *w_or_null, const void *packed_or_null, size_t packed_bytes,
+                   unsigned long long layout_tag, const float *bias_or_null, float *out, long long out_batch_stride,
+                   int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                   int dw, int groups, int transposed, int adj_h, int adj_w, int activation, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Stream plumbing for the host side (no reference equivalent: MXNet's engine does this).
  * A hot-path pass is ~10 short launches; capturing it once into a hipGraph and replaying it
  * removes the per-launch host cost.  Capture is plain hipStreamBeginCapture on `stream`.

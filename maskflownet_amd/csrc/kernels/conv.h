@@ -1,0 +1,359 @@
+// conv.h -- Convolution / Deconvolution forward for gfx950 as an implicit GEMM on fp32 MFMA.
+//
+// the pyramid, decoder and context convolutions of MaskFlownet_S
+// (/root/reference/network/MaskFlownet.py:79-163: nn.Conv2D 3x3 with stride 1|2 and dilation 1..16 + LeakyReLU(0.1),
+// nn.Conv2DTranspose 4x4 stride 2 pad 1 for upfeat*).  Semantics: MXNet Convolution / Deconvolution
+// (oracle/mfn_ref_body.inc conv2d_fwd / conv2d_transpose_fwd).
+//
+//   out[o, p] = bias[o] + sum_{c,t} W[o, c, t] * x[c, src_t(p)]       (zero outside the image)
+//
+// Same GEMM skeleton as the deformable convolution (deform_conv.h): a wave owns 32 output pixels (a 4x8 patch) x
+// 32*MT filters, K = (channel pair, tap); v_mfma_f32_32x32x2_f32 takes B[k][j] from lane j + 32k, so lane (j, half)
+// loads the T taps of channel 2*cp + half for pixel j -- plain dword loads at per-lane offsets computed once, the
+// next pair's loads in flight while the current pair's T*MT MFMAs issue -- and A streams from the packed weights
+// (dc_pack_weights_kernel's [M-group][pair][tap][half][filter] layout) through a double-buffered LDS-DMA stage.
+// PT = 4: the block's four waves are four pixel tiles sharing the weight stage; PT = 1: four K slices of one
+// pixel tile, added through LDS (coarse levels: few pixels, many channels).
+// conv_generic_kernel covers every other parameter set (groups, other kernel sizes, narrow images).
+#pragma once
+#include "../mfn_rt.h"
+#include "deform_conv.h"
+
+namespace mfn {
+
+struct ConvParams {
+  const float *x;
+  const float *w;     // original layout [generic kernel]: (Cout, Cin/g, kh, kw), transposed: (Cin, Cout/g, kh, kw)
+  const float *wt;    // packed [mgroup][ncp_pad][T][2][32*MT]
+  const float *bias;
+  float *out;
+  int N, Cin, H, W, Cout, Ho, Wo;
+  int kh, kw, sh, sw, ph, pw, dh, dw, groups;
+  int transposed;
+  int tiles_x, tiles_y, ntiles;
+  float inv_tpi, inv_tiles_x;
+  int ncp_pad, cps_per_slice, mgroups;
+  size_t out_nstride;   // elements between consecutive images of `out` (Cout*Ho*Wo when dense; larger = a channel slice
+                        // of a concat buffer, x = concat(conv(x), x) MaskFlownet.py:219)
+  int leaky;            // fused LeakyReLU(0.1) (the reference's conv() = Conv2D + activate)
+  int st_policy, xcd;
+};
+
+// source coordinate of tap (i, jj) for output pixel (ho, wo) along one axis
+template <bool TRANS>
+__device__ __forceinline__ bool conv_src(int o, int tap, int stride, int pad, int dil, int dim, int &src) {
+  if (!TRANS) {
+    src = o * stride - pad + tap * dil;
+    return src >= 0 && src < dim;
+  }
+  const int num = o + pad - tap * dil;   // o = src*stride - pad + tap*dil
+  if (num < 0) { src = 0; return false; }
+  src = num / stride;
+  return (num - src * stride == 0) && src < dim;
+}
+
+// channel pairs per weight chunk: the two stage buffers of a block (KS K-slices x KC pairs x T taps x 2 x 32*MT floats
+// each) stay within 72 KB; 0 = this (MT, PT) combination does not fit
+constexpr int conv_kc(int mt, int pt, int t) {
+  const int unit = (4 / pt) * t * 32 * mt;
+  return 4 * unit <= 4608 ? 4 : (2 * unit <= 4608 ? 2 : 0);
+}
+
+template <int MT, int PT, int KH, int KWD, bool TRANS>
+__global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvParams p) {
+  constexpr int T = KH * KWD;
+  constexpr int NW = 4, NTH = 256;
+  constexpr int KS = NW / PT;              // K slices inside the block
+  constexpr int RL = 32 * MT;
+  constexpr int KC = conv_kc(MT, PT, T);
+  static_assert(KC >= 2, "weight stage does not fit the LDS budget");
+  constexpr int CHUNK_F = KC * T * 2 * RL;
+  constexpr int CH4 = CHUNK_F / 4;
+  constexpr int NI = (KS * CH4 + NTH - 1) / NTH;
+  constexpr int STAGE_F = NI * NTH * 4;
+  MFN_DYN_SHARED(float, lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = MFN_UNIFORM(tid >> 6);
+  const int half = lane >> 5, j = lane & 31;
+  const int pt = wave / KS, ks = wave % KS;
+  const int bx = p.xcd ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tile = bx * PT + pt;
+  const int mg = blockIdx.z;
+  const int m0 = mg * RL;
+
+  const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo;
+  const int plane = H * W;
+  const size_t oplane = (size_t)Ho * Wo;
+
+  // tile -> (image, tile row, tile column); 4x8-pixel tiles never span two images
+  int n, ty, tx;
+  {
+    const int tpi = p.tiles_y * p.tiles_x;
+    const int tl = min(tile, p.ntiles - 1);
+    auto divmod = [](int a, int b, float inv_b, int &q, int &r) {
+      q = (int)((float)a * inv_b);
+      r = a - q * b;
+      if (r < 0) { --q; r += b; }
+      if (r >= b) { ++q; r -= b; }
+    };
+    int rt;
+    divmod(tl, tpi, p.inv_tpi, n, rt);
+    divmod(rt, p.tiles_x, p.inv_tiles_x, ty, tx);
+  }
+  n = MFN_UNIFORM(n);
+  const int tile_ho0 = ty * 4, tile_wo0 = tx * 8;
+  const int ho_ = tile_ho0 + (j >> 3), wo_ = tile_wo0 + (j & 7);
+  const bool px_valid = tile < p.ntiles && ho_ < Ho && wo_ < Wo;
+  const int ho = min(ho_, Ho - 1), wo = min(wo_, Wo - 1);
+
+  // ---- weight staging plan (as dc_lds_kernel) -------------------------------------------------------------
+  const size_t mg_floats = (size_t)p.ncp_pad * T * 2 * RL;
+  const mfn_rsrc_t wrsrc = mfn_make_rsrc(p.wt + (size_t)mg * mg_floats, (unsigned)(mg_floats * 4));
+  unsigned voff[NI];
+  MFN_UNROLL
+  for (int i = 0; i < NI; ++i) {
+    const int it = (i * NW + wave) * 64 + lane;
+    const int k = it / CH4, idx = it - k * CH4;
+    voff[i] = k < KS ? (unsigned)(((size_t)k * p.cps_per_slice * T * 2 * RL + (size_t)idx * 4) * 4) : 0xFFFFFF00u;
+  }
+  auto issue = [&](int ch) {
+    float *buf = lds + (ch & 1) * STAGE_F;
+    const unsigned soff = (unsigned)((size_t)ch * CHUNK_F * 4);
+    MFN_UNROLL
+    for (int i = 0; i < NI; ++i) mfn_dma16_so(wrsrc, buf + (i * NW + wave) * 256, voff[i], soff);
+  };
+  issue(0);
+
+  // ---- tap geometry: per-lane element offset of every tap, relative to channel 2*cp of image n, + validity ----------
+  unsigned off[T];
+  bool val[T];   // loop-invariant lane masks (SGPR pairs): one v_cndmask per tap
+  MFN_UNROLL
+  for (int i = 0; i < KH; ++i) {
+    int sy;
+    const bool vy = conv_src<TRANS>(ho, i, p.sh, p.ph, p.dh, H, sy);
+    MFN_UNROLL
+    for (int q = 0; q < KWD; ++q) {
+      int sx;
+      const bool vx = conv_src<TRANS>(wo, q, p.sw, p.pw, p.dw, W, sx);
+      const bool v = vy && vx && px_valid;
+      off[i * KWD + q] = (unsigned)((v ? sy * W + sx : 0) + half * plane);
+      val[i * KWD + q] = v;
+    }
+  }
+
+  f32x16 acc[MT];
+  MFN_UNROLL
+  for (int mt = 0; mt < MT; ++mt)
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  const float *xn = p.x + (size_t)n * p.Cin * plane;          // uniform
+  const int cp_base = ks * p.cps_per_slice;
+  const int nchunks = p.cps_per_slice / KC;
+  const int ncp = (p.Cin + 1) / 2;
+  const int npairs = MFN_UNIFORM(max(0, min(p.cps_per_slice, ncp - cp_base)));   // pairs of this slice that exist
+
+  // loads of one channel pair: lane (j, half) reads channel 2*cp + half through a uniform base + its 32-bit offset.
+  // An odd Cin's last pair has no second channel: those lanes read the first one and drop the value (their packed
+  // weights are zero as well, but the value could be non-finite).
+  auto load_pair = [&](int cp, float (&v)[T]) {
+    const float *base = xn + (size_t)(2 * cp) * plane;      // uniform
+    if (2 * cp + 1 < p.Cin) {                                // uniform
+      MFN_UNROLL
+      for (int t = 0; t < T; ++t) {
+        const float r = base[off[t]];
+        v[t] = val[t] ? r : 0.f;
+      }
+    } else {
+      MFN_UNROLL
+      for (int t = 0; t < T; ++t) {
+        const float r = base[off[t] - (unsigned)(half * plane)];
+        v[t] = (half == 0 && val[t]) ? r : 0.f;
+      }
+    }
+  };
+
+  static_assert(KC % 2 == 0, "pair k lives in operand buffer k & 1 across chunk boundaries");
+  float vb[2][T];
+  if (npairs > 0) load_pair(cp_base, vb[0]);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    // chunk ch's weights have landed for this wave (they are older than the T loads of the prefetched pair) ...
+    MFN_WAIT_VM(T);
+    MFN_WAIT_LGKM0();
+    MFN_RAW_BARRIER();   // ... and for every wave; nobody reads the other buffer any more
+    if (ch + 1 < nchunks) issue(ch + 1);
+    const float *abuf = lds + (ch & 1) * STAGE_F + ks * CHUNK_F + half * RL + j;
+    MFN_UNROLL
+    for (int kk = 0; kk < KC; ++kk) {
+      const int k = ch * KC + kk;
+      if (k < npairs) {   // uniform
+        if (k + 1 < npairs) load_pair(cp_base + k + 1, vb[(kk + 1) & 1]);   // in flight while pair k's MFMAs issue
+        const float *ap = abuf + (size_t)kk * T * 2 * RL;
+        MFN_UNROLL
+        for (int t = 0; t < T; ++t)
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], vb[kk & 1][t], acc[mt]);
+      }
+    }
+  }
+
+  // ---- in-block K-slice reduction through LDS ------------------------------------------------------------------
+  if (KS > 1) {
+    MFN_WAIT_LGKM0();
+    MFN_RAW_BARRIER();
+    float *red = lds;   // [ks-1][MT*16][64]
+    if (ks != 0) {
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt)
+        MFN_UNROLL
+        for (int r = 0; r < 16; ++r) red[(size_t)(((ks - 1) * MT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+    }
+    __syncthreads();
+    if (ks != 0) return;
+    for (int k = 1; k < KS; ++k) {
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt)
+        MFN_UNROLL
+        for (int r = 0; r < 16; ++r) acc[mt][r] += red[(size_t)(((k - 1) * MT + mt) * 16 + r) * 64 + lane];
+    }
+    MFN_WAIT_LGKM0();  // (only this wave is left) the transposition buffer below reuses this memory
+  } else {
+    MFN_WAIT_LGKM0();
+    MFN_RAW_BARRIER();  // weight stages are dead: their memory becomes the transposition buffers
+  }
+
+  // ---- epilogue: bias, LeakyReLU(0.1), stores.  D reg r of lane (j, half): filter (r&3)+8*(r>>2)+4*half, pixel j ----
+  float *obase = p.out + (size_t)n * p.out_nstride;
+  const bool vec = (Wo % 4 == 0) && ((((size_t)p.out) & 15) == 0) && (p.out_nstride % 4 == 0);
+  if (vec) {
+    // transpose the 32x32 tile through LDS so that a lane holds 4 adjacent pixels of one filter: 16-byte stores
+    constexpr int TS = 40;
+    float *tr = lds + (KS > 1 ? 0 : pt) * (32 * TS);
+    const int quad = lane & 7, orow = lane >> 3;
+    const int px0 = quad * 4;
+    const int oy = tile_ho0 + (px0 >> 3), ox = tile_wo0 + (px0 & 7);
+    const bool tile_ok = tile < p.ntiles;
+    MFN_UNROLL
+    for (int mt = 0; mt < MT; ++mt) {
+      MFN_WAIT_LGKM0();
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + j] = acc[mt][r];
+      MFN_WAIT_LGKM0();
+      MFN_WAVE_SYNC_EMU();
+      MFN_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        const int ol = i * 8 + orow;
+        const int o = m0 + mt * 32 + ol;
+        const float4 v = *reinterpret_cast<const float4 *>(tr + ol * TS + px0);
+        if (tile_ok && o < p.Cout && oy < Ho && ox < Wo) {
+          const float b = p.bias ? p.bias[o] : 0.f;
+          float e[4] = {v.x + b, v.y + b, v.z + b, v.w + b};
+          if (p.leaky) {
+            MFN_UNROLL
+            for (int q = 0; q < 4; ++q) e[q] = fmaxf(e[q], 0.1f * e[q]);
+          }
+          mfn_store4_stream(obase + (size_t)o * oplane + (size_t)oy * Wo + ox, e[0], e[1], e[2], e[3], p.st_policy);
+        }
+      }
+      MFN_WAVE_SYNC_EMU();
+    }
+  } else if (px_valid) {
+    float *on = obase + (size_t)ho * Wo + wo;
+    MFN_UNROLL
+    for (int mt = 0; mt < MT; ++mt)
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) {
+        const int o = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < p.Cout) {
+          float v = acc[mt][r] + (p.bias ? p.bias[o] : 0.f);
+          if (p.leaky) v = fmaxf(v, 0.1f * v);
+          on[(size_t)o * oplane] = v;
+        }
+      }
+  }
+}
+
+template <int MT, int PT, int KH, int KWD>
+inline size_t conv_lds_bytes() {
+  constexpr int T = KH * KWD, RL = 32 * MT, KS = 4 / PT;
+  constexpr int KC = conv_kc(MT, PT, T);
+  constexpr int CH4 = KC * T * 2 * RL / 4;
+  constexpr int NI = (KS * CH4 + 255) / 256;
+  const size_t stage = (size_t)2 * NI * 256 * 16;
+  const size_t red = KS > 1 ? (size_t)(KS - 1) * MT * 16 * 64 * 4 : 0;
+  const size_t tr = (size_t)4 * 32 * 40 * 4;
+  size_t m = stage > red ? stage : red;
+  return m > tr ? m : tr;
+}
+
+template <int MT, int PT, int KH, int KWD, bool TRANS>
+inline int conv_mfma_launch(const ConvParams &p, hipStream_t stream, const char *name) {
+  const int bx = cdiv(p.ntiles, PT);
+  if (bx <= 0) return 0;
+  return launch(name, conv_mfma_kernel<MT, PT, KH, KWD, TRANS>, dim3(bx, 1, p.mgroups), dim3(256),
+                conv_lds_bytes<MT, PT, KH, KWD>(), stream, p);
+}
+
+// weights -> wt[mg][cp][t][half][RL]; regular: w (Cout, Cin, T), transposed: w (Cin, Cout, T)
+struct ConvPackParams { const float *w; float *wt; int Cin, Cout, RL, mgroups, ncp_pad, T, transposed; };
+__global__ __launch_bounds__(256) void conv_pack_weights_kernel(ConvPackParams p) {
+  const size_t total = (size_t)p.mgroups * p.ncp_pad * p.T * 2 * p.RL;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int r = (int)(idx % p.RL);
+  const int half = (int)((idx / p.RL) & 1);
+  const int t = (int)((idx / ((size_t)2 * p.RL)) % p.T);
+  const int cp = (int)((idx / ((size_t)2 * p.RL * p.T)) % p.ncp_pad);
+  const int mg = (int)(idx / ((size_t)2 * p.RL * p.T * p.ncp_pad));
+  const int c = 2 * cp + half, o = mg * p.RL + r;
+  float v = 0.f;
+  if (c < p.Cin && o < p.Cout)
+    v = p.transposed ? p.w[((size_t)c * p.Cout + o) * p.T + t] : p.w[((size_t)o * p.Cin + c) * p.T + t];
+  p.wt[idx] = v;
+}
+inline int conv_pack_launch(ConvPackParams pp, hipStream_t stream) {
+  const size_t total = (size_t)pp.mgroups * pp.ncp_pad * pp.T * 2 * pp.RL;
+  return launch("conv_pack_weights", conv_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pp);
+}
+
+// ---- generic fallback: one thread per output element ------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_generic_kernel(ConvParams p) {
+  const size_t oplane = (size_t)p.Ho * p.Wo;
+  const size_t total = (size_t)p.N * p.Cout * oplane;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int wo = (int)(idx % p.Wo), ho = (int)((idx / p.Wo) % p.Ho);
+  const int o = (int)((idx / oplane) % p.Cout);
+  const int n = (int)(idx / (oplane * p.Cout));
+  const int cpg = p.Cin / p.groups, opg = p.Cout / p.groups;
+  const int g = o / opg, ol = o - g * opg;
+  const size_t plane = (size_t)p.H * p.W;
+  float s = 0.f;
+  for (int cl = 0; cl < cpg; ++cl) {
+    const int c = g * cpg + cl;
+    const float *pl = p.x + ((size_t)n * p.Cin + c) * plane;
+    for (int i = 0; i < p.kh; ++i)
+      for (int q = 0; q < p.kw; ++q) {
+        int sy, sx;
+        bool v;
+        if (p.transposed) v = conv_src<true>(ho, i, p.sh, p.ph, p.dh, p.H, sy) & conv_src<true>(wo, q, p.sw, p.pw, p.dw, p.W, sx);
+        else v = conv_src<false>(ho, i, p.sh, p.ph, p.dh, p.H, sy) & conv_src<false>(wo, q, p.sw, p.pw, p.dw, p.W, sx);
+        if (!v) continue;
+        const float wv = p.transposed ? p.w[(((size_t)c * opg + ol) * p.kh + i) * p.kw + q]
+                                      : p.w[(((size_t)o * cpg + cl) * p.kh + i) * p.kw + q];
+        s = fmaf(wv, pl[(size_t)sy * p.W + sx], s);
+      }
+  }
+  s += p.bias ? p.bias[o] : 0.f;
+  if (p.leaky) s = fmaxf(s, 0.1f * s);
+  p.out[(size_t)n * p.out_nstride + (size_t)o * oplane + (size_t)ho * p.Wo + wo] = s;
+}
+inline int conv_generic_launch(const ConvParams &p, hipStream_t stream) {
+  const size_t total = (size_t)p.N * p.Cout * p.Ho * p.Wo;
+  if (!total) return 0;
+  return launch("conv_generic", conv_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p);
+}
+
+}  // namespace mfn

@@ -387,6 +387,111 @@ class OpSet:
             Cout, kh, kw, ph, pw, dh, dw, num_group, self.ad.ptr(ws), self.ad.nbytes(ws), self.ad.stream(x)))
         return out
 
+    # ---- Convolution / Deconvolution (nn.Conv2D / nn.Conv2DTranspose of MaskFlownet.py:79-163) ----
+    def conv_out_shape(self, H, W, kernel, stride=(1, 1), pad=(0, 0), dilate=(1, 1), transposed=False, adj=(0, 0)):
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw), (ah, aw) = map(self._pair, (kernel, stride, pad, dilate, adj))
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        self.check(self.ns.conv2d_out_shape(H, W, kh, kw, sh, sw, ph, pw, dh, dw, int(bool(transposed)), ah, aw,
+                                            ctypes.byref(ho), ctypes.byref(wo)))
+        return ho.value, wo.value
+
+    def _conv(self, what, transposed, data, weight, bias, kernel, stride, dilate, pad, adj, num_filter, num_group, no_bias,
+              out, activation, packed):
+        if activation not in (None, "leaky"):
+            raise ValueError("%s: activation must be None or 'leaky'" % what)
+        if no_bias:
+            bias = None
+        elif bias is None:
+            raise ValueError("%s: bias is required unless no_bias=True" % what)
+        x, w = self._in(data, weight)
+        b = self._in(bias)[0] if bias is not None else None
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw), (ah, aw) = map(self._pair, (kernel, stride, pad, dilate, adj))
+        if self.ad.ndim(x) != 4:
+            raise ValueError("%s: data must be 4-D" % what)
+        N, Cin, H, W = self.ad.shape(x)
+        g = int(num_group)
+        if transposed:
+            if self.ad.ndim(w) != 4 or self.ad.shape(w)[0] != Cin:
+                raise ValueError("%s: weight shape %s, expected (%d, num_filter/num_group, %d, %d)" % (what, self.ad.shape(w), Cin, kh, kw))
+            Cout = self.ad.shape(w)[1] * g
+            want_w = (Cin, Cout // g, kh, kw)
+        else:
+            Cout = self.ad.shape(w)[0]
+            want_w = (Cout, Cin // g, kh, kw)
+        if num_filter is not None and int(num_filter) != Cout:
+            raise ValueError("%s: num_filter=%s but weight has %d filters" % (what, num_filter, Cout))
+        if Cin % g or Cout % g:
+            raise ValueError("%s: channels must divide num_group" % what)
+        if self.ad.shape(w) != want_w:
+            raise ValueError("%s: weight shape %s, expected %s" % (what, self.ad.shape(w), want_w))
+        if b is not None and self.ad.shape(b) != (Cout,):
+            raise ValueError("%s: bias shape %s, expected (%d,)" % (what, self.ad.shape(b), Cout))
+        Ho, Wo = self.conv_out_shape(H, W, (kh, kw), (sh, sw), (ph, pw), (dh, dw), transposed, (ah, aw))
+        shape = (N, Cout, Ho, Wo)
+        if out is None:
+            out = self.ad.empty(x, shape)
+            nstride = 0
+        else:
+            # `out` may be a channel slice of a concat buffer (x = concat(conv(x), x), MaskFlownet.py:219): dense per
+            # image, images a whole (Ctot, h, w) apart
+            if self.ad.shape(out) != shape:
+                raise ValueError("%s: out has shape %s, expected %s" % (what, self.ad.shape(out), shape))
+            st = self.ad.elem_strides(out)
+            dense_img = all(d <= 1 or a == e for d, a, e in zip(shape[1:], st[1:], (Ho * Wo, Wo, 1)))
+            if N * Cout * Ho * Wo != 0 and (not dense_img or (N > 1 and st[0] < Cout * Ho * Wo)):
+                raise ValueError("%s: out must be contiguous or a channel slice buf[:, c0:c0+%d] of a contiguous NCHW "
+                                 "buffer (strides %s)" % (what, Cout, st))
+            nstride = int(st[0]) if N > 1 else 0
+        dims = (N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, g, int(bool(transposed)))
+        p = lambda a: self.ad.ptr(a) if a is not None else None
+        if packed is not None:
+            packed.require(dims)
+            self.check(self.ns.conv2d_fwd(p(x), None, self.ad.ptr(packed.buf), packed.nbytes, packed.tag, p(b), self.ad.ptr(out),
+                                          nstride, *dims, ah, aw, 1 if activation == "leaky" else 0, None, 0, self.ad.stream(x)))
+            return out
+        nbytes = self.ns.conv2d_workspace_bytes(*dims)
+        ws = self._workspace(x, nbytes) if nbytes else None
+        self.check(self.ns.conv2d_fwd(p(x), p(w), None, 0, 0, p(b), self.ad.ptr(out), nstride, *dims, ah, aw,
+                                      1 if activation == "leaky" else 0, p(ws), self.ad.nbytes(ws) if ws is not None else 0,
+                                      self.ad.stream(x)))
+        return out
+
+    def Convolution(self, data, weight, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0), num_filter=None,
+                    num_group=1, no_bias=False, layout="NCHW", out=None, activation=None, packed=None):
+        """MXNet Convolution (2-D, NCHW).  activation='leaky': the LeakyReLU(0.1) every conv() of the reference is followed
+        by (MaskFlownet.py:165-173), fused; out: optional destination, e.g. a channel slice of a concat buffer."""
+        if layout not in (None, "NCHW"):
+            raise ValueError("Convolution: only layout='NCHW' is supported")
+        return self._conv("Convolution", False, data, weight, bias, kernel, stride, dilate, pad, (0, 0), num_filter, num_group,
+                          no_bias, out, activation, packed)
+
+    def Deconvolution(self, data, weight, bias=None, kernel=(4, 4), stride=(2, 2), dilate=(1, 1), pad=(1, 1), adj=(0, 0),
+                      num_filter=None, num_group=1, no_bias=False, layout="NCHW", out=None, activation=None, packed=None):
+        """MXNet Deconvolution (2-D, NCHW; weight (Cin, num_filter/num_group, kh, kw)) -- nn.Conv2DTranspose of deconv(),
+        MaskFlownet.py:175-183."""
+        if layout not in (None, "NCHW"):
+            raise ValueError("Deconvolution: only layout='NCHW' is supported")
+        return self._conv("Deconvolution", True, data, weight, bias, kernel, stride, dilate, pad, adj, num_filter, num_group,
+                          no_bias, out, activation, packed)
+
+    def pack_conv_weights(self, weight, data_shape, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0), num_group=1,
+                          transposed=False):
+        """Lay constant Convolution / Deconvolution weights out once for inputs of `data_shape` (mfn_conv2d_pack_weights)."""
+        (w,) = self._in(weight)
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw) = map(self._pair, (kernel, stride, pad, dilate))
+        N, Cin, H, W = (int(v) for v in data_shape)
+        g = int(num_group)
+        Cout = self.ad.shape(w)[1] * g if transposed else self.ad.shape(w)[0]
+        dims = (N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, g, int(bool(transposed)))
+        nbytes = self.ns.conv2d_packed_weight_bytes(*dims)
+        if not nbytes:
+            raise ValueError("pack_conv_weights: bad shape %s" % (dims,))
+        buf = self.ad.empty_bytes(w, nbytes)
+        tag = ctypes.c_ulonglong()
+        self.check(self.ns.conv2d_pack_weights(self.ad.ptr(w), *dims, self.ad.ptr(buf), nbytes, ctypes.byref(tag),
+                                               self.ad.stream(w)))
+        return PackedDeformWeights(buf, nbytes, dims, tag.value)
+
     def offsets_from_flow(self, flow, scale, stride, taps=9, out=None):
         (fl,) = self._in(flow)
         N, two, H, W = self.ad.shape(fl)
@@ -506,3 +611,11 @@ def offsets_from_flow(*a, **k):
 
 def Upsample(*a, **k):
     return default_ops().Upsample(*a, **k)
+
+
+def Convolution(*a, **k):
+    return default_ops().Convolution(*a, **k)
+
+
+def Deconvolution(*a, **k):
+    return default_ops().Deconvolution(*a, **k)

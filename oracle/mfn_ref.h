@@ -87,7 +87,18 @@ extern "C" {
   int mfn_ref##SFX##_offsets_from_flow(const REAL *flow_yx, REAL *offset, int N, int H, int W,      \
                                        int taps, REAL scale, REAL stride);                          \
   /* MaskFlownet.py:35-62 Upsample(factor): edge-pad + transposed conv with a triangle kernel. */   \
-  int mfn_ref##SFX##_upsample(const REAL *img, REAL *out, int N, int C, int H, int W, int factor);
+  int mfn_ref##SFX##_upsample(const REAL *img, REAL *out, int N, int C, int H, int W, int factor);   \
+  /* MXNet Convolution / Deconvolution behind nn.Conv2D / nn.Conv2DTranspose of MaskFlownet.py:79-163 */ \
+  int mfn_ref##SFX##_conv2d_out_shape(int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,  \
+                                      int dh, int dw, int transposed, int adj_h, int adj_w, int *Ho, \
+                                      int *Wo);                                                      \
+  int mfn_ref##SFX##_conv2d_fwd(const REAL *x, const REAL *w, const REAL *bias_or_null, REAL *out,  \
+                                int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh,      \
+                                int sw, int ph, int pw, int dh, int dw, int groups);                 \
+  int mfn_ref##SFX##_conv2d_transpose_fwd(const REAL *x, const REAL *w, const REAL *bias_or_null,   \
+                                          REAL *out, int N, int Cin, int H, int W, int Cout, int kh, \
+                                          int kw, int sh, int sw, int ph, int pw, int dh, int dw,    \
+                                          int groups, int adj_h, int adj_w);
 
 MFN_REF_DECLARE(, float)
 MFN_REF_DECLARE(64, double)

@@ -225,5 +225,41 @@ def upsample(img, factor, dtype=np.float32):
     return out
 
 
+def convolution(x, weight, bias=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0), num_group=1,
+                dtype=np.float32):
+    """MXNet Convolution (nn.Conv2D of MaskFlownet.py:79-163)."""
+    xx, w = _c(x, dtype), _c(weight, dtype)
+    b = _c(bias, dtype) if bias is not None else None
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = map(_pair, (kernel, stride, pad, dilate))
+    N, Cin, H, W = xx.shape
+    Cout = w.shape[0]
+    assert w.shape == (Cout, Cin // num_group, kh, kw), w.shape
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    _check(lib().mfn_ref_conv2d_out_shape(H, W, kh, kw, sh, sw, ph, pw, dh, dw, 0, 0, 0, ctypes.byref(ho), ctypes.byref(wo)),
+           "conv2d_out_shape")
+    out = np.empty((N, Cout, ho.value, wo.value), dtype=dtype)
+    _check(_fn("conv2d_fwd", dtype)(_p(xx), _p(w), _p(b), _p(out), N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw,
+                                    num_group), "conv2d_fwd")
+    return out
+
+
+def deconvolution(x, weight, bias=None, kernel=(4, 4), stride=(2, 2), dilate=(1, 1), pad=(1, 1), adj=(0, 0), num_group=1,
+                  dtype=np.float32):
+    """MXNet Deconvolution (nn.Conv2DTranspose of MaskFlownet.py:146-149); weight (Cin, Cout/num_group, kh, kw)."""
+    xx, w = _c(x, dtype), _c(weight, dtype)
+    b = _c(bias, dtype) if bias is not None else None
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw), (ah, aw) = map(_pair, (kernel, stride, pad, dilate, adj))
+    N, Cin, H, W = xx.shape
+    Cout = w.shape[1] * num_group
+    assert w.shape == (Cin, Cout // num_group, kh, kw), w.shape
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    _check(lib().mfn_ref_conv2d_out_shape(H, W, kh, kw, sh, sw, ph, pw, dh, dw, 1, ah, aw, ctypes.byref(ho), ctypes.byref(wo)),
+           "conv2d_out_shape")
+    out = np.empty((N, Cout, ho.value, wo.value), dtype=dtype)
+    _check(_fn("conv2d_transpose_fwd", dtype)(_p(xx), _p(w), _p(b), _p(out), N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh,
+                                              dw, num_group, ah, aw), "conv2d_transpose_fwd")
+    return out
+
+
 def version():
     return lib().mfn_ref_version().decode()

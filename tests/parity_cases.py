@@ -319,3 +319,35 @@ def case_deform_bwd(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, **
     errs = [check_close(to_host(gx), wx, what="deform gx %s" % (kw,)), check_close(to_host(goff), woff, tol=5e-5, what="deform goffset"),
             check_close(to_host(gw), ww, tol=5e-5, what="deform gw"), check_close(to_host(gb), wb, tol=5e-5, what="deform gbias")]
     return max(errs)
+
+
+def case_conv(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, bias=True, leaky=False, tol=TOL, **kw):
+    """Convolution (nn.Conv2D of MaskFlownet.py:79-163) against the oracle's im2col + GEMM restatement."""
+    rng = np.random.default_rng(600 + seed)
+    kernel = kw.get("kernel", (3, 3))
+    g = kw.get("num_group", 1)
+    x = feat(rng, (N, Cin, H, W))
+    w = (rng.standard_normal((Cout, Cin // g) + tuple(kernel)) * np.sqrt(2.0 / (1.01 * Cin // g * kernel[0] * kernel[1]))).astype(np.float32)
+    b = (rng.standard_normal(Cout) * 0.1).astype(np.float32) if bias else None
+    want = oracle.convolution(x, w, b, **kw)
+    if leaky:
+        want = np.where(want > 0, want, np.float32(0.1) * want)
+    got = ops.Convolution(to_dev(x), to_dev(w), to_dev(b) if bias else None, num_filter=Cout, no_bias=not bias,
+                          activation="leaky" if leaky else None, **kw)
+    return check_close(to_host(got), want, tol=tol, what="conv %s %s" % ((N, Cin, Cout, H, W), kw))
+
+
+def case_deconv(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, bias=True, leaky=False, **kw):
+    """Deconvolution (nn.Conv2DTranspose 4x4 / stride 2 / pad 1 of deconv(), MaskFlownet.py:175-183)."""
+    rng = np.random.default_rng(700 + seed)
+    kernel = kw.get("kernel", (4, 4))
+    g = kw.get("num_group", 1)
+    x = feat(rng, (N, Cin, H, W))
+    w = (rng.standard_normal((Cin, Cout // g) + tuple(kernel)) * np.sqrt(2.0 / (1.01 * Cin * 4))).astype(np.float32)
+    b = (rng.standard_normal(Cout) * 0.1).astype(np.float32) if bias else None
+    want = oracle.deconvolution(x, w, b, **kw)
+    if leaky:
+        want = np.where(want > 0, want, np.float32(0.1) * want)
+    got = ops.Deconvolution(to_dev(x), to_dev(w), to_dev(b) if bias else None, num_filter=Cout, no_bias=not bias,
+                            activation="leaky" if leaky else None, **kw)
+    return check_close(to_host(got), want, what="deconv %s %s" % ((N, Cin, Cout, H, W), kw))

@@ -400,3 +400,57 @@ def test_destination_buffers_are_validated_and_old_workspaces_outlive_a_regrow(o
     big = ops._workspace(x, ops.ad.nbytes(small) + 4096)
     assert big is not small and any(r is small for r in ops._retired)
     ops._retired.clear()
+
+
+# ---- f-4b: Convolution / Deconvolution (nn.Conv2D / nn.Conv2DTranspose of MaskFlownet.py:79-163) -------------------
+@pytest.mark.parametrize("mt,pt", [(1, 4), (2, 4), (3, 4), (4, 4), (1, 1), (2, 1)])
+def test_conv3x3_mfma_tilings(ops, oracle, mt, pt):
+    emu_ops.set_tuning(conv_mt=mt, conv_pt=pt)
+    try:
+        pc.case_conv(ops, oracle, ident, ident, 2, 7, 40, 6, 12, pad=(1, 1), leaky=True)          # odd Cin, ragged filters / tiles
+    finally:
+        emu_ops.set_tuning(conv_mt=0, conv_pt=0)
+
+
+@pytest.mark.parametrize("kw", [dict(pad=(1, 1), stride=(2, 2)), dict(pad=(2, 2), dilate=(2, 2)), dict(pad=(4, 4), dilate=(4, 4)),
+                                dict(pad=(0, 0)), dict(pad=(1, 1), bias=False)])
+def test_conv3x3_strides_and_dilations(ops, oracle, kw):
+    kw = dict(kw)
+    bias = kw.pop("bias", True)
+    pc.case_conv(ops, oracle, ident, ident, 1, 6, 10, 11, 19, bias=bias, **kw)
+
+
+@pytest.mark.parametrize("kw", [dict(kernel=(1, 1)), dict(kernel=(5, 3), pad=(2, 1)), dict(kernel=(3, 3), pad=(1, 1), num_group=2)])
+def test_conv_generic_parameter_space(ops, oracle, kw):
+    pc.case_conv(ops, oracle, ident, ident, 2, 6, 8, 7, 9, **kw)
+    pc.case_conv(ops, oracle, ident, ident, 1, 4, 6, 5, 4, pad=(1, 1))          # Wo < 8: generic kernel
+
+
+@pytest.mark.parametrize("pt", [1, 4])
+def test_deconv4x4_mfma(ops, oracle, pt):
+    emu_ops.set_tuning(conv_pt=pt)
+    try:
+        pc.case_deconv(ops, oracle, ident, ident, 2, 9, 16, 5, 6, leaky=True)       # upfeat: Cout = 16, odd Cin
+    finally:
+        emu_ops.set_tuning(conv_pt=0)
+    pc.case_deconv(ops, oracle, ident, ident, 1, 4, 6, 4, 5, kernel=(3, 3), stride=(2, 2), pad=(1, 1), adj=(1, 1))   # generic kernel
+
+
+def test_conv_writes_into_a_concat_slice_and_takes_packed_weights(ops, oracle):
+    """x = concat(conv(x), x) (MaskFlownet.py:219): the layer writes its channels straight into the concat buffer."""
+    rng = np.random.default_rng(5)
+    x = pc.feat(rng, (2, 6, 8, 16))
+    w = (rng.standard_normal((10, 6, 3, 3)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(10).astype(np.float32)
+    buf = np.full((2, 16, 8, 16), np.float32(7.0))
+    buf[:, 10:] = x
+    ops.Convolution(x, w, b, pad=(1, 1), num_filter=10, activation="leaky", out=buf[:, :10])
+    want = oracle.convolution(x, w, b, pad=(1, 1))
+    pc.check_close(buf[:, :10], np.where(want > 0, want, np.float32(0.1) * want))
+    np.testing.assert_array_equal(buf[:, 10:], x)
+    pk = ops.pack_conv_weights(w, x.shape, kernel=(3, 3), pad=(1, 1))
+    a = ops.Convolution(x, w, b, pad=(1, 1), num_filter=10)
+    c = ops.Convolution(x, w, b, pad=(1, 1), num_filter=10, packed=pk)
+    np.testing.assert_array_equal(a, c)
+    with pytest.raises(ValueError, match="laid out for"):
+        ops.Convolution(x[:1], w, b, pad=(1, 1), num_filter=10, packed=pk)

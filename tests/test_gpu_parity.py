@@ -561,3 +561,65 @@ def test_output_store_cache_policies_are_bit_identical(T, policy):
             assert T.equal(a, b)
     finally:
         _lib.set_tuning(store_policy=-1)
+
+
+# ---- f-4b: the pyramid / decoder / context convolutions of MaskFlownet_S (MaskFlownet.py:79-163) ---------------------------
+# (N, Cin, Cout, H, W, kwargs): one layer of every kind at its 384x512 shape (N = 1: the oracle is a scalar loop)
+CONV_LAYERS = [
+    (1, 3, 16, 384, 512, dict(stride=(2, 2), pad=(1, 1))),       # conv1a
+    (1, 16, 16, 192, 256, dict(pad=(1, 1))),                     # conv1b
+    (1, 64, 96, 48, 64, dict(stride=(2, 2), pad=(1, 1))),        # conv4a
+    (2, 128, 196, 12, 16, dict(stride=(2, 2), pad=(1, 1))),      # conv6a (output 6x8)
+    (2, 81, 128, 6, 8, dict(pad=(1, 1))),                        # conv6_0 on the level-6 cost volume
+    (1, 131, 128, 96, 128, dict(pad=(1, 1))),                    # conv2_0: corr2 + c12 + feat2 + flow2
+    (1, 547, 32, 96, 128, dict(pad=(1, 1))),                     # conv2_4 (densely connected)
+    (1, 128, 128, 96, 128, dict(pad=(4, 4), dilate=(4, 4))),     # dc_conv3
+    (1, 96, 64, 96, 128, dict(pad=(16, 16), dilate=(16, 16))),   # dc_conv5
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,kw", CONV_LAYERS)
+def test_conv_network_layers(ops, oracle, dev, N, Cin, Cout, H, W, kw):
+    pc.case_conv(ops, oracle, dev, host, N, Cin, Cout, H, W, leaky=True, **kw)
+
+
+def test_conv_heads_without_activation(ops, oracle, dev):
+    pc.case_conv(ops, oracle, dev, host, 1, 579, 2, 96, 128, pad=(1, 1))      # pred_flow2: two filters
+    pc.case_conv(ops, oracle, dev, host, 2, 529, 1, 12, 16, pad=(1, 1))       # pred_mask5: one filter
+    pc.case_conv(ops, oracle, dev, host, 1, 16, 32, 96, 128, pad=(1, 1), bias=False)
+
+
+@pytest.mark.parametrize("N,Cin,H,W", [(2, 529, 6, 8), (1, 563, 48, 64)])      # upfeat5, upfeat2
+def test_deconv_upfeat_layers(ops, oracle, dev, N, Cin, H, W):
+    pc.case_deconv(ops, oracle, dev, host, N, Cin, 16, H, W, leaky=True)
+
+
+@pytest.mark.parametrize("mt,pt", [(1, 1), (1, 4), (2, 1), (2, 4), (3, 4), (4, 4)])
+def test_conv_every_tiling(ops, oracle, dev, mt, pt):
+    from maskflownet_amd import _lib
+    _lib.set_tuning(conv_mt=mt, conv_pt=pt)
+    try:
+        pc.case_conv(ops, oracle, dev, host, 2, 35, 100, 20, 24, pad=(1, 1), leaky=True)
+    finally:
+        _lib.set_tuning(conv_mt=0, conv_pt=0)
+
+
+def test_conv_full_batch_matches_torch_and_concat_slice(ops, T):
+    """Bench batch (N = 8): against torch's own convolution (a different summation order: 2e-5), written straight into the
+    decoder's concat buffer."""
+    import torch.nn.functional as F
+    g = T.Generator(device="cuda").manual_seed(11)
+    x = T.randn(8, 131, 96, 128, device="cuda", generator=g)
+    w = T.randn(128, 131, 3, 3, device="cuda", generator=g) * 0.03
+    b = T.randn(128, device="cuda", generator=g)
+    buf = T.zeros(8, 259, 96, 128, device="cuda")
+    buf[:, 128:] = x
+    ops.Convolution(buf[:, 128:].contiguous(), w, b, pad=(1, 1), num_filter=128, activation="leaky", out=buf[:, :128])
+    want = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.1)
+    assert (buf[:, :128] - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    assert T.equal(buf[:, 128:], x)
+    wd = T.randn(563, 16, 4, 4, device="cuda", generator=g) * 0.02
+    xd = T.randn(8, 563, 48, 64, device="cuda", generator=g)
+    got = ops.Deconvolution(xd, wd, None, no_bias=True, num_filter=16)
+    want = F.conv_transpose2d(xd, wd, None, stride=2, padding=1)
+    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
