@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--flow", default="smooth", choices=["smooth", "rough"],
                     help="flow fields of the synthetic batch: smooth = Upsample(2)-recursive fields as inside the network "
                          "(default); rough = SURVEY.md 8(d)'s i.i.d. N(0, 2 px) + 2%% outliers per pixel")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the informational end-to-end network forward")
     ap.add_argument("--no-epe", action="store_true",
                     help="skip the network-level EPE delta (MaskFlownet-S end to end, HIP hot path vs the CPU reference path)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -397,6 +398,31 @@ def network_epe_delta(H, W, device):
             "seconds": round(time.perf_counter() - t0, 1)}
 
 
+def end_to_end(N, H, W, device, torch, steps=30):
+    """Informational: the whole MaskFlownet-S forward (71 convolutions / deconvolutions + the hot path) on libmfn_hip.so
+    as one hipGraph -- maskflownet_amd/network.py; seeded MSRAPrelu weights, random images."""
+    from maskflownet_amd import network
+    net = network.MaskFlownetS(network.random_params(seed=1), N, H, W, device=device)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    net.set_input(torch.rand(N, 3, H, W, generator=g) - 0.5, torch.rand(N, 3, H, W, generator=g) - 0.5)
+    net.capture()
+    for _ in range(5):
+        net.replay()
+    net.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        net.replay()
+    net.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ok = bool(torch.isfinite(net.b["flow_full"]).all().item())
+    return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_forward": round(dt * 1e3, 3), "batch": N,
+            "GFLOP_per_forward": round(net.flops() / 1e9, 1), "achieved_TFLOPs": round(net.flops() / dt / 1e12, 1),
+            "frac_of_fp32_peak": round(net.flops() / dt / 1e12 / FP32_PEAK_TFLOPS, 3), "finite": ok,
+            "what": "MaskFlownet-S forward %dx%d end to end (pyramid + decoder + context convolutions, cost volumes, deformable "
+                    "matching, upsampling, warp), every layer a libmfn_hip.so kernel, fp32, one hipGraph replay per forward" % (H, W),
+            "note": "not the headline: `value` above is the matching hot path BASELINE.json's north_star names"}
+
+
 def make_buffers(spec):
     import importlib
     mod, _, fn = spec.partition(":")
@@ -574,6 +600,11 @@ def main():
             res["cpu_baseline_multithread"] = cpu_baseline_threads(wl, min(args.cpu_seconds, 8.0), os.cpu_count() or 1)
         except Exception as e:
             res["cpu_baseline_multithread"] = {"error": repr(e)}
+    if gpu and world == 1 and not args.no_e2e and wl.kind == "S":
+        try:
+            res["e2e"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch)
+        except Exception as e:
+            res["e2e"] = {"error": repr(e)}
     if gpu and world == 1 and not args.no_epe and wl.kind != "train":
         try:
             res["epe"] = network_epe_delta(wl.H, wl.W, "cuda:%d" % torch.cuda.current_device())

@@ -240,8 +240,9 @@ int mfn_offsets_from_flow(const float *flow_yx, float *offset, int N, int H, int
  * mfn_conv2d_out_shape.  3x3 convolutions and 4x4 transposed convolutions with groups == 1 run fused gather + fp32-MFMA
  * implicit GEMM kernels (no im2col buffer); every other parameter set runs a generic kernel.
  * activation: MFN_ACT_NONE | MFN_ACT_LEAKY_0_1 (fused, bit-identical to the separate elementwise op).
- * out_batch_stride: elements between consecutive output images (0 = dense): lets a layer write straight into its
- * channel slice of the decoder's concat buffer (x = concat(conv(x), x), MaskFlownet.py:219-223).
+ * out_batch_stride / in_batch_stride: elements between consecutive output / input images (0 = dense): a layer writes
+ * straight into its channel slice of the decoder's concat buffer and the next layer reads the buffer's channel suffix
+ * (x = concat(conv(x), x), MaskFlownet.py:219-223) -- no concat copies.
  * Weights: give `w` (re-laid-out into `workspace` on every call, mfn_conv2d_workspace_bytes) or a buffer made once by
  * mfn_conv2d_pack_weights + its layout tag (mfn_conv2d_packed_weight_bytes; a tag that does not match the plan of the
  * current shape / tuning is refused, never silently used).
@@ -255,9 +256,9 @@ size_t mfn_conv2d_packed_weight_bytes(int N, int Cin, int H, int W, int Cout, in
 int mfn_conv2d_pack_weights(const float *w, int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                             int ph, int pw, int dh, int dw, int groups, int transposed, void *packed,
                             size_t packed_bytes, unsigned long long *layout_tag, void *stream);
-int mfn_conv2d_fwd(const float *x, const float *w_or_null, const void *packed_or_null, size_t packed_bytes,
-                   unsigned long long layout_tag, const float *bias_or_null, float *out, long long out_batch_stride,
-                   int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+int mfn_conv2d_fwd(const float *x, long long in_batch_stride, const float *w_or_null, const void *packed_or_null,
+                   size_t packed_bytes, unsigned long long layout_tag, const float *bias_or_null, float *out,
+                   long long out_batch_stride, int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
                    int dw, int groups, int transposed, int adj_h, int adj_w, int activation, void *workspace,
                    size_t workspace_bytes, void *stream);
 

@@ -33,8 +33,14 @@ struct ConvParams {
   int tiles_x, tiles_y, ntiles;
   float inv_tpi, inv_tiles_x;
   int ncp_pad, cps_per_slice, mgroups;
+  size_t x_nstride;     // elements between consecutive images of `x` (Cin*H*W when dense; larger = the channel suffix
+                        // buf[:, c0:] of a concat buffer, the input of the next densely connected layer)
   size_t out_nstride;   // elements between consecutive images of `out` (Cout*Ho*Wo when dense; larger = a channel slice
                         // of a concat buffer, x = concat(conv(x), x) MaskFlownet.py:219)
+  int shuffle2;         // 1: the launch is a 4x4 / stride-2 / pad-1 transposed convolution run as a 3x3 convolution on the
+                        // INPUT grid with 4*Cout pseudo-filters o' = 4*o + 2*py + px (one per output parity; five of a
+                        // parity's nine taps carry zero weights): filter o' of grid pixel (y, x) is out[o][2y+py][2x+px].
+                        // Cout / Ho / Wo / bias describe the pseudo problem: Cout = 4 * real filters, Ho x Wo = H x W.
   int leaky;            // fused LeakyReLU(0.1) (the reference's conv() = Conv2D + activate)
   int st_policy, xcd;
 };
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
     MFN_UNROLL
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-  const float *xn = p.x + (size_t)n * p.Cin * plane;          // uniform
+  const float *xn = p.x + (size_t)n * p.x_nstride;            // uniform
   const int cp_base = ks * p.cps_per_slice;
   const int nchunks = p.cps_per_slice / KC;
   const int ncp = (p.Cin + 1) / 2;
@@ -226,8 +232,24 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
 
   // ---- epilogue: bias, LeakyReLU(0.1), stores.  D reg r of lane (j, half): filter (r&3)+8*(r>>2)+4*half, pixel j ----
   float *obase = p.out + (size_t)n * p.out_nstride;
-  const bool vec = (Wo % 4 == 0) && ((((size_t)p.out) & 15) == 0) && (p.out_nstride % 4 == 0);
-  if (vec) {
+  const bool vec = !p.shuffle2 && (Wo % 4 == 0) && ((((size_t)p.out) & 15) == 0) && (p.out_nstride % 4 == 0);
+  if (p.shuffle2) {
+    if (px_valid) {
+      const size_t rplane = 4 * oplane;   // real output plane: (2 Ho) x (2 Wo)
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt)
+        MFN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+          const int op = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // pseudo-filter
+          if (op < p.Cout) {
+            const int o = op >> 2, py = (op >> 1) & 1, pxx = op & 1;
+            float v = acc[mt][r] + (p.bias ? p.bias[o] : 0.f);
+            if (p.leaky) v = fmaxf(v, 0.1f * v);
+            obase[(size_t)o * rplane + (size_t)(2 * ho + py) * (2 * Wo) + 2 * wo + pxx] = v;
+          }
+        }
+    }
+  } else if (vec) {
     // transpose the 32x32 tile through LDS so that a lane holds 4 adjacent pixels of one filter: 16-byte stores
     constexpr int TS = 40;
     float *tr = lds + (KS > 1 ? 0 : pt) * (32 * TS);
@@ -309,8 +331,17 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(ConvPackParams p
   const int mg = (int)(idx / ((size_t)2 * p.RL * p.T * p.ncp_pad));
   const int c = 2 * cp + half, o = mg * p.RL + r;
   float v = 0.f;
-  if (c < p.Cin && o < p.Cout)
-    v = p.transposed ? p.w[((size_t)c * p.Cout + o) * p.T + t] : p.w[((size_t)o * p.Cin + c) * p.T + t];
+  if (c < p.Cin && o < p.Cout) {
+    if (p.transposed == 2) {   // 4x4 / stride 2 / pad 1 transposed conv as 3x3 conv with pseudo-filters o = 4*o_real + 2*py + px:
+      // output row 2y+py takes input rows y-1, y, y+1 (3x3 tap r) through kernel rows {3, 1, -} (py = 0) / {-, 2, 0} (py = 1)
+      const int orl = o >> 2, py = (o >> 1) & 1, px = o & 1, r = t / 3, sx = t - 3 * r;
+      const int iy = py ? (r == 1 ? 2 : (r == 2 ? 0 : -1)) : (r == 0 ? 3 : (r == 1 ? 1 : -1));
+      const int ix = px ? (sx == 1 ? 2 : (sx == 2 ? 0 : -1)) : (sx == 0 ? 3 : (sx == 1 ? 1 : -1));
+      if (iy >= 0 && ix >= 0) v = p.w[(((size_t)c * (p.Cout >> 2) + orl) * 4 + iy) * 4 + ix];
+    } else {
+      v = p.transposed ? p.w[((size_t)c * p.Cout + o) * p.T + t] : p.w[((size_t)o * p.Cin + c) * p.T + t];
+    }
+  }
   p.wt[idx] = v;
 }
 inline int conv_pack_launch(ConvPackParams pp, hipStream_t stream) {
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvParams p) {
   float s = 0.f;
   for (int cl = 0; cl < cpg; ++cl) {
     const int c = g * cpg + cl;
-    const float *pl = p.x + ((size_t)n * p.Cin + c) * plane;
+    const float *pl = p.x + (size_t)n * p.x_nstride + (size_t)c * plane;
     for (int i = 0; i < p.kh; ++i)
       for (int q = 0; q < p.kw; ++q) {
         int sy, sx;

@@ -403,11 +403,18 @@ class OpSet:
             bias = None
         elif bias is None:
             raise ValueError("%s: bias is required unless no_bias=True" % what)
-        x, w = self._in(data, weight)
+        (w,) = self._in(weight)
         b = self._in(bias)[0] if bias is not None else None
         (kh, kw), (sh, sw), (ph, pw), (dh, dw), (ah, aw) = map(self._pair, (kernel, stride, pad, dilate, adj))
-        if self.ad.ndim(x) != 4:
+        if self.ad.ndim(data) != 4:
             raise ValueError("%s: data must be 4-D" % what)
+        # `data` may be the channel suffix buf[:, c0:] of a concat buffer: dense per image, images further apart
+        xst, xsh = self.ad.elem_strides(data), self.ad.shape(data)
+        if xsh[0] > 1 and all(d <= 1 or a == e for d, a, e in zip(xsh[1:], xst[1:], (xsh[2] * xsh[3], xsh[3], 1))) \
+                and xst[0] > xsh[1] * xsh[2] * xsh[3]:
+            x, x_nstride = self.ad.prepare_strided(data), int(xst[0])
+        else:
+            (x,), x_nstride = self._in(data), 0
         N, Cin, H, W = self.ad.shape(x)
         g = int(num_group)
         if transposed:
@@ -446,12 +453,13 @@ class OpSet:
         p = lambda a: self.ad.ptr(a) if a is not None else None
         if packed is not None:
             packed.require(dims)
-            self.check(self.ns.conv2d_fwd(p(x), None, self.ad.ptr(packed.buf), packed.nbytes, packed.tag, p(b), self.ad.ptr(out),
-                                          nstride, *dims, ah, aw, 1 if activation == "leaky" else 0, None, 0, self.ad.stream(x)))
+            self.check(self.ns.conv2d_fwd(p(x), x_nstride, None, self.ad.ptr(packed.buf), packed.nbytes, packed.tag, p(b),
+                                          self.ad.ptr(out), nstride, *dims, ah, aw, 1 if activation == "leaky" else 0, None, 0,
+                                          self.ad.stream(x)))
             return out
         nbytes = self.ns.conv2d_workspace_bytes(*dims)
         ws = self._workspace(x, nbytes) if nbytes else None
-        self.check(self.ns.conv2d_fwd(p(x), p(w), None, 0, 0, p(b), self.ad.ptr(out), nstride, *dims, ah, aw,
+        self.check(self.ns.conv2d_fwd(p(x), x_nstride, p(w), None, 0, 0, p(b), self.ad.ptr(out), nstride, *dims, ah, aw,
                                       1 if activation == "leaky" else 0, p(ws), self.ad.nbytes(ws) if ws is not None else 0,
                                       self.ad.stream(x)))
         return out
@@ -541,6 +549,13 @@ class TorchAdapter:
             raise RuntimeError("%s: out lives on %s, the inputs on %s" % (what, out.device, like.device))
         if not out.is_contiguous():
             raise ValueError("%s: out must be contiguous (strides %s)" % (what, tuple(out.stride())))
+
+    def prepare_strided(self, a):
+        """A float32 device tensor used in place through its strides (no .contiguous() copy)."""
+        t = self.torch
+        if not isinstance(a, t.Tensor) or not a.is_cuda or a.dtype != t.float32:
+            raise TypeError("expected a float32 torch.Tensor on a ROCm device")
+        return a
 
     def ptr(self, a):
         return a.data_ptr()

@@ -24,6 +24,11 @@ class NumpyAdapter:
         if not out.flags["C_CONTIGUOUS"]:
             raise ValueError("%s: out must be contiguous" % what)
 
+    def prepare_strided(self, a):
+        if not isinstance(a, np.ndarray) or a.dtype != np.float32:
+            raise TypeError("float32 ndarray expected")
+        return a
+
     def ptr(self, a):
         return a.ctypes.data
 

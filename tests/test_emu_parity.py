@@ -427,12 +427,16 @@ def test_conv_generic_parameter_space(ops, oracle, kw):
 
 
 @pytest.mark.parametrize("pt", [1, 4])
-def test_deconv4x4_mfma(ops, oracle, pt):
-    emu_ops.set_tuning(conv_pt=pt)
+@pytest.mark.parametrize("shuffle", [1, 0])
+def test_deconv4x4_mfma(ops, oracle, pt, shuffle):
+    """shuffle=1: as a 3x3 convolution with four pseudo-filters per filter (one per output parity) on the input grid;
+    shuffle=0: the masked-tap transposed kernel."""
+    emu_ops.set_tuning(conv_pt=pt, conv_shuffle=shuffle)
     try:
-        pc.case_deconv(ops, oracle, ident, ident, 2, 9, 16, 5, 6, leaky=True)       # upfeat: Cout = 16, odd Cin
+        pc.case_deconv(ops, oracle, ident, ident, 2, 9, 16, 5, 8, leaky=True)       # upfeat: Cout = 16, odd Cin
+        pc.case_deconv(ops, oracle, ident, ident, 1, 4, 10, 6, 9, bias=False)       # ragged tiles, filters not a multiple of 8
     finally:
-        emu_ops.set_tuning(conv_pt=0)
+        emu_ops.set_tuning(conv_pt=0, conv_shuffle=1)
     pc.case_deconv(ops, oracle, ident, ident, 1, 4, 6, 4, 5, kernel=(3, 3), stride=(2, 2), pad=(1, 1), adj=(1, 1))   # generic kernel
 
 
@@ -448,6 +452,13 @@ def test_conv_writes_into_a_concat_slice_and_takes_packed_weights(ops, oracle):
     want = oracle.convolution(x, w, b, pad=(1, 1))
     pc.check_close(buf[:, :10], np.where(want > 0, want, np.float32(0.1) * want))
     np.testing.assert_array_equal(buf[:, 10:], x)
+    # the next densely connected layer reads the buffer's channel suffix in place (no copy) and prepends its output
+    w2 = (rng.standard_normal((4, 16, 3, 3)) * 0.2).astype(np.float32)
+    big = np.full((2, 20, 8, 16), np.float32(-3.0))
+    big[:, 4:] = buf
+    ops.Convolution(big[:, 4:], w2, None, pad=(1, 1), num_filter=4, no_bias=True, out=big[:, :4])
+    pc.check_close(big[:, :4], oracle.convolution(buf, w2, None, pad=(1, 1)))
+    np.testing.assert_array_equal(big[:, 4:], buf)
     pk = ops.pack_conv_weights(w, x.shape, kernel=(3, 3), pad=(1, 1))
     a = ops.Convolution(x, w, b, pad=(1, 1), num_filter=10)
     c = ops.Convolution(x, w, b, pad=(1, 1), num_filter=10, packed=pk)

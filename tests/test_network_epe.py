@@ -52,6 +52,18 @@ def test_harness_has_the_references_structure():
     assert nr.epe_delta(other, out)["epe_delta_rel"] > 1e-2
 
 
+def test_product_network_module_knows_the_same_layers():
+    from maskflownet_amd import network
+    shapes = network.layer_shapes()
+    assert len(shapes) == 71 and sum(int(np.prod(w)) + int(np.prod(b)) for _, w, b in shapes) == 10514256
+    P = nr.Params(seed=0)
+    nr.Net(P, nr.OracleMatching(), "cpu").forward(*nr.synthetic_pair(1, 64, 64, seed=1))
+    assert {n + ".weight": w for n, w, _ in shapes} == {k: v.shape for k, v in P.store.items() if k.endswith(".weight")}
+    rp = network.random_params(seed=3)
+    assert set(rp) == set(P.store) and all(rp[k].shape == P.store[k].shape for k in rp)
+    assert network.from_reference_keys({"conv1a.0.weight": 1, "deform5.weight": 2}) == {"conv1a.weight": 1, "deform5.weight": 2}
+
+
 def test_emulated_kernels_through_the_network():
     im1, im2 = nr.synthetic_pair(1, 64, 64, seed=4)
     ref = nr.Net(nr.Params(seed=2), nr.OracleMatching(), "cpu").forward(im1, im2)
@@ -79,3 +91,28 @@ def test_gpu_network_epe_delta_vs_cpu_reference():
     for k in ("warped", "occlusion"):
         ref = np.abs(cpu[k]).max()
         assert np.abs(hip[k] - cpu[k]).max() <= 2e-4 * ref, k
+
+
+@pytest.mark.gpu
+def test_gpu_network_end_to_end_on_hip_kernels():
+    """maskflownet_amd.network.MaskFlownetS: every layer (71 convolutions / deconvolutions + the matching hot path) on
+    libmfn_hip.so, eager and as one hipGraph, against the CPU reference path (torch CPU convolutions + oracle operators)."""
+    import torch
+    from maskflownet_amd import network
+    im1, im2 = nr.synthetic_pair(2, 384, 512)
+    P = nr.Params(seed=7)
+    cpu = nr.Net(P, nr.OracleMatching(), "cpu").forward(im1, im2)       # creates every parameter
+    net = network.MaskFlownetS(P.store, 2, 384, 512)
+    out = net(im1, im2)
+    got = {k: (v.cpu().numpy() if hasattr(v, "cpu") else [p.cpu().numpy() for p in v]) for k, v in out.items()}
+    d = nr.epe_delta(got, cpu)
+    print("end-to-end HIP network vs CPU reference path: %r" % (d,))
+    assert d["epe_delta_rel"] <= 1e-4, d
+    for a, b in zip(got["predictions"], cpu["predictions"]):
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
+    assert np.abs(got["warped"] - cpu["warped"]).max() <= 5e-4 * np.abs(cpu["warped"]).max()
+    assert np.abs(got["occlusion"] - cpu["occlusion"]).max() <= 1e-4
+    net.capture()
+    again = net(im1, im2)
+    assert torch.equal(again["flow_full"], out["flow_full"])             # the graph replays the same launches
+    assert net.flops() > 7.5e10 * 2                                       # ~40 GFLOP per pair (SURVEY.md 8 f-4)
