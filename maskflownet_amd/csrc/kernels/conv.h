@@ -65,8 +65,12 @@ constexpr int conv_kc(int mt, int pt, int t) {
   return 4 * unit <= 4608 ? 4 : (2 * unit <= 4608 ? 2 : 0);
 }
 
-template <int MT, int PT, int KH, int KWD, bool TRANS>
+// ROW3 (3x3, column dilation 1, pad_w <= 1): the three taps of a kernel row are three adjacent floats -- one
+// dword-aligned global_load_dwordx3 per row instead of three dword gathers.  With one or two filter tiles per wave the
+// kernel is bound by what the texture addresser takes per gather instruction, not by the MFMAs (conv4_2: 46 TFLOP/s).
+template <int MT, int PT, int KH, int KWD, bool TRANS, bool ROW3 = false>
 __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvParams p) {
+  static_assert(!ROW3 || (KH == 3 && KWD == 3 && !TRANS), "ROW3 is the 3x3 convolution's row gather");
   constexpr int T = KH * KWD;
   constexpr int NW = 4, NTH = 256;
   constexpr int KS = NW / PT;              // K slices inside the block
@@ -133,19 +137,35 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
   issue(0);
 
   // ---- tap geometry: per-lane element offset of every tap, relative to channel 2*cp of image n, + validity ----------
-  unsigned off[T];
+  unsigned off[ROW3 ? 3 : T];   // ROW3: one offset per kernel row (its leftmost loaded column)
   bool val[T];   // loop-invariant lane masks (SGPR pairs): one v_cndmask per tap
-  MFN_UNROLL
-  for (int i = 0; i < KH; ++i) {
-    int sy;
-    const bool vy = conv_src<TRANS>(ho, i, p.sh, p.ph, p.dh, H, sy);
+  bool mL = false, mR = false;  // ROW3: the row's three loaded floats start one column right / left of tap 0
+  if (ROW3) {
+    const int sx0 = wo * p.sw - p.pw;                 // column of tap 0
+    const int cs = min(max(sx0, 0), W - 3);           // first loaded column
+    mL = sx0 - cs == -1;                               // left image edge: loaded [0,1,2] are taps 1, 2 and one beyond
+    mR = sx0 - cs == 1;                                // right edge: loaded [W-3..W-1] are one before, taps 0 and 1
     MFN_UNROLL
-    for (int q = 0; q < KWD; ++q) {
-      int sx;
-      const bool vx = conv_src<TRANS>(wo, q, p.sw, p.pw, p.dw, W, sx);
-      const bool v = vy && vx && px_valid;
-      off[i * KWD + q] = (unsigned)((v ? sy * W + sx : 0) + half * plane);
-      val[i * KWD + q] = v;
+    for (int i = 0; i < 3; ++i) {
+      int sy;
+      const bool vy = conv_src<false>(ho, i, p.sh, p.ph, p.dh, H, sy);
+      off[i] = (unsigned)((vy ? sy : 0) * W + cs + half * plane);
+      MFN_UNROLL
+      for (int q = 0; q < 3; ++q) val[i * 3 + q] = vy && px_valid && sx0 + q >= 0 && sx0 + q < W;
+    }
+  } else {
+    MFN_UNROLL
+    for (int i = 0; i < KH; ++i) {
+      int sy;
+      const bool vy = conv_src<TRANS>(ho, i, p.sh, p.ph, p.dh, H, sy);
+      MFN_UNROLL
+      for (int q = 0; q < KWD; ++q) {
+        int sx;
+        const bool vx = conv_src<TRANS>(wo, q, p.sw, p.pw, p.dw, W, sx);
+        const bool v = vy && vx && px_valid;
+        off[(i * KWD + q) % (ROW3 ? 3 : T)] = (unsigned)((v ? sy * W + sx : 0) + half * plane);
+        val[i * KWD + q] = v;
+      }
     }
   }
 
@@ -166,6 +186,22 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
   // weights are zero as well, but the value could be non-finite).
   auto load_pair = [&](int cp, float (&v)[T]) {
     const float *base = xn + (size_t)(2 * cp) * plane;      // uniform
+    if (ROW3) {
+      const bool pair_ok = 2 * cp + 1 < p.Cin;               // uniform; otherwise the upper half re-reads channel 2*cp
+      const unsigned adj = pair_ok ? 0u : (unsigned)(half * plane);
+      const bool c_ok = pair_ok || half == 0;
+      MFN_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        const f3u r = mfn_load3u(base + (off[i] - adj));
+        const float t0 = mR ? r.y : r.x;
+        const float t1 = mL ? r.x : (mR ? r.z : r.y);
+        const float t2 = mL ? r.y : r.z;
+        v[i * 3 + 0] = (c_ok && val[i * 3 + 0]) ? t0 : 0.f;
+        v[i * 3 + 1] = (c_ok && val[i * 3 + 1]) ? t1 : 0.f;
+        v[i * 3 + 2] = (c_ok && val[i * 3 + 2]) ? t2 : 0.f;
+      }
+      return;
+    }
     if (2 * cp + 1 < p.Cin) {                                // uniform
       MFN_UNROLL
       for (int t = 0; t < T; ++t) {
@@ -181,12 +217,21 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
     }
   };
 
-  static_assert(KC % 2 == 0, "pair k lives in operand buffer k & 1 across chunk boundaries");
-  float vb[2][T];
-  if (npairs > 0) load_pair(cp_base, vb[0]);
+  // Operand pipeline: the loads of pair k + PD are issued before the MFMAs of pair k.  With one or two filter tiles per
+  // wave a pair's MFMAs last 0.25 - 0.5 us, less than a global load under load: three pairs ahead there (PD = 3),
+  // one pair ahead with three or four filter tiles.  Every iteration issues exactly one pair's loads (clamped to the
+  // slice's last pair), so the counted waits below are exact.
+  constexpr int PD = (MT <= 2 && KC == 4) ? 3 : 1;
+  constexpr int NB = PD + 1;
+  constexpr int LOADS = ROW3 ? 3 : T;
+  static_assert(KC % NB == 0, "pair k lives in operand buffer k % NB across chunk boundaries");
+  float vb[NB][T];
+  const int cp_last = min(cp_base + max(npairs - 1, 0), max(ncp - 1, 0));
+  MFN_UNROLL
+  for (int d = 0; d < PD; ++d) load_pair(min(cp_base + d, cp_last), vb[d]);
   for (int ch = 0; ch < nchunks; ++ch) {
-    // chunk ch's weights have landed for this wave (they are older than the T loads of the prefetched pair) ...
-    MFN_WAIT_VM(T);
+    // chunk ch's weights have landed for this wave (they are older than the PD pairs of operand loads in flight) ...
+    MFN_WAIT_VM(PD * LOADS);
     MFN_WAIT_LGKM0();
     MFN_RAW_BARRIER();   // ... and for every wave; nobody reads the other buffer any more
     if (ch + 1 < nchunks) issue(ch + 1);
@@ -194,13 +239,13 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
     MFN_UNROLL
     for (int kk = 0; kk < KC; ++kk) {
       const int k = ch * KC + kk;
+      load_pair(min(cp_base + k + PD, cp_last), vb[(kk + PD) % NB]);
       if (k < npairs) {   // uniform
-        if (k + 1 < npairs) load_pair(cp_base + k + 1, vb[(kk + 1) & 1]);   // in flight while pair k's MFMAs issue
         const float *ap = abuf + (size_t)kk * T * 2 * RL;
         MFN_UNROLL
         for (int t = 0; t < T; ++t)
           MFN_UNROLL
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], vb[kk & 1][t], acc[mt]);
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], vb[kk % NB][t], acc[mt]);
       }
     }
   }
@@ -310,11 +355,11 @@ inline size_t conv_lds_bytes() {
   return m > tr ? m : tr;
 }
 
-template <int MT, int PT, int KH, int KWD, bool TRANS>
+template <int MT, int PT, int KH, int KWD, bool TRANS, bool ROW3 = false>
 inline int conv_mfma_launch(const ConvParams &p, hipStream_t stream, const char *name) {
   const int bx = cdiv(p.ntiles, PT);
   if (bx <= 0) return 0;
-  return launch(name, conv_mfma_kernel<MT, PT, KH, KWD, TRANS>, dim3(bx, 1, p.mgroups), dim3(256),
+  return launch(name, conv_mfma_kernel<MT, PT, KH, KWD, TRANS, ROW3>, dim3(bx, 1, p.mgroups), dim3(256),
                 conv_lds_bytes<MT, PT, KH, KWD>(), stream, p);
 }
 

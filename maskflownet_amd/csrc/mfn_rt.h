@@ -14,6 +14,8 @@ typedef f32x16_emu f32x16;
 typedef f32x4_emu f32x4;
 struct f4u { float x, y, z, w; };  // 16 bytes at 4-byte alignment
 static inline f4u mfn_load4u(const float *p) { f4u v; memcpy(&v, p, 16); return v; }
+struct f3u { float x, y, z; };      // 12 bytes at 4-byte alignment
+static inline f3u mfn_load3u(const float *p) { f3u v; memcpy(&v, p, 12); return v; }
 static inline int mfn_f2i(float f) { int i; memcpy(&i, &f, 4); return i; }  // bit pattern
 struct f2u { float x, y; };  // 8 bytes at 4-byte alignment
 static inline f2u mfn_load2u(const float *p) { f2u v; memcpy(&v, p, 8); return v; }
@@ -75,6 +77,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // vector loads) instead of four global_load_dword -- a quarter of the L1 (TA/TCP) accesses
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ f4u mfn_load4u(const float *p) { return *reinterpret_cast<const f4u *>(p); }
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));   // one global_load_dwordx3 at dword alignment
+__device__ __forceinline__ f3u mfn_load3u(const float *p) { return *reinterpret_cast<const f3u *>(p); }
 __device__ __forceinline__ int mfn_f2i(float f) { return __builtin_bit_cast(int, f); }  // bit pattern
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ f2u mfn_load2u(const float *p) { return *reinterpret_cast<const f2u *>(p); }

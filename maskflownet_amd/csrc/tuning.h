@@ -30,6 +30,8 @@
 //   conv.generic 1: force the generic one-thread-per-output convolution kernel
 //   conv.shuffle 0: run 4x4 / stride-2 / pad-1 transposed convolutions with the masked-tap kernel instead of as a 3x3 convolution
 //                with four pseudo-filters per filter (one per output parity)
+//   conv.row3    one dwordx3 load per kernel row instead of three dword gathers (3x3, column dilation 1): 1 = for strided
+//                convolutions (default), 2 = always, 0 = never
 //   conv.mt / conv.pt  32-filter tiles per wave (1..4) / pixel tiles per block (4, or 1 = four in-block K slices); 0 = plan
 #pragma once
 #include <string.h>
@@ -38,7 +40,7 @@ struct Tuning {
   int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0, corr_bwdsplit = 1;
   int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
-  int conv_generic = 0, conv_mt = 0, conv_pt = 0, conv_shuffle = 1;
+  int conv_generic = 0, conv_mt = 0, conv_pt = 0, conv_shuffle = 1, conv_row3 = 1;
   int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
@@ -61,6 +63,7 @@ struct Tuning {
     if (!strcmp(key, "conv.mt")) return &conv_mt;
     if (!strcmp(key, "conv.pt")) return &conv_pt;
     if (!strcmp(key, "conv.shuffle")) return &conv_shuffle;
+    if (!strcmp(key, "conv.row3")) return &conv_row3;
     if (!strcmp(key, "dc.mt")) return &dc_mt;
     if (!strcmp(key, "dc.pt")) return &dc_pt;
     if (!strcmp(key, "dc.ksb")) return &dc_ksb;

@@ -99,6 +99,10 @@ class MaskFlownetS:
         N = self.N
         with torch.cuda.stream(self.stream):
             self.P = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.dev) for k, v in params.items()}
+            # pred_flow_l and pred_mask_l read the same decoder output: one convolution with three filters
+            for l in (6, 5, 4, 3):
+                self.P["heads%d.weight" % l] = torch.cat([self.P["pred_flow%d.weight" % l], self.P["pred_mask%d.weight" % l]]).contiguous()
+                self.P["heads%d.bias" % l] = torch.cat([self.P["pred_flow%d.bias" % l], self.P["pred_mask%d.bias" % l]]).contiguous()
             e = lambda *shape: torch.empty(*shape, device=self.dev)
             self.b["im"] = e(2 * N, 3, H, W)
             h, w = H, W
@@ -111,7 +115,7 @@ class MaskFlownetS:
                 cin0 = 81 if l == 6 else 81 + PYRAMID[l] + UPFEAT + 2
                 self.b["x%d" % l] = e(N, DEC_SUM + cin0, h, w)
                 self.b["flow%d" % l] = e(N, 2, h, w)
-                self.b["dflow%d" % l] = e(N, 2, h, w)
+                self.b["dflow%d" % l] = e(N, 3 if l > 2 else 2, h, w)   # flow increment (2) [+ mask (1)]
                 if l > 2:
                     self.b["mask%d" % l] = e(N, 1, h, w)
                 if l < 6:
@@ -177,13 +181,13 @@ class MaskFlownetS:
             for k, ch in enumerate(DECODER):        # x = concat(conv(x), x): outputs are prepended in place
                 self._conv("conv%d_%d" % (l, k), xb[:, off:], xb[:, off - ch:off])
                 off -= ch
-            self._conv("pred_flow%d" % l, xb, b["dflow%d" % l], act=False)
+            self._conv(("heads%d" if l > 2 else "pred_flow%d") % l, xb, b["dflow%d" % l], act=False)
             if l == 6:
-                b["flow6"].copy_(b["dflow6"])
+                b["flow6"].copy_(b["dflow6"][:, :2])
             else:
-                t.add(b["flow_up%d" % l], b["dflow%d" % l], out=b["flow%d" % l])
+                t.add(b["flow_up%d" % l], b["dflow%d" % l][:, :2], out=b["flow%d" % l])
             if l > 2:
-                self._conv("pred_mask%d" % l, xb, b["mask%d" % l], act=False)
+                b["mask%d" % l].copy_(b["dflow%d" % l][:, 2:3])
                 nxt, Cn = b["x%d" % (l - 1)], PYRAMID[l - 1]
                 self._conv("upfeat%d" % (l - 1), xb, nxt[:, DEC_SUM + 81 + Cn:DEC_SUM + 81 + Cn + UPFEAT], transposed=True)
         y = b["x2"]
