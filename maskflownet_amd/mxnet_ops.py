@@ -447,6 +447,80 @@ if mx is not None:
         def create_operator(self, ctx, shapes, dtypes):
             return _DeformConv(self.p)
 
+    # ---- Convolution / Deconvolution (Gluon nn.Conv2D / nn.Conv2DTranspose of MaskFlownet.py:79-163) ----
+    class _Conv(_Op):
+        def __init__(self, p, transposed):
+            self.p, self.transposed = p, transposed
+            self.ws = None
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            if req[0] == "null":
+                return
+            x, w = in_data[:2]
+            b = in_data[2] if len(in_data) > 2 else None
+            n, cin, h, wd = x.shape
+            cout = out_data[0].shape[1]
+            p = self.p
+            dims = (n, cin, h, wd, cout, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"], p["dh"], p["dw"], p["g"],
+                    int(self.transposed))
+            lib = self._begin(x)
+            need = lib.conv2d_workspace_bytes(*dims)
+            if need and (self.ws is None or self.ws.size * 4 < need or self.ws.context != x.context):
+                self.ws = mx.nd.empty(((need + 3) // 4,), ctx=x.context)
+            out = _Out(self, out_data[0], req[0])
+            _check(lib.conv2d_fwd(_ptr(x), 0, _ptr(w), None, 0, 0, _ptr(b), _ptr(out.buf), 0, *dims, p["ah"], p["aw"], 0,
+                                  _ptr(self.ws) if need else None, self.ws.size * 4 if need else 0, None))
+            self._end()
+            out.finish()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            if any(_REQ[r] for r in req):
+                raise NotImplementedError("mfn_convolution / mfn_deconvolution are forward-only (SURVEY.md 8 f-4b): keep "
+                                          "MXNet's own operators where gradients flow")
+
+    class _ConvPropBase(mx.operator.CustomOpProp):
+        TRANSPOSED = False
+
+        def __init__(self, kernel="(1, 1)", stride="(1, 1)", dilate="(1, 1)", pad="(0, 0)", adj="(0, 0)", num_filter="0",
+                     num_group="1", no_bias="False", layout="None", workspace="1024", cudnn_tune="None", cudnn_off="False",
+                     target_shape="()"):
+            super().__init__(need_top_grad=True)
+            if str(layout) not in ("None", "NCHW"):
+                raise ValueError("only layout='NCHW' is supported, got %r" % (layout,))
+            (kh, kw), (sh, sw), (dh, dw), (ph, pw), (ah, aw) = (_tuple(kernel), _tuple(stride), _tuple(dilate), _tuple(pad),
+                                                                _tuple(adj))
+            self.p = dict(kh=kh, kw=kw, sh=sh, sw=sw, dh=dh, dw=dw, ph=ph, pw=pw, ah=ah, aw=aw, g=int(num_group))
+            self.no_bias = _bool(no_bias)
+            self.num_filter = int(num_filter)
+
+        def list_arguments(self):
+            return ["data", "weight"] + ([] if self.no_bias else ["bias"])
+
+        def list_outputs(self):
+            return ["output"]
+
+        def infer_shape(self, in_shape):
+            n, cin, h, w = in_shape[0]
+            p = self.p
+            ho, wo = ctypes.c_int(), ctypes.c_int()
+            _check(_lib_ns().conv2d_out_shape(h, w, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"], p["dh"], p["dw"],
+                                              int(self.TRANSPOSED), p["ah"], p["aw"], ctypes.byref(ho), ctypes.byref(wo)))
+            cout = self.num_filter
+            wshape = (cin, cout // p["g"], p["kh"], p["kw"]) if self.TRANSPOSED else (cout, cin // p["g"], p["kh"], p["kw"])
+            shapes = [tuple(in_shape[0]), wshape] + ([] if self.no_bias else [(cout,)])
+            return shapes, [(n, cout, ho.value, wo.value)], []
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return _Conv(self.p, self.TRANSPOSED)
+
+    @mx.operator.register("mfn_convolution")
+    class _ConvolutionProp(_ConvPropBase):
+        TRANSPOSED = False
+
+    @mx.operator.register("mfn_deconvolution")
+    class _DeconvolutionProp(_ConvPropBase):
+        TRANSPOSED = True
+
     # ---- Upsample(factor) (MaskFlownet.py:35-62), forward / inference ----------------------------------
     class _Upsample(_Op):
         def __init__(self, factor):
@@ -505,15 +579,20 @@ if mx is not None:
                ("GridGenerator", None, "mfn_grid_generator", ("data",)),
                ("BilinearSampler", None, "mfn_bilinear_sampler", ("data", "grid")),
                ("DeformableConvolution", "contrib", "mfn_deform_conv", ("data", "offset", "weight", "bias")))
+    # the network's other layers, inference only: install(convolutions=True)
+    _CONV_ROUTES = (("Convolution", None, "mfn_convolution", ("data", "weight", "bias")),
+                    ("Deconvolution", None, "mfn_deconvolution", ("data", "weight", "bias")))
     _saved = []
 
-    def install(namespaces=None):
+    def install(namespaces=None, convolutions=False):
         """Route the four operators of the hot path to libmfn_hip.so in mx.nd and mx.sym (both, so that the model
-        keeps working after hybridize(), pipeline.py:25).  uninstall() restores MXNet's own."""
+        keeps working after hybridize(), pipeline.py:25).  convolutions=True also routes F.Convolution / F.Deconvolution
+        (what Gluon's nn.Conv2D / nn.Conv2DTranspose call; forward only -- for --valid / --predict runs).
+        uninstall() restores MXNet's own."""
         for F in (namespaces if namespaces is not None else (mx.nd, mx.sym)):
             if not hasattr(F, "Custom"):
                 continue
-            for name, sub, op_type, arg_names in _ROUTES:
+            for name, sub, op_type, arg_names in _ROUTES + (_CONV_ROUTES if convolutions else ()):
                 holder = getattr(F, sub) if sub else F
                 _saved.append((holder, name, getattr(holder, name, None)))
                 setattr(holder, name, _route(F, op_type, arg_names))

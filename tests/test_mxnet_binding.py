@@ -258,6 +258,35 @@ def test_warp_fused_and_operator_pair(cpu_binding, oracle, clip):
     pc.check_close(FL.grad.asnumpy(), gf, tol=2e-5)
 
 
+def test_gluon_conv_kwargs_route_to_the_convolution_kernels(cpu_binding, oracle):
+    """What Gluon's nn.Conv2D / nn.Conv2DTranspose hand to F.Convolution / F.Deconvolution (gluon/nn/conv_layers.py: kernel,
+    stride, dilate, pad, num_filter, num_group, no_bias, layout [, adj]) for the reference's conv() / deconv() blocks
+    (MaskFlownet.py:165-183), through install(convolutions=True)."""
+    mx, m = cpu_binding
+    m.install(convolutions=True)
+    rng = np.random.default_rng(31)
+    x = pc.feat(rng, (1, 6, 8, 16))
+    w = (rng.standard_normal((10, 6, 3, 3)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(10).astype(np.float32)
+    kw = {"kernel": (3, 3), "stride": (2, 2), "dilate": (1, 1), "pad": (1, 1), "num_filter": 10, "num_group": 1,
+          "no_bias": False, "layout": "NCHW"}
+    out = mx.nd.Convolution(mx.nd.array(x), mx.nd.array(w), mx.nd.array(b), name="fwd", **kw)
+    assert out.writes == 0
+    pc.check_close(out.asnumpy(), oracle.convolution(x, w, b, stride=(2, 2), pad=(1, 1)))
+    wd = (rng.standard_normal((6, 16, 4, 4)) * 0.2).astype(np.float32)
+    kwd = {"kernel": (4, 4), "stride": (2, 2), "dilate": (1, 1), "pad": (1, 1), "adj": (0, 0), "num_filter": 16, "num_group": 1,
+           "no_bias": True, "layout": "NCHW"}
+    out = mx.nd.Deconvolution(mx.nd.array(x), mx.nd.array(wd), name="fwd", **kwd)
+    assert out.shape == (1, 16, 16, 32)
+    pc.check_close(out.asnumpy(), oracle.deconvolution(x, wd, None))
+    X = mx.nd.array(x)
+    X.attach_grad()
+    with mx.autograd.record():
+        y = mx.nd.Convolution(X, mx.nd.array(w), mx.nd.array(b), name="fwd", **kw)
+    with pytest.raises(NotImplementedError):
+        y.backward()
+
+
 def test_forward_only_ops_raise_in_backward(cpu_binding, oracle):
     mx, m = cpu_binding
     x = mx.nd.array(np.ones((1, 2, 4, 8), np.float32))
