@@ -72,6 +72,8 @@ struct CorrParams {
   int xcd_swizzle;     // 1: remap blockIdx so that neighbouring tiles share an XCD's L2
   int leaky;           // fused epilogue (f-1): LeakyReLU(0.1) on the output (MaskFlownet.py:217)
   int ablate;          // measurement only: 1 = drop the output stores, 2 = drop the global loads
+  int stagger;         // LDS-DMA kernel: the k-th resident block of a CU (dispatch round k) starts k * stagger shader
+                       // cycles late, so that the blocks of a CU do not walk their stages in lockstep (0 = off)
   // channel slicing for levels with few pixels and many channels: blockIdx.y = slice, each slice
   // reduces `slice_channels` channels and writes RAW partial sums to partial + slice*N*D*D*H*W;
   // corr_reduce_kernel then sums the slices in a fixed order and normalises (deterministic).
@@ -674,6 +676,15 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
 
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
+#if !defined(MFN_EMU)
+  if (p.stagger) {  // dispatch round of this block: blocks go round-robin over 8 XCDs x 32 CUs
+    const int round = (int)(blockIdx.x >> 8);
+    if (round) {
+      const unsigned long long t_end = __builtin_readcyclecounter() + (unsigned long long)round * (unsigned)p.stagger;
+      while (__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+#endif
   if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)nblk);
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int n = bid / tiles_per_img;

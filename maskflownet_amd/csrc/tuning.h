@@ -10,6 +10,7 @@
 //   corr.generic 1: force the generic one-thread-per-output kernel
 //   corr.bwdsplit 1: the correlation backward computes g1 and g2 in separate blocks of one launch, 2: in separate launches,
 //                 0: one thread computes both
+//   corr.stagger shader cycles by which the LDS-DMA correlation kernel delays the k-th dispatch round of blocks (0 = off)
 //   store.corr / store.dc / store.warp / store.off   the same per kernel family (override store.policy)
 //   store.policy cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
@@ -37,7 +38,7 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0, corr_bwdsplit = 1;
+  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0, corr_bwdsplit = 1, corr_stagger = 0;
   int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
   int conv_generic = 0, conv_mt = 0, conv_pt = 0, conv_shuffle = 1, conv_row3 = 1;
@@ -58,6 +59,7 @@ struct Tuning {
     if (!strcmp(key, "corr.band")) return &corr_band;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
     if (!strcmp(key, "corr.bwdsplit")) return &corr_bwdsplit;
+    if (!strcmp(key, "corr.stagger")) return &corr_stagger;
     if (!strcmp(key, "warp.vec")) return &warp_vec;
     if (!strcmp(key, "conv.generic")) return &conv_generic;
     if (!strcmp(key, "conv.mt")) return &conv_mt;

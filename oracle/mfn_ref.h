@@ -104,6 +104,10 @@ MFN_REF_DECLARE(, float)
 MFN_REF_DECLARE(64, double)
 
 const char *mfn_ref_version(void);
+/* DeformableConvolution forward: 0 = bilinear fractions as MXNet's deformable_im2col.h computes them (default),
+ * 1 = from absolute coordinates as SURVEY.md A.3 states them (mfn_ref.c). */
+void mfn_ref_set_dc_fraction_mode(int mode);
+int mfn_ref_get_dc_fraction_mode(void);
 
 #ifdef __cplusplus
 }

@@ -261,5 +261,10 @@ def deconvolution(x, weight, bias=None, kernel=(4, 4), stride=(2, 2), dilate=(1,
     return out
 
 
+def set_dc_fraction_mode(mode):
+    """0: MXNet's deformable_im2col.h as written (default); 1: SURVEY.md A.3's absolute-coordinate statement."""
+    lib().mfn_ref_set_dc_fraction_mode(int(mode))
+
+
 def version():
     return lib().mfn_ref_version().decode()

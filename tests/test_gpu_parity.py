@@ -623,3 +623,17 @@ def test_conv_full_batch_matches_torch_and_concat_slice(ops, T):
     got = ops.Deconvolution(xd, wd, None, no_bias=True, num_filter=16)
     want = F.conv_transpose2d(xd, wd, None, stride=2, padding=1)
     assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_hot_path_pass_at_bench_size_against_the_oracle(T, cfg):
+    """BASELINE configs[1] / configs[2] at their full size (N=8 384x512, N=4 448x1024): every output of the pass the
+    bench times, replayed from its hipGraph, against the oracle's pass over the same synthetic batch."""
+    from maskflownet_amd import hotpath
+    from oracle import hotpath_ref
+    wl = hotpath.HotPathWorkload(cfg, device="cuda").capture()
+    wl.replay()
+    wl.synchronize()
+    want = hotpath_ref.oracle_pass(wl.host, wl.N)
+    for name, got in zip(wl.output_names(), wl.outputs()):
+        pc.check_close(host(got), want[name], what="%s %s" % (cfg, name))

@@ -137,3 +137,25 @@ def test_backward_zero_offset_matches_conv2d_autograd(oracle):
     np.testing.assert_allclose(gx, xt.grad.numpy(), atol=1e-11)
     np.testing.assert_allclose(gw, wt.grad.numpy(), atol=1e-11)
     np.testing.assert_allclose(gb, bt.grad.numpy(), atol=1e-11)
+
+
+def test_fraction_source_flag_a3_vs_mxnet_kernel(oracle):
+    """SURVEY.md A.3 states the bilinear fractions from the absolute coordinate h_im; MXNet's deformable_im2col.h takes
+    them from the (h_in, w_in)-relative map_h.  The oracle follows the kernel (mode 0) and keeps A.3's form behind a named
+    flag (mode 1): same samples, fp32 results within ~1e-6 -- which one a real MXNet binary does cannot be checked here."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, 6, 11, 13)).astype(np.float32)
+    off = (rng.standard_normal((2, 18, 11, 13)) * 2.5).astype(np.float32)
+    w = (rng.standard_normal((5, 6, 3, 3)) * 0.3).astype(np.float32)
+    a = oracle.deformable_convolution(x, off, w, None, pad=(1, 1))
+    try:
+        oracle.set_dc_fraction_mode(1)
+        b = oracle.deformable_convolution(x, off, w, None, pad=(1, 1))
+        b64 = oracle.deformable_convolution(x, off, w, None, pad=(1, 1), dtype=np.float64)
+    finally:
+        oracle.set_dc_fraction_mode(0)
+    a64 = oracle.deformable_convolution(x, off, w, None, pad=(1, 1), dtype=np.float64)
+    scale = np.abs(a64).max()
+    assert not np.array_equal(a, b)                                   # two different fp32 evaluations ...
+    assert np.abs(a - b).max() <= 5e-6 * scale                        # ... of the same sample
+    assert np.abs(a64 - b64).max() <= 1e-12 * scale                   # identical in exact arithmetic
