@@ -444,8 +444,8 @@ def main():
     if args.backend == "gloo" and gpu:
         sys.exit("bench.py: --backend gloo is the CPU dry run of the launcher and needs --buffers")
     dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
+    if world > 1 or "WORLD_SIZE" in os.environ:   # under a launcher the process group is real even for one rank: RCCL
+        import torch.distributed as dist_mod       # init, barrier, MAX and checksum all-reduce run as they do for N ranks
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if gpu:
@@ -542,7 +542,7 @@ def main():
                    "flow_fields": ("smooth: the reference's Upsample(2) applied recursively to a coarse field, as flow_l is inside "
                                    "the network" if args.flow == "smooth" else
                                    "rough: SURVEY.md 8(d), i.i.d. N(0, 2 px) per pixel + 2% outliers in [-h, h]"),
-                   "backend": (args.backend if world > 1 else None),
+                   "backend": (args.backend if dist is not None else None),
                    **({"tuning_overrides": args.tuning} if args.tuning else {}), "parallelism": "batch shard x%d" % world},
         "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
         "algorithmic_GFLOP_per_step_per_gpu": round(sum(af.values()) / 1e9, 3),

@@ -59,3 +59,30 @@ def test_world_size_must_match_gpus():
 def test_gloo_backend_needs_dry_run_buffers():
     r = _run(["--gpus", "1", "--backend", "gloo", "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0 and "dry run" in r.stderr
+
+
+@pytest.mark.gpu
+def test_rccl_path_runs_on_the_gpu_with_one_rank():
+    """The box has one GPU, so N > 1 cannot run here; what can: the very same code path with a real RCCL process group
+    of one rank under torch.distributed.run (init, barrier, MAX all-reduce of the step time, checksum all-reduce, and
+    for the training pass the all-reduce of the flat gradient bucket)."""
+    for config in ("tiny", "tiny_train"):
+        env = dict(os.environ)
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                            "127.0.0.1", "--master-port", str(29400 + os.getpid() % 500), os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                            "--config", config, "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-epe", "--no-e2e"],
+                           cwd=ROOT, env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert rec["n_gpus"] == 1 and rec["config"]["backend"] == "nccl" and rec["checksum_allreduce_ok"] is True
+        assert rec["value"] > 0 and rec["data"] == "synthetic"
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_gpus_is_refused():
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "0", "--config", "tiny"])
+    assert r.returncode != 0 and "refusing" in r.stderr
