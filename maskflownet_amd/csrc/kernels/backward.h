@@ -925,6 +925,15 @@ constexpr size_t dc_bwd_shared_lds_bytes(int ns) { return (size_t)ns * 32 * (dcs
 // words of a pixel's geometry record
 enum { DCS_AY = 0, DCS_BY = 3, DCS_AX = 6, DCS_BX = 9, DCS_M9 = 12, DCS_FH0 = 21, DCS_FH1 = 24, DCS_FW0 = 27, DCS_FW1 = 30,
        DCS_CELL = 36, DCS_LY0 = 37, DCS_LX0 = 38, DCS_FL = 39 };  // the four ints: one 16-byte read
+// Hand-over of the gx windows (r02, tuning key dc.bwdscratch, NOT the default): instead of flushing its merged 32-channel x 12 x 24 window into gx with ~2 atomics per
+// (pixel, channel) -- 6.5 M device-scope fp32 atomics at level 2, the launch's bound -- a two-strip block stores the window
+// to its slot of a global scratch (plain coalesced stores) and its origin to a table; dc_bwd_gx_gather_kernel then adds, for
+// every gx element, the cells of the windows that cover it (each element has one owner: no atomics).  Measured on the
+// cfg5 pass: shared kernel 547 -> 492 us, gather pass +50 us, step 1.229 -> 1.240 ms -- the flush was not the bound (round
+// 1's reading of the req-by-req timings was wrong: the blocks' per-pixel instructions are).  Blocks whose window
+// follows an offset of more than DCS_FMAX pixels keep the atomic flush (origin = DCS_NO_WINDOW): the gather pass only looks
+// at the windows of tiles at most DCS_RY rows / DCS_RX columns of tiles away.
+constexpr int DCS_FMAX = 8, DCS_RY = 5, DCS_RX = 2, DCS_NO_WINDOW = (int)0x80000000;
 struct DcBwdSParams {
   const float *gout, *x, *offset, *w;
   float *gx, *goffset;
@@ -933,6 +942,8 @@ struct DcBwdSParams {
   int tiles_x, tiles_y;
   int req_x, req_offset;
   unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, per-pixel phase, total} shader cycles
+  float *scratch;                // [block][channel block][32][BR][WC] window slots, or NULL: flush with atomics
+  int *origins;                  // [block][2]: window origin (row, column) or DCS_NO_WINDOW
 };
 
 // one axis of the record: forward weights of tap row i on lines i / i+1 (dc_axis), validity, and the weights of
@@ -979,6 +990,7 @@ __global__ __launch_bounds__(64 * NS) void dc_bwd_input_shared_kernel(DcBwdSPara
   const size_t flag_idx = ((size_t)(n * tpi + ty8 * p.tiles_x + txi)) * 4 + sb * NS + wave;
   const int cb = blockIdx.y * 32;
   int wy0, wx0;  // window origin: follows the offset of the sub-tile's centre pixel; strip w sits 2w rows lower
+  bool far_window;  // the window sits more than DCS_FMAX pixels from its tile: outside the gather pass's search range
   {
     const int cy = min(ty0 + NS, H - 1), cx = min(tx0 + TW / 2, W - 1);
     const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
@@ -986,6 +998,7 @@ __global__ __launch_bounds__(64 * NS) void dc_bwd_input_shared_kernel(DcBwdSPara
     const float fh = fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), fw = fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
     wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - (WR - 5) / 2 + 2 * wave);
     wx0 = MFN_UNIFORM(tx0 - p.pw + (int)fw - (WC - (TW + 3)) / 2);
+    far_window = MFN_UNIFORM((int)(fabsf(fh) > (float)DCS_FMAX || fabsf(fw) > (float)DCS_FMAX)) != 0;
   }
   for (int e = lane; e < 32 * PL; e += 64) win[e] = 0.f;
 
@@ -1230,6 +1243,12 @@ __global__ __launch_bounds__(64 * NS) void dc_bwd_input_shared_kernel(DcBwdSPara
   constexpr int BR = WR + 2 * (NS - 1);     // rows of the block window
   constexpr int CELLS = 32 * BR * WC;
   static_assert(CELLS % (4 * NT) == 0, "merge loop: four cells per thread per trip");
+  const bool hand_over = NS == 2 && p.scratch != nullptr && !far_window;   // uniform
+  if (NS == 2 && p.origins && blockIdx.y == 0 && tid == 0) {
+    p.origins[2 * bx] = hand_over ? bwy0 : DCS_NO_WINDOW;
+    p.origins[2 * bx + 1] = wx0;
+  }
+  float *slot = hand_over ? p.scratch + ((size_t)bx * gridDim.y + blockIdx.y) * CELLS : nullptr;
   for (int e0 = tid; e0 < CELLS; e0 += 4 * NT) {  // four cells per trip, their LDS reads issued together (no branches)
     float v[4];
     int cl[4], R[4], cc[4];
@@ -1250,6 +1269,11 @@ __global__ __launch_bounds__(64 * NS) void dc_bwd_input_shared_kernel(DcBwdSPara
       }
       v[q] = s_;
     }
+    if (hand_over) {   // the window as it is: consecutive threads, consecutive cells
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) slot[e0 + NT * q] = v[q];
+      continue;
+    }
     MFN_UNROLL
     for (int q = 0; q < 4; ++q) {
       const int yy = bwy0 + R[q], xx = wx0 + cc[q];
@@ -1262,6 +1286,52 @@ __global__ __launch_bounds__(64 * NS) void dc_bwd_input_shared_kernel(DcBwdSPara
     unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
     // low halves as the tile kernel's record; high half of [0]: wave 0's wait at the block barrier
     b_[0] = ((tk1 - tk0) & 0xffffffffull) | ((tk4 - tk3) << 32); b_[1] = tk2 - tk1; b_[2] = tk3 - tk2; b_[3] = MFN_CYCLES() - tk0;
+  }
+}
+
+// ---- gather pass of the window hand-over: gx[n][c][y][x] += sum over the windows that cover (y, x) ------------------
+// One block per 4x16-pixel tile and 32-channel block (the shared kernel's two-strip tiling): thread = (pixel, group of 8
+// channels).  Candidate windows: the tiles within DCS_RY tile rows / DCS_RX tile columns (a window is 12 x 24 cells placed
+// at most DCS_FMAX pixels from its tile); a uniform box test rejects the ones that do not reach this tile.
+struct DcBwdGatherParams {
+  const float *scratch;
+  const int *origins;
+  float *gx;
+  int N, Cin, H, W, tiles_x, tiles_y4, cblocks;
+};
+__global__ __launch_bounds__(256) void dc_bwd_gx_gather_kernel(DcBwdGatherParams p) {
+  constexpr int BR = DCS_WR + 2, WC = 24, PLC = BR * WC, CELLS = 32 * PLC;
+  const int tid = threadIdx.x;
+  const int px = tid & 63, cg = tid >> 6;
+  const int bt = (int)mfn_xcd_remap(blockIdx.x, gridDim.x);
+  const int tpi = p.tiles_x * p.tiles_y4;
+  const int n = bt / tpi, rt = bt - n * tpi;
+  const int ty = rt / p.tiles_x, tx = rt - ty * p.tiles_x;
+  const int y0 = ty * 4, x0 = tx * 16;
+  const int y = y0 + (px >> 4), x = x0 + (px & 15);
+  const int cbi = blockIdx.y;
+  float acc[8];
+  MFN_UNROLL
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const int ylo = max(ty - DCS_RY, 0), yhi = min(ty + DCS_RY, p.tiles_y4 - 1);
+  const int xlo = max(tx - DCS_RX, 0), xhi = min(tx + DCS_RX, p.tiles_x - 1);
+  for (int sy = ylo; sy <= yhi; ++sy)
+    for (int sx = xlo; sx <= xhi; ++sx) {
+      const int b = (n * p.tiles_y4 + sy) * p.tiles_x + sx;
+      const int oy = p.origins[2 * b], ox = p.origins[2 * b + 1];                      // uniform
+      if (oy == DCS_NO_WINDOW || oy >= y0 + 4 || oy + BR <= y0 || ox >= x0 + 16 || ox + WC <= x0) continue;
+      const int ry = y - oy, rx = x - ox;
+      if ((unsigned)ry < (unsigned)BR && (unsigned)rx < (unsigned)WC) {
+        const float *src = p.scratch + ((size_t)b * p.cblocks + cbi) * CELLS + (size_t)(cg * 8) * PLC + ry * WC + rx;
+        MFN_UNROLL
+        for (int k = 0; k < 8; ++k) acc[k] += src[(size_t)k * PLC];
+      }
+    }
+  if (y < p.H && x < p.W) {
+    float *dst = p.gx + ((size_t)n * p.Cin + cbi * 32 + cg * 8) * ((size_t)p.H * p.W) + (size_t)y * p.W + x;
+    MFN_UNROLL
+    for (int k = 0; k < 8; ++k)
+      if (cbi * 32 + cg * 8 + k < p.Cin && acc[k] != 0.f) dst[(size_t)k * p.H * p.W] += acc[k];
   }
 }
 

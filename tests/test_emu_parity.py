@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0)
+                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -317,6 +317,16 @@ def test_deform_conv_backward_shared_offsets(ops, oracle, kind):
     full = kind in ("integer", "mixed")
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 34 if kind == "smooth" else 4, 4, 7 if kind == "smooth" else 11, 19, kind,
                               req=("write", "write" if full else "null", "write", "write"))
+
+
+@pytest.mark.parametrize("kind", ["smooth", "outside", "rough"])
+def test_deform_conv_backward_gx_window_hand_over(ops, oracle, kind):
+    """dc.bwdscratch=1 (measured, not the default): the gx windows go through the workspace and a gather pass adds them;
+    windows that follow a far offset ('outside') and neighbourhoods that leave their window ('rough') keep the atomics."""
+    emu_ops.set_tuning(dc_bwdscratch=1)
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 34 if kind == "smooth" else 4, 4, 9, 35, kind,
+                              req=("write", "null", "null", "null"))
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 16, kind, seed=2, req=("write", "null", "null", "null"))
 
 
 def test_deform_conv_backward_shared_offsets_partial_requests_and_switch(ops, oracle):

@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0)
+    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdscratch=0)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -294,6 +294,18 @@ def test_deform_conv_backward_shared_offsets(ops, oracle, dev, kind, N, C, H, W)
     """One (dy,dx) per pixel for all nine taps (MaskFlownet.py:230): dc_bwd_input_shared_kernel takes the strips that
     qualify, the tap-by-tap kernel the rest ('mixed'); borders, far-outside and rough flows included."""
     pc.case_deform_bwd_shared(ops, oracle, dev, host, N, C, C if C != 40 else 36, H, W, kind)
+
+
+@pytest.mark.parametrize("kind", ["smooth", "outside", "rough", "mixed"])
+def test_deform_conv_backward_gx_window_hand_over(ops, oracle, dev, kind):
+    """dc.bwdscratch=1: gx windows handed over through the workspace + gather pass instead of the atomic flush."""
+    from maskflownet_amd import _lib
+    _lib.set_tuning(dc_bwdscratch=1)
+    try:
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 64, 64, 48, 64, kind)
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 40, 36, 27, 45, kind, seed=1)
+    finally:
+        _lib.set_tuning(dc_bwdscratch=0)
 
 
 def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracle, dev, T):
