@@ -182,39 +182,34 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
   const int npairs = MFN_UNIFORM(max(0, min(p.cps_per_slice, ncp - cp_base)));   // pairs of this slice that exist
 
   // loads of one channel pair: lane (j, half) reads channel 2*cp + half through a uniform base + its 32-bit offset.
-  // An odd Cin's last pair has no second channel: those lanes read the first one and drop the value (their packed
-  // weights are zero as well, but the value could be non-finite).
+  // The RAW values go to the operand buffer; validity is applied where they are used (tap_value), pairs later: a select
+  // next to the load makes hipcc wait for the load right there, before the MFMAs it is meant to overlap with.
+  // An odd Cin's last pair has no second channel: those lanes read the first one and the value is dropped at use (their
+  // packed weights are zero as well, but the value could be non-finite).
   auto load_pair = [&](int cp, float (&v)[T]) {
     const float *base = xn + (size_t)(2 * cp) * plane;      // uniform
+    const unsigned adj = (2 * cp + 1 < p.Cin) ? 0u : (unsigned)(half * plane);   // uniform choice
     if (ROW3) {
-      const bool pair_ok = 2 * cp + 1 < p.Cin;               // uniform; otherwise the upper half re-reads channel 2*cp
-      const unsigned adj = pair_ok ? 0u : (unsigned)(half * plane);
-      const bool c_ok = pair_ok || half == 0;
       MFN_UNROLL
       for (int i = 0; i < 3; ++i) {
         const f3u r = mfn_load3u(base + (off[i] - adj));
-        const float t0 = mR ? r.y : r.x;
-        const float t1 = mL ? r.x : (mR ? r.z : r.y);
-        const float t2 = mL ? r.y : r.z;
-        v[i * 3 + 0] = (c_ok && val[i * 3 + 0]) ? t0 : 0.f;
-        v[i * 3 + 1] = (c_ok && val[i * 3 + 1]) ? t1 : 0.f;
-        v[i * 3 + 2] = (c_ok && val[i * 3 + 2]) ? t2 : 0.f;
-      }
-      return;
-    }
-    if (2 * cp + 1 < p.Cin) {                                // uniform
-      MFN_UNROLL
-      for (int t = 0; t < T; ++t) {
-        const float r = base[off[t]];
-        v[t] = val[t] ? r : 0.f;
+        v[i * 3 + 0] = r.x; v[i * 3 + 1] = r.y; v[i * 3 + 2] = r.z;
       }
     } else {
       MFN_UNROLL
-      for (int t = 0; t < T; ++t) {
-        const float r = base[off[t] - (unsigned)(half * plane)];
-        v[t] = (half == 0 && val[t]) ? r : 0.f;
-      }
+      for (int t = 0; t < T; ++t) v[t] = base[off[t] - adj];
     }
+  };
+  // tap t of the pair in operand buffer v; lone: the pair is an odd Cin's last one (upper half has no channel)
+  auto tap_value = [&](const float (&v)[T], int t, bool lone) -> float {
+    float r;
+    if (ROW3) {
+      const int i = t / 3, q = t - 3 * i;
+      r = q == 0 ? (mR ? v[i * 3 + 1] : v[i * 3]) : (q == 1 ? (mL ? v[i * 3] : (mR ? v[i * 3 + 2] : v[i * 3 + 1])) : (mL ? v[i * 3 + 1] : v[i * 3 + 2]));
+    } else {
+      r = v[t];
+    }
+    return (val[t] && !(lone && half)) ? r : 0.f;
   };
 
   // Operand pipeline: the loads of pair k + PD are issued before the MFMAs of pair k.  With one or two filter tiles per
@@ -229,24 +224,44 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
   const int cp_last = min(cp_base + max(npairs - 1, 0), max(ncp - 1, 0));
   MFN_UNROLL
   for (int d = 0; d < PD; ++d) load_pair(min(cp_base + d, cp_last), vb[d]);
+  // A operands: the packed weights hold a lane's MT filter values of a (tap, half) next to each other
+  // ([pair][tap][half][lane j][mt]): one 16- / 8-byte LDS read per tap.  The reads of pair k+1 are issued before the MFMAs
+  // of pair k (second register set) -- except across a chunk boundary, where the other stage buffer is only valid after
+  // the barrier.
+  float areg[2][T][MT];
+  auto load_a = [&](const float *ap, float (&a)[T][MT]) {
+    MFN_UNROLL
+    for (int t = 0; t < T; ++t) {
+      const float *q = ap + (size_t)t * 2 * RL;
+      if (MT == 4) { const float4 v = *reinterpret_cast<const float4 *>(q); a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3 % MT] = v.w; }
+      else if (MT == 2) { const float2 v = *reinterpret_cast<const float2 *>(q); a[t][0] = v.x; a[t][1 % MT] = v.y; }
+      else { MFN_UNROLL for (int mt = 0; mt < MT; ++mt) a[t][mt] = q[mt]; }
+    }
+  };
   for (int ch = 0; ch < nchunks; ++ch) {
     // chunk ch's weights have landed for this wave (they are older than the PD pairs of operand loads in flight) ...
     MFN_WAIT_VM(PD * LOADS);
     MFN_WAIT_LGKM0();
     MFN_RAW_BARRIER();   // ... and for every wave; nobody reads the other buffer any more
     if (ch + 1 < nchunks) issue(ch + 1);
-    const float *abuf = lds + (ch & 1) * STAGE_F + ks * CHUNK_F + half * RL + j;
+    const float *abuf = lds + (ch & 1) * STAGE_F + ks * CHUNK_F + (half * 32 + j) * MT;
+    load_a(abuf, areg[0]);
     MFN_UNROLL
     for (int kk = 0; kk < KC; ++kk) {
       const int k = ch * KC + kk;
+      if (kk + 1 < KC) load_a(abuf + (size_t)(kk + 1) * T * 2 * RL, areg[(kk + 1) & 1]);
       load_pair(min(cp_base + k + PD, cp_last), vb[(kk + PD) % NB]);
+      MFN_SCHED_BARRIER();
       if (k < npairs) {   // uniform
-        const float *ap = abuf + (size_t)kk * T * 2 * RL;
+        const bool lone = 2 * (cp_base + k) + 1 >= p.Cin;   // uniform
         MFN_UNROLL
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; t < T; ++t) {
+          const float bv = tap_value(vb[kk % NB], t, lone);
           MFN_UNROLL
-          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], vb[kk % NB][t], acc[mt]);
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(areg[kk & 1][t][mt], bv, acc[mt]);
+        }
       }
+      MFN_SCHED_BARRIER();
     }
   }
 
@@ -363,18 +378,19 @@ inline int conv_mfma_launch(const ConvParams &p, hipStream_t stream, const char 
                 conv_lds_bytes<MT, PT, KH, KWD>(), stream, p);
 }
 
-// weights -> wt[mg][cp][t][half][RL]; regular: w (Cout, Cin, T), transposed: w (Cin, Cout, T)
+// weights -> wt[mg][cp][t][half][lane j][mt] (filter mg*RL + mt*32 + j); regular: w (Cout, Cin, T), transposed: w (Cin, Cout, T)
 struct ConvPackParams { const float *w; float *wt; int Cin, Cout, RL, mgroups, ncp_pad, T, transposed; };
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(ConvPackParams p) {
   const size_t total = (size_t)p.mgroups * p.ncp_pad * p.T * 2 * p.RL;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const int r = (int)(idx % p.RL);
+  const int r = (int)(idx % p.RL);           // position inside a (tap, half) row: lane j's MT filter values are adjacent
   const int half = (int)((idx / p.RL) & 1);
   const int t = (int)((idx / ((size_t)2 * p.RL)) % p.T);
   const int cp = (int)((idx / ((size_t)2 * p.RL * p.T)) % p.ncp_pad);
   const int mg = (int)(idx / ((size_t)2 * p.RL * p.T * p.ncp_pad));
-  const int c = 2 * cp + half, o = mg * p.RL + r;
+  const int mtn = p.RL / 32, jl = r / mtn, mt = r - jl * mtn;
+  const int c = 2 * cp + half, o = mg * p.RL + mt * 32 + jl;
   float v = 0.f;
   if (c < p.Cin && o < p.Cout) {
     if (p.transposed == 2) {   // 4x4 / stride 2 / pad 1 transposed conv as 3x3 conv with pseudo-filters o = 4*o_real + 2*py + px:
