@@ -683,6 +683,7 @@ struct DcBwdIParams {
   int req_x, req_offset;
   unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, scatter, total} shader cycles
   const int *skip;               // per (tile, strip): non-zero = already done by dc_bwd_input_shared_kernel; may be NULL
+  int skip_tiles;                // 1: `skip` holds one flag per 4x8-pixel tile [n][cdiv(H,4)][cdiv(W,8)] (dc_bwd_input_pix_kernel)
 };
 constexpr int DCI_TH = 8, DCI_TW = 16, DCI_WR = 10, DCI_WC = 28, DCI_GW = 16;
 constexpr int DCI_PLANE = DCI_WR * DCI_WC + 1;  // odd channel-plane stride: the 32 lanes (channels) hit distinct banks
@@ -705,7 +706,20 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   const int cb = blockIdx.y * 32;
   // strips the shared-offset kernel has finished: skipped here (a block whose four strips are all done leaves at once)
   bool skipw = false;
-  if (p.skip) {
+  int done_l = 0, done_r = 0;  // 4x8-tile flags of this strip's left / right half (skip_tiles)
+  if (p.skip && p.skip_tiles) {
+    // the 8x16 tile is four 4x8 tiles (a, b); tiles past the image edge count as done
+    const int ty4 = (H + 3) >> 2, tx8 = (W + 7) >> 3;
+    const int ta = 2 * (rt / p.tiles_x), tb = 2 * (rt % p.tiles_x);
+    auto flag = [&](int a, int b) {
+      return (ta + a < ty4 && tb + b < tx8) ? p.skip[((size_t)n * ty4 + ta + a) * tx8 + tb + b] : 1;
+    };
+    const int f00 = flag(0, 0), f01 = flag(0, 1), f10 = flag(1, 0), f11 = flag(1, 1);
+    if (MFN_UNIFORM((int)(f00 && f01 && f10 && f11))) return;
+    done_l = MFN_UNIFORM((wave >> 1) ? f10 : f00);
+    done_r = MFN_UNIFORM((wave >> 1) ? f11 : f01);
+    skipw = done_l && done_r;
+  } else if (p.skip) {
     const int *sk = p.skip + (size_t)bx * 4;
     const int s0 = sk[0], s1 = sk[1], s2 = sk[2], s3 = sk[3];
     if (MFN_UNIFORM((int)(s0 && s1 && s2 && s3))) return;
@@ -725,7 +739,8 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
 
   // this lane as a PIXEL of the strip (geometry build, MFMA A operand) ...
   const int py = ty0 + 2 * wave + (j >> 4), px = tx0 + (j & 15);
-  const bool pix_ok = py < H && px < W;
+  // pixels of 4x8 tiles that dc_bwd_input_pix_kernel has finished take no part here
+  const bool pix_ok = py < H && px < W && !(((j & 15) >> 3) ? done_r : done_l);
   const int pyc = min(py, H - 1), pxc = min(px, W - 1);
   const size_t pix = (size_t)pyc * W + pxc;
   // ... and as a CHANNEL (MFMA B operand, D column, owner of one window plane)

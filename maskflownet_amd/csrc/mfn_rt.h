@@ -46,6 +46,10 @@ static inline float mfn_half_sum_top(float v) {
 // emulated lanes are free-running threads: where the hardware's in-order LDS pipe orders two lanes' accesses, the
 // emulation needs a wave barrier
 #define MFN_WAVE_SYNC_EMU() (hipemu::wave().bar.arrive_and_wait())
+// a lane's sequence of LDS read-add-writes that the hardware interleaves with the other lanes' instruction by instruction
+// (in order): the free-running emulated lanes run the whole sequence one lane at a time instead -- same sums
+#define MFN_EMU_LOCK() (hipemu::t_block->mu.lock())
+#define MFN_EMU_UNLOCK() (hipemu::t_block->mu.unlock())
 MFN_WAVE_REDUCE_EMU(mfn_wave_min_i32, std::min)
 MFN_WAVE_REDUCE_EMU(mfn_wave_max_i32, std::max)
 // LDS-DMA emulation: synchronous copy (ordering of the real asynchronous engine is checked on the GPU)
@@ -64,6 +68,8 @@ static inline void mfn_dma16_so(mfn_rsrc_t r, float *lds_wave_base, unsigned vof
 #define MFN_WAIT_VM(n) (hipemu::wave().bar.arrive_and_wait())
 #define MFN_WAIT_LGKM0() (hipemu::wave().bar.arrive_and_wait())
 #define MFN_RAW_BARRIER() __syncthreads()
+#define MFN_LDS_BARRIER() __syncthreads()
+#define MFN_COMPILER_FENCE() ((void)0)
 #define MFN_STAMP(buf, k) ((void)0)
 #define MFN_CYCLES() 0ull
 #else
@@ -110,6 +116,8 @@ __device__ __forceinline__ int mfn_wave_min_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 #define MFN_WAVE_SYNC_EMU() ((void)0)
+#define MFN_EMU_LOCK() ((void)0)
+#define MFN_EMU_UNLOCK() ((void)0)
 // sum over the 32 lanes of each half-wave as a DPP scan (no LDS); valid in the top lane (31 / 63) of the half
 __device__ __forceinline__ float mfn_half_sum_top(float v) {
 #define MFN_DPP_ADD_(ctrl, rmask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
@@ -161,6 +169,12 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 #define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
+// block barrier for data handed over through LDS: this wave's LDS operations are complete before it, and the compiler keeps
+// every memory access on its side of it (the bare s_barrier builtin does not stop hipcc from hoisting later LDS reads above it)
+// the compiler keeps memory accesses on their side of this point (no instruction): LDS accesses whose ORDER matters to other
+// lanes of the wave -- the in-order LDS pipe does the rest
+#define MFN_COMPILER_FENCE() asm volatile("" ::: "memory")
+#define MFN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // measurement only: constant-rate (100 MHz) wall clock stamps, one writer per block
 #define MFN_CYCLES() ((unsigned long long)clock64())
 // measurement only: bit 0 of the buffer address selects the shader-cycle counter instead of the 100 MHz wall clock.

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -69,6 +70,7 @@ struct Block {
   std::unique_ptr<std::barrier<>> bar;
   std::vector<std::unique_ptr<Wave>> waves;
   std::vector<unsigned char> lds;
+  std::mutex mu;  // MFN_EMU_LOCK: sections that the hardware orders through its in-order LDS pipe
 };
 
 extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
