@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0)
+                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -319,17 +319,37 @@ def test_deform_conv_backward_shared_offsets(ops, oracle, kind):
                               req=("write", "write" if full else "null", "write", "write"))
 
 
+@pytest.mark.parametrize("kind", ["smooth", "integer", "outside", "rough", "mixed"])
+def test_deform_conv_backward_lane_is_pixel(ops, oracle, kind):
+    """dc_bwd_input_pix_kernel (W % 4 == 0, Cin % 4 == 0): 8x16 regions of four 4x8 tiles, ragged at the right and bottom
+    edges; pixels that share a plane cell (turns and merged pairs: 'smooth' has sub-pixel noise, 'integer' lattice steps),
+    neighbourhoods that leave the source window / the region's plane ('outside', 'rough': global loads and direct
+    atomics), per-tap offsets ('mixed': flag 0, the tile kernel does those 4x8 tiles pixel by pixel)."""
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 11, 20, kind, req=("write", "write", "null", "null"))
+
+
+def test_deform_conv_backward_lane_is_pixel_channel_blocks_and_requests(ops, oracle):
+    # two channel blocks (the second ragged: 36 channels), three filter chunks (the last ragged: 36 filters), two images
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 36, 36, 9, 16, "smooth", req=("write", "write", "null", "null"))
+    # one gradient at a time, and accumulation into the caller's buffers
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "outside", req=("write", "null", "null", "null"))
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "rough", seed=1, req=("null", "write", "null", "null"))
+    emu_ops.set_tuning(dc_bwdpix=0)   # the lane = channel kernel gives the same gradients
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "smooth", seed=2, req=("write", "write", "null", "null"))
+
+
 @pytest.mark.parametrize("kind", ["smooth", "outside", "rough"])
 def test_deform_conv_backward_gx_window_hand_over(ops, oracle, kind):
     """dc.bwdscratch=1 (measured, not the default): the gx windows go through the workspace and a gather pass adds them;
     windows that follow a far offset ('outside') and neighbourhoods that leave their window ('rough') keep the atomics."""
-    emu_ops.set_tuning(dc_bwdscratch=1)
+    emu_ops.set_tuning(dc_bwdscratch=1, dc_bwdpix=0)
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 34 if kind == "smooth" else 4, 4, 9, 35, kind,
                               req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 16, kind, seed=2, req=("write", "null", "null", "null"))
 
 
 def test_deform_conv_backward_shared_offsets_partial_requests_and_switch(ops, oracle):
+    emu_ops.set_tuning(dc_bwdpix=0)   # the lane = channel kernel and its block shapes
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", req=("null", "write", "null", "null"))
     emu_ops.set_tuning(dc_bwdstrips=4)   # four-strip blocks

@@ -296,16 +296,47 @@ def test_deform_conv_backward_shared_offsets(ops, oracle, dev, kind, N, C, H, W)
     pc.case_deform_bwd_shared(ops, oracle, dev, host, N, C, C if C != 40 else 36, H, W, kind)
 
 
+@pytest.mark.parametrize("kind", ["smooth", "rough", "mixed"])
+def test_deform_conv_backward_shared_offsets_lane_is_channel(ops, oracle, dev, kind):
+    """dc.bwdpix=0: dc_bwd_input_shared_kernel (lane = channel), what the shapes above ran on before dc_backward.h."""
+    from maskflownet_amd import _lib
+    _lib.set_tuning(dc_bwdpix=0)
+    try:
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 96, 96, 24, 32, kind)
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 96, 128, kind)
+    finally:
+        _lib.set_tuning(dc_bwdpix=1)
+
+
+def test_deform_conv_backward_lane_is_pixel_requests_and_accumulation(ops, oracle, dev):
+    """dc_bwd_input_pix_kernel with one gradient requested at a time, with ragged channel / filter blocks, at the full
+    bench batch of level 4, and adding into the caller's buffers (req 'add')."""
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("write", "null", "null", "null"))
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "outside", req=("null", "write", "null", "null"))
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 44, 52, 27, 44, "smooth")
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 8, 96, 96, 24, 32, "smooth", seed=3)
+    rng = np.random.default_rng(5)
+    N, C, H, W = 2, 32, 24, 32
+    x, w = pc.feat(rng, (N, C, H, W)), (rng.standard_normal((C, C, 3, 3)) * 0.2).astype(np.float32)
+    off, go = pc.shared_offsets(rng, N, H, W, "smooth"), rng.standard_normal((N, C, H, W)).astype(np.float32)
+    want = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=(3, 3), pad=(1, 1))
+    base = [rng.standard_normal(t.shape).astype(np.float32) for t in want[:2]]
+    got = ops.DeformableConvolution_backward(dev(go), dev(x), dev(off), dev(w), kernel=(3, 3), pad=(1, 1),
+                                             req=("add", "add", "null", "null"), out=(dev(base[0]), dev(base[1]), None, None))
+    pc.check_close(host(got[0]), want[0] + base[0], tol=2e-5, what="lane = pixel gx, req add")
+    pc.check_close(host(got[1]), want[1] + base[1], tol=5e-5, what="lane = pixel goffset, req add")
+
+
 @pytest.mark.parametrize("kind", ["smooth", "outside", "rough", "mixed"])
 def test_deform_conv_backward_gx_window_hand_over(ops, oracle, dev, kind):
     """dc.bwdscratch=1: gx windows handed over through the workspace + gather pass instead of the atomic flush."""
     from maskflownet_amd import _lib
-    _lib.set_tuning(dc_bwdscratch=1)
+    _lib.set_tuning(dc_bwdscratch=1, dc_bwdpix=0)
     try:
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 64, 64, 48, 64, kind)
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 40, 36, 27, 45, kind, seed=1)
     finally:
-        _lib.set_tuning(dc_bwdscratch=0)
+        _lib.set_tuning(dc_bwdscratch=0, dc_bwdpix=1)
 
 
 def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracle, dev, T):
@@ -313,14 +344,14 @@ def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracl
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("null", "write", "write", "write"))
     try:
-        for strips in (2, 4):   # both block shapes of the shared-offset kernel, whatever the heuristic would pick
-            _lib.set_tuning(dc_bwdstrips=strips)
+        for strips in (2, 4):   # both block shapes of the lane = channel kernel, whatever the heuristic would pick
+            _lib.set_tuning(dc_bwdstrips=strips, dc_bwdpix=0)
             pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 40, 36, 27, 45, "smooth")
             pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "mixed")
         _lib.set_tuning(dc_bwdshared=0)
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth")
     finally:
-        _lib.set_tuning(dc_bwdshared=1, dc_bwdstrips=0)
+        _lib.set_tuning(dc_bwdshared=1, dc_bwdstrips=0, dc_bwdpix=1)
     # straight through the C ABI with workspace = NULL: tap-by-tap kernel only, same gradients
     rng = np.random.default_rng(1)
     N, C, H, W = 1, 8, 16, 16

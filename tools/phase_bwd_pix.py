@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Measurement: per-block shader cycles of dc_bwd_input_pix_kernel by phase (setup / MFMA / offset gradient / input
-gradient + flush; wave 0 of each block), the share of 4x8 tiles it takes, and the launch's duration, per cfg2 level."""
+"""Measurement: per-block shader cycles of dc_bwd_input_pix_kernel by phase (setup + MFMA / offset gradient / input
+gradient / flush; wave 0 of each block), the share of 4x8 tiles it takes, and the launch's duration, per cfg2 level."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from maskflownet_amd import _lib, hotpath
 from maskflownet_amd.ops import default_ops
+DETAIL = "detail" in sys.argv[1:]
 for kv in sys.argv[1:]:
+    if "=" not in kv:
+        continue
     k, v = kv.split("=")
     _lib.set_tuning(**{k: int(v)})
 lib = _lib.lib(); ops = default_ops()
@@ -28,9 +31,14 @@ for l in (2, 3, 4, 5):
         lib.profile_enable(0); torch.cuda.synchronize()
         buf = ctypes.create_string_buffer(8192); lib.profile_dump(buf, 8192); lib.profile_reset()
         us = {ln.split()[0]: float(ln.split()[2]) / int(ln.split()[1]) * 1e3 for ln in buf.value.decode().splitlines()}
-        lib.debug_set_timeline(tl.data_ptr()); fn(); torch.cuda.synchronize(); lib.debug_set_timeline(None)
-        t = tl.cpu().numpy().reshape(nblk, 4).astype(np.float64)
+        lib.debug_set_timeline(tl.data_ptr() | (1 if DETAIL else 0)); fn(); torch.cuda.synchronize(); lib.debug_set_timeline(None)
+        raw = tl.cpu().numpy().reshape(nblk, 4)
+        mf = (raw[:, 0] >> 32).astype(np.float64); raw[:, 0] &= 0xffffffff
+        t = np.concatenate([raw.astype(np.float64), mf[:, None]], axis=1)[:, [0, 4, 1, 2, 3]]
         nfl = n * ((h + 3) // 4) * ((w + 7) // 8)
         fl = max((ws.view(torch.int32)[:nfl].cpu().numpy() for ws in ops._ws.values()), key=lambda a: a.mean())
-        print("L%d gx=%-5s goffset=%-5s blocks %4d tiles taken %.3f | median cycles setup %6.0f  mfma %6.0f  phase A %6.0f  phase B + flush %6.0f  sum %6.0f | pix %.1f us, tile %.1f us"
+        if DETAIL:
+            print("L%d gx=%-5s goffset=%-5s phase B, first group: median cycles fold + shuffles %6.0f  walk %6.0f  barrier wait %6.0f" % (l, req[0], req[1], *np.median(t[:, 2:5], axis=0)), flush=True)
+            continue
+        print("L%d gx=%-5s goffset=%-5s blocks %4d tiles taken %.3f | median cycles setup %6.0f  mfma %6.0f  phase A %6.0f  phase B %6.0f  flush %6.0f  sum %6.0f | pix %.1f us, tile %.1f us"
               % (l, req[0], req[1], nblk, fl.mean(), *np.median(t, axis=0), np.median(t.sum(1)), us.get("dc_bwd_input_pix", 0), us.get("dc_bwd_input_tile", 0)), flush=True)
