@@ -169,11 +169,11 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 #define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
-// block barrier for data handed over through LDS: this wave's LDS operations are complete before it, and the compiler keeps
-// every memory access on its side of it (the bare s_barrier builtin does not stop hipcc from hoisting later LDS reads above it)
 // the compiler keeps memory accesses on their side of this point (no instruction): LDS accesses whose ORDER matters to other
 // lanes of the wave -- the in-order LDS pipe does the rest
 #define MFN_COMPILER_FENCE() asm volatile("" ::: "memory")
+// block barrier for data handed over through LDS: this wave's LDS operations are complete before it, and the compiler keeps
+// every memory access on its side of it (the bare s_barrier builtin does not stop hipcc from hoisting later LDS reads above it)
 #define MFN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // measurement only: constant-rate (100 MHz) wall clock stamps, one writer per block
 #define MFN_CYCLES() ((unsigned long long)clock64())

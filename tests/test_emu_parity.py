@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1)
+                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1, dc_bwdwpix=1, dc_bwdwblocks=0)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -336,6 +336,22 @@ def test_deform_conv_backward_lane_is_pixel_channel_blocks_and_requests(ops, ora
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "rough", seed=1, req=("null", "write", "null", "null"))
     emu_ops.set_tuning(dc_bwdpix=0)   # the lane = channel kernel gives the same gradients
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "smooth", seed=2, req=("write", "write", "null", "null"))
+
+
+@pytest.mark.parametrize("kind", ["smooth", "outside", "mixed"])
+def test_deform_conv_backward_weight_lane_is_pixel(ops, oracle, kind):
+    """dc_bwd_weight_pix_kernel + dc_bwd_weight_reduce_kernel: ragged tiles, staged windows ('smooth'), the per-tap
+    producer ('outside' windows that do not fit, 'mixed' per-tap offsets); then a long tile pipeline (two blocks walk 16
+    tiles each: geometry of the next four tiles one tile ahead, two window sets) and the kernel it replaced."""
+    req = ("null", "null", "write", "write")
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 11, 20, kind, req=req)
+    emu_ops.set_tuning(dc_bwdwblocks=2)
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 8, 8, 13, 28, kind, seed=1, req=req)
+    if kind == "smooth":
+        emu_ops.set_tuning(dc_bwdwblocks=0)
+        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 40, 9, 16, kind, seed=2, req=req)   # ragged channel / filter tiles
+        emu_ops.set_tuning(dc_bwdwpix=0)
+        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 11, 20, kind, seed=3, req=req)
 
 
 @pytest.mark.parametrize("kind", ["smooth", "outside", "rough"])

@@ -366,6 +366,43 @@ def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracl
     want = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=(3, 3), pad=(1, 1))
     pc.check_close(host(gx), want[0], tol=2e-5, what="NULL workspace gx")
     pc.check_close(host(goff), want[1], tol=5e-5, what="NULL workspace goffset")
+    # ... and the parameter gradients without a workspace: the blocks' sums meet in gw / gbias through atomics
+    gw, gb = T.empty_like(tw), T.empty(C, device="cuda")
+    _lib.check(lib.deform_conv_bwd(tgo.data_ptr(), tx.data_ptr(), toff.data_ptr(), tw.data_ptr(), None, None, gw.data_ptr(),
+                                   gb.data_ptr(), N, C, H, W, C, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, None, 0,
+                                   T.cuda.current_stream().cuda_stream))
+    pc.check_close(host(gw), want[2], tol=5e-5, what="NULL workspace gw")
+    pc.check_close(host(gb), want[3], tol=5e-5, what="NULL workspace gbias")
+
+
+@pytest.mark.parametrize("kind", ["smooth", "rough", "mixed"])
+def test_deform_conv_backward_weight_gradient_kernels(ops, oracle, dev, kind):
+    """dc_bwd_weight_pix_kernel (columns produced as the forward kernel does, slabs + deterministic reduce) at a shape with
+    several tiles per block, two channel blocks and three filter tiles; with few blocks (long tile pipelines); and the
+    per-tap kernel it replaced (dc.bwdwpix=0)."""
+    from maskflownet_amd import _lib
+    req = ("null", "null", "write", "write")
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 4, 64, 96, 48, 64, kind, req=req)
+    try:
+        _lib.set_tuning(dc_bwdwblocks=16)
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 32, 32, 48, 64, kind, seed=1, req=req)
+        _lib.set_tuning(dc_bwdwblocks=0, dc_bwdwpix=0)
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 32, 32, 48, 64, kind, seed=1, req=req)
+    finally:
+        _lib.set_tuning(dc_bwdwblocks=0, dc_bwdwpix=1)
+
+
+def test_deform_conv_backward_weight_gradient_is_deterministic(ops, dev):
+    """The slab reduction adds in a fixed order: two runs give bit-identical parameter gradients."""
+    rng = np.random.default_rng(8)
+    N, C, H, W = 8, 32, 48, 64
+    x, w = pc.feat(rng, (N, C, H, W)), (rng.standard_normal((C, C, 3, 3)) * 0.2).astype(np.float32)
+    off, go = pc.shared_offsets(rng, N, H, W, "smooth"), rng.standard_normal((N, C, H, W)).astype(np.float32)
+    args = [dev(a) for a in (go, x, off, w)]
+    a = ops.DeformableConvolution_backward(*args, kernel=(3, 3), pad=(1, 1), req=("null", "null", "write", "write"))
+    a = [host(t).copy() for t in a[2:]]
+    b = ops.DeformableConvolution_backward(*args, kernel=(3, 3), pad=(1, 1), req=("null", "null", "write", "write"))
+    assert np.array_equal(a[0], host(b[2])) and np.array_equal(a[1], host(b[3]))
 
 
 @pytest.mark.parametrize("kw", [dict(kernel=(3, 3), pad=(1, 1), stride=(2, 2)), dict(kernel=(3, 3), pad=(2, 2), dilate=(2, 2)),
