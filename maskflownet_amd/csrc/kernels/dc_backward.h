@@ -101,13 +101,18 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
     const int row = it / 72, seg = it - row * 72;
     voff[i] = row < KO ? (unsigned)row * rowbytes + (unsigned)seg * 16u : 0xFFFFFF00u;
   }
+  // blockIdx.z: a slice of the filters (coarse levels have fewer regions than the chip has CUs; everything after the K
+  // loop is linear in the column gradients, so every slice adds its share of both gradients)
+  const int nchunks_all = (p.Cout + KO - 1) / KO;
+  const int cpz = (nchunks_all + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int ch_lo = (int)blockIdx.z * cpz;
+  const int nchunks = max(0, min(nchunks_all, ch_lo + cpz) - ch_lo);
   auto issue_w = [&](int ch, int buf) {
     float *dst = lds + buf * DCP_STAGE_F;
-    const unsigned soff = (unsigned)ch * (unsigned)KO * rowbytes;
+    const unsigned soff = (unsigned)(ch_lo + ch) * (unsigned)KO * rowbytes;
     MFN_UNROLL
     for (int i = 0; i < NI; ++i) mfn_dma16_so(wrsrc, dst + (i * 4 + wave) * 256, voff[i], soff);
   };
-  const int nchunks = (p.Cout + KO - 1) / KO;
 
   // ---- this lane's pixel: region -> (image, region row, region column); wave w = tile (w >> 1, w & 1) of the region
   int n, ho, wo, tyi, txi, ry0, rx0;
@@ -142,12 +147,11 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
   auto load_g = [&](int ch, float (&g)[KS]) {
     MFN_UNROLL
     for (int kk = 0; kk < KS; ++kk) {
-      const int o = ch * KO + 2 * kk + half;
+      const int o = (ch_lo + ch) * KO + 2 * kk + half;
       g[kk] = gptr[(size_t)min(o, p.Cout - 1) * plane];
     }
   };
-  load_g(0, gb0);
-  issue_w(0, 0);
+  if (nchunks > 0) { load_g(0, gb0); issue_w(0, 0); }
   if (nchunks > 1) { load_g(1, gb1); issue_w(1, 1); }
 
   // ---- tap geometry (deform_conv.h: dc_axis; backward.h: dcs_axis) ---------------------------------------------------
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
           MFN_UNROLL
           for (int t = 0; t < T; ++t) a[(kk + 1) & 1][t] = ap[(kk + 1) * 2 * DCP_ROWF + t];
         }
-        const bool o_ok = ch * KO + 2 * kk + half < p.Cout;
+        const bool o_ok = (ch_lo + ch) * KO + 2 * kk + half < p.Cout;
         const float bv = (o_ok && px_valid) ? cur[kk] : 0.f;
         MFN_SCHED_BARRIER();
         MFN_UNROLL
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
       const float v = (half ? w2 : h2) * m9;
       float *dst = p.goffset + ((size_t)n * 2 * T + 2 * t + half) * plane + pix;
       if (px_valid) {
-        if (gridDim.y == 1) *dst += v;       // zero-filled (write) or the caller's values (add); nobody else writes this pixel
+        if (gridDim.y == 1 && gridDim.z == 1) *dst += v;  // zero-filled (write) or the caller's values (add); nobody else writes this pixel
         else if (v != 0.f) atomicAdd(dst, v);
       }
     }
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
     }
   }
   if (p.timeline && tid == 0) {
-    unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    unsigned long long *b_ = p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
     const unsigned long long tk4 = MFN_CYCLES();
     b_[0] = ((tks - tk0) & 0xffffffffull) | ((tk1 - tks) << 32);
     if (!p.tl_detail) { b_[1] = tk2 - tk1; b_[2] = tk3 - tk2; b_[3] = tk4 - tk3; }

@@ -27,6 +27,7 @@
 //   dc.generic   1: force the generic one-thread-per-output kernel
 //   dc.bwdshared 0: input/offset gradient tap by tap only (no shared-offset kernel)
 //   dc.bwdpix    0: shared-offset backward with lane = channel (dc_bwd_input_shared_kernel) instead of lane = pixel (dc_backward.h)
+//   dc.bwdksplit filter slices (blockIdx.z) of the lane = pixel input / offset gradient: 0 auto (256 / blocks), 1, 2, ...
 //   dc.bwdwpix   0: weight gradient with per-tap gathers (dc_bwd_weight_mfma_kernel) instead of the forward's column producer (dc_backward.h)
 //   dc.bwdstrips 2x16-pixel strips per block of the shared-offset backward kernel: 0 auto, 2, 4
 //   dc.bwdscratch 1: the shared-offset backward hands its gx windows over through the workspace and a gather pass adds them
@@ -47,7 +48,7 @@ struct Tuning {
   int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
   int conv_generic = 0, conv_mt = 0, conv_pt = 0, conv_shuffle = 1, conv_row3 = 1;
-  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0, dc_bwdscratch = 0, dc_bwdpix = 1, dc_bwdwpix = 1;
+  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0, dc_bwdscratch = 0, dc_bwdpix = 1, dc_bwdwpix = 1, dc_bwdksplit = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
@@ -86,6 +87,7 @@ struct Tuning {
     if (!strcmp(key, "dc.bwdscratch")) return &dc_bwdscratch;
     if (!strcmp(key, "dc.bwdpix")) return &dc_bwdpix;
     if (!strcmp(key, "dc.bwdwpix")) return &dc_bwdwpix;
+    if (!strcmp(key, "dc.bwdksplit")) return &dc_bwdksplit;
     return nullptr;
   }
 };
