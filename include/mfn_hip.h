@@ -203,13 +203,15 @@ int mfn_deform_conv_matching_fwd(const float *x, const float *flow_yx, float flo
                                  int pw, int dh, int dw, int groups, void *workspace, size_t workspace_bytes,
                                  void *stream);
 /* Backward (training).  gx,goffset,gw,gbias as the forward's x,offset,w,bias; req_* per output
- * (MFN_REQ_NULL skips it and the pointer may be NULL).  The column gradient is formed on the fly;
- * the only scratch is one int per 2x16-pixel strip (mfn_deform_conv_bwd_workspace_bytes; 0 for
- * shapes without the shared-offset kernel): with it, strips whose nine taps share one offset
- * (MaskFlownet.py:230) take all taps in one pass.  workspace may be NULL (tap-by-tap kernel only,
- * same results up to summation order).  gx and
- * goffset are accumulated with fp32 atomics (as MXNet's GPU kernels do): bit-level results can
- * differ from run to run by summation order. */
+ * (MFN_REQ_NULL skips it and the pointer may be NULL).  The column gradient is formed on the fly.
+ * Scratch (mfn_deform_conv_bwd_workspace_bytes; 0 for shapes other than 3x3 / stride 1 / dilation 1
+ * / one group): one flag per 4x8-pixel tile -- tiles whose nine taps share one offset
+ * (MaskFlownet.py:230) take all taps in one pass -- and the per-block partial sums of the weight /
+ * bias gradient, which a second kernel adds in a fixed order.  workspace may be NULL or smaller
+ * (tap-by-tap input gradient, parameter gradients through atomics: same results up to summation
+ * order).  gx and goffset are accumulated with fp32 atomics (as MXNet's GPU kernels do): their
+ * bit-level results can differ from run to run by summation order; with the workspace gw and gbias
+ * are deterministic. */
 size_t mfn_deform_conv_bwd_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw,
                                            int sh, int sw, int ph, int pw, int dh, int dw,
                                            int groups, int deform_groups);

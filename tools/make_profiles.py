@@ -71,3 +71,42 @@ for name in ("bench", "bench_fused", "bench_cfg3", "bench_repack", "bench_stream
             continue
         open(os.path.join(P, "%s_%s.json.log" % (tag, name)), "w").write(line + "\n")
         print("wrote", "%s_%s.json.log" % (tag, name))
+
+# training-step pass (cfg5): gpurun_out/prof_cfg5/cfg5_results.db from
+#   rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cfg5 -o cfg5 -- python bench.py --config cfg5 --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-e2e
+db5 = os.path.join(G, "prof_cfg5", "cfg5_results.db")
+if os.path.exists(db5):
+    cur = sqlite3.connect(db5).cursor()
+    rows = cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    with open(os.path.join(P, "%s_bench_cfg5_kernel_stats.md" % tag), "w") as f:
+        f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --config cfg5 --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-e2e`\n\n" % tag)
+        f.write("MI355X (gfx950), ROCm 7.2.  Source: rocprofv3 rocpd database (top_kernels view); durations in microseconds.\n"
+                "Training-step pass (BASELINE configs[4], 8 pairs of 384x512 per GPU): the S forward pass, then corr_bwd -> deform_bwd per "
+                "level.  `dc_bwd_input_pix_kernel` = input + offset gradient of the deformable conv in the forward's orientation "
+                "(kernels/dc_backward.h); `dc_bwd_input_tile_kernel` only sees its skip list here; `dc_bwd_weight_pix_kernel<MTOT>` + "
+                "`dc_bwd_weight_reduce_kernel` = weight + bias gradient (columns as the forward produces them, per-block slabs, "
+                "fixed-order sum); `corr_bwd_block_kernel` computes g1 and g2 in separate blocks; `fill_zero4_kernel` zeroes the "
+                "write-mode gradients of a call.  bench.py also runs the pass on two more streams (`pipelined`) and eager passes for "
+                "`roofline` / `kernels`.\n\n")
+        f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
+        for name, calls, tot, avg, pct in rows:
+            short = name.replace("void ", "").replace("mfn::", "")
+            if len(short) > 90:
+                short = short[:87] + "..."
+            f.write("| `%s` | %d | %.1f | %.3f | %.2f |\n" % (short, calls, tot, avg, pct))
+    print("wrote", "%s_bench_cfg5_kernel_stats.md" % tag)
+for name in ("bench_cfg5",):
+    src = os.path.join(G, name + ".log")
+    if os.path.exists(src):
+        line = open(src).read().strip().splitlines()[-1]
+        try:
+            json.loads(line)
+        except Exception:
+            continue
+        open(os.path.join(P, "%s_%s.json.log" % (tag, name)), "w").write(line + "\n")
+        print("wrote", "%s_%s.json.log" % (tag, name))
+for name in ("atomic_patterns_ubench", "bwd_levels", "bwd_pix_phases", "bwd_wpix_phases"):
+    src = os.path.join(G, name + ".txt")
+    if os.path.exists(src):
+        open(os.path.join(P, "%s_%s.txt" % (tag, name)), "w").write(open(src).read())
+        print("wrote", "%s_%s.txt" % (tag, name))
