@@ -452,6 +452,34 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       MFN_UNROLL
       for (int q = 0; q < 3; ++q) tr[m][q] = ax.a[q] * v[m][q] + ax.b[q] * v[m][q + 1];
     };
+    // the same for two neighbourhood rows at once: v_pk_mul_f32 + v_pk_fma_f32, one issue slot for two values (the mul is
+    // rounded, then the fma: bit-identical to the scalar form).  fp32 MFMA shares the VALU's issue slots, so the 12 saved
+    // of a pair's 42 are worth 48 of its 745 cycles.
+    // vp[h][q] = rows 2h and 2h + 1 of neighbourhood column q in ONE 64-bit register pair (the two ds_read_b32 write its
+    // halves): no moves to build the packed operands
+    auto gather2 = [&](int buf, f32x2 (&vp)[2][4]) {
+      const float *xb = xwin + buf * XW_F;
+      MFN_UNROLL
+      for (int h = 0; h < 2; ++h)
+        MFN_UNROLL
+        for (int q = 0; q < 4; ++q) {
+          vp[h][q].x = (MFN_DC_ABLATE & 2) ? (float)(2 * h + q + buf) : xb[loff[2 * h][q]];
+          vp[h][q].y = (MFN_DC_ABLATE & 2) ? (float)(2 * h + 1 + q + buf) : xb[loff[2 * h + 1][q]];
+        }
+    };
+    auto interp_rows2 = [&](const f32x2 (&vp)[2][4], f32x2 (&trp)[2][3], int h) {
+      MFN_UNROLL
+      for (int q = 0; q < 3; ++q)
+        trp[h][q] = mfn_fma2(mfn_f2(ax.b[q], ax.b[q]), vp[h][q + 1], mfn_mul2(mfn_f2(ax.a[q], ax.a[q]), vp[h][q]));
+    };
+    auto interp_col2 = [&](const f32x2 (&trp)[2][3], float (&cv)[9], int i) {
+      MFN_UNROLL
+      for (int q = 0; q < 3; ++q) {
+        const float lo = i == 0 ? trp[0][q].x : (i == 1 ? trp[0][q].y : trp[1][q].x);
+        const float hi = i == 0 ? trp[0][q].y : (i == 1 ? trp[1][q].x : trp[1][q].y);
+        cv[i * 3 + q] = ay.a[i] * lo + ay.b[i] * hi;
+      }
+    };
     auto interp_col = [&](const float (&tr)[4][3], float (&cv)[9], int i) {
       MFN_UNROLL
       for (int q = 0; q < 3; ++q) cv[i * 3 + q] = ay.a[i] * tr[i][q] + ay.b[i] * tr[i + 1][q];
@@ -462,6 +490,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], b, acc[mt]);
     };
     float v[4][4], tr[4][3], cv[9], cvn[9];
+    f32x2 vp[2][4], trp[2][3];
     if (nf > 0) issue_x(cp_base, 0);
     if (nf > 1) issue_x(cp_base + 1, 1);
     if (nf > 2) issue_x(cp_base + 2, 2);
@@ -477,7 +506,10 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
     // One pipeline step for pair k.  Pair p lives in window buffer p % 3; the buffer numbers are compile-time
     // (the loop below is unrolled over the ring) so that the 16 gather addresses are loop-invariant registers
     // and the buffer is an instruction offset -- fp32 MFMA shares the VALU's ALUs, every saved VALU counts.
-    auto step = [&](int k, auto bn_c) {
+    // cur / nxt: the nine column values of pair k (consumed here) and of pair k + 1 (formed here): the two sets swap roles
+    // from step to step and the loop below is unrolled over six steps (window ring x value sets), so that no value is
+    // copied at the loop's back edge -- with a copy hipcc spent ~14 v_mov per step on the ALUs the MFMAs need
+    auto step = [&](int k, auto bn_c, float (&cur)[9], float (&nxt)[9]) {
       constexpr int BN = decltype(bn_c)::value;  // buffer of pair k+1 (read now)
       constexpr int BF = (BN + 2) % 3;           // buffer of pair k = where pair k+3 is streamed to
       const int ch = k / KC, kk = k - ch * KC;
@@ -503,30 +535,34 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       w_in_flight = w_now;
       const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
       if (k + 1 < nf) {
-        gather(BN, v);
-        mfma_tap(ap, 0, cv[0]); interp_row(v, tr, 0);
-        mfma_tap(ap, 1, cv[1]); interp_row(v, tr, 1);
-        mfma_tap(ap, 2, cv[2]); interp_row(v, tr, 2);
-        mfma_tap(ap, 3, cv[3]); interp_row(v, tr, 3);
-        mfma_tap(ap, 4, cv[4]); interp_col(tr, cvn, 0);
-        mfma_tap(ap, 5, cv[5]); interp_col(tr, cvn, 1);
-        mfma_tap(ap, 6, cv[6]); interp_col(tr, cvn, 2);
-        mfma_tap(ap, 7, cv[7]);
-        mfma_tap(ap, 8, cv[8]);
-        MFN_UNROLL
-        for (int t = 0; t < T; ++t) cv[t] = cvn[t];
+        gather2(BN, vp);
+        mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
+        mfma_tap(ap, 1, cur[1]);
+        mfma_tap(ap, 2, cur[2]); interp_rows2(vp, trp, 1);
+        mfma_tap(ap, 3, cur[3]);
+        mfma_tap(ap, 4, cur[4]); interp_col2(trp, nxt, 0);
+        mfma_tap(ap, 5, cur[5]); interp_col2(trp, nxt, 1);
+        mfma_tap(ap, 6, cur[6]); interp_col2(trp, nxt, 2);
+        mfma_tap(ap, 7, cur[7]);
+        mfma_tap(ap, 8, cur[8]);
       } else {
         MFN_UNROLL
-        for (int t = 0; t < T; ++t) mfma_tap(ap, t, cv[t]);
+        for (int t = 0; t < T; ++t) mfma_tap(ap, t, cur[t]);
       }
       MFN_SCHED_BARRIER();
     };
     for (int k = 0; k < nf;) {
-      step(k, DcInt<1>{});
+      step(k, DcInt<1>{}, cv, cvn);
       if (++k >= nf) break;
-      step(k, DcInt<2>{});
+      step(k, DcInt<2>{}, cvn, cv);
       if (++k >= nf) break;
-      step(k, DcInt<0>{});
+      step(k, DcInt<0>{}, cv, cvn);
+      if (++k >= nf) break;
+      step(k, DcInt<1>{}, cvn, cv);
+      if (++k >= nf) break;
+      step(k, DcInt<2>{}, cv, cvn);
+      if (++k >= nf) break;
+      step(k, DcInt<0>{}, cvn, cv);
       ++k;
     }
     k_done = nf;
