@@ -83,6 +83,20 @@ class _DeformConvFn(torch.autograd.Function):
         return gx, goff, gw, gb, None
 
 
+class _OffsetsFromFlowFn(torch.autograd.Function):
+    """repeat9(flow * scale / stride) (MaskFlownet.py:230) with its gradient: d flow = scale / stride * sum over the taps."""
+
+    @staticmethod
+    def forward(ctx, flow, scale, stride, taps):
+        ctx.ratio, ctx.taps = float(scale) / float(stride), int(taps)
+        return ops.offsets_from_flow(flow, scale, stride, taps=taps)
+
+    @staticmethod
+    def backward(ctx, goff):
+        n, _, h, w = goff.shape
+        return goff.reshape(n, ctx.taps, 2, h, w).sum(dim=1) * ctx.ratio, None, None, None
+
+
 def _any_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
@@ -207,10 +221,10 @@ class DeformableConv2D(nn.Module):
         if kw["stride"] != (1, 1) or kw["num_deformable_group"] != 1:
             raise ValueError("forward_shared needs stride 1 and one deformable group")
         if _any_grad(x, flow, self.weight, self.bias):
-            # no silent gradient cut: the fused kernel has no autograd graph; forward() with the materialised
-            # offsets (ops.offsets_from_flow) is the differentiable form
-            raise NotImplementedError("forward_shared is the fused inference path; train through forward() "
-                                      "(or call it under torch.no_grad())")
+            # the fused kernel has no autograd graph: under autograd the call takes the differentiable form, the offsets
+            # materialised (as the reference does) and DeformableConvolution's own backward -- same values
+            taps = kw["kernel"][0] * kw["kernel"][1]
+            return self.forward(x, _OffsetsFromFlowFn.apply(flow, flow_scale, flow_stride, taps))
         out = ops.deformable_convolution_shared(x, flow, flow_scale, flow_stride, self.weight, self.bias,
                                                 kernel=kw["kernel"], dilate=kw["dilate"], pad=kw["pad"],
                                                 num_group=kw["num_group"], packed=self._packed(x))
@@ -225,7 +239,13 @@ class DeformableConv2D(nn.Module):
         if kw["stride"] != (1, 1) or kw["num_deformable_group"] != 1:
             raise ValueError("forward_matching needs stride 1 and one deformable group")
         if _any_grad(x, flow, mask, tradeoff, self.weight, self.bias):
-            raise NotImplementedError("forward_matching is the fused inference path; train through forward()")
+            # differentiable form of the same arithmetic (MaskFlownet.py:230-233), elementwise part in torch
+            out = self.forward_shared(x, flow, flow_scale, flow_stride)
+            if mask is not None:
+                out = out * torch.sigmoid(mask)
+            if tradeoff is not None:
+                out = out + tradeoff
+            return torch.nn.functional.leaky_relu(out, 0.1) if leaky else out
         return ops.default_ops().deformable_matching(x, flow, flow_scale, flow_stride, self.weight, self.bias, mask,
                                                      tradeoff, leaky=leaky, kernel=kw["kernel"], dilate=kw["dilate"],
                                                      pad=kw["pad"], num_group=kw["num_group"], packed=self._packed(x))

@@ -450,6 +450,43 @@ def test_layer_mirror_trains_through_the_c_abi(oracle, T):
     assert layer.Reconstruction2D(2, block_grad=True)(img, flt).requires_grad  # grad still flows into x
 
 
+def test_layer_fused_calls_are_differentiable(oracle, T):
+    """DeformableConv2D.forward_shared / forward_matching under autograd: the same values as the fused inference kernels,
+    gradients (d/dx, d/dflow = scale / stride * sum over the taps, d/dW, d/db) against the oracle."""
+    from maskflownet_amd import layer
+    rng = np.random.default_rng(19)
+    N, C, H, W = 2, 32, 24, 32
+    scale, stride = 20.0, 8.0
+    x = pc.feat(rng, (N, C, H, W))
+    fl = (pc.flow_field(rng, N, H, W) * np.float32(stride / scale)).astype(np.float32)
+    dc = layer.DeformableConv2D(C, kernel_size=3, strides=1, padding=1, in_channels=C, prefix="deform3").cuda()
+    tx, tf = T.from_numpy(x).cuda().requires_grad_(), T.from_numpy(fl).cuda().requires_grad_()
+    with T.no_grad():
+        fused = dc.forward_shared(tx, tf, scale, stride)
+    out = dc.forward_shared(tx, tf, scale, stride)
+    assert out.requires_grad
+    pc.check_close(out.detach().cpu().numpy(), fused.cpu().numpy(), what="forward_shared: differentiable form vs fused kernel")
+    go = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    out.backward(T.from_numpy(go).cuda())
+    w, b = dc.weight.detach().cpu().numpy(), dc.bias.detach().cpu().numpy()
+    off = np.repeat((fl * np.float32(scale / stride))[:, None], 9, axis=1).reshape(N, 18, H, W)
+    gx, goff, gw, gb = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=(3, 3), pad=(1, 1))
+    gflow = goff.reshape(N, 9, 2, H, W).sum(axis=1) * np.float32(scale / stride)
+    pc.check_close(tx.grad.cpu().numpy(), gx, tol=5e-5, what="forward_shared d/dx")
+    pc.check_close(tf.grad.cpu().numpy(), gflow, tol=5e-5, what="forward_shared d/dflow")
+    pc.check_close(dc.weight.grad.cpu().numpy(), gw, tol=5e-5, what="forward_shared d/dW")
+    pc.check_close(dc.bias.grad.cpu().numpy(), gb, tol=5e-5, what="forward_shared d/db")
+    # forward_matching: the epilogue in torch under autograd, one launch without
+    mask = T.from_numpy(rng.standard_normal((N, 1, H, W)).astype(np.float32)).cuda().requires_grad_()
+    trade = T.from_numpy(rng.standard_normal((N, C, H, W)).astype(np.float32)).cuda()
+    with T.no_grad():
+        fused_m = dc.forward_matching(tx, tf, scale, stride, mask=mask, tradeoff=trade)
+    outm = dc.forward_matching(tx, tf, scale, stride, mask=mask, tradeoff=trade)
+    pc.check_close(outm.detach().cpu().numpy(), fused_m.cpu().numpy(), what="forward_matching: differentiable form vs fused kernel")
+    outm.sum().backward()
+    assert mask.grad is not None and float(mask.grad.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("shape,kw", [((8, 64, 64, 48, 64), dict(kernel=(3, 3), pad=(1, 1))),     # level 3: mt=2
                                       ((8, 196, 196, 6, 8), dict(kernel=(3, 3), pad=(1, 1))),     # level 6: split K
                                       ((2, 5, 40, 9, 11), dict(kernel=(3, 3), pad=(1, 1))),
