@@ -28,7 +28,8 @@
 //   dc.bwdshared 0: input/offset gradient tap by tap only (no shared-offset kernel)
 //   dc.bwdpix    0: shared-offset backward with lane = channel (dc_bwd_input_shared_kernel) instead of lane = pixel (dc_backward.h)
 //   dc.bwdksplit filter slices (blockIdx.z) of the lane = pixel input / offset gradient: 0 auto (256 / blocks), 1, 2, ...
-//   dc.bwdwpix   0: weight gradient with per-tap gathers (dc_bwd_weight_mfma_kernel) instead of the forward's column producer (dc_backward.h)
+//   dc.bwdwpix   weight gradient: 1 (default) the forward's column producer + slab reduce (dc_backward.h) up to 96 filters, 2: up
+//                to 128 filters (deterministic sums at every level), 0: per-tap gathers + atomics (dc_bwd_weight_mfma_kernel)
 //   dc.bwdstrips 2x16-pixel strips per block of the shared-offset backward kernel: 0 auto, 2, 4
 //   dc.bwdscratch 1: the shared-offset backward hands its gx windows over through the workspace and a gather pass adds them
 //                 (no atomics; measured r02: dc_bwd_input_shared 547 -> 492 us per cfg5 pass + 50 us of gather = no gain, the

@@ -350,6 +350,8 @@ def test_deform_conv_backward_weight_lane_is_pixel(ops, oracle, kind):
     if kind == "smooth":
         emu_ops.set_tuning(dc_bwdwblocks=0)
         pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 40, 9, 16, kind, seed=2, req=req)   # ragged channel / filter tiles
+        emu_ops.set_tuning(dc_bwdwpix=2)
+        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 100, 9, 16, kind, seed=4, req=req)   # four filter tiles
         emu_ops.set_tuning(dc_bwdwpix=0)
         pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 11, 20, kind, seed=3, req=req)
 

@@ -388,6 +388,8 @@ def test_deform_conv_backward_weight_gradient_kernels(ops, oracle, dev, kind):
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 32, 32, 48, 64, kind, seed=1, req=req)
         _lib.set_tuning(dc_bwdwblocks=0, dc_bwdwpix=0)
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 32, 32, 48, 64, kind, seed=1, req=req)
+        _lib.set_tuning(dc_bwdwpix=2)   # four filter tiles per block (by default level 5 keeps the per-tap kernel)
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 128, 128, 12, 16, kind, seed=2, req=req)
     finally:
         _lib.set_tuning(dc_bwdwblocks=0, dc_bwdwpix=1)
 
