@@ -954,6 +954,335 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_weight_pix_kernel(DcBwdWPParams
   }
 }
 
+// ---- the same with producer and consumer waves (default) ----------------------------------------------------------------------
+// dc_bwd_weight_pix_kernel's waves all produce, then all multiply: per tile 2.6 k cycles of producing (LDS / memory round
+// trips, little arithmetic) + 3.5 k of MFMA + two barriers.  Here a block is EIGHT waves: waves 0-3 produce the columns of
+// tile i + 1 into one half of a double buffer while waves 4-7 multiply tile i out of the other half; a SIMD holds one wave
+// of each kind, so the producer's round trips run under the consumer's MFMAs.  One barrier per tile.  With the LDS taken by
+// the two column buffers the producers read the 4x4 neighbourhoods straight from global memory (one dword-aligned 16-byte
+// load per neighbourhood row, as the forward's second tier; tiles with clamped columns: 16 dword loads), one tile ahead.
+constexpr size_t dc_bwd_weight_pc_lds_bytes(int mtot) {
+  return ((size_t)8 * DCW_SLOT + 2 * DCW_COL_F + (size_t)2 * mtot * 32 * DCW_RS) * sizeof(float);
+}
+template <int MTOT>
+__global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams p) {
+  constexpr int T = 9, UN = 9 * MTOT, UMAX = (UN + 3) / 4, RS = DCW_RS, GOUT_F = MTOT * 32 * DCW_RS;
+  MFN_DYN_SHARED(float, lds);
+  float *geom = lds;                                   // [2 sets][4 slots][DCW_SLOT]
+  float *colB = lds + 8 * DCW_SLOT;                    // [2][9 taps][32 channels][RS]
+  float *goutB = colB + 2 * DCW_COL_F;                 // [2][MTOT * 32 filters][RS]
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wave = MFN_UNIFORM((int)threadIdx.x >> 6);
+  const bool producer = wave < 4;                      // uniform per wave
+  const int pw = wave & 3;
+  const int half = lane >> 5, j = lane & 31;
+  const int H = p.H, W = p.W;
+  const size_t plane = (size_t)H * W;
+  const int cb = blockIdx.y * 32;
+  const int t0 = blockIdx.x * p.tiles_per_block, t1 = min(t0 + p.tiles_per_block, p.ntiles);
+  const int ntile = t1 - t0;
+
+  float bsum[MTOT * 4];  // producer thread (filter row tid >> 5, pixel tid & 31): filters (tid >> 5) + 8 i
+  MFN_UNROLL
+  for (int i = 0; i < MTOT * 4; ++i) bsum[i] = 0.f;
+
+  // ---- geometry of one tile per producer wave, parked in LDS (as dc_bwd_weight_pix_kernel; the neighbourhood's lines are
+  // kept as offsets inside a channel plane)
+  struct GeoIn { float off[2 * T]; int n, ho, wo; bool px_valid; };
+  auto geo_load = [&](int tile, GeoIn &q) {
+    const bool tile_ok = tile < t1;
+    const int tpi = p.tiles_y * p.tiles_x;
+    const int tl = min(tile, p.ntiles - 1);
+    auto divmod = [](int a, int b, float inv_b, int &qq, int &r) {
+      qq = (int)((float)a * inv_b);
+      r = a - qq * b;
+      if (r < 0) { --qq; r += b; }
+      if (r >= b) { ++qq; r -= b; }
+    };
+    int rt, ty, tx;
+    divmod(tl, tpi, p.inv_tpi, q.n, rt);
+    divmod(rt, p.tiles_x, p.inv_tiles_x, ty, tx);
+    q.ho = ty * 4 + (j >> 3);
+    q.wo = tx * 8 + (j & 7);
+    q.px_valid = tile_ok && q.ho < H && q.wo < W;
+    q.ho = min(q.ho, H - 1);
+    q.wo = min(q.wo, W - 1);
+    const float *op = p.offset + (size_t)q.n * 2 * T * plane + (size_t)q.ho * W + q.wo;
+    MFN_UNROLL
+    for (int t = 0; t < 2 * T; ++t) q.off[t] = op[(size_t)t * plane];
+  };
+  auto geo_store = [&](const GeoIn &q, int set) {
+    const int h_in = q.ho - p.ph, w_in = q.wo - p.pw;
+    const float oh = q.off[0], ow = q.off[1];
+    bool regular = true;
+    MFN_UNROLL
+    for (int t = 1; t < T; ++t) regular = regular && (q.off[2 * t] == oh) && (q.off[2 * t + 1] == ow);
+    float a_y[3], b_y[3], a_x[3], b_x[3];
+    int iy[4], ix[4];
+    {
+      int lo0 = 0;
+      MFN_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        bool v; int lo, hi; float l;
+        dc_axis(oh, h_in, i, H, v, lo, hi, l);
+        v = v && q.px_valid;
+        const int ulo = (int)fminf(fmaxf(floorf((float)i + oh), -1.0e6f), 1.0e6f);  // unclamped floor
+        if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i);
+        a_y[i] = v ? 1.f - l : 0.f;
+        b_y[i] = v ? l : 0.f;
+      }
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m) iy[m] = min(max(h_in + lo0 + m, 0), H - 1);
+      MFN_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        bool v; int lo, hi; float l;
+        dc_axis(ow, w_in, i, W, v, lo, hi, l);
+        v = v && q.px_valid;
+        const int ulo = (int)fminf(fmaxf(floorf((float)i + ow), -1.0e6f), 1.0e6f);
+        if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i);
+        a_x[i] = v ? 1.f - l : 0.f;
+        b_x[i] = v ? l : 0.f;
+      }
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m) ix[m] = min(max(w_in + lo0 + m, 0), W - 1);
+    }
+    const bool fast = __all(regular || !q.px_valid) != 0;
+    // every lane's four columns consecutive (not clamped at the image's left / right edge): one 16-byte load per row
+    const bool consec = __all(ix[3] - ix[0] == 3) != 0;
+    float *g = geom + (set * 4 + pw) * DCW_SLOT;
+    if (half == 0) {
+      MFN_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        g[(0 + i) * 32 + j] = a_y[i]; g[(3 + i) * 32 + j] = b_y[i];
+        g[(6 + i) * 32 + j] = a_x[i]; g[(9 + i) * 32 + j] = b_x[i];
+      }
+      int *gi = reinterpret_cast<int *>(g);
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m) { gi[(12 + m) * 32 + j] = iy[m] * W; gi[(16 + m) * 32 + j] = ix[m]; }
+      gi[20 * 32 + j] = q.ho * W + q.wo;
+      gi[21 * 32 + j] = q.px_valid ? 1 : 0;
+      gi[22 * 32 + j] = q.ho;
+      gi[23 * 32 + j] = q.wo;
+    }
+    if (lane == 0) {
+      int *hd = reinterpret_cast<int *>(g + DCW_GWD * 32);
+      hd[0] = fast ? (consec ? 2 : 1) : 0; hd[2] = q.n;
+    }
+  };
+  // ---- producer: what tile i needs from memory goes into registers one tile ahead: its gout values and the 4x4
+  // neighbourhoods of this wave's eight channels (four pairs; lane = pixel, half = channel of the pair)
+  float gvn[MTOT * 4];
+  f4u xv[4][4];
+  auto tile_loads = [&](int i) {
+    const float *g = geom + (((i >> 2) & 1) * 4 + (i & 3)) * DCW_SLOT;
+    const int *gi = reinterpret_cast<const int *>(g);
+    const int *hd = reinterpret_cast<const int *>(g + DCW_GWD * 32);
+    const int mode = MFN_UNIFORM(hd[0]), n = MFN_UNIFORM(hd[2]);
+    {
+      const int px = tid & 31, osub = tid >> 5;
+      const float *gp = p.gout + (size_t)n * p.Cout * plane + gi[20 * 32 + px];
+      MFN_UNROLL
+      for (int k = 0; k < MTOT * 4; ++k) gvn[k] = gp[(size_t)min(osub + 8 * k, p.Cout - 1) * plane];
+    }
+    if (mode != 0) {
+      int row[4], col[4];
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m) { row[m] = gi[(12 + m) * 32 + j]; col[m] = gi[(16 + m) * 32 + j]; }
+      MFN_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        // channels past Cin (ragged last block) are written as zeros: any valid plane is read in their place
+        const int c = min(cb + 2 * (4 * pw + k) + half, p.Cin - 1);
+        const float *pl = p.x + ((size_t)n * p.Cin + c) * plane;
+        if (mode == 2) {
+          MFN_UNROLL
+          for (int m = 0; m < 4; ++m) xv[k][m] = mfn_load4u(pl + row[m] + col[0]);
+        } else {
+          MFN_UNROLL
+          for (int m = 0; m < 4; ++m) {
+            xv[k][m].x = pl[row[m] + col[0]]; xv[k][m].y = pl[row[m] + col[1]];
+            xv[k][m].z = pl[row[m] + col[2]]; xv[k][m].w = pl[row[m] + col[3]];
+          }
+        }
+      }
+    }
+  };
+  auto produce = [&](int i) {   // gout tile and columns of tile i (values loaded by tile_loads(i)) -> buffer i & 1
+    const float *g = geom + (((i >> 2) & 1) * 4 + (i & 3)) * DCW_SLOT;
+    const int *gi = reinterpret_cast<const int *>(g);
+    const int *hd = reinterpret_cast<const int *>(g + DCW_GWD * 32);
+    const int mode = MFN_UNIFORM(hd[0]), n = MFN_UNIFORM(hd[2]);
+    float *colT = colB + (i & 1) * DCW_COL_F, *goutT = goutB + (i & 1) * GOUT_F;
+    {
+      const int px = tid & 31, osub = tid >> 5;
+      const bool pvx = gi[21 * 32 + px] != 0;
+      MFN_UNROLL
+      for (int k = 0; k < MTOT * 4; ++k) {
+        const float v = (pvx && osub + 8 * k < p.Cout) ? gvn[k] : 0.f;
+        goutT[(osub + 8 * k) * RS + px] = v;
+        bsum[k] += v;
+      }
+    }
+    if (mode != 0) {
+      float a_y[3], b_y[3], a_x[3], b_x[3];
+      MFN_UNROLL
+      for (int k = 0; k < 3; ++k) {
+        a_y[k] = g[(0 + k) * 32 + j]; b_y[k] = g[(3 + k) * 32 + j]; a_x[k] = g[(6 + k) * 32 + j]; b_x[k] = g[(9 + k) * 32 + j];
+      }
+      MFN_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        const int cl = 2 * (4 * pw + k) + half;   // channel of this lane inside the block
+        const bool c_ok = cb + cl < p.Cin;
+        float tr[4][3];
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m) {
+          tr[m][0] = a_x[0] * xv[k][m].x + b_x[0] * xv[k][m].y;
+          tr[m][1] = a_x[1] * xv[k][m].y + b_x[1] * xv[k][m].z;
+          tr[m][2] = a_x[2] * xv[k][m].z + b_x[2] * xv[k][m].w;
+        }
+        MFN_UNROLL
+        for (int ii = 0; ii < 3; ++ii)
+          MFN_UNROLL
+          for (int q = 0; q < 3; ++q) {
+            const float cv = a_y[ii] * tr[ii][q] + b_y[ii] * tr[ii + 1][q];
+            colT[((ii * 3 + q) * 32 + cl) * RS + j] = c_ok ? cv : 0.f;
+          }
+      }
+    } else {
+      // per-tap geometry (dc_make_tap) and four global loads per value: arbitrary offsets, irregular floors
+      const bool pv = gi[21 * 32 + j] != 0;
+      const int ho = gi[22 * 32 + j], wo = gi[23 * 32 + j];
+      const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)ho * W + wo;
+      MFN_NOUNROLL
+      for (int k = 0; k < 4; ++k) {
+        const int cl = 2 * (4 * pw + k) + half;
+        const bool c_ok = cb + cl < p.Cin;
+        const float *pl = p.x + ((size_t)n * p.Cin + (c_ok ? cb + cl : 0)) * plane;
+        MFN_NOUNROLL
+        for (int t = 0; t < T; ++t) {
+          const int ti = t / 3, tj = t - 3 * ti;
+          const DcTap tp = dc_make_tap(op[(size_t)(2 * t) * plane], op[(size_t)(2 * t + 1) * plane], ho - p.ph, wo - p.pw, ti, tj, H, W,
+                                       pv && c_ok);
+          const int bb = tp.base & 0x3FFFFFFF, dwi = (tp.base >> 30) & 1;
+          const float cv = tp.w1 * pl[bb] + tp.w2 * pl[bb + dwi] + tp.w3 * pl[bb + tp.dhW] + tp.w4 * pl[bb + tp.dhW + dwi];
+          colT[(t * 32 + cl) * RS + j] = cv;
+        }
+      }
+    }
+  };
+  // one producer step: tile i into its buffer, then the requests for tile i + 1 (and, around every fourth tile, the
+  // geometry of the next four)
+  GeoIn gin;
+  auto producer_step = [&](int i) {
+    const bool next_group = ((i >> 2) + 1) * 4 < ntile;   // uniform: a group of tiles after this one
+    produce(i);
+    if ((i & 3) == 2 && next_group) geo_store(gin, ((i >> 2) + 1) & 1);   // visible after this step's barrier
+    if (i + 1 < ntile && ((i + 1) & 3) != 0) tile_loads(i + 1);   // (the first tile of a group: after that barrier, below)
+    if ((i & 3) == 1 && next_group) geo_load(t0 + ((i >> 2) + 1) * 4 + pw, gin);
+  };
+
+  // the slab of filter tile f: both kinds of waves store their half of it once the consumers have staged it
+  float *stg = colB;  // [32 filters][DCW_STG]
+  auto store_slab = [&](int f) {
+    if (p.slabs) {
+      float *slab = p.slabs + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * MTOT + f) * (32 * 288);
+      for (int e = threadIdx.x; e < 32 * 288; e += 512) {
+        const int ol = e / 288, col = e - ol * 288;
+        slab[e] = stg[ol * DCW_STG + col];
+      }
+    } else {
+      for (int e = threadIdx.x; e < 32 * 288; e += 512) {
+        const int ol = e / 288, col = e - ol * 288;
+        const int o = f * 32 + ol, c = cb + col / 9;
+        const float v = stg[ol * DCW_STG + col];
+        if (o < p.Cout && c < p.Cin && v != 0.f) atomicAdd(p.gw + ((size_t)o * p.Cin + cb) * 9 + col, v);
+      }
+    }
+  };
+  // Two instruction streams with the same sequence of block barriers (the hardware counts arrivals, it does not match
+  // program counters): in one stream the consumers' accumulators would stay live through the producers' code (spills).
+  if (producer) {
+    geo_load(t0 + pw, gin);
+    geo_store(gin, 0);
+    MFN_LDS_BARRIER();
+    tile_loads(0);
+    producer_step(0);
+    MFN_LDS_BARRIER();
+    for (int i = 0; i < ntile; ++i) {
+      if (i + 1 < ntile) {
+        // the geometry of a new group became visible with the barrier above: its first tile's requests go out now
+        if (((i + 1) & 3) == 0) tile_loads(i + 1);
+        producer_step(i + 1);
+      }
+      MFN_LDS_BARRIER();  // tile i + 1 is complete, tile i's buffer is free
+    }
+    // bias gradient: row sums of gout over this block's pixels (channel block 0)
+    if (p.gbias && blockIdx.y == 0) {
+      MFN_UNROLL
+      for (int i = 0; i < MTOT * 4; ++i) {
+        float v = bsum[i];
+        for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 32);
+        const int o = (tid >> 5) + 8 * i;
+        if ((tid & 31) == 0 && o < p.Cout) {
+          if (p.bias_slabs) p.bias_slabs[(size_t)blockIdx.x * (MTOT * 32) + o] = v;
+          else if (v != 0.f) atomicAdd(p.gbias + o, v);
+        }
+      }
+    }
+    for (int f = 0; f < MTOT; ++f) {
+      MFN_LDS_BARRIER();
+      store_slab(f);
+      MFN_LDS_BARRIER();
+    }
+  } else {
+    f32x16 acc[UMAX];
+    MFN_UNROLL
+    for (int u = 0; u < UMAX; ++u)
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    MFN_LDS_BARRIER();
+    MFN_LDS_BARRIER();
+    for (int i = 0; i < ntile; ++i) {
+      // ---- D[filter][channel] of tap t, filter tile f: accumulator tile u = t + 9 f, every fourth one is this wave's --------
+      const float *colT = colB + (i & 1) * DCW_COL_F, *goutT = goutB + (i & 1) * GOUT_F;
+      MFN_UNROLL
+      for (int ul = 0; ul < UMAX; ++ul) {
+        const int u = pw + 4 * ul;
+        if (u < UN) {  // uniform
+          const int t = u % 9, f = u / 9;
+          const float4 *bp = reinterpret_cast<const float4 *>(colT + (t * 32 + j) * RS + half * 16);
+          const float4 *ap = reinterpret_cast<const float4 *>(goutT + (f * 32 + j) * RS + half * 16);
+          float4 a4[4], b4[4];
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q) { a4[q] = ap[q]; b4[q] = bp[q]; }
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q) {
+            acc[ul] = MFN_MFMA_32x32x2(a4[q].x, b4[q].x, acc[ul]);
+            acc[ul] = MFN_MFMA_32x32x2(a4[q].y, b4[q].y, acc[ul]);
+            acc[ul] = MFN_MFMA_32x32x2(a4[q].z, b4[q].z, acc[ul]);
+            acc[ul] = MFN_MFMA_32x32x2(a4[q].w, b4[q].w, acc[ul]);
+          }
+        }
+      }
+      MFN_LDS_BARRIER();
+    }
+    // the sums leave as contiguous (c, t) rows: D reg r of lane (j, half) = filter (r&3)+8*(r>>2)+4*half, channel j
+    for (int f = 0; f < MTOT; ++f) {
+      MFN_UNROLL
+      for (int ul = 0; ul < UMAX; ++ul) {
+        const int u = pw + 4 * ul;
+        if (u < UN && u / 9 == f) {  // uniform
+          const int t = u % 9;
+          MFN_UNROLL
+          for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * half) * DCW_STG + j * 9 + t] = acc[ul][r];
+        }
+      }
+      MFN_LDS_BARRIER();
+      store_slab(f);
+      MFN_LDS_BARRIER();
+    }
+  }
+}
+
 // gw[o][c][t] (+)= sum over the blocks of a channel block of their slabs, in a fixed order (deterministic).  A block of 256
 // threads = 16 consecutive gw elements x 16 groups of slabs, added through LDS (64 x 4: 20 us at level 2, too few loads in
 // flight).

@@ -30,6 +30,7 @@
 //   dc.bwdksplit filter slices (blockIdx.z) of the lane = pixel input / offset gradient: 0 auto (256 / blocks), 1, 2, ...
 //   dc.bwdwpix   weight gradient: 1 (default) the forward's column producer + slab reduce (dc_backward.h) up to 96 filters, 2: up
 //                to 128 filters (deterministic sums at every level), 0: per-tap gathers + atomics (dc_bwd_weight_mfma_kernel)
+//   dc.bwdwpc    1 (default): the slab kernel with producer and consumer waves (eight per block), 0: four waves that do both
 //   dc.bwdstrips 2x16-pixel strips per block of the shared-offset backward kernel: 0 auto, 2, 4
 //   dc.bwdscratch 1: the shared-offset backward hands its gx windows over through the workspace and a gather pass adds them
 //                 (no atomics; measured r02: dc_bwd_input_shared 547 -> 492 us per cfg5 pass + 50 us of gather = no gain, the
@@ -49,7 +50,7 @@ struct Tuning {
   int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
   int conv_generic = 0, conv_mt = 0, conv_pt = 0, conv_shuffle = 1, conv_row3 = 1;
-  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0, dc_bwdscratch = 0, dc_bwdpix = 1, dc_bwdwpix = 1, dc_bwdksplit = 0;
+  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0, dc_bwdscratch = 0, dc_bwdpix = 1, dc_bwdwpix = 1, dc_bwdksplit = 0, dc_bwdwpc = 1;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
@@ -89,6 +90,7 @@ struct Tuning {
     if (!strcmp(key, "dc.bwdpix")) return &dc_bwdpix;
     if (!strcmp(key, "dc.bwdwpix")) return &dc_bwdwpix;
     if (!strcmp(key, "dc.bwdksplit")) return &dc_bwdksplit;
+    if (!strcmp(key, "dc.bwdwpc")) return &dc_bwdwpc;
     return nullptr;
   }
 };
