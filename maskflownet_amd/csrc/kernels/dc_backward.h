@@ -39,23 +39,39 @@
 
 namespace mfn {
 
-constexpr int DCP_KO = 16;                       // filters per weight chunk = 8 k-steps of 9 MFMAs
 constexpr int DCP_ROWF = 288;                    // floats of one filter's segment: 32 channels x 9 taps
-constexpr int DCP_WNI = 5;                       // weight DMA instructions per thread and chunk: 16 x 72 items in 1280 slots
-constexpr int DCP_STAGE_F = DCP_WNI * 256 * 4;   // floats per weight stage buffer (three of them)
 constexpr int DCP_ROWS = 16, DCP_COLS = 24;      // source window of a 4x8 tile
 constexpr int DCP_XW_NI = 3;                     // 2 channels x 16 rows x 6 float4 = 192 slots = 3 wave DMA instructions
 constexpr int DCP_XW_F = DCP_XW_NI * 256;        // floats of a channel-pair source window
 constexpr int DCP_PR = 22, DCP_PC = 32;          // gx plane of the 8x16 region
-constexpr int DCP_PLANE = DCP_PR * DCP_PC + 8;   // plane stride: planes 4 apart (the two half-waves) sit 32 banks apart
 constexpr int DCP_FS = (DCP_PR * DCP_PC + 63) / 64;  // most 64-cell slices a plane's flush can take
 constexpr int DCP_EXCH = 32;                     // ints of the block's touched-box exchange
-constexpr int DCP_STASH = 21;                    // words a lane parks in LDS over phase A (what only phase B / the end needs)
-constexpr int DCP_LDS_A = 3 * DCP_STAGE_F + 4 * 3 * DCP_XW_F, DCP_LDS_B = 32 * DCP_PLANE;
-// K loop and phase A: weight stages + four x-window rings; phase B reuses the same memory for the planes
-constexpr size_t dc_bwd_pix_lds_bytes() {
-  return ((size_t)(DCP_LDS_A > DCP_LDS_B ? DCP_LDS_A : DCP_LDS_B) + DCP_EXCH + 4 * DCP_STASH * 64) * sizeof(float);
-}
+// Three forms of the kernel.  <1, 1, 1> (default): both gradients from one pass over gout, one wave per SIMD (466 registers,
+// 119 KB of LDS).  <0, 1, 2> and <1, 0, 2> (dc.bwdsplit2=1): one gradient each at TWO blocks per CU -- every phase of this kernel
+// waits on its own LDS / memory round trips, and a second wave on the SIMD fills them; the price is the column-gradient GEMM
+// and the setup done twice.  Measured (levels 5..2): 20 + 51 / 33 + 64 / 39 + 77 / 53 + 114 us against 54 / 69 / 106 / 161 for the
+// one-launch form: not a gain -- the input gradient's flush is ~190 atomic instructions per block either way.  What
+// shrinks to make two blocks fit: 8-filter weight chunks, three source windows in flight instead of eight (the other wave
+// covers the rest), 16 of the 32 planes live at a time (the channels whose MFMA row has (row & 3) < 2 first, then the others).
+template <bool WX, bool WO, int OCC> struct DcpCfg {
+  static constexpr bool SPLIT = OCC >= 2;
+  static constexpr int KO = SPLIT ? 8 : 16;                  // filters per weight chunk
+  static constexpr int NI = SPLIT ? 3 : 5;                   // weight DMA instructions per thread and chunk (KO x 72 items)
+  static constexpr int STAGE_F = NI * 256 * 4;               // floats per weight stage buffer (three of them)
+  static constexpr int RD = SPLIT ? 3 : 8;                   // source windows in flight (three are the wave's own ring)
+  static constexpr int NSET = SPLIT ? 2 : 1;                 // plane sets walked one after the other
+  static constexpr int NPL = 32 / NSET;                      // planes live at a time
+  // plane stride: the two half-waves' planes (MFMA rows 4 apart) sit 32 banks apart
+  static constexpr int PLANE = DCP_PR * DCP_PC + (SPLIT ? 16 : 8);
+  static constexpr int STASH = WX ? 21 : 6;                  // words a lane parks in LDS (what only phase B / the end needs)
+  // per wave next to the weight stages: its three source windows (offset gradient), or at least the scratch of the turn
+  // assignment (one int per plane cell)
+  static constexpr int XW_WAVE = WO ? 3 * DCP_XW_F : DCP_PR * DCP_PC;
+  static constexpr int LDS_A = 3 * STAGE_F + 4 * XW_WAVE, LDS_B = WX ? NPL * PLANE : 0;
+  static constexpr int LDS_MAIN = LDS_A > LDS_B ? LDS_A : LDS_B;
+  // K loop and phase A: weight stages + four x-window rings; phase B reuses the same memory for the planes
+  static constexpr size_t lds_bytes() { return ((size_t)LDS_MAIN + DCP_EXCH + 4 * STASH * 64) * sizeof(float); }
+};
 
 struct DcBwdPParams {
   const float *gout, *x, *offset, *w;
@@ -70,15 +86,20 @@ struct DcBwdPParams {
   int tl_detail;                 // ... or, instead of the last three, phase B's first group: {fold + shuffles, walk, barrier wait}
 };
 
-__global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p) {
-  constexpr int T = 9, KO = DCP_KO, KS = KO / 2, NI = DCP_WNI, ROWS = DCP_ROWS, COLS = DCP_COLS, XW_NI = DCP_XW_NI;
-  constexpr int PR = DCP_PR, PC = DCP_PC, PL = DCP_PLANE;
+template <bool WX, bool WO, int OCC>
+__global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams p) {
+  using Cfg = DcpCfg<WX, WO, OCC>;
+  constexpr int T = 9, KO = Cfg::KO, KS = KO / 2, NI = Cfg::NI, ROWS = DCP_ROWS, COLS = DCP_COLS, XW_NI = DCP_XW_NI;
+  constexpr int PR = DCP_PR, PC = DCP_PC, PL = Cfg::PLANE, RD = Cfg::RD, NSET = Cfg::NSET, CPG = 4 / NSET;
+  constexpr int DCP_STAGE_F = Cfg::STAGE_F, DCP_STASH = Cfg::STASH;
+  if (!WX) p.req_x = 0;        // the form decides which gradients are formed
+  if (!WO) p.req_offset = 0;
   MFN_DYN_SHARED(float, lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = MFN_UNIFORM(tid >> 6);
   const int half = lane >> 5, j = lane & 31;
-  int *exch = reinterpret_cast<int *>(lds + (DCP_LDS_A > DCP_LDS_B ? DCP_LDS_A : DCP_LDS_B));  // [4 waves][8]
-  float *xwin = lds + 3 * DCP_STAGE_F + wave * (3 * DCP_XW_F);  // this wave's three pair windows (ring)
+  int *exch = reinterpret_cast<int *>(lds + Cfg::LDS_MAIN);  // [4 waves][8]
+  float *xwin = lds + 3 * DCP_STAGE_F + wave * Cfg::XW_WAVE;  // this wave's three pair windows (ring)
   // What only phase B or the final store needs waits in LDS, word k of lane l at [k][l] (the accumulators alone are 144
   // registers)
   float *stash = reinterpret_cast<float *>(exch) + DCP_EXCH + wave * (DCP_STASH * 64) + lane;
@@ -292,17 +313,21 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
     MFN_UNROLL
     for (int i = 0; i < 3; ++i) {
       const float vy = px_valid ? vyf[i] : 0.f, vx = px_valid ? vxf[i] : 0.f;
-      stash[(0 + i) * 64] = vy * geo[DCS_AY + i];
-      stash[(3 + i) * 64] = vy * geo[DCS_BY + i];
-      stash[(6 + i) * 64] = vx * geo[DCS_AX + i];
-      stash[(9 + i) * 64] = vx * geo[DCS_BX + i];
-      stash[(14 + i) * 64] = vy;
-      stash[(17 + i) * 64] = vx;
+      stash[(0 + i) * 64] = vy;
+      stash[(3 + i) * 64] = vx;
+      if (WX) {
+        stash[(6 + i) * 64] = vy * geo[DCS_AY + i];
+        stash[(9 + i) * 64] = vy * geo[DCS_BY + i];
+        stash[(12 + i) * 64] = vx * geo[DCS_AX + i];
+        stash[(15 + i) * 64] = vx * geo[DCS_BX + i];
+      }
     }
-    int *si = reinterpret_cast<int *>(stash);
-    si[12 * 64] = cry * PC + crx;
-    si[13 * 64] = (px_valid && !inplane) ? -2 : turn;   // -2: the neighbourhood leaves the plane -> straight to gx
-    si[20 * 64] = partner;
+    if (WX) {
+      int *si = reinterpret_cast<int *>(stash);
+      si[18 * 64] = cry * PC + crx;
+      si[19 * 64] = (px_valid && !inplane) ? -2 : turn;   // -2: the neighbourhood leaves the plane -> straight to gx
+      si[20 * 64] = partner;
+    }
   }
 
   const unsigned long long tks = MFN_CYCLES();
@@ -390,38 +415,58 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
         }
     };
     // software pipeline: step r gathers the neighbourhood of pair r + 1, sums pair r from registers, then hands the
-    // buffer it has just read to window r + 9: eight windows in flight (one wave per SIMD: nobody else covers the ~2 us a
-    // window takes).  Ring buffers 0..2 are the wave's own, 3..7 its share of the weight stages, dead after the K loop.
-    // DMA completion is in issue order: the waits count the newer windows that may still fly.
-    auto xbuf = [&](int b) { return b < 3 ? xwin + b * DCP_XW_F : lds + (wave * 5 + (b - 3)) * DCP_XW_F; };
+    // buffer it has just read to window r + 1 + RD: RD windows in flight (one wave per SIMD: eight -- nobody else covers the
+    // ~2 us a window takes; two waves per SIMD: three).  Ring buffers 0..2 are the wave's own, 3.. its share of the weight
+    // stages, dead after the K loop.  DMA completion is in issue order: the waits count the newer windows that may still fly.
+    auto xbuf = [&](int b) { return b < 3 ? xwin + b * DCP_XW_F : lds + (wave * (RD - 3) + (b - 3)) * DCP_XW_F; };
     auto issue_xb = [&](int r) {
       const int c0 = cb + ((row_q(r) + rot) & 31);
       const unsigned soff = (unsigned)((size_t)min(c0, p.Cin - 1) * plane * 4);
-      float *dst = xbuf(r & 7);
+      float *dst = xbuf(r % RD);
       MFN_UNROLL
       for (int i = 0; i < XW_NI; ++i) mfn_dma16_so(xrsrc, dst + i * 256, xvoff[i], soff);
+    };
+    // two waves per SIMD: no register pair for the look-ahead (a spill would put scratch stores between the counted DMA
+    // waits), and no need -- the other wave runs while this one waits for its gather
+    auto phase_a1 = [&](auto dma_c) {
+      constexpr bool DMA = decltype(dma_c)::value;
+      auto step_1 = [&](auto r_c) {
+        constexpr int r = decltype(r_c)::value;
+        constexpr int newer = (15 - r) < 2 ? (15 - r) : 2;   // windows r + 1, r + 2
+        float X[4][4];
+        if (DMA) MFN_WAIT_VM(newer * XW_NI);
+        gather(dma_c, r, xbuf(r % 3), X);
+        MFN_WAIT_LGKM0();
+        if (DMA && r + 3 < 16) issue_xb(r + 3);
+        sums(r_c, X);
+      };
+      step_1(DcInt<0>{}); step_1(DcInt<1>{}); step_1(DcInt<2>{}); step_1(DcInt<3>{});
+      step_1(DcInt<4>{}); step_1(DcInt<5>{}); step_1(DcInt<6>{}); step_1(DcInt<7>{});
+      step_1(DcInt<8>{}); step_1(DcInt<9>{}); step_1(DcInt<10>{}); step_1(DcInt<11>{});
+      step_1(DcInt<12>{}); step_1(DcInt<13>{}); step_1(DcInt<14>{}); step_1(DcInt<15>{});
     };
     auto phase_a = [&](auto dma_c) {
     constexpr bool DMA = decltype(dma_c)::value;
     float Xa[4][4], Xb[4][4];
     if (DMA) {
-      issue_xb(3); issue_xb(4); issue_xb(5); issue_xb(6); issue_xb(7);
-      MFN_WAIT_VM(7 * XW_NI);
+      MFN_UNROLL
+      for (int b = 3; b < RD; ++b) issue_xb(b);
+      MFN_WAIT_VM((RD - 1) * XW_NI);
     }
     gather(dma_c, 0, xbuf(0), Xa);
     MFN_WAIT_LGKM0();
-    if (DMA) issue_xb(8);
+    if (DMA) issue_xb(RD);
     auto step_a = [&](auto r_c, float (&Xc)[4][4], float (&Xn)[4][4]) {
       constexpr int r = decltype(r_c)::value;
       if (r + 1 < 16) {
-        constexpr int newer = (14 - r) < 7 ? (14 - r) : 7;   // windows r + 2 .. min(r + 8, 15)
+        constexpr int newer = (14 - r) < (RD - 1) ? (14 - r) : (RD - 1);   // windows r + 2 .. min(r + RD, 15)
         if (DMA) MFN_WAIT_VM(newer * XW_NI);
-        gather(dma_c, r + 1, xbuf((r + 1) & 7), Xn);
+        gather(dma_c, r + 1, xbuf((r + 1) % RD), Xn);
       }
       sums(r_c, Xc);
-      if (r + 9 < 16) {
+      if (r + 1 + RD < 16) {
         MFN_WAIT_LGKM0();
-        if (DMA) issue_xb(r + 9);
+        if (DMA) issue_xb(r + 1 + RD);
       }
     };
     step_a(DcInt<0>{}, Xa, Xb); step_a(DcInt<1>{}, Xb, Xa); step_a(DcInt<2>{}, Xa, Xb); step_a(DcInt<3>{}, Xb, Xa);
@@ -431,12 +476,16 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
     };
     // two copies on purpose: with the global loads of the rare path in the same code, hipcc waits vmcnt(0) before every
     // gather of the DMA path (a register with a load pending on the OTHER path) and the window ring degenerates
-    if (xfit) phase_a(DcInt<1>{}); else phase_a(DcInt<0>{});
+    if (Cfg::SPLIT) {
+      if (xfit) phase_a1(DcInt<1>{}); else phase_a1(DcInt<0>{});
+    } else {
+      if (xfit) phase_a(DcInt<1>{}); else phase_a(DcInt<0>{});
+    }
     // the two half-waves hold the other 16 channels of the same pixel; half 0 writes d/dh, half 1 d/dw
     MFN_UNROLL
     for (int t = 0; t < T; ++t) {
       const float h2 = sh[t] + __shfl_xor(sh[t], 32), w2 = sw[t] + __shfl_xor(sw[t], 32);
-      const float m9 = stash[(14 + t / 3) * 64] * stash[(17 + t % 3) * 64];
+      const float m9 = stash[(0 + t / 3) * 64] * stash[(3 + t % 3) * 64];
       const float v = (half ? w2 : h2) * m9;
       float *dst = p.goffset + ((size_t)n * 2 * T + 2 * t + half) * plane + pix;
       if (px_valid) {
@@ -449,35 +498,66 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
   if (!p.req_x) return;   // uniform
 
   // ---- phase B: input gradient -----------------------------------------------------------------------------------------
+  // NSET plane sets, one after the other (one set of 32 planes, or two of 16: the channels whose MFMA row has (row & 3) < 2,
+  // then the others).  Per set: zero the planes, four groups of CPG channels (chains) per wave, flush.
   MFN_WAIT_VM(0);
   MFN_LDS_BARRIER();      // the stage buffers and window rings are dead: the planes take their place
-  for (int e = tid; e < 32 * PL / 4; e += 256) reinterpret_cast<float4 *>(lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-  MFN_LDS_BARRIER();
+  float ay[3], by[3], ax[3], bxw[3];
+  MFN_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    ay[i] = stash[(6 + i) * 64]; by[i] = stash[(9 + i) * 64]; ax[i] = stash[(12 + i) * 64]; bxw[i] = stash[(15 + i) * 64];
+  }
+  const int cell0 = reinterpret_cast<const int *>(stash)[18 * 64];  // neighbourhood corner (0, 0) in a plane
+  const int myturn = reinterpret_cast<const int *>(stash)[19 * 64];
+  const int mypartner = reinterpret_cast<const int *>(stash)[20 * 64];
+  const int psrc = mypartner >= 0 ? mypartner + 32 * half : lane;  // the lane whose values are added to this lane's
+  const float pmask = mypartner >= 0 ? 1.f : 0.f;
+  const bool any_merged = MFN_UNIFORM(merged) != 0;
+  // plane of MFMA row rho in its set: 32 planes: rho; 16 planes: (rho >> 2) * 2 + (rho & 1)
+  auto plane_of = [](int rho) { return NSET == 1 ? rho : ((rho >> 2) * 2 + (rho & 1)); };
+  // the flush plan: 64 consecutive cells of the planes' touched box per atomic instruction
+  int fy0 = 1 << 28, fy1 = -(1 << 28), fx0 = 1 << 28, fx1 = -(1 << 28);
+  MFN_UNROLL
+  for (int w2 = 0; w2 < 4; ++w2) {
+    const int *e = exch + w2 * 8;
+    fy0 = min(fy0, e[0]); fy1 = max(fy1, e[1]); fx0 = min(fx0, e[2]); fx1 = max(fx1, e[3]);
+  }
+  fy0 = MFN_UNIFORM(fy0); fy1 = MFN_UNIFORM(fy1); fx0 = MFN_UNIFORM(fx0); fx1 = MFN_UNIFORM(fx1);
+  const bool any_cells = fy1 >= fy0;
+  const int ncols = any_cells ? fx1 - fx0 + 1 : 1, ncells = any_cells ? (fy1 - fy0 + 1) * ncols : 0;
+  int floff[DCP_FS], fgoff[DCP_FS];
   {
-    float ay[3], by[3], ax[3], bxw[3];
+    const float inv_ncols = 1.f / (float)ncols;
     MFN_UNROLL
-    for (int i = 0; i < 3; ++i) {
-      ay[i] = stash[(0 + i) * 64]; by[i] = stash[(3 + i) * 64]; ax[i] = stash[(6 + i) * 64]; bxw[i] = stash[(9 + i) * 64];
+    for (int sl = 0; sl < DCP_FS; ++sl) {
+      const int e = sl * 64 + lane;
+      int row = (int)((float)e * inv_ncols), col = e - row * ncols;  // cell counts are far below 2^24: off by one at most
+      if (col < 0) { --row; col += ncols; }
+      if (col >= ncols) { ++row; col -= ncols; }
+      const int yy = py0 + fy0 + row, xx = px0 + fx0 + col;
+      floff[sl] = min(max((fy0 + row) * PC + fx0 + col, 0), PR * PC - 1);
+      fgoff[sl] = (e < ncells && yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
     }
-    const int cell0 = reinterpret_cast<const int *>(stash)[12 * 64];  // neighbourhood corner (0, 0) in a plane
-    const int myturn = reinterpret_cast<const int *>(stash)[13 * 64];
-    const int mypartner = reinterpret_cast<const int *>(stash)[20 * 64];
-    const int psrc = mypartner >= 0 ? mypartner + 32 * half : lane;  // the lane whose values are added to this lane's
-    const float pmask = mypartner >= 0 ? 1.f : 0.f;
-    const bool any_merged = MFN_UNIFORM(merged) != 0;
-    unsigned long long td0 = 0, td1 = 0, td2 = 0, td3 = 0;
+  }
+  unsigned long long td0 = 0, td1 = 0, td2 = 0, td3 = 0, tflush = 0;
+
+  auto set_b = [&](auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    for (int e = tid; e < Cfg::NPL * PL / 4; e += 256) reinterpret_cast<float4 *>(lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    MFN_LDS_BARRIER();
     auto group_b = [&](auto g_c) {
-      constexpr int g = decltype(g_c)::value;   // steps 4g .. 4g + 3: MFMA rows 8g + c + 4 half, c = 0..3
-      if (g == 0 && p.timeline) td0 = MFN_CYCLES();
+      constexpr int g = decltype(g_c)::value;   // chains c = 0 .. CPG-1: accumulator register 4g + CS + c, MFMA rows 8g + CS + c + 4 half
+      constexpr int CS = SET * CPG;
+      if (SET == 0 && g == 0 && p.timeline) td0 = MFN_CYCLES();
       if (fast) {
-        // the nine taps folded onto the 4x4 neighbourhood, along x first, then along y; four channels (chains)
-        float G[4][4][4];
+        // the nine taps folded onto the 4x4 neighbourhood, along x first, then along y
+        float G[CPG][4][4];
         MFN_UNROLL
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < CPG; ++c) {
           float R[3][4];
           MFN_UNROLL
           for (int i = 0; i < 3; ++i) {
-            const float c0 = acc[3 * i][4 * g + c], c1 = acc[3 * i + 1][4 * g + c], c2 = acc[3 * i + 2][4 * g + c];
+            const float c0 = acc[3 * i][4 * g + CS + c], c1 = acc[3 * i + 1][4 * g + CS + c], c2 = acc[3 * i + 2][4 * g + CS + c];
             R[i][0] = c0 * ax[0];
             R[i][1] = fmaf(c0, bxw[0], c1 * ax[1]);
             R[i][2] = fmaf(c1, bxw[1], c2 * ax[2]);
@@ -493,16 +573,16 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
         }
         if (any_merged) {  // uniform: every lane takes part in the shuffles
           MFN_UNROLL
-          for (int c = 0; c < 4; ++c)
+          for (int c = 0; c < CPG; ++c)
             MFN_UNROLL
             for (int u = 0; u < 4; ++u)
               MFN_UNROLL
               for (int v = 0; v < 4; ++v) G[c][u][v] = fmaf(__shfl(G[c][u][v], psrc), pmask, G[c][u][v]);
         }
-        if (g == 0 && p.timeline) { MFN_OPAQUE(G[3][3][3]); td1 = MFN_CYCLES(); }
-        float *pl[4];
+        if (SET == 0 && g == 0 && p.timeline) { MFN_OPAQUE(G[CPG - 1][3][3]); td1 = MFN_CYCLES(); }
+        float *pl[CPG];
         MFN_UNROLL
-        for (int c = 0; c < 4; ++c) pl[c] = lds + (size_t)((8 * g + c + 4 * half + rot) & 31) * PL + cell0;
+        for (int c = 0; c < CPG; ++c) pl[c] = lds + (size_t)plane_of((8 * g + CS + c + 4 * half + rot) & 31) * PL + cell0;
         // (emulation: free-running lanes take a whole walk one lane at a time, mfn_rt.h)
         for (int t = 0; t < nturns; ++t) {
           if (myturn == t) {
@@ -511,11 +591,11 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
             for (int u = 0; u < 4; ++u)
               MFN_UNROLL
               for (int v = 0; v < 4; ++v) {
-                float o[4];
+                float o[CPG];
                 MFN_UNROLL
-                for (int c = 0; c < 4; ++c) o[c] = pl[c][u * PC + v];
+                for (int c = 0; c < CPG; ++c) o[c] = pl[c][u * PC + v];
                 MFN_UNROLL
-                for (int c = 0; c < 4; ++c) pl[c][u * PC + v] = o[c] + G[c][u][v];
+                for (int c = 0; c < CPG; ++c) pl[c][u * PC + v] = o[c] + G[c][u][v];
                 // the next cell's reads are ISSUED after this cell's writes: another lane's cell (u, v) is this lane's
                 // cell (u', v'); the in-order LDS pipe then orders them
                 MFN_COMPILER_FENCE();
@@ -526,8 +606,8 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
         if (__any(myturn == -2)) {  // neighbourhoods outside the plane: straight to gx
           if (myturn == -2) {
             MFN_UNROLL
-            for (int c = 0; c < 4; ++c) {
-              const int ch = cb + ((8 * g + c + 4 * half + rot) & 31);
+            for (int c = 0; c < CPG; ++c) {
+              const int ch = cb + ((8 * g + CS + c + 4 * half + rot) & 31);
               float *gim = p.gx + ((size_t)n * p.Cin + min(ch, p.Cin - 1)) * plane;
               MFN_UNROLL
               for (int u = 0; u < 4; ++u)
@@ -541,53 +621,38 @@ __global__ __launch_bounds__(256, 1) void dc_bwd_input_pix_kernel(DcBwdPParams p
           }
         }
       }
-      if (g == 0 && p.timeline) { MFN_WAIT_LGKM0(); td2 = MFN_CYCLES(); }
+      if (SET == 0 && g == 0 && p.timeline) { MFN_WAIT_LGKM0(); td2 = MFN_CYCLES(); }
       MFN_LDS_BARRIER();  // the waves stay within one group of each other: their rotated channel sets never meet
-      if (g == 0 && p.timeline) td3 = MFN_CYCLES();
+      if (SET == 0 && g == 0 && p.timeline) td3 = MFN_CYCLES();
     };
     group_b(DcInt<0>{}); group_b(DcInt<1>{}); group_b(DcInt<2>{}); group_b(DcInt<3>{});
-    if (p.timeline && p.tl_detail && tid == 0) {
-      unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-      b_[1] = td1 - td0; b_[2] = td2 - td1; b_[3] = td3 - td2;
-    }
-  }
-  if (p.timeline) tk3 = MFN_CYCLES();
-  // ---- flush: wave w takes planes w, w + 4, ...; 64 consecutive cells of the touched box per instruction -------------
-  {
-    int y0 = 1 << 28, y1 = -(1 << 28), x0 = 1 << 28, x1 = -(1 << 28);
-    MFN_UNROLL
-    for (int w2 = 0; w2 < 4; ++w2) {
-      const int *e = exch + w2 * 8;
-      y0 = min(y0, e[0]); y1 = max(y1, e[1]); x0 = min(x0, e[2]); x1 = max(x1, e[3]);
-    }
-    y0 = MFN_UNIFORM(y0); y1 = MFN_UNIFORM(y1); x0 = MFN_UNIFORM(x0); x1 = MFN_UNIFORM(x1);
-    if (y1 >= y0) {
-      const int ncols = x1 - x0 + 1, ncells = (y1 - y0 + 1) * ncols;
-      const float inv_ncols = 1.f / (float)ncols;
-      int loff[DCP_FS], goff[DCP_FS];
-      MFN_UNROLL
-      for (int s = 0; s < DCP_FS; ++s) {
-        const int e = s * 64 + lane;
-        int row = (int)((float)e * inv_ncols), col = e - row * ncols;  // cell counts are far below 2^24: off by one at most
-        if (col < 0) { --row; col += ncols; }
-        if (col >= ncols) { ++row; col -= ncols; }
-        const int yy = py0 + y0 + row, xx = px0 + x0 + col;
-        loff[s] = min((y0 + row) * PC + x0 + col, PR * PC - 1);
-        goff[s] = (e < ncells && yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
-      }
-      for (int pi = wave; pi < 32; pi += 4) {
-        if (cb + pi >= p.Cin) break;  // uniform
+    // ---- flush of the set: wave w takes planes w, w + 4, ... ---------------------------------------------------------------
+    const unsigned long long tf0 = p.timeline ? MFN_CYCLES() : 0ull;
+    if (any_cells) {
+      for (int pi = wave; pi < Cfg::NPL; pi += 4) {
+        // plane pi of the set holds MFMA row (32 planes: pi; 16 planes: (pi >> 1) * 4 + (pi & 1) + 2 * SET) = that channel
+        const int rho = NSET == 1 ? pi : ((pi >> 1) * 4 + (pi & 1) + 2 * SET);
+        if (cb + rho >= p.Cin) continue;  // uniform
         const float *pp = lds + (size_t)pi * PL;
-        float *gim = p.gx + ((size_t)n * p.Cin + cb + pi) * plane;
+        float *gim = p.gx + ((size_t)n * p.Cin + cb + rho) * plane;
         float fv[DCP_FS];
         MFN_UNROLL
-        for (int s = 0; s < DCP_FS; ++s) fv[s] = pp[loff[s]];
+        for (int sl = 0; sl < DCP_FS; ++sl) fv[sl] = pp[floff[sl]];
         MFN_UNROLL
-        for (int s = 0; s < DCP_FS; ++s)
-          if (s * 64 < ncells && goff[s] >= 0 && fv[s] != 0.f) atomicAdd(gim + goff[s], fv[s]);
+        for (int sl = 0; sl < DCP_FS; ++sl)
+          if (sl * 64 < ncells && fgoff[sl] >= 0 && fv[sl] != 0.f) atomicAdd(gim + fgoff[sl], fv[sl]);
       }
     }
+    if (SET + 1 < NSET) MFN_LDS_BARRIER();  // the planes are free for the next set
+    if (p.timeline) tflush += MFN_CYCLES() - tf0;
+  };
+  set_b(DcInt<0>{});
+  if (NSET > 1) set_b(DcInt<NSET - 1>{});
+  if (p.timeline && p.tl_detail && tid == 0) {
+    unsigned long long *b_ = p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+    b_[1] = td1 - td0; b_[2] = td2 - td1; b_[3] = td3 - td2;
   }
+  if (p.timeline) tk3 = MFN_CYCLES() - tflush;
   if (p.timeline && tid == 0) {
     unsigned long long *b_ = p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
     const unsigned long long tk4 = MFN_CYCLES();

@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1, dc_bwdwpix=1, dc_bwdwblocks=0)
+                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1, dc_bwdwpix=1, dc_bwdwblocks=0, dc_bwdwpc=1, dc_bwdsplit2=0, dc_bwdksplit=0)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -338,6 +338,17 @@ def test_deform_conv_backward_lane_is_pixel_channel_blocks_and_requests(ops, ora
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "smooth", seed=2, req=("write", "write", "null", "null"))
 
 
+@pytest.mark.parametrize("kind", ["smooth", "rough"])
+def test_deform_conv_backward_lane_is_pixel_split_launches(ops, oracle, kind):
+    """dc.bwdsplit2=1: one launch per gradient, the forms with 8-filter weight chunks, three source windows in flight and two
+    sets of 16 planes (two blocks per CU on the GPU; measured slower there, kept as a tested variant); three filter
+    slices (blockIdx.z)."""
+    emu_ops.set_tuning(dc_bwdsplit2=1)
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 20, 11, 20, kind, req=("write", "write", "null", "null"))
+    emu_ops.set_tuning(dc_bwdsplit2=1, dc_bwdksplit=3)
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 40, 9, 16, kind, seed=1, req=("write", "write", "null", "null"))
+
+
 @pytest.mark.parametrize("kind", ["smooth", "outside", "mixed"])
 def test_deform_conv_backward_weight_lane_is_pixel(ops, oracle, kind):
     """dc_bwd_weight_pix_kernel + dc_bwd_weight_reduce_kernel: ragged tiles, staged windows ('smooth'), the per-tap
@@ -352,7 +363,9 @@ def test_deform_conv_backward_weight_lane_is_pixel(ops, oracle, kind):
         pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 40, 9, 16, kind, seed=2, req=req)   # ragged channel / filter tiles
         emu_ops.set_tuning(dc_bwdwpix=2)
         pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 100, 9, 16, kind, seed=4, req=req)   # four filter tiles
-        emu_ops.set_tuning(dc_bwdwpix=0)
+        emu_ops.set_tuning(dc_bwdwpix=1, dc_bwdwpc=0, dc_bwdwblocks=2)   # four waves that produce, then multiply
+        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 8, 8, 13, 28, kind, seed=5, req=req)
+        emu_ops.set_tuning(dc_bwdwpix=0, dc_bwdwpc=1, dc_bwdwblocks=0)
         pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 11, 20, kind, seed=3, req=req)
 
 

@@ -390,8 +390,24 @@ def test_deform_conv_backward_weight_gradient_kernels(ops, oracle, dev, kind):
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 32, 32, 48, 64, kind, seed=1, req=req)
         _lib.set_tuning(dc_bwdwpix=2)   # four filter tiles per block (by default level 5 keeps the per-tap kernel)
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 128, 128, 12, 16, kind, seed=2, req=req)
+        _lib.set_tuning(dc_bwdwpix=1, dc_bwdwpc=0)   # four waves that produce, then multiply (before the producer / consumer split)
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 64, 64, 48, 64, kind, seed=3, req=req)
     finally:
-        _lib.set_tuning(dc_bwdwblocks=0, dc_bwdwpix=1)
+        _lib.set_tuning(dc_bwdwblocks=0, dc_bwdwpix=1, dc_bwdwpc=1)
+
+
+@pytest.mark.parametrize("kind", ["smooth", "outside", "rough"])
+def test_deform_conv_backward_lane_is_pixel_split_launches(ops, oracle, dev, kind):
+    """dc.bwdsplit2=1: one launch per gradient at two blocks per CU (measured slower than the one-launch form, kept as a
+    tested variant); dc.bwdksplit: filter slices over blockIdx.z."""
+    from maskflownet_amd import _lib
+    try:
+        _lib.set_tuning(dc_bwdsplit2=1)
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 64, 64, 48, 64, kind, req=("write", "write", "null", "null"))
+        _lib.set_tuning(dc_bwdsplit2=0, dc_bwdksplit=3)
+        pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 96, 96, 24, 32, kind, seed=1, req=("write", "write", "null", "null"))
+    finally:
+        _lib.set_tuning(dc_bwdsplit2=0, dc_bwdksplit=0)
 
 
 def test_deform_conv_backward_weight_gradient_is_deterministic(ops, dev):
