@@ -303,7 +303,7 @@ def test_deform_conv_backward(ops, oracle, kw):
 
 
 @pytest.mark.parametrize("shape", [(1, 36, 34, 5, 18),    # two channel blocks (ragged), partial 8x16 tiles, 2 filter tiles
-                                   (2, 5, 70, 3, 17)])    # three filter tiles, odd sizes, two images
+                                   (2, 5, 70, 3, 9)])     # three filter tiles, odd sizes, two images
 def test_deform_conv_backward_mfma_paths(ops, oracle, shape):
     # tile kernel (LDS window + out-of-window fallback: offsets of sigma 1.5 px around 0) and MFMA weight gradient
     pc.case_deform_bwd(ops, oracle, ident, ident, *shape, kernel=(3, 3), pad=(1, 1))
@@ -315,7 +315,7 @@ def test_deform_conv_backward_shared_offsets(ops, oracle, kind):
     # between OS threads) is slow: goffset is requested where the border rules matter most and in the mixed case, on few
     # channels; the GPU test runs every kind with every gradient at the network's shapes.
     full = kind in ("integer", "mixed")
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 34 if kind == "smooth" else 4, 4, 7 if kind == "smooth" else 11, 19, kind,
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 34 if kind == "smooth" else 4, 4, 7 if kind in ("smooth", "mixed") else 11, 19, kind,
                               req=("write", "write" if full else "null", "write", "write"))
 
 
@@ -330,7 +330,7 @@ def test_deform_conv_backward_lane_is_pixel(ops, oracle, kind):
 
 def test_deform_conv_backward_lane_is_pixel_channel_blocks_and_requests(ops, oracle):
     # two channel blocks (the second ragged: 36 channels), three filter chunks (the last ragged: 36 filters), two images
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 36, 36, 9, 16, "smooth", req=("write", "write", "null", "null"))
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 36, 9, 16, "smooth", req=("write", "write", "null", "null"))
     # one gradient at a time, and accumulation into the caller's buffers
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "outside", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "rough", seed=1, req=("null", "write", "null", "null"))
@@ -344,9 +344,10 @@ def test_deform_conv_backward_lane_is_pixel_split_launches(ops, oracle, kind):
     sets of 16 planes (two blocks per CU on the GPU; measured slower there, kept as a tested variant); three filter
     slices (blockIdx.z)."""
     emu_ops.set_tuning(dc_bwdsplit2=1)
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 20, 11, 20, kind, req=("write", "write", "null", "null"))
-    emu_ops.set_tuning(dc_bwdsplit2=1, dc_bwdksplit=3)
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 40, 9, 16, kind, seed=1, req=("write", "write", "null", "null"))
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 12, 9, 16, kind, req=("write", "write", "null", "null"))
+    if kind == "smooth":
+        emu_ops.set_tuning(dc_bwdsplit2=1, dc_bwdksplit=3)
+        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 40, 5, 16, kind, seed=1, req=("write", "write", "null", "null"))
 
 
 @pytest.mark.parametrize("kind", ["smooth", "outside", "mixed"])
@@ -360,11 +361,11 @@ def test_deform_conv_backward_weight_lane_is_pixel(ops, oracle, kind):
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 8, 8, 13, 28, kind, seed=1, req=req)
     if kind == "smooth":
         emu_ops.set_tuning(dc_bwdwblocks=0)
-        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 40, 9, 16, kind, seed=2, req=req)   # ragged channel / filter tiles
+        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 40, 5, 16, kind, seed=2, req=req)   # ragged channel / filter tiles
         emu_ops.set_tuning(dc_bwdwpix=2)
-        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 100, 9, 16, kind, seed=4, req=req)   # four filter tiles
+        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 100, 5, 8, kind, seed=4, req=req)   # four filter tiles
         emu_ops.set_tuning(dc_bwdwpix=1, dc_bwdwpc=0, dc_bwdwblocks=2)   # four waves that produce, then multiply
-        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 8, 8, 13, 28, kind, seed=5, req=req)
+        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 8, 8, 9, 24, kind, seed=5, req=req)
         emu_ops.set_tuning(dc_bwdwpix=0, dc_bwdwpc=1, dc_bwdwblocks=0)
         pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 11, 20, kind, seed=3, req=req)
 
