@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Measurement: shader cycles of dc_bwd_weight_pix_kernel by phase (wave 0 of each block, summed over the block's tiles)
-and the launch's duration, per cfg2 level (weight + bias gradient requested alone)."""
+"""Measurement: shader cycles of dc_bwd_weight_pix_kernel (the four-wave form, dc.bwdwpc=0, up to 128 filters) by phase (wave 0
+of each block, summed over the block's tiles) and the launch's duration, per cfg2 level (weight + bias gradient requested alone)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +10,7 @@ from maskflownet_amd.ops import default_ops
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
     _lib.set_tuning(**{k: int(v)})
+_lib.set_tuning(dc_bwdwpc=0, dc_bwdwpix=2)
 lib = _lib.lib(); ops = default_ops()
 wl = hotpath.HotPathWorkload("cfg2", mode="dropin")
 wl.run_eager()
