@@ -221,6 +221,21 @@ int mfn_deform_conv_bwd(const float *gout, const float *x, const float *offset, 
                         int dh, int dw, int groups, int deform_groups, int req_x, int req_offset,
                         int req_w, int req_bias, void *workspace, size_t workspace_bytes,
                         void *stream);
+/* Backward of the fused call mfn_deform_conv_shared_fwd (training with the offsets never built by the caller):
+ * gflow (N,2,H,W) = d loss / d flow_yx = flow_scale / flow_stride * sum over the taps of the offset gradient; gx, gw, gbias
+ * and the req_* as mfn_deform_conv_bwd.  The workspace (mfn_deform_conv_shared_bwd_workspace_bytes, required, 16-byte
+ * aligned) holds the offsets and their gradient.  mfn_offsets_from_flow_bwd is the gradient of mfn_offsets_from_flow on its
+ * own (req: MFN_REQ_WRITE or MFN_REQ_ADD). */
+size_t mfn_deform_conv_shared_bwd_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw, int ph,
+                                                  int pw, int dh, int dw, int groups);
+int mfn_deform_conv_shared_bwd(const float *gout, const float *x, const float *flow_yx, float flow_scale,
+                               float flow_stride, const float *w, float *gx, float *gflow, float *gw,
+                               float *gbias, int N, int Cin, int H, int W, int Cout, int kh, int kw, int ph,
+                               int pw, int dh, int dw, int groups, int req_x, int req_flow, int req_w,
+                               int req_bias, void *workspace, size_t workspace_bytes, void *stream);
+int mfn_offsets_from_flow_bwd(const float *goffset, float *gflow_yx, int N, int H, int W, int taps,
+                              float flow_scale, float flow_stride, int req, void *stream);
+
 /* Upsample(factor) of flow / mask between pyramid levels -- replaces the Gluon block
  * /root/reference/network/MaskFlownet.py:35-62 (edge pad + Deconvolution with the triangle kernel
  * 1-|f-1-a|/f, kernel 2f-1, stride f, pad f-1, last row/column dropped; call sites :228-229 ... :311).

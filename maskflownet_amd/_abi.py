@@ -30,6 +30,9 @@ SIGNATURES = {
     "deform_conv_fwd": (_i, [_f] * 5 + [_i] * 15 + [C.c_void_p, C.c_size_t, _s]),
     "deform_conv_shared_fwd": (_i, [_f, _f, C.c_float, C.c_float, _f, _f, _f] + [_i] * 12 + [C.c_void_p, C.c_size_t, _s]),
     "offsets_from_flow": (_i, [_f, _f, _i, _i, _i, _i, C.c_float, C.c_float, _s]),
+    "offsets_from_flow_bwd": (_i, [_f, _f, _i, _i, _i, _i, C.c_float, C.c_float, _i, _s]),
+    "deform_conv_shared_bwd_workspace_bytes": (C.c_size_t, [_i] * 12),
+    "deform_conv_shared_bwd": (_i, [_f, _f, _f, C.c_float, C.c_float, _f, _f, _f, _f, _f] + [_i] * 16 + [C.c_void_p, C.c_size_t, _s]),
     "debug_set_timeline": (_i, [C.c_void_p]),
     "correlation_bwd": (_i, [_f] * 5 + [_i] * 12 + [_s]),
     "warp_bwd": (_i, [_f] * 5 + [_i] * 7 + [_s]),

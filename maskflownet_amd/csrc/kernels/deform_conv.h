@@ -798,6 +798,20 @@ __global__ __launch_bounds__(256) void offsets_from_flow_kernel(OffsetsParams p)
   float *o = p.offset + n * 2 * p.taps * plane + t * plane + pix;
   for (int k = 0; k < p.taps; ++k) mfn_store1_stream(o + (size_t)2 * k * plane, v, p.st_policy);
 }
+// gradient of the above: gflow[n][dir][pixel] (+)= scale / stride * sum over the taps of goffset[n][2 tap + dir][pixel]
+struct OffsetsBwdParams { const float *goffset; float *gflow; int N, H, W, taps; float scale, stride; int req; };
+__global__ __launch_bounds__(256) void offsets_from_flow_bwd_kernel(OffsetsBwdParams p) {
+  const size_t plane = (size_t)p.H * p.W;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over N*2*plane
+  if (idx >= (size_t)p.N * 2 * plane) return;
+  const size_t n = idx / (2 * plane), r = idx - n * 2 * plane;
+  const size_t t = r / plane, pix = r - t * plane;
+  const float *g = p.goffset + n * 2 * p.taps * plane + t * plane + pix;
+  float sum = 0.f;
+  for (int k = 0; k < p.taps; ++k) sum += g[(size_t)2 * k * plane];
+  const float v = sum * (p.scale / p.stride);
+  p.gflow[idx] = p.req == 3 ? p.gflow[idx] + v : v;
+}
 inline int offsets_from_flow_launch(OffsetsParams p, hipStream_t stream) {
   const size_t total = (size_t)p.N * 2 * p.H * p.W;
   if (!total) return 0;

@@ -83,18 +83,28 @@ class _DeformConvFn(torch.autograd.Function):
         return gx, goff, gw, gb, None
 
 
-class _OffsetsFromFlowFn(torch.autograd.Function):
-    """repeat9(flow * scale / stride) (MaskFlownet.py:230) with its gradient: d flow = scale / stride * sum over the taps."""
+class _SharedDeformConvFn(torch.autograd.Function):
+    """The fused call (MaskFlownet.py:230: every tap of a pixel gets flow * scale / stride) with its own backward:
+    mfn_deform_conv_shared_fwd / mfn_deform_conv_shared_bwd -- the offset tensor is never the caller's."""
 
     @staticmethod
-    def forward(ctx, flow, scale, stride, taps):
-        ctx.ratio, ctx.taps = float(scale) / float(stride), int(taps)
-        return ops.offsets_from_flow(flow, scale, stride, taps=taps)
+    def forward(ctx, x, flow, weight, bias, scale, stride, kw, packed):
+        ctx.save_for_backward(x, flow, weight)
+        ctx.kw, ctx.scale, ctx.stride = kw, float(scale), float(stride)
+        ctx.has_bias = bias is not None
+        return ops.deformable_convolution_shared(x, flow, scale, stride, weight, bias, kernel=kw["kernel"], dilate=kw["dilate"],
+                                                 pad=kw["pad"], num_group=kw["num_group"], packed=packed)
 
     @staticmethod
-    def backward(ctx, goff):
-        n, _, h, w = goff.shape
-        return goff.reshape(n, ctx.taps, 2, h, w).sum(dim=1) * ctx.ratio, None, None, None
+    def backward(ctx, gout):
+        x, flow, weight = ctx.saved_tensors
+        kw = ctx.kw
+        need = ctx.needs_input_grad
+        req = ["write" if need[i] else "null" for i in range(3)] + ["write" if (ctx.has_bias and need[3]) else "null"]
+        gx, gfl, gw, gb = ops.deformable_convolution_shared_backward(
+            gout, x, flow, ctx.scale, ctx.stride, weight, kernel=kw["kernel"], dilate=kw["dilate"], pad=kw["pad"],
+            num_group=kw["num_group"], no_bias=not ctx.has_bias, req=tuple(req))
+        return gx, gfl, gw, gb, None, None, None, None
 
 
 def _any_grad(*ts):
@@ -221,10 +231,9 @@ class DeformableConv2D(nn.Module):
         if kw["stride"] != (1, 1) or kw["num_deformable_group"] != 1:
             raise ValueError("forward_shared needs stride 1 and one deformable group")
         if _any_grad(x, flow, self.weight, self.bias):
-            # the fused kernel has no autograd graph: under autograd the call takes the differentiable form, the offsets
-            # materialised (as the reference does) and DeformableConvolution's own backward -- same values
-            taps = kw["kernel"][0] * kw["kernel"][1]
-            return self.forward(x, _OffsetsFromFlowFn.apply(flow, flow_scale, flow_stride, taps))
+            # under autograd: the same fused forward kernel, and the fused backward (mfn_deform_conv_shared_bwd)
+            out = _SharedDeformConvFn.apply(x, flow, self.weight, self.bias, flow_scale, flow_stride, kw, self._packed(x))
+            return self.act(out) if self.act is not None else out
         out = ops.deformable_convolution_shared(x, flow, flow_scale, flow_stride, self.weight, self.bias,
                                                 kernel=kw["kernel"], dilate=kw["dilate"], pad=kw["pad"],
                                                 num_group=kw["num_group"], packed=self._packed(x))

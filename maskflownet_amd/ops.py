@@ -311,6 +311,63 @@ class OpSet:
                                            self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(x)))
         return gx, goff, gw, gb
 
+    def deformable_convolution_shared_backward(self, out_grad, data, flow, flow_scale, flow_stride, weight, kernel=(3, 3),
+                                               dilate=(1, 1), pad=(1, 1), num_group=1, no_bias=False,
+                                               req=("write", "write", "write", "write"), out=None):
+        """Gradients of deformable_convolution_shared w.r.t. (data, flow, weight, bias): the fused call's backward
+        (mfn_deform_conv_shared_bwd).  d/dflow = flow_scale / flow_stride * sum over the taps of the offset gradient.
+        out: optional (gx, gflow, gweight, gbias) buffers (required for req "add")."""
+        go, x, fl, w = self._in(out_grad, data, flow, weight)
+        (kh, kw), (ph, pw), (dh, dw) = map(self._pair, (kernel, pad, dilate))
+        N, Cin, H, W = self.ad.shape(x)
+        Cout = self.ad.shape(w)[0]
+        if self.ad.shape(fl) != (N, 2, H, W):
+            raise ValueError("deformable_convolution_shared_backward: flow must be (N,2,H,W) = %s, got %s"
+                             % ((N, 2, H, W), self.ad.shape(fl)))
+        rq = [_REQ[r] for r in req]
+        if no_bias:
+            rq[3] = 0
+        want = (self.ad.shape(x), self.ad.shape(fl), self.ad.shape(w), (Cout,))
+        given = tuple(out) if out is not None else (None, None, None, None)
+        if len(given) != 4:
+            raise ValueError("deformable_convolution_shared_backward: out must be (gx, gflow, gweight, gbias)")
+        grads = []
+        for i, (g, shp) in enumerate(zip(given, want)):
+            if not rq[i]:
+                grads.append(None)
+            elif g is None:
+                if rq[i] == _REQ["add"]:
+                    raise ValueError("deformable_convolution_shared_backward: req 'add' needs the buffer to add into (out[%d])" % i)
+                grads.append(self.ad.empty(x, shp))
+            else:
+                (g,) = self._in(g)
+                if self.ad.shape(g) != tuple(shp):
+                    raise ValueError("deformable_convolution_shared_backward: out[%d] has shape %s, expected %s"
+                                     % (i, self.ad.shape(g), tuple(shp)))
+                grads.append(g)
+        gx, gfl, gw, gb = grads
+        p = lambda a: self.ad.ptr(a) if a is not None else None
+        nbytes = self.ns.deform_conv_shared_bwd_workspace_bytes(N, Cin, H, W, Cout, kh, kw, ph, pw, dh, dw, num_group)
+        ws = self._workspace(x, nbytes)
+        self.check(self.ns.deform_conv_shared_bwd(self.ad.ptr(go), self.ad.ptr(x), self.ad.ptr(fl), float(flow_scale),
+                                                  float(flow_stride), self.ad.ptr(w), p(gx), p(gfl), p(gw), p(gb), N, Cin, H, W,
+                                                  Cout, kh, kw, ph, pw, dh, dw, num_group, rq[0], rq[1], rq[2], rq[3],
+                                                  self.ad.ptr(ws), self.ad.nbytes(ws), self.ad.stream(x)))
+        return gx, gfl, gw, gb
+
+    def offsets_from_flow_backward(self, offset_grad, scale, stride, taps=9, req="write", out=None):
+        """Gradient of offsets_from_flow: (N,2,H,W) = scale / stride * sum over the taps."""
+        (go,) = self._in(offset_grad)
+        N, c, H, W = self.ad.shape(go)
+        if c != 2 * taps:
+            raise ValueError("offsets_from_flow_backward: offset gradient must be (N,%d,H,W)" % (2 * taps))
+        if req == "add" and out is None:
+            raise ValueError("offsets_from_flow_backward: req 'add' needs the buffer to add into")
+        out = self._out(out, go, (N, 2, H, W), "offsets_from_flow_backward")
+        self.check(self.ns.offsets_from_flow_bwd(self.ad.ptr(go), self.ad.ptr(out), N, H, W, int(taps), float(scale),
+                                                 float(stride), _REQ[req], self.ad.stream(go)))
+        return out
+
     def deformable_convolution_shared(self, data, flow, flow_scale, flow_stride, weight, bias=None, kernel=(3, 3),
                                       dilate=(1, 1), pad=(1, 1), num_group=1, out=None, packed=None):
         """DeformableConvolution with offset = repeat9(flow*flow_scale/flow_stride) (MaskFlownet.py:230)
@@ -622,6 +679,14 @@ def deformable_convolution_shared(*a, **k):
 
 def offsets_from_flow(*a, **k):
     return default_ops().offsets_from_flow(*a, **k)
+
+
+def offsets_from_flow_backward(*a, **k):
+    return default_ops().offsets_from_flow_backward(*a, **k)
+
+
+def deformable_convolution_shared_backward(*a, **k):
+    return default_ops().deformable_convolution_shared_backward(*a, **k)
 
 
 def Upsample(*a, **k):

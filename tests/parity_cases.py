@@ -304,6 +304,30 @@ def case_deform_bwd_shared(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, kin
     return max(errs)
 
 
+def case_deform_shared_bwd(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, scale=20.0, stride=8.0, req=("write",) * 4,
+                           kernel=(3, 3), pad=(1, 1), dilate=(1, 1)):
+    """Backward of the fused call (mfn_deform_conv_shared_bwd) against the oracle's composition: offsets = repeat9(flow * scale /
+    stride) (MaskFlownet.py:230), DeformableConvolution's backward, d/dflow = scale / stride * sum over the taps."""
+    rng = np.random.default_rng(900 + seed)
+    T = kernel[0] * kernel[1]
+    x = feat(rng, (N, Cin, H, W))
+    w = (rng.standard_normal((Cout, Cin) + tuple(kernel)) * 0.2).astype(np.float32)
+    fl = (flow_field(rng, N, H, W) * np.float32(stride / scale)).astype(np.float32)
+    go = rng.standard_normal((N, Cout, H, W)).astype(np.float32)
+    off = np.repeat((fl * np.float32(scale) / np.float32(stride))[:, None], T, axis=1).reshape(N, 2 * T, H, W)
+    gx, goff, gw, gb = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=kernel, pad=pad, dilate=dilate)
+    gflow = goff.reshape(N, T, 2, H, W).sum(axis=1) * (np.float32(scale) / np.float32(stride))
+    got = ops.deformable_convolution_shared_backward(to_dev(go), to_dev(x), to_dev(fl), scale, stride, to_dev(w), kernel=kernel,
+                                                     pad=pad, dilate=dilate, req=req)
+    errs = []
+    for g, r, rq, nm in zip(got, (gx, gflow, gw, gb), req, ("gx", "gflow", "gw", "gbias")):
+        if rq in ("null", None):
+            assert g is None
+            continue
+        errs.append(check_close(to_host(g), r, tol=2e-5 if nm == "gx" else 5e-5, what="fused deform backward %s %s" % (nm, (N, Cin, Cout, H, W))))
+    return max(errs)
+
+
 def case_deform_bwd(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, **kw):
     rng = np.random.default_rng(51 + seed)
     ng, ndg = kw.get("num_group", 1), kw.get("num_deformable_group", 1)

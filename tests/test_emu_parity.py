@@ -390,6 +390,21 @@ def test_deform_conv_backward_shared_offsets_partial_requests_and_switch(ops, or
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", seed=3, req=("write", "write", "null", "null"))
 
 
+def test_deform_conv_shared_backward(ops, oracle):
+    """mfn_deform_conv_shared_bwd / mfn_offsets_from_flow_bwd: the fused call's gradients, d/dflow included; a 3x3 shape on the
+    lane = pixel kernels, a dilated one on the general path, partial requests."""
+    pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 5, 16)
+    pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 6, 4, 5, seed=1, pad=(2, 2), dilate=(2, 2), scale=5.0, stride=4.0)
+    pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 4, 8, seed=2, req=("null", "write", "null", "null"))
+    rng = np.random.default_rng(4)
+    goff = rng.standard_normal((2, 18, 5, 6)).astype(np.float32)
+    base = rng.standard_normal((2, 2, 5, 6)).astype(np.float32)
+    want = goff.reshape(2, 9, 2, 5, 6).sum(axis=1) * np.float32(20.0 / 16.0)
+    pc.check_close(ops.offsets_from_flow_backward(goff, 20.0, 16.0), want, tol=1e-6, what="offsets_from_flow backward")
+    pc.check_close(ops.offsets_from_flow_backward(goff, 20.0, 16.0, req="add", out=base.copy()), want + base, tol=1e-6,
+                   what="offsets_from_flow backward, req add")
+
+
 def test_backward_req_add_and_null(ops, oracle):
     rng = np.random.default_rng(2)
     f1, f2 = pc.feat(rng, (1, 3, 6, 8)), pc.feat(rng, (1, 3, 6, 8))

@@ -468,6 +468,12 @@ def test_layer_mirror_trains_through_the_c_abi(oracle, T):
     assert layer.Reconstruction2D(2, block_grad=True)(img, flt).requires_grad  # grad still flows into x
 
 
+@pytest.mark.parametrize("N,C,H,W,stride", [(2, 128, 12, 16, 32.0), (2, 64, 48, 64, 8.0), (1, 32, 96, 128, 4.0), (2, 12, 11, 21, 8.0)])
+def test_deform_conv_shared_backward(ops, oracle, dev, N, C, H, W, stride):
+    """The fused call's backward (mfn_deform_conv_shared_bwd) at the network's level shapes and an odd one, d/dflow included."""
+    pc.case_deform_shared_bwd(ops, oracle, dev, host, N, C, C, H, W, stride=stride)
+
+
 def test_layer_fused_calls_are_differentiable(oracle, T):
     """DeformableConv2D.forward_shared / forward_matching under autograd: the same values as the fused inference kernels,
     gradients (d/dx, d/dflow = scale / stride * sum over the taps, d/dW, d/db) against the oracle."""
