@@ -222,14 +222,15 @@ def grad_bucket_layout(N, H, W):
     return lay, off
 
 
-def output_names(kind="S"):
-    """Names of everything a pass of `kind` writes, in launch order of the forward / cascade / backward parts."""
+def output_names(kind="S", mode="dropin"):
+    """Names of everything a pass of `kind` writes, in launch order of the forward / cascade / backward parts (the training
+    pass: d/doffset (18 planes) in drop-in mode, d/dflow (2 planes) in fused mode)."""
     keys = ["corr6"] + [k for l in (5, 4, 3, 2) for k in ("deform%d" % l, "corr%d" % l)] + ["warp"]
     if kind == "full":
         keys += [k % l for l in (6, 5, 4, 3, 2) for k in ("deform_u%d", "corr_u%d", "corr_v%d")]
     if kind == "train":
         keys += [k % l for l in (6, 5, 4, 3, 2) for k in ("g_c1_%d", "g_warp_%d")]
-        keys += [k % l for l in (5, 4, 3, 2) for k in ("g_c2_%d", "g_offset_%d", "gw_%d", "gb_%d")]
+        keys += [k % l for l in (5, 4, 3, 2) for k in ("g_c2_%d", "g_offset_%d" if mode == "dropin" else "g_flow_%d", "gw_%d", "gb_%d")]
     return keys
 
 
@@ -283,9 +284,6 @@ class HotPathWorkload:
         self.kind = cfg[3] if len(cfg) > 3 else "S"
         if self.kind not in KINDS:
             raise ValueError("unknown pass kind %r" % (self.kind,))
-        if self.kind == "train" and mode != "dropin":
-            raise ValueError("the train pass needs the materialised offsets of mode='dropin' (DeformableConvolution's "
-                             "backward reads them)")
         self.mode = mode
         self.device = getattr(bufs, "device", None)
         self.ops = bufs.ops
@@ -329,7 +327,10 @@ class HotPathWorkload:
                 self.o["g_warp_%d" % l] = bufs.empty((n, c, h, w))   # d loss / d data2 of corr_l
                 if l != 6:
                     self.o["g_c2_%d" % l] = bufs.empty((n, c, h, w))
-                    self.o["g_offset_%d" % l] = bufs.empty((n, 18, h, w))
+                    if mode == "dropin":
+                        self.o["g_offset_%d" % l] = bufs.empty((n, 18, h, w))
+                    else:
+                        self.o["g_flow_%d" % l] = bufs.empty((n, 2, h, w))
         self.graph = None
         self.prepack = bool(prepack)
         self.packed = {}
@@ -404,10 +405,15 @@ class HotPathWorkload:
             seq.append(("corr_bwd%d" % l, lambda l=l: ops.Correlation_backward(
                 t["gcorr_%d" % l], t["c1_%d" % l], o["deform%d" % l], 1, MD, 1, 1, MD, True,
                 g1=o["g_c1_%d" % l], g2=o["g_warp_%d" % l])))
-            seq.append(("deform_bwd%d" % l, lambda l=l: ops.DeformableConvolution_backward(
-                o["g_warp_%d" % l], t["c2_%d" % l], o["offset%d" % l], t["w_%d" % l], kernel=(3, 3), stride=(1, 1),
-                dilate=(1, 1), pad=(1, 1),
-                out=(o["g_c2_%d" % l], o["g_offset_%d" % l], o["gw_%d" % l], o["gb_%d" % l]))))
+            if self.mode == "dropin":
+                seq.append(("deform_bwd%d" % l, lambda l=l: ops.DeformableConvolution_backward(
+                    o["g_warp_%d" % l], t["c2_%d" % l], o["offset%d" % l], t["w_%d" % l], kernel=(3, 3), stride=(1, 1),
+                    dilate=(1, 1), pad=(1, 1),
+                    out=(o["g_c2_%d" % l], o["g_offset_%d" % l], o["gw_%d" % l], o["gb_%d" % l]))))
+            else:   # the fused call's own backward: d/dflow instead of the 18 offset planes
+                seq.append(("deform_bwd%d" % l, lambda l=l: ops.deformable_convolution_shared_backward(
+                    o["g_warp_%d" % l], t["c2_%d" % l], t["flow_%d" % l], SCALE, STRIDES[l], t["w_%d" % l],
+                    out=(o["g_c2_%d" % l], o["g_flow_%d" % l], o["gw_%d" % l], o["gb_%d" % l]))))
         seq.append(("corr_bwd6", lambda: ops.Correlation_backward(
             t["gcorr_6"], t["c1_6"], t["c2_6"], 1, MD, 1, 1, MD, True, g1=o["g_c1_6"], g2=o["g_warp_6"])))
         return seq
@@ -466,7 +472,7 @@ class HotPathWorkload:
         return [self.o[k] for k in self.output_names()]
 
     def output_names(self):
-        return output_names(self.kind)
+        return output_names(self.kind, self.mode)
 
     def checksum(self):
         """[sum |out|, element count] over all outputs -- the 2-float record ranks all-reduce."""

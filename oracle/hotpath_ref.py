@@ -51,5 +51,11 @@ def oracle_pass(host, n_pairs, kind="S", mode="dropin"):
                 gx, goff, gw, gb = oracle.deformable_convolution_backward(g2, host["c2_%d" % l][sl], offs[l],
                                                                           host["w_%d" % l], with_bias=True,
                                                                           kernel=(3, 3), pad=(1, 1))
-                out["g_c2_%d" % l], out["g_offset_%d" % l], out["gw_%d" % l], out["gb_%d" % l] = gx, goff, gw, gb
+                out["g_c2_%d" % l], out["gw_%d" % l], out["gb_%d" % l] = gx, gw, gb
+                if mode == "fused":   # d/dflow = scale / stride * sum over the nine taps (MaskFlownet.py:230)
+                    n_, _, h_, w_ = goff.shape
+                    out["g_flow_%d" % l] = (goff.reshape(n_, 9, 2, h_, w_).sum(axis=1)
+                                            * (np.float32(SCALE) / np.float32(STRIDES[l]))).astype(np.float32)
+                else:
+                    out["g_offset_%d" % l] = goff
     return out

@@ -123,7 +123,7 @@ class _EmuBuffers:
 
 
 @pytest.mark.parametrize("kind,mode", [("S", "dropin"), ("S", "fused"), ("full", "dropin"), ("full", "fused"),
-                                       ("train", "dropin")])
+                                       ("train", "dropin"), ("train", "fused")])
 def test_call_lists_of_every_pass_through_the_emulated_kernels(kind, mode, monkeypatch):
     """The operator sequences bench.py replays (S / full / train, drop-in and fused), run on the emulated kernels
     with numpy buffers: every output of the pass against the oracle's pass, the gradient bucket included.  Narrow
@@ -148,9 +148,7 @@ def test_call_lists_of_every_pass_through_the_emulated_kernels(kind, mode, monke
             assert np.array_equal(wl.grad_bucket[off:off + int(np.prod(shp))], np.asarray(wl.o[name]).reshape(-1))
 
 
-def test_train_pass_refuses_fused_mode():
-    with pytest.raises(ValueError, match="dropin"):
-        hotpath.HotPathWorkload((1, 64, 64, "train"), mode="fused", buffers=_EmuBuffers())
+def test_unknown_pass_kind_is_refused():
     with pytest.raises(ValueError, match="kind"):
         hotpath.HotPathWorkload((1, 64, 64, "half"), buffers=_EmuBuffers())
 
