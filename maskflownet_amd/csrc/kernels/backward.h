@@ -684,6 +684,10 @@ struct DcBwdIParams {
   unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, scatter, total} shader cycles
   const int *skip;               // per (tile, strip): non-zero = already done by dc_bwd_input_shared_kernel; may be NULL
   int skip_tiles;                // 1: `skip` holds one flag per 4x8-pixel tile [n][cdiv(H,4)][cdiv(W,8)] (dc_bwd_input_pix_kernel)
+  // flow mode (mfn_deform_conv_shared_bwd; dc_backward.h: DcBwdPParams): offsets from flow[n][dir][pixel], d/dflow instead of goffset
+  const float *flow;
+  float *gflow;
+  float flow_scale, flow_stride;
 };
 constexpr int DCI_TH = 8, DCI_TW = 16, DCI_WR = 10, DCI_WC = 28, DCI_GW = 16;
 constexpr int DCI_PLANE = DCI_WR * DCI_WC + 1;  // odd channel-plane stride: the 32 lanes (channels) hit distinct banks
@@ -729,8 +733,16 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   int wy0, wx0;
   {
     const int cy = min(ty0 + TH / 2, H - 1), cx = min(tx0 + TW / 2, W - 1);
-    const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
-    const float oh = op[(size_t)(2 * (T / 2)) * plane], ow = op[(size_t)(2 * (T / 2) + 1) * plane];
+    float oh, ow;
+    if (p.flow) {
+      const float *fp = p.flow + (size_t)n * 2 * plane + (size_t)cy * W + cx;
+      oh = fp[0] * p.flow_scale / p.flow_stride;
+      ow = fp[plane] * p.flow_scale / p.flow_stride;
+    } else {
+      const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
+      oh = op[(size_t)(2 * (T / 2)) * plane];
+      ow = op[(size_t)(2 * (T / 2) + 1) * plane];
+    }
     const float fh = fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), fw = fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
     wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - (WR - 5) / 2 + 2 * wave);  // a strip needs 2 + dh*(kh-1) + 1 = 5 rows: centred
     wx0 = MFN_UNIFORM(tx0 - p.pw + (int)fw - (WC - (TW + p.dw * (p.kw - 1) + 1)) / 2);
@@ -757,8 +769,16 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
     // ---- geometry of the strip's 32 pixels for tap t (lanes 0..31 write, everyone reads it back as broadcasts)
     MFN_WAIT_LGKM0();  // the previous tap's readers are done (wave-private table: no block barrier)
     if (half == 0) {
-      const float *op = p.offset + (size_t)n * 2 * T * plane + pix;
-      const float oh = op[(size_t)(2 * t) * plane], ow = op[(size_t)(2 * t + 1) * plane];
+      float oh, ow;
+      if (p.flow) {
+        const float *fp = p.flow + (size_t)n * 2 * plane + pix;
+        oh = fp[0] * p.flow_scale / p.flow_stride;
+        ow = fp[plane] * p.flow_scale / p.flow_stride;
+      } else {
+        const float *op = p.offset + (size_t)n * 2 * T * plane + pix;
+        oh = op[(size_t)(2 * t) * plane];
+        ow = op[(size_t)(2 * t + 1) * plane];
+      }
       const int ti = t / p.kw, tj = t - ti * p.kw;
       const int h_in = pyc - p.ph, w_in = pxc - p.pw;
       bool vh, vw;
@@ -841,9 +861,16 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
           const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
           const int y = ty0 + 2 * wave + (pp >> 4), x = tx0 + (pp & 15);
           if (y < H && x < W && (sh_[r] != 0.f || sw_[r] != 0.f)) {
-            float *gof = p.goffset + ((size_t)n * 2 * T + 2 * t) * plane + (size_t)y * W + x;
-            atomicAdd(gof, sh_[r]);
-            atomicAdd(gof + plane, sw_[r]);
+            if (p.flow) {
+              float *gf = p.gflow + (size_t)n * 2 * plane + (size_t)y * W + x;
+              const float ratio = p.flow_scale / p.flow_stride;
+              atomicAdd(gf, sh_[r] * ratio);
+              atomicAdd(gf + plane, sw_[r] * ratio);
+            } else {
+              float *gof = p.goffset + ((size_t)n * 2 * T + 2 * t) * plane + (size_t)y * W + x;
+              atomicAdd(gof, sh_[r]);
+              atomicAdd(gof + plane, sw_[r]);
+            }
           }
         }
       }

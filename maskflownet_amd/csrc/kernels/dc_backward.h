@@ -84,6 +84,11 @@ struct DcBwdPParams {
   int xcd;
   unsigned long long *timeline;  // measurement only: per block {setup | MFMA << 32, phase A, phase B, flush} shader cycles of wave 0
   int tl_detail;                 // ... or, instead of the last three, phase B's first group: {fold + shuffles, walk, barrier wait}
+  // flow mode (mfn_deform_conv_shared_bwd): every tap's offset IS flow[n][dir][pixel] * flow_scale / flow_stride -- no offset
+  // tensor is read (offset == NULL), and d/dflow[n][dir][pixel] (req_offset: its request) takes the place of goffset
+  const float *flow;
+  float *gflow;
+  float flow_scale, flow_stride;
 };
 
 template <bool WX, bool WO, int OCC>
@@ -180,14 +185,16 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
   float vyf[3], vxf[3];
   bool ok = true;
   int lo0y, lo0x;
-  const float *offn = p.offset + (size_t)n * 2 * T * plane;
+  const bool fm = p.flow != nullptr;  // uniform: the offsets come from the flow field (the forward's arithmetic, kernels/deform_conv.h)
+  const float *offn = fm ? p.flow + (size_t)n * 2 * plane : p.offset + (size_t)n * 2 * T * plane;
+  auto ldo = [&](const float *q) { const float v = *q; return fm ? v * p.flow_scale / p.flow_stride : v; };
   // offsets of the tile's and the region's centre pixels (uniform): where the windows are placed.  Requested first:
   // two more memory round trips behind the geometry otherwise.
   float ctile[2], creg[2];
   {
     const float *o1 = offn + (size_t)min(tyi * 4 + 2, H - 1) * W + min(txi * 8 + 4, W - 1);
     const float *o2 = offn + (size_t)min(ry0 + 4, H - 1) * W + min(rx0 + 8, W - 1);
-    ctile[0] = o1[0]; ctile[1] = o1[plane]; creg[0] = o2[0]; creg[1] = o2[plane];
+    ctile[0] = ldo(o1); ctile[1] = ldo(o1 + plane); creg[0] = ldo(o2); creg[1] = ldo(o2 + plane);
   }
   auto centre_floor = [&](const float (&c)[2], int &fh, int &fw) {
     fh = MFN_UNIFORM((int)fminf(fmaxf(floorf(c[0]), -1.0e6f), 1.0e6f));
@@ -195,9 +202,11 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
   };
   {
     const float *op = offn + pix;
-    const float oh = op[0], ow = op[plane];
-    MFN_UNROLL
-    for (int t = 1; t < T; ++t) ok = ok && (op[(size_t)(2 * t) * plane] == oh) && (op[(size_t)(2 * t + 1) * plane] == ow);
+    const float oh = ldo(op), ow = ldo(op + plane);
+    if (!fm) {
+      MFN_UNROLL
+      for (int t = 1; t < T; ++t) ok = ok && (op[(size_t)(2 * t) * plane] == oh) && (op[(size_t)(2 * t + 1) * plane] == ow);
+    }
     lo0y = (int)fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f);
     lo0x = (int)fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
     dcs_axis(oh, h_in, H, lo0y, geo, DCS_AY, DCS_BY, DCS_FH0, DCS_FH1, vyf, ok);
@@ -482,16 +491,24 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
       if (xfit) phase_a(DcInt<1>{}); else phase_a(DcInt<0>{});
     }
     // the two half-waves hold the other 16 channels of the same pixel; half 0 writes d/dh, half 1 d/dw
+    float vsum = 0.f;
     MFN_UNROLL
     for (int t = 0; t < T; ++t) {
       const float h2 = sh[t] + __shfl_xor(sh[t], 32), w2 = sw[t] + __shfl_xor(sw[t], 32);
       const float m9 = stash[(0 + t / 3) * 64] * stash[(3 + t % 3) * 64];
       const float v = (half ? w2 : h2) * m9;
+      if (fm) { vsum += v; continue; }
       float *dst = p.goffset + ((size_t)n * 2 * T + 2 * t + half) * plane + pix;
       if (px_valid) {
         if (gridDim.y == 1 && gridDim.z == 1) *dst += v;  // zero-filled (write) or the caller's values (add); nobody else writes this pixel
         else if (v != 0.f) atomicAdd(dst, v);
       }
+    }
+    if (fm && px_valid) {  // d/dflow: the nine taps share the offset, so their gradients add up (MaskFlownet.py:230)
+      const float v = vsum * (p.flow_scale / p.flow_stride);
+      float *dst = p.gflow + ((size_t)n * 2 + half) * plane + pix;
+      if (gridDim.y == 1 && gridDim.z == 1) *dst += v;
+      else if (v != 0.f) atomicAdd(dst, v);
     }
   }
   if (p.timeline) tk2 = MFN_CYCLES();
@@ -693,6 +710,9 @@ struct DcBwdWPParams {
   float *slabs;                  // [channel block][block][Cout / 32 tiles][32][288] partial sums, or NULL: add to gw with atomics
   float *bias_slabs;             // [block][Cout / 32 tiles * 32] of the channel-block-0 blocks, or NULL: atomics
   unsigned long long *timeline;  // measurement only: per block, wave 0: {wait + gout store | loads << 32, produce | barrier << 32, consume | barrier << 32, total}
+  // flow mode (mfn_deform_conv_shared_bwd; DcBwdPParams): offsets from flow[n][dir][pixel]; dc_bwd_weight_pc_kernel only
+  const float *flow;
+  float flow_scale, flow_stride;
 };
 
 template <int MTOT>
@@ -1072,9 +1092,16 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
     q.px_valid = tile_ok && q.ho < H && q.wo < W;
     q.ho = min(q.ho, H - 1);
     q.wo = min(q.wo, W - 1);
-    const float *op = p.offset + (size_t)q.n * 2 * T * plane + (size_t)q.ho * W + q.wo;
-    MFN_UNROLL
-    for (int t = 0; t < 2 * T; ++t) q.off[t] = op[(size_t)t * plane];
+    if (p.flow) {  // flow mode: one offset for all taps, in the forward's arithmetic
+      const float *fp = p.flow + (size_t)q.n * 2 * plane + (size_t)q.ho * W + q.wo;
+      const float oh = fp[0] * p.flow_scale / p.flow_stride, ow = fp[plane] * p.flow_scale / p.flow_stride;
+      MFN_UNROLL
+      for (int t = 0; t < T; ++t) { q.off[2 * t] = oh; q.off[2 * t + 1] = ow; }
+    } else {
+      const float *op = p.offset + (size_t)q.n * 2 * T * plane + (size_t)q.ho * W + q.wo;
+      MFN_UNROLL
+      for (int t = 0; t < 2 * T; ++t) q.off[t] = op[(size_t)t * plane];
+    }
   };
   auto geo_store = [&](const GeoIn &q, int set) {
     const int h_in = q.ho - p.ph, w_in = q.wo - p.pw;
@@ -1216,7 +1243,9 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
       // per-tap geometry (dc_make_tap) and four global loads per value: arbitrary offsets, irregular floors
       const bool pv = gi[21 * 32 + j] != 0;
       const int ho = gi[22 * 32 + j], wo = gi[23 * 32 + j];
-      const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)ho * W + wo;
+      const float *op = p.flow ? p.flow + (size_t)n * 2 * plane + (size_t)ho * W + wo
+                               : p.offset + (size_t)n * 2 * T * plane + (size_t)ho * W + wo;
+      const float fsc = p.flow ? p.flow_scale : 1.f, fst = p.flow ? p.flow_stride : 1.f;  // (v * 1 / 1 == v)
       MFN_NOUNROLL
       for (int k = 0; k < 4; ++k) {
         const int cl = 2 * (4 * pw + k) + half;
@@ -1225,8 +1254,9 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
         MFN_NOUNROLL
         for (int t = 0; t < T; ++t) {
           const int ti = t / 3, tj = t - 3 * ti;
-          const DcTap tp = dc_make_tap(op[(size_t)(2 * t) * plane], op[(size_t)(2 * t + 1) * plane], ho - p.ph, wo - p.pw, ti, tj, H, W,
-                                       pv && c_ok);
+          const int tq = p.flow ? 0 : t;
+          const DcTap tp = dc_make_tap(op[(size_t)(2 * tq) * plane] * fsc / fst, op[(size_t)(2 * tq + 1) * plane] * fsc / fst,
+                                       ho - p.ph, wo - p.pw, ti, tj, H, W, pv && c_ok);
           const int bb = tp.base & 0x3FFFFFFF, dwi = (tp.base >> 30) & 1;
           const float cv = tp.w1 * pl[bb] + tp.w2 * pl[bb + dwi] + tp.w3 * pl[bb + tp.dhW] + tp.w4 * pl[bb + tp.dhW + dwi];
           colT[(t * 32 + cl) * RS + j] = cv;

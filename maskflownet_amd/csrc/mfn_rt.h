@@ -246,8 +246,9 @@ __host__ __device__ __forceinline__ unsigned mfn_xcd_remap(unsigned b, unsigned 
 // ---- launch plumbing -------------------------------------------------------------------------
 #if defined(MFN_EMU)
 template <class K, class... Args>
-inline int launch(const char * /*name*/, K kernel, dim3 grid, dim3 block, size_t shmem,
+inline int launch(const char *name, K kernel, dim3 grid, dim3 block, size_t shmem,
                   hipStream_t /*stream*/, Args... args) {
+  hipemu::note_launch(name);  // tests read the sequence of kernels a call dispatched to
   hipemu::launch(grid, block, shmem, [=]() { kernel(args...); });
   return 0;
 }

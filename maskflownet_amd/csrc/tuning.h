@@ -27,6 +27,9 @@
 //   dc.generic   1: force the generic one-thread-per-output kernel
 //   dc.bwdshared 0: input/offset gradient tap by tap only (no shared-offset kernel)
 //   dc.bwdpix    0: shared-offset backward with lane = channel (dc_bwd_input_shared_kernel) instead of lane = pixel (dc_backward.h)
+//   dc.bwdflow   0: mfn_deform_conv_shared_bwd always composes (offsets into the workspace -> mfn_deform_conv_bwd -> sum of
+//                the taps' offset gradients); 1 (default): where the lane = pixel kernels apply they read the flow field and
+//                write d/dflow themselves -- no offset tensor, no goffset
 //   dc.bwdsplit2 1: input and offset gradient in separate launches of the lane = pixel kernel, two blocks per CU each (measured
 //                r02, levels 5..2: 71 / 97 / 116 / 167 us against 54 / 69 / 106 / 161: the column-gradient GEMM and the setup
 //                are done twice and the gx flush's atomic instructions do not get faster); 0 (default): one launch forms
@@ -54,7 +57,7 @@ struct Tuning {
   int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
   int conv_generic = 0, conv_mt = 0, conv_pt = 0, conv_shuffle = 1, conv_row3 = 1;
-  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0, dc_bwdscratch = 0, dc_bwdpix = 1, dc_bwdwpix = 1, dc_bwdksplit = 0, dc_bwdwpc = 1, dc_bwdsplit2 = 0;
+  int dc_mt = 0, dc_pt = 0, dc_ksb = 0, dc_fast = 1, dc_generic = 0, dc_stage = 1, dc_tile = 0, dc_nw = 0, dc_xcd = 1, dc_bwdshared = 1, dc_bwdwblocks = 0, dc_bwdstrips = 0, dc_bwdscratch = 0, dc_bwdpix = 1, dc_bwdwpix = 1, dc_bwdksplit = 0, dc_bwdwpc = 1, dc_bwdsplit2 = 0, dc_bwdflow = 1;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
@@ -96,6 +99,7 @@ struct Tuning {
     if (!strcmp(key, "dc.bwdksplit")) return &dc_bwdksplit;
     if (!strcmp(key, "dc.bwdwpc")) return &dc_bwdwpc;
     if (!strcmp(key, "dc.bwdsplit2")) return &dc_bwdsplit2;
+    if (!strcmp(key, "dc.bwdflow")) return &dc_bwdflow;
     return nullptr;
   }
 };

@@ -15,3 +15,16 @@ using std::max;
 using std::min;
 
 #include "../../maskflownet_amd/csrc/api_impl.inc"
+
+// the kernels the calls since the last query dispatched to, "name;name;..." (cleared by the query): which path a call took
+extern "C" int mfn_emu_test_launch_log(char *buf, int cap) {
+  std::string &log = hipemu::launch_log();
+  const int n = (int)log.size();
+  if (buf && cap > 0) {
+    const int m = n < cap - 1 ? n : cap - 1;
+    memcpy(buf, log.data(), (size_t)m);
+    buf[m] = 0;
+  }
+  log.clear();
+  return n;
+}

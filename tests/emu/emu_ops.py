@@ -78,3 +78,13 @@ def set_tuning(**kw):
     ops = emu_ops()
     for k, v in kw.items():
         ops.check(ops.ns.set_tuning(k.replace("_", ".", 1).encode(), int(v)))
+
+
+def launch_log():
+    """Names of the kernels launched since the last call, "name;name;..." (which path a call dispatched to)."""
+    ops = emu_ops()
+    fn = ops.ns._cdll.mfn_emu_test_launch_log
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]
+    buf = ctypes.create_string_buffer(1 << 16)
+    fn(buf, len(buf))
+    return buf.value.decode()

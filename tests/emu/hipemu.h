@@ -25,6 +25,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 #include <pthread.h>
@@ -82,6 +83,10 @@ extern thread_local unsigned t_lane, t_wave;
 
 inline void *dyn_shared() { return t_block->lds.data(); }
 inline Wave &wave() { return *t_block->waves[t_wave]; }
+
+// names of the kernels launched since the last query (emu_api.cpp: mfn_emu_test_launch_log)
+inline std::string &launch_log() { static std::string log; return log; }
+inline void note_launch(const char *name) { launch_log() += name; launch_log() += ';'; }
 
 template <class F>
 void launch(dim3 grid, dim3 block, size_t shmem, F &&body) {

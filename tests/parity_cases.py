@@ -305,22 +305,28 @@ def case_deform_bwd_shared(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, kin
 
 
 def case_deform_shared_bwd(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, scale=20.0, stride=8.0, req=("write",) * 4,
-                           kernel=(3, 3), pad=(1, 1), dilate=(1, 1)):
+                           kernel=(3, 3), pad=(1, 1), dilate=(1, 1), flow_gain=1.0):
     """Backward of the fused call (mfn_deform_conv_shared_bwd) against the oracle's composition: offsets = repeat9(flow * scale /
     stride) (MaskFlownet.py:230), DeformableConvolution's backward, d/dflow = scale / stride * sum over the taps."""
     rng = np.random.default_rng(900 + seed)
     T = kernel[0] * kernel[1]
     x = feat(rng, (N, Cin, H, W))
     w = (rng.standard_normal((Cout, Cin) + tuple(kernel)) * 0.2).astype(np.float32)
-    fl = (flow_field(rng, N, H, W) * np.float32(stride / scale)).astype(np.float32)
+    fl = (flow_field(rng, N, H, W) * np.float32(flow_gain * stride / scale)).astype(np.float32)
     go = rng.standard_normal((N, Cout, H, W)).astype(np.float32)
     off = np.repeat((fl * np.float32(scale) / np.float32(stride))[:, None], T, axis=1).reshape(N, 2 * T, H, W)
     gx, goff, gw, gb = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=kernel, pad=pad, dilate=dilate)
     gflow = goff.reshape(N, T, 2, H, W).sum(axis=1) * (np.float32(scale) / np.float32(stride))
+    want = [gx, gflow, gw, gb]
+    out = None
+    if "add" in req:  # accumulate on top of the caller's values
+        base = [rng.standard_normal(a.shape).astype(np.float32) for a in want]
+        want = [a + b if rq == "add" else a for a, b, rq in zip(want, base, req)]
+        out = tuple(to_dev(b) if rq == "add" else None for b, rq in zip(base, req))
     got = ops.deformable_convolution_shared_backward(to_dev(go), to_dev(x), to_dev(fl), scale, stride, to_dev(w), kernel=kernel,
-                                                     pad=pad, dilate=dilate, req=req)
+                                                     pad=pad, dilate=dilate, req=req, out=out)
     errs = []
-    for g, r, rq, nm in zip(got, (gx, gflow, gw, gb), req, ("gx", "gflow", "gw", "gbias")):
+    for g, r, rq, nm in zip(got, want, req, ("gx", "gflow", "gw", "gbias")):
         if rq in ("null", None):
             assert g is None
             continue

@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1, dc_bwdwpix=1, dc_bwdwblocks=0, dc_bwdwpc=1, dc_bwdsplit2=0, dc_bwdksplit=0)
+                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1, dc_bwdwpix=1, dc_bwdwblocks=0, dc_bwdwpc=1, dc_bwdsplit2=0, dc_bwdksplit=0, dc_bwdflow=1)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -396,6 +396,18 @@ def test_deform_conv_shared_backward(ops, oracle):
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 5, 16)
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 6, 4, 5, seed=1, pad=(2, 2), dilate=(2, 2), scale=5.0, stride=4.0)
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 4, 8, seed=2, req=("null", "write", "null", "null"))
+    # flow mode of the lane = pixel kernels (dc.bwdflow, the default where they apply): accumulation into the caller's buffers,
+    # filter slices and two channel blocks adding into d/dflow, offsets too large for a regular floor (per-pixel kernels)
+    emu_ops.launch_log()
+    pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 20, 5, 8, seed=3, req=("add", "add", "add", "add"))
+    log = emu_ops.launch_log()
+    assert "dc_bwd_input_pix" in log and "dc_bwd_weight_pc" in log and "offsets_from_flow" not in log, log
+    pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 36, 4, 4, 8, seed=4, req=("null", "write", "write", "write"))
+    pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 4, 8, seed=5, flow_gain=3.0e6)
+    emu_ops.set_tuning(dc_bwdflow=0)   # the composition gives the same gradients
+    emu_ops.launch_log()
+    pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 5, 8, seed=6, req=("write", "add", "write", "write"))
+    assert "offsets_from_flow;" in emu_ops.launch_log()
     rng = np.random.default_rng(4)
     goff = rng.standard_normal((2, 18, 5, 6)).astype(np.float32)
     base = rng.standard_normal((2, 2, 5, 6)).astype(np.float32)

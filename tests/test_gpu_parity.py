@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdscratch=0)
+    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdscratch=0, dc_bwdflow=1)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -472,6 +472,40 @@ def test_layer_mirror_trains_through_the_c_abi(oracle, T):
 def test_deform_conv_shared_backward(ops, oracle, dev, N, C, H, W, stride):
     """The fused call's backward (mfn_deform_conv_shared_bwd) at the network's level shapes and an odd one, d/dflow included."""
     pc.case_deform_shared_bwd(ops, oracle, dev, host, N, C, C, H, W, stride=stride)
+
+
+def test_deform_conv_shared_backward_flow_mode(ops, oracle, dev, T):
+    """dc.bwdflow (default 1): where the lane = pixel kernels apply, mfn_deform_conv_shared_bwd hands them the flow field -- no
+    offsets_from_flow launch, no per-tap offset gradient -- and gives the composition's gradients: accumulation into the caller's
+    buffers, partial requests, filter slices and channel blocks adding into d/dflow, offsets too large for a regular floor."""
+    import ctypes
+    from maskflownet_amd import _lib
+
+    def launches(name):
+        c, ms = ctypes.c_int(0), ctypes.c_double(0)
+        _lib.lib().profile_query(name.encode(), ctypes.byref(c), ctypes.byref(ms))
+        return c.value
+
+    T.cuda.synchronize(); _lib.lib().profile_reset(); _lib.lib().profile_enable(1)
+    try:
+        pc.case_deform_shared_bwd(ops, oracle, dev, host, 2, 64, 64, 48, 64, seed=1)
+    finally:
+        _lib.lib().profile_enable(0)
+    T.cuda.synchronize()
+    assert launches("offsets_from_flow") == 0 and launches("dc_bwd_input_pix") == 1 and launches("dc_bwd_weight_pc") == 1
+    pc.case_deform_shared_bwd(ops, oracle, dev, host, 2, 32, 32, 24, 32, seed=2, req=("add", "add", "add", "add"))
+    pc.case_deform_shared_bwd(ops, oracle, dev, host, 1, 72, 40, 12, 16, seed=3, req=("null", "write", "write", "null"))
+    pc.case_deform_shared_bwd(ops, oracle, dev, host, 1, 16, 16, 10, 20, seed=4, req=("write", "add", "null", "write"))
+    pc.case_deform_shared_bwd(ops, oracle, dev, host, 1, 32, 32, 16, 24, seed=5, flow_gain=3.0e6)
+    pc.case_deform_shared_bwd(ops, oracle, dev, host, 1, 32, 32, 16, 24, seed=6, flow_gain=6.0)   # windows that do not fit: per-pixel paths
+    _lib.set_tuning(dc_bwdflow=0)
+    T.cuda.synchronize(); _lib.lib().profile_reset(); _lib.lib().profile_enable(1)
+    try:
+        pc.case_deform_shared_bwd(ops, oracle, dev, host, 2, 64, 64, 48, 64, seed=1)
+    finally:
+        _lib.lib().profile_enable(0)
+    T.cuda.synchronize()
+    assert launches("offsets_from_flow") == 2   # the offsets and the sum of their gradients
 
 
 def test_layer_fused_calls_are_differentiable(oracle, T):
