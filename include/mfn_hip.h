@@ -224,8 +224,10 @@ int mfn_deform_conv_bwd(const float *gout, const float *x, const float *offset, 
 /* Backward of the fused call mfn_deform_conv_shared_fwd (training with the offsets never built by the caller):
  * gflow (N,2,H,W) = d loss / d flow_yx = flow_scale / flow_stride * sum over the taps of the offset gradient; gx, gw, gbias
  * and the req_* as mfn_deform_conv_bwd.  The workspace (mfn_deform_conv_shared_bwd_workspace_bytes, required, 16-byte
- * aligned) holds the offsets and their gradient.  mfn_offsets_from_flow_bwd is the gradient of mfn_offsets_from_flow on its
- * own (req: MFN_REQ_WRITE or MFN_REQ_ADD). */
+ * aligned) has room for the offsets and their gradient: shapes outside the lane = pixel kernels (3x3, pad 1, one group,
+ * W % 4 == 0, Cin % 4 == 0, Cout <= 96) are composed as mfn_offsets_from_flow -> mfn_deform_conv_bwd ->
+ * mfn_offsets_from_flow_bwd; inside, the kernels read the flow field and write gflow themselves.  mfn_offsets_from_flow_bwd
+ * is the gradient of mfn_offsets_from_flow on its own (req: MFN_REQ_WRITE or MFN_REQ_ADD). */
 size_t mfn_deform_conv_shared_bwd_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw, int ph,
                                                   int pw, int dh, int dw, int groups);
 int mfn_deform_conv_shared_bwd(const float *gout, const float *x, const float *flow_yx, float flow_scale,
