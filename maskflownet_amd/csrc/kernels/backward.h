@@ -218,6 +218,136 @@ __global__ __launch_bounds__(256, 3) void corr_bwd_block_kernel(CorrBwdParams p)
   }
 }
 
+// LDS-staged form for the fine levels (W = 64, 128, 256).  The block kernel above is bound by the L1: 21 (g1) / 39 (g2) sixteen-
+// byte loads per lane and displacement row against 144 FMAs -- 0.6 GB through the vector caches for one gradient at level 2,
+// 46 B/clk/CU of the 64 the L1 delivers; halving its instruction count (no selects) changed nothing.  Here a block is
+// 256 / (W/4) image rows x 4 channels and first copies the rows of the OTHER feature map it will touch -- its own rows +- md,
+// with four zero columns on either side and zero rows outside the image -- into LDS once: every feature value leaves the L1
+// once instead of ~27 times (3 overlapping windows x 9 displacement rows), the 12-wide windows come out of LDS (three
+// ds_read_b128, no selects: the border is in the copy), and the vector caches are left with the nine gout quads per
+// displacement row.  g2 reads those as UNALIGNED quads at x - dx (one load per displacement instead of a 12-wide window of
+// which a third is used); what an edge lane's quad takes from the neighbouring row is zeroed by a select (lane masks okl /
+// okr), rows outside the image are skipped by per-lane loop bounds.  Same terms in the same order per output as the block
+// kernel.  blockIdx.y = which of the requested gradients.
+struct CorrBwdLdsParams {
+  CorrBwdParams b;
+  int rows_per_block, row_blocks;  // 256 / (W/4); cdiv(H, rows_per_block)
+};
+constexpr size_t corr_bwd_lds_bytes(int W, int md) { return (size_t)4 * (256 / (W / 4) + 2 * md) * (W + 8) * sizeof(float); }
+template <int MD>
+__global__ __launch_bounds__(256, 3) void corr_bwd_lds_kernel(CorrBwdLdsParams pp) {
+  const CorrBwdParams &p = pp.b;
+  constexpr int CB = 4, D = 2 * MD + 1;
+  MFN_DYN_SHARED(float, lds);
+  const int W = p.W, H = p.H, C = p.C;
+  const int QW = W >> 2, CG = (C + CB - 1) / CB, RB = pp.rows_per_block, RS = RB + 2 * MD, PW = W + 8, PQ = QW + 2;
+  const size_t plane = (size_t)H * W;
+  // block -> (image, channel group, row block); neighbouring row blocks read overlapping rows: one XCD per contiguous range
+  const unsigned bx = mfn_xcd_remap(blockIdx.x, gridDim.x);
+  const int rb = (int)(bx % (unsigned)pp.row_blocks), cg = (int)((bx / (unsigned)pp.row_blocks) % (unsigned)CG);
+  const int n = (int)(bx / ((unsigned)pp.row_blocks * (unsigned)CG));
+  const int y0 = rb * RB, c0 = cg * CB;
+  // which gradient this block forms
+  const bool second = p.req1 && p.req2 ? blockIdx.y == 1 : p.req2 != 0;
+  const float *src = (second ? p.f1 : p.f2) + (size_t)n * C * plane;
+  // ---- the copy: [4 channels][RS rows y0 - MD ...][PW columns -4 ... W + 3], zero outside the image
+  for (int e = threadIdx.x; e < CB * RS * PQ; e += 256) {
+    const int qc = e % PQ, rr = (e / PQ) % RS, k = e / (PQ * RS);
+    const int yy = y0 - MD + rr, xx = 4 * (qc - 1);
+    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const float4 v = zero_unless(ok, *reinterpret_cast<const float4 *>(src + (size_t)min(c0 + k, C - 1) * plane +
+                                                                       (size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 4)));
+    *reinterpret_cast<float4 *>(lds + ((size_t)k * RS + rr) * PW + 4 * qc) = v;
+  }
+  MFN_LDS_BARRIER();
+  const int r = (int)threadIdx.x / QW, qx = (int)threadIdx.x - r * QW;
+  const int y = y0 + r, x = 4 * qx;
+  if (y >= H) return;
+  const float *go = p.gout + (size_t)n * D * D * plane;
+  // 12-wide window [x - 4, x + 8) of copied row rr (columns are shifted by 4 in the copy)
+  auto window = [&](int k, int rr, float (&v)[12]) {
+    const float *row = lds + ((size_t)k * RS + rr) * PW + x;
+    const float4 a = *reinterpret_cast<const float4 *>(row), b = *reinterpret_cast<const float4 *>(row + 4),
+                 c = *reinterpret_cast<const float4 *>(row + 8);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+  };
+  float acc[CB][4];
+  MFN_UNROLL
+  for (int k = 0; k < CB; ++k)
+    MFN_UNROLL
+    for (int q = 0; q < 4; ++q) acc[k][q] = 0.f;
+  if (!second) {  // g1[c,y,x+q] = sum_d gout[d,y,x+q] * f2[c,y+dy,x+q+dx]; copied row of y + dy: r + iy
+    // the D gout quads of displacement row iy + 1 are requested before row iy is multiplied (left alone hipcc turns the loops
+    // inside out and waits for one quad at a time: nine round trips per row)
+    const float *gp = go + (size_t)y * W + x;
+    float4 g[D], gn[D];
+    MFN_UNROLL
+    for (int ix = 0; ix < D; ++ix) gn[ix] = *reinterpret_cast<const float4 *>(gp + (size_t)ix * plane);
+    MFN_UNROLL
+    for (int iy = 0; iy < D; ++iy) {
+      MFN_UNROLL
+      for (int ix = 0; ix < D; ++ix) g[ix] = gn[ix];
+      if (iy + 1 < D) {
+        MFN_UNROLL
+        for (int ix = 0; ix < D; ++ix) gn[ix] = *reinterpret_cast<const float4 *>(gp + (size_t)((iy + 1) * D + ix) * plane);
+      }
+      MFN_COMPILER_FENCE();
+      MFN_UNROLL
+      for (int k = 0; k < CB; ++k) {
+        float bv[12];
+        window(k, r + iy, bv);
+        MFN_UNROLL
+        for (int ix = 0; ix < D; ++ix) {  // window index of pixel q displaced by dx = ix - MD: q + dx + 4
+          constexpr int base = 4 - MD;
+          acc[k][0] = fmaf(g[ix].x, bv[base + ix + 0], acc[k][0]);
+          acc[k][1] = fmaf(g[ix].y, bv[base + ix + 1], acc[k][1]);
+          acc[k][2] = fmaf(g[ix].z, bv[base + ix + 2], acc[k][2]);
+          acc[k][3] = fmaf(g[ix].w, bv[base + ix + 3], acc[k][3]);
+        }
+      }
+    }
+  } else {  // g2[c,y,x+q] = sum_d gout[d,y-dy,x+q-dx] * f1[c,y-dy,x+q-dx]; copied row of y - dy: r + 2 MD - iy
+    const bool okl = x >= 4, okr = x + 8 <= W;
+    const int lo = max(0, y + MD - H + 1), hi = min(D, y + MD + 1);  // source rows inside the image
+    for (int iy = lo; iy < hi; ++iy) {
+      const int ys = y - (iy - MD);
+      float av[CB][12];
+      MFN_UNROLL
+      for (int k = 0; k < CB; ++k) window(k, r + 2 * MD - iy, av[k]);
+      MFN_UNROLL
+      for (int ix = 0; ix < D; ++ix) {
+        // the four source pixels x + q - dx of this displacement: one unaligned quad (it stays inside the tensor: a displacement
+        // to the left never belongs to the first plane, one to the right never to the last); window index j = q + 4 - dx
+        const mfn_quad gl = mfn_load4_unaligned(go + (size_t)(iy * D + ix) * plane + (size_t)ys * W + x - (ix - MD));
+        constexpr int base = 4 + MD;
+        float gq[4] = {gl.x, gl.y, gl.z, gl.w};
+        MFN_UNROLL
+        for (int q = 0; q < 4; ++q) {
+          const int j = base - ix + q;
+          if (j < 4) gq[q] = okl ? gq[q] : 0.f;
+          if (j >= 8) gq[q] = okr ? gq[q] : 0.f;
+        }
+        MFN_UNROLL
+        for (int k = 0; k < CB; ++k)
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q) acc[k][q] = fmaf(gq[q], av[k][base - ix + q], acc[k][q]);
+      }
+    }
+  }
+  const float inv = 1.0f / (float)C;
+  float *gdst = second ? p.g2 : p.g1;
+  const int req = second ? p.req2 : p.req1;
+  MFN_UNROLL
+  for (int k = 0; k < CB; ++k) {
+    if (c0 + k >= C) break;
+    const size_t o = ((size_t)n * C + c0 + k) * plane + (size_t)y * W + x;
+    float4 rv = make_float4(acc[k][0] * inv, acc[k][1] * inv, acc[k][2] * inv, acc[k][3] * inv);
+    if (req == 3) { const float4 old = *reinterpret_cast<const float4 *>(gdst + o); rv.x += old.x; rv.y += old.y; rv.z += old.z; rv.w += old.w; }
+    mfn_store4_stream(gdst + o, rv.x, rv.y, rv.z, rv.w, p.st_policy);
+  }
+}
+
 struct CorrBwdGenericParams {
   const float *gout, *f1, *f2;
   float *g1, *g2;

@@ -27,6 +27,8 @@
 //   dc.generic   1: force the generic one-thread-per-output kernel
 //   dc.bwdshared 0: input/offset gradient tap by tap only (no shared-offset kernel)
 //   dc.bwdpix    0: shared-offset backward with lane = channel (dc_bwd_input_shared_kernel) instead of lane = pixel (dc_backward.h)
+//   corr.bwdlds  0: corr_bwd_block_kernel at every level; 1 (default): corr_bwd_lds_kernel where W is 64, 128 or 256 (the other
+//                feature map's rows copied to LDS once per block, g2's gout quads as unaligned loads)
 //   dc.bwdflow   0: mfn_deform_conv_shared_bwd always composes (offsets into the workspace -> mfn_deform_conv_bwd -> sum of
 //                the taps' offset gradients); 1 (default): where the lane = pixel kernels apply they read the flow field and
 //                write d/dflow themselves -- no offset tensor, no goffset
@@ -53,7 +55,7 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0, corr_bwdsplit = 1, corr_stagger = 0;
+  int corr_tw = 0, corr_variant = -1, corr_xcd = 1, corr_generic = 0, corr_ablate = 0, corr_slices = 0, corr_lanemap = 0, corr_band = 0, corr_direct = 0, corr_bwdsplit = 1, corr_stagger = 0, corr_bwdlds = 1;
   int store_policy = -1, store_corr = -1, store_dc = -1, store_warp = -1, store_off = -1;
   int warp_vec = 0;
   int conv_generic = 0, conv_mt = 0, conv_pt = 0, conv_shuffle = 1, conv_row3 = 1;
@@ -61,6 +63,7 @@ struct Tuning {
   int *slot(const char *key) {
     if (!strcmp(key, "corr.tw")) return &corr_tw;
     if (!strcmp(key, "corr.variant")) return &corr_variant;
+    if (!strcmp(key, "corr.bwdlds")) return &corr_bwdlds;
     if (!strcmp(key, "corr.xcd")) return &corr_xcd;
     if (!strcmp(key, "corr.generic")) return &corr_generic;
     if (!strcmp(key, "corr.ablate")) return &corr_ablate;

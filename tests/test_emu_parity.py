@@ -21,7 +21,7 @@ def ops():
 def _reset_tuning():
     yield
     emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1, dc_bwdwpix=1, dc_bwdwblocks=0, dc_bwdwpc=1, dc_bwdsplit2=0, dc_bwdksplit=0, dc_bwdflow=1)
+                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1, dc_bwdwpix=1, dc_bwdwblocks=0, dc_bwdwpc=1, dc_bwdsplit2=0, dc_bwdksplit=0, dc_bwdflow=1, corr_bwdlds=1, corr_bwdsplit=1)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -288,6 +288,19 @@ def test_correlation_backward(ops, oracle, kw):
 def test_correlation_backward_register_blocked(ops, oracle, shape, kw):
     # W % 4 == 0: 4 px x 4 channels per thread (ragged channel group, image narrower than the window)
     pc.case_correlation_bwd(ops, oracle, ident, ident, shape, **kw)
+
+
+@pytest.mark.parametrize("shape,kw", [((1, 5, 6, 64), dict()), ((1, 4, 20, 64), dict(max_displacement=2, pad_size=2)), ((1, 3, 9, 128), dict())])
+def test_correlation_backward_lds_staged(ops, oracle, shape, kw):
+    """corr_bwd_lds_kernel (W = 64, 128, 256): the other feature map's rows copied to LDS with their zero border, unaligned gout
+    quads for g2 with the edge lanes' selects, ragged channel group and row block, images lower than the search window; the
+    block kernel (corr.bwdlds=0) gives the same values."""
+    emu_ops.launch_log()
+    pc.case_correlation_bwd(ops, oracle, ident, ident, shape, **kw)
+    assert "corr_bwd_lds;" in emu_ops.launch_log()
+    emu_ops.set_tuning(corr_bwdlds=0)
+    pc.case_correlation_bwd(ops, oracle, ident, ident, shape, seed=2, **kw)
+    assert "corr_bwd_block;" in emu_ops.launch_log()
 
 
 @pytest.mark.parametrize("clip", [False, True])

@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdscratch=0, dc_bwdflow=1)
+    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdscratch=0, dc_bwdflow=1, corr_bwdlds=1)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -269,6 +269,28 @@ def test_deform_conv_zero_offset_is_conv2d_at_full_size(ops, T):
                                    (8, 32, 96, 128), (4, 64, 56, 128)])
 def test_correlation_backward_levels(ops, oracle, dev, shape):
     pc.case_correlation_bwd(ops, oracle, dev, host, shape)
+
+
+@pytest.mark.parametrize("shape,kw", [((2, 30, 21, 64), dict()), ((1, 64, 48, 64), dict()), ((1, 32, 96, 128), dict()), ((1, 18, 13, 256), dict()),
+                                      ((2, 16, 3, 128), dict()), ((1, 16, 40, 128), dict(max_displacement=2, pad_size=2))])
+def test_correlation_backward_lds_staged(ops, oracle, dev, shape, kw):
+    """corr_bwd_lds_kernel against the oracle, request by request, and against the block kernel (corr.bwdlds=0), whose BITS it
+    reproduces: same terms in the same order, zeros outside the image add nothing."""
+    from maskflownet_amd import _lib
+    pc.case_correlation_bwd(ops, oracle, dev, host, shape, **kw)
+    rng = np.random.default_rng(77)
+    md = kw.get("max_displacement", 4)
+    f1, f2 = pc.feat(rng, shape), pc.feat(rng, shape)
+    go = rng.standard_normal((shape[0], (2 * md + 1) ** 2, shape[2], shape[3])).astype(np.float32)
+    base = rng.standard_normal(shape).astype(np.float32)
+    a1, a2 = ops.Correlation_backward(dev(go), dev(f1), dev(f2), 1, md, 1, 1, md, True)
+    c1, _ = ops.Correlation_backward(dev(go), dev(f1), dev(f2), 1, md, 1, 1, md, True, req1="add", req2="null", g1=dev(base))
+    _, c2 = ops.Correlation_backward(dev(go), dev(f1), dev(f2), 1, md, 1, 1, md, True, req1="null", req2="write")
+    _lib.set_tuning(corr_bwdlds=0)
+    b1, b2 = ops.Correlation_backward(dev(go), dev(f1), dev(f2), 1, md, 1, 1, md, True)
+    assert np.array_equal(host(a1), host(b1)) and np.array_equal(host(a2), host(b2))
+    assert np.array_equal(host(c2), host(b2))
+    pc.check_close(host(c1), host(b1) + base, tol=1e-6, what="corr_bwd_lds req add")
 
 
 @pytest.mark.parametrize("kw", [dict(max_displacement=2, pad_size=2), dict(max_displacement=4, stride2=2, pad_size=4),

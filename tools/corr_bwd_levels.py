@@ -14,7 +14,9 @@ for l in (6, 5, 4, 3, 2):
     n, c, h, w = hotpath.level_shapes(8, 384, 512)[l]
     f1, f2, go = torch.randn(n, c, h, w, device="cuda"), torch.randn(n, c, h, w, device="cuda"), torch.randn(n, 81, h, w, device="cuda")
     g1, g2 = torch.empty_like(f1), torch.empty_like(f2)
-    fn = lambda: ops.Correlation_backward(go, f1, f2, 1, 4, 1, 1, 4, True, g1=g1, g2=g2)
+    part = os.environ.get("MFN_PART", "both")   # g1 / g2: one gradient requested
+    kw = dict(g1=g1, g2=g2) if part == "both" else (dict(g1=g1, req2="null") if part == "g1" else dict(g2=g2, req1="null"))
+    fn = lambda: ops.Correlation_backward(go, f1, f2, 1, 4, 1, 1, 4, True, **kw)
     for _ in range(3): fn()
     torch.cuda.synchronize(); lib.profile_reset(); lib.profile_enable(1)
     for _ in range(20): fn()
