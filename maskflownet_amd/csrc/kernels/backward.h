@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 3) void corr_bwd_block_kernel(CorrBwdParams p)
   }
 }
 
-// LDS-staged form for the fine levels (W = 64, 128, 256).  The block kernel above is bound by the L1: 21 (g1) / 39 (g2) sixteen-
+// LDS-staged form for W = 8, 16, ... 256 (every level of the network).  The block kernel above is bound by the L1: 21 (g1) / 39 (g2) sixteen-
 // byte loads per lane and displacement row against 144 FMAs -- 0.6 GB through the vector caches for one gradient at level 2,
 // 46 B/clk/CU of the 64 the L1 delivers; halving its instruction count (no selects) changed nothing.  Here a block is
 // 256 / (W/4) image rows x 4 channels and first copies the rows of the OTHER feature map it will touch -- its own rows +- md,
@@ -228,19 +228,25 @@ __global__ __launch_bounds__(256, 3) void corr_bwd_block_kernel(CorrBwdParams p)
 // displacement row.  g2 reads those as UNALIGNED quads at x - dx (one load per displacement instead of a 12-wide window of
 // which a third is used); what an edge lane's quad takes from the neighbouring row is zeroed by a select (lane masks okl /
 // okr), rows outside the image are skipped by per-lane loop bounds.  Same terms in the same order per output as the block
-// kernel.  blockIdx.y = which of the requested gradients.
+// kernel.  blockIdx.y = which of the requested gradients.  At the coarse levels (a handful of waves, each a chain of D
+// dependent rounds) the gain is the shorter round: no selects, gout of the next round already on its way.
+// Both gradients, cfg2 levels 6..2: 8.1 / 8.8 / 11.5 / 18.3 / 33.8 us against 14.5 / 15.1 / 20.5 / 29.9 / 54.6.
 struct CorrBwdLdsParams {
   CorrBwdParams b;
   int rows_per_block, row_blocks;  // 256 / (W/4); cdiv(H, rows_per_block)
 };
-constexpr size_t corr_bwd_lds_bytes(int W, int md) { return (size_t)4 * (256 / (W / 4) + 2 * md) * (W + 8) * sizeof(float); }
+inline size_t corr_bwd_lds_bytes(int H, int W, int md) {
+  const int rb = 256 / (W / 4);
+  return (size_t)4 * ((rb < H ? rb : H) + 2 * md) * (W + 8) * sizeof(float);
+}
 template <int MD>
 __global__ __launch_bounds__(256, 3) void corr_bwd_lds_kernel(CorrBwdLdsParams pp) {
   const CorrBwdParams &p = pp.b;
   constexpr int CB = 4, D = 2 * MD + 1;
   MFN_DYN_SHARED(float, lds);
   const int W = p.W, H = p.H, C = p.C;
-  const int QW = W >> 2, CG = (C + CB - 1) / CB, RB = pp.rows_per_block, RS = RB + 2 * MD, PW = W + 8, PQ = QW + 2;
+  // (an image lower than a block's rows: only its rows are copied)
+  const int QW = W >> 2, CG = (C + CB - 1) / CB, RB = pp.rows_per_block, RS = min(RB, H) + 2 * MD, PW = W + 8, PQ = QW + 2;
   const size_t plane = (size_t)H * W;
   // block -> (image, channel group, row block); neighbouring row blocks read overlapping rows: one XCD per contiguous range
   const unsigned bx = mfn_xcd_remap(blockIdx.x, gridDim.x);

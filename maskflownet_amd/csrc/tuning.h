@@ -27,8 +27,8 @@
 //   dc.generic   1: force the generic one-thread-per-output kernel
 //   dc.bwdshared 0: input/offset gradient tap by tap only (no shared-offset kernel)
 //   dc.bwdpix    0: shared-offset backward with lane = channel (dc_bwd_input_shared_kernel) instead of lane = pixel (dc_backward.h)
-//   corr.bwdlds  0: corr_bwd_block_kernel at every level; 1 (default): corr_bwd_lds_kernel where W is 64, 128 or 256 (the other
-//                feature map's rows copied to LDS once per block, g2's gout quads as unaligned loads)
+//   corr.bwdlds  0: corr_bwd_block_kernel at every level; 1 (default): corr_bwd_lds_kernel where W is 8, 16, ... 256 (the other
+//                feature map's rows copied to LDS once per block, g2's gout quads as unaligned loads, gout requested a row ahead)
 //   dc.bwdflow   0: mfn_deform_conv_shared_bwd always composes (offsets into the workspace -> mfn_deform_conv_bwd -> sum of
 //                the taps' offset gradients); 1 (default): where the lane = pixel kernels apply they read the flow field and
 //                write d/dflow themselves -- no offset tensor, no goffset

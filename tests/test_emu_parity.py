@@ -290,11 +290,12 @@ def test_correlation_backward_register_blocked(ops, oracle, shape, kw):
     pc.case_correlation_bwd(ops, oracle, ident, ident, shape, **kw)
 
 
-@pytest.mark.parametrize("shape,kw", [((1, 5, 6, 64), dict()), ((1, 4, 20, 64), dict(max_displacement=2, pad_size=2)), ((1, 3, 9, 128), dict())])
+@pytest.mark.parametrize("shape,kw", [((1, 5, 6, 64), dict()), ((1, 4, 20, 64), dict(max_displacement=2, pad_size=2)), ((1, 3, 9, 128), dict()),
+                                      ((2, 3, 5, 8), dict()), ((1, 6, 12, 16), dict()), ((1, 4, 7, 32), dict(max_displacement=2, pad_size=2))])
 def test_correlation_backward_lds_staged(ops, oracle, shape, kw):
-    """corr_bwd_lds_kernel (W = 64, 128, 256): the other feature map's rows copied to LDS with their zero border, unaligned gout
-    quads for g2 with the edge lanes' selects, ragged channel group and row block, images lower than the search window; the
-    block kernel (corr.bwdlds=0) gives the same values."""
+    """corr_bwd_lds_kernel (W = 8 ... 256): the other feature map's rows copied to LDS with their zero border, unaligned gout
+    quads for g2 with the edge lanes' selects, ragged channel group and row block, images lower than the search window or than
+    a block's rows; the block kernel (corr.bwdlds=0) gives the same values."""
     emu_ops.launch_log()
     pc.case_correlation_bwd(ops, oracle, ident, ident, shape, **kw)
     assert "corr_bwd_lds;" in emu_ops.launch_log()

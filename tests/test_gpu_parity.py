@@ -272,7 +272,8 @@ def test_correlation_backward_levels(ops, oracle, dev, shape):
 
 
 @pytest.mark.parametrize("shape,kw", [((2, 30, 21, 64), dict()), ((1, 64, 48, 64), dict()), ((1, 32, 96, 128), dict()), ((1, 18, 13, 256), dict()),
-                                      ((2, 16, 3, 128), dict()), ((1, 16, 40, 128), dict(max_displacement=2, pad_size=2))])
+                                      ((2, 16, 3, 128), dict()), ((1, 16, 40, 128), dict(max_displacement=2, pad_size=2)),
+                                      ((8, 196, 6, 8), dict()), ((2, 128, 12, 16), dict()), ((3, 94, 24, 32), dict()), ((1, 7, 70, 32), dict())])
 def test_correlation_backward_lds_staged(ops, oracle, dev, shape, kw):
     """corr_bwd_lds_kernel against the oracle, request by request, and against the block kernel (corr.bwdlds=0), whose BITS it
     reproduces: same terms in the same order, zeros outside the image add nothing."""
