@@ -187,25 +187,34 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
   int lo0y, lo0x;
   const bool fm = p.flow != nullptr;  // uniform: the offsets come from the flow field (the forward's arithmetic, kernels/deform_conv.h)
   const float *offn = fm ? p.flow + (size_t)n * 2 * plane : p.offset + (size_t)n * 2 * T * plane;
-  auto ldo = [&](const float *q) { const float v = *q; return fm ? v * p.flow_scale / p.flow_stride : v; };
-  // offsets of the tile's and the region's centre pixels (uniform): where the windows are placed.  Requested first:
-  // two more memory round trips behind the geometry otherwise.
+  // offsets of the tile's and the region's centre pixels (uniform): where the windows are placed -- and this pixel's own.
+  // ALL requested before the first is used: written as `ok = ok && load == ...` hipcc made every load conditional on the one
+  // before, twenty round trips one after the other (11 k of the 17 k cycles of this kernel's setup at level 2).
   float ctile[2], creg[2];
-  {
-    const float *o1 = offn + (size_t)min(tyi * 4 + 2, H - 1) * W + min(txi * 8 + 4, W - 1);
-    const float *o2 = offn + (size_t)min(ry0 + 4, H - 1) * W + min(rx0 + 8, W - 1);
-    ctile[0] = ldo(o1); ctile[1] = ldo(o1 + plane); creg[0] = ldo(o2); creg[1] = ldo(o2 + plane);
-  }
+  auto scaled = [&](float v) { return fm ? v * p.flow_scale / p.flow_stride : v; };
   auto centre_floor = [&](const float (&c)[2], int &fh, int &fw) {
     fh = MFN_UNIFORM((int)fminf(fmaxf(floorf(c[0]), -1.0e6f), 1.0e6f));
     fw = MFN_UNIFORM((int)fminf(fmaxf(floorf(c[1]), -1.0e6f), 1.0e6f));
   };
   {
+    const float *o1 = offn + (size_t)min(tyi * 4 + 2, H - 1) * W + min(txi * 8 + 4, W - 1);
+    const float *o2 = offn + (size_t)min(ry0 + 4, H - 1) * W + min(rx0 + 8, W - 1);
     const float *op = offn + pix;
-    const float oh = ldo(op), ow = ldo(op + plane);
+    float cv[4] = {o1[0], o1[plane], o2[0], o2[plane]};
+    float ov[2 * T];
+    ov[0] = op[0]; ov[1] = op[plane];
     if (!fm) {
       MFN_UNROLL
-      for (int t = 1; t < T; ++t) ok = ok && (op[(size_t)(2 * t) * plane] == oh) && (op[(size_t)(2 * t + 1) * plane] == ow);
+      for (int t = 2; t < 2 * T; ++t) ov[t] = op[(size_t)t * plane];
+    }
+    MFN_COMPILER_FENCE();
+    ctile[0] = scaled(cv[0]); ctile[1] = scaled(cv[1]); creg[0] = scaled(cv[2]); creg[1] = scaled(cv[3]);
+    const float oh = scaled(ov[0]), ow = scaled(ov[1]);
+    if (!fm) {  // one offset for all nine taps?
+      int same = 1;
+      MFN_UNROLL
+      for (int t = 1; t < T; ++t) same &= (int)(ov[2 * t] == oh) & (int)(ov[2 * t + 1] == ow);
+      ok = same != 0;
     }
     lo0y = (int)fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f);
     lo0x = (int)fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
