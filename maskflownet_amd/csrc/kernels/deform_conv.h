@@ -633,8 +633,47 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
     const int prow = p.tile_w == 16 ? px0 >> 4 : px0 >> 3, pcol = px0 & (p.tile_w - 1);
     const int oy = tile_ho0 + prow, ox = tile_wo0 + pcol;
     const bool tile_ok = tile < p.ntiles;
+    const bool st_ok = tile_ok && oy < Ho;
+    // What the stores add to the sums is requested HERE, ahead of the transposition, with clamped addresses and no per-lane
+    // condition: written as `cond ? p.bias[o] : 0` inside the store loop every load sat in its own branch with a full wait
+    // behind it (4 MT round trips per lane at the end of every block; with the matching epilogue 16 MT more, and a sigmoid
+    // with its division per stored VALUE although the mask term is the same for all filters of a pixel).
+    const bool epi = ep && !raw;
+    float bq[MT][4];
+    MFN_UNROLL
+    for (int mt = 0; mt < MT; ++mt)
+      MFN_UNROLL
+      for (int i = 0; i < 4; ++i) bq[mt][i] = 0.f;
+    if (p.bias && !raw) {
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt)
+        MFN_UNROLL
+        for (int i = 0; i < 4; ++i) bq[mt][i] = p.bias[min(m0 + mt * 32 + i * 8 + orow, p.Cout - 1)];
+    }
+    const size_t pix0 = st_ok ? (size_t)n * oplane + (size_t)oy * Wo : 0;  // this lane's output row (clamped: loads only)
+    int oxq[4];
+    MFN_UNROLL
+    for (int q = 0; q < 4; ++q) oxq[q] = st_ok ? min(ox + q, Wo - 1) : 0;
+    float sg[4] = {1.f, 1.f, 1.f, 1.f};
+    if (epi && p.ep_mask) {
+      float mv[4];
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) mv[q] = p.ep_mask[pix0 + oxq[q]];
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) sg[q] = 1.f / (1.f + expf(-mv[q]));
+    }
+    const size_t obatch = st_ok ? (size_t)n * p.Cout * oplane + (size_t)oy * Wo : 0;
     MFN_UNROLL
     for (int mt = 0; mt < MT; ++mt) {
+      float addv[4][4];
+      if (epi && p.ep_add) {  // this filter tile's add terms travel while the tile is transposed
+        MFN_UNROLL
+        for (int i = 0; i < 4; ++i) {
+          const size_t orow_off = obatch + (size_t)min(m0 + mt * 32 + i * 8 + orow, p.Cout - 1) * oplane;
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q) addv[i][q] = p.ep_add[orow_off + oxq[q]];
+        }
+      }
       MFN_WAIT_LGKM0();  // the previous tile's reads are done (wave-private buffer: no barrier needed)
       MFN_UNROLL
       for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + j] = acc[mt][r];
@@ -644,18 +683,17 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         const int ol = i * 8 + orow;
         const int o = m0 + mt * 32 + ol;
         float4 v = *reinterpret_cast<const float4 *>(tr + ol * TS + px0);
-        if (tile_ok && o < p.Cout && oy < Ho) {
-          const float b = (p.bias && !raw) ? p.bias[o] : 0.f;
-          const size_t oidx = (size_t)o * oplane + (size_t)oy * Wo + ox;
-          float *dst = obase + oidx;
-          float e[4] = {v.x + b, v.y + b, v.z + b, v.w + b};
-          if (ep && !raw) {
-            MFN_UNROLL
-            for (int q = 0; q < 4; ++q)
-              if (ox + q < Wo)
-                e[q] = dc_epilogue(e[q], p.ep_mask, p.ep_add, p.ep_leaky, (size_t)n * oplane + (size_t)oy * Wo + ox + q,
-                                   (size_t)n * p.Cout * oplane + oidx + q);
+        float e[4] = {v.x + bq[mt][i], v.y + bq[mt][i], v.z + bq[mt][i], v.w + bq[mt][i]};
+        if (epi) {  // dc_epilogue, value by value
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q) {
+            if (p.ep_mask) e[q] = e[q] * sg[q];
+            if (p.ep_add) e[q] = e[q] + addv[i][q];
+            if (p.ep_leaky) e[q] = fmaxf(e[q], 0.1f * e[q]);
           }
+        }
+        if (st_ok && o < p.Cout) {
+          float *dst = obase + (size_t)o * oplane + (size_t)oy * Wo + ox;
           if (ox + 3 < Wo) {
             mfn_store4_stream(dst, e[0], e[1], e[2], e[3], raw ? 0 : p.st_policy);  // partial sums are re-read: plain
           } else {
