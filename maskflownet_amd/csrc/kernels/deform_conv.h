@@ -247,8 +247,13 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       offh[t] = op[(size_t)(2 * t) * oplane];
       offw[t] = op[(size_t)(2 * t + 1) * oplane];
     }
+    // all eighteen requested before the first is compared: behind a short-circuit `&&` hipcc sinks each pair of loads into
+    // its own branch -- nine dependent round trips at the head of every block
+    MFN_COMPILER_FENCE();
+    int same = 1;
     MFN_UNROLL
-    for (int t = 1; t < T; ++t) shared = shared && (offh[t] == offh[0]) && (offw[t] == offw[0]);
+    for (int t = 1; t < T; ++t) same &= (int)(offh[t] == offh[0]) & (int)(offw[t] == offw[0]);
+    shared = same != 0;
   } else {
     const float *fp = p.flow + (size_t)n * 2 * oplane + (size_t)ho * Wo + wo;
     const float oh = fp[0] * p.flow_scale / p.flow_stride;       // MaskFlownet.py:230
