@@ -1398,15 +1398,32 @@ __global__ __launch_bounds__(256) void dc_bwd_weight_reduce_kernel(DcBwdWRParams
   const size_t idx = (size_t)(bias ? blockIdx.x - p.wblocks : blockIdx.x) * 16 + el;
   const size_t total = bias ? (size_t)p.Cout : (size_t)p.Cout * p.Cin * 9;
   float sum = 0.f;
+  // slabs grp, grp + 16, ... added in that order, eight requests in flight (one load, one wait, one add at a time was 16 round
+  // trips per thread: most of this kernel's 8.7 us)
+  auto slab_sum = [&](const float *base, size_t stride) {
+    float acc = 0.f;
+    for (int b = grp; b < p.nblk; b += 16 * 8) {
+      float v[8];
+      MFN_UNROLL
+      for (int u = 0; u < 8; ++u) {
+        const int bb = b + 16 * u;
+        const float x = base[(size_t)min(bb, p.nblk - 1) * stride];
+        v[u] = bb < p.nblk ? x : 0.f;
+      }
+      MFN_UNROLL
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    return acc;
+  };
   if (idx < total) {
     if (bias) {
-      for (int b = grp; b < p.nblk; b += 16) sum += p.bias_slabs[(size_t)b * (p.mtot * 32) + idx];
+      sum = slab_sum(p.bias_slabs + idx, (size_t)p.mtot * 32);
     } else {
       const int o = (int)(idx / ((size_t)p.Cin * 9)), rem = (int)(idx - (size_t)o * p.Cin * 9);
       const int c = rem / 9, t = rem - c * 9;
       const int cbk = c >> 5, col = (c & 31) * 9 + t, f = o >> 5, ol = o & 31;
       const float *sp = p.slabs + (((size_t)cbk * p.nblk) * p.mtot + f) * (32 * 288) + ol * 288 + col;
-      for (int b = grp; b < p.nblk; b += 16) sum += sp[(size_t)b * p.mtot * (32 * 288)];
+      sum = slab_sum(sp, (size_t)p.mtot * (32 * 288));
     }
   }
   part[grp * 16 + el] = sum;

@@ -85,7 +85,7 @@ if os.path.exists(db5):
                 "level.  `dc_bwd_input_pix_kernel` = input + offset gradient of the deformable conv in the forward's orientation "
                 "(kernels/dc_backward.h); `dc_bwd_input_tile_kernel` only sees its skip list here; `dc_bwd_weight_pix_kernel<MTOT>` + "
                 "`dc_bwd_weight_reduce_kernel` = weight + bias gradient (columns as the forward produces them, per-block slabs, "
-                "fixed-order sum); `corr_bwd_block_kernel` computes g1 and g2 in separate blocks; `fill_zero4_kernel` zeroes the "
+                "fixed-order sum); `corr_bwd_lds_kernel` computes g1 and g2 in separate blocks (the other feature map's rows through LDS); `fill_zero4_kernel` zeroes the "
                 "write-mode gradients of a call.  bench.py also runs the pass on two more streams (`pipelined`) and eager passes for "
                 "`roofline` / `kernels`.\n\n")
         f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
@@ -95,7 +95,7 @@ if os.path.exists(db5):
                 short = short[:87] + "..."
             f.write("| `%s` | %d | %.1f | %.3f | %.2f |\n" % (short, calls, tot, avg, pct))
     print("wrote", "%s_bench_cfg5_kernel_stats.md" % tag)
-for name in ("bench_cfg5",):
+for name in ("bench_cfg5", "bench_cfg5_fused"):
     src = os.path.join(G, name + ".log")
     if os.path.exists(src):
         line = open(src).read().strip().splitlines()[-1]
@@ -105,7 +105,7 @@ for name in ("bench_cfg5",):
             continue
         open(os.path.join(P, "%s_%s.json.log" % (tag, name)), "w").write(line + "\n")
         print("wrote", "%s_%s.json.log" % (tag, name))
-for name in ("atomic_patterns_ubench", "bwd_levels", "bwd_pix_phases", "bwd_wpix_phases"):
+for name in ("atomic_patterns_ubench", "bwd_levels", "bwd_pix_phases", "bwd_wpix_phases", "corr_bwd_levels"):
     src = os.path.join(G, name + ".txt")
     if os.path.exists(src):
         open(os.path.join(P, "%s_%s.txt" % (tag, name)), "w").write(open(src).read())
