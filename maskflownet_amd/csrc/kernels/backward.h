@@ -39,9 +39,13 @@ __global__ __launch_bounds__(256) void fill_zero4_kernel(Fill4Params f) {
     const unsigned q0 = k ? f.qend[k - 1] : 0u;
     if (q >= q0 && q < f.qend[k]) {
       const size_t b = (size_t)(q - q0) * 4;
-      MFN_UNROLL
-      for (int e = 0; e < 4; ++e)
-        if (b + e < f.n[k]) f.p[k][b + e] = 0.f;
+      if (b + 3 < f.n[k] && (reinterpret_cast<size_t>(f.p[k]) & 15) == 0) {  // one 16-byte store
+        *reinterpret_cast<float4 *>(f.p[k] + b) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        MFN_UNROLL
+        for (int e = 0; e < 4; ++e)
+          if (b + e < f.n[k]) f.p[k][b + e] = 0.f;
+      }
     }
   }
 }

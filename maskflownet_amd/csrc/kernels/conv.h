@@ -297,17 +297,24 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
     if (px_valid) {
       const size_t rplane = 4 * oplane;   // real output plane: (2 Ho) x (2 Wo)
       MFN_UNROLL
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        // the 16 pseudo-filters of this lane are 4 real filters (r >> 2): their bias requested up front
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+          MFN_UNROLL
+          for (int g = 0; g < 4; ++g) b4[g] = p.bias[min((m0 + mt * 32 + 8 * g + 4 * half) >> 2, (p.Cout >> 2) - 1)];
+        }
         MFN_UNROLL
         for (int r = 0; r < 16; ++r) {
           const int op = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // pseudo-filter
           if (op < p.Cout) {
             const int o = op >> 2, py = (op >> 1) & 1, pxx = op & 1;
-            float v = acc[mt][r] + (p.bias ? p.bias[o] : 0.f);
+            float v = acc[mt][r] + b4[r >> 2];
             if (p.leaky) v = fmaxf(v, 0.1f * v);
             obase[(size_t)o * rplane + (size_t)(2 * ho + py) * (2 * Wo) + 2 * wo + pxx] = v;
           }
         }
+      }
     }
   } else if (vec) {
     // transpose the 32x32 tile through LDS so that a lane holds 4 adjacent pixels of one filter: 16-byte stores
@@ -317,6 +324,19 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
     const int px0 = quad * 4;
     const int oy = tile_ho0 + (px0 >> 3), ox = tile_wo0 + (px0 & 7);
     const bool tile_ok = tile < p.ntiles;
+    // this lane's 4 MT bias values, requested ahead of the transposition (a conditional load inside the store loop sits in its
+    // own branch with a full wait behind it; deform_conv.h: dc_lds_kernel's epilogue)
+    float bq[MT][4];
+    MFN_UNROLL
+    for (int mt = 0; mt < MT; ++mt)
+      MFN_UNROLL
+      for (int i = 0; i < 4; ++i) bq[mt][i] = 0.f;
+    if (p.bias) {
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt)
+        MFN_UNROLL
+        for (int i = 0; i < 4; ++i) bq[mt][i] = p.bias[min(m0 + mt * 32 + i * 8 + orow, p.Cout - 1)];
+    }
     MFN_UNROLL
     for (int mt = 0; mt < MT; ++mt) {
       MFN_WAIT_LGKM0();
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
         const int o = m0 + mt * 32 + ol;
         const float4 v = *reinterpret_cast<const float4 *>(tr + ol * TS + px0);
         if (tile_ok && o < p.Cout && oy < Ho && ox < Wo) {
-          const float b = p.bias ? p.bias[o] : 0.f;
+          const float b = bq[mt][i];
           float e[4] = {v.x + b, v.y + b, v.z + b, v.w + b};
           if (p.leaky) {
             MFN_UNROLL
