@@ -500,24 +500,43 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
       if (xfit) phase_a(DcInt<1>{}); else phase_a(DcInt<0>{});
     }
     // the two half-waves hold the other 16 channels of the same pixel; half 0 writes d/dh, half 1 d/dw
-    float vsum = 0.f;
+    float vt[T], vsum = 0.f;
     MFN_UNROLL
     for (int t = 0; t < T; ++t) {
       const float h2 = sh[t] + __shfl_xor(sh[t], 32), w2 = sw[t] + __shfl_xor(sw[t], 32);
       const float m9 = stash[(0 + t / 3) * 64] * stash[(3 + t % 3) * 64];
-      const float v = (half ? w2 : h2) * m9;
-      if (fm) { vsum += v; continue; }
-      float *dst = p.goffset + ((size_t)n * 2 * T + 2 * t + half) * plane + pix;
+      vt[t] = (half ? w2 : h2) * m9;
+      vsum += vt[t];
+    }
+    // one writer per value (no channel blocks, no filter slices): plain stores -- the buffer is zero-filled in write mode, so
+    // only "add" reads it, all nine values requested before the first is used (`*dst += v` tap by tap was nine dependent
+    // round trips).  Otherwise atomics.
+    const bool single = gridDim.y == 1 && gridDim.z == 1;
+    if (fm) {  // d/dflow: the nine taps share the offset, so their gradients add up (MaskFlownet.py:230)
       if (px_valid) {
-        if (gridDim.y == 1 && gridDim.z == 1) *dst += v;  // zero-filled (write) or the caller's values (add); nobody else writes this pixel
+        const float v = vsum * (p.flow_scale / p.flow_stride);
+        float *dst = p.gflow + ((size_t)n * 2 + half) * plane + pix;
+        if (single) *dst = p.req_offset == 3 ? *dst + v : v;
         else if (v != 0.f) atomicAdd(dst, v);
       }
-    }
-    if (fm && px_valid) {  // d/dflow: the nine taps share the offset, so their gradients add up (MaskFlownet.py:230)
-      const float v = vsum * (p.flow_scale / p.flow_stride);
-      float *dst = p.gflow + ((size_t)n * 2 + half) * plane + pix;
-      if (gridDim.y == 1 && gridDim.z == 1) *dst += v;
-      else if (v != 0.f) atomicAdd(dst, v);
+    } else if (px_valid) {
+      float *dst = p.goffset + ((size_t)n * 2 * T + half) * plane + pix;
+      if (single) {
+        if (p.req_offset == 3) {
+          float old[T];
+          MFN_UNROLL
+          for (int t = 0; t < T; ++t) old[t] = dst[(size_t)(2 * t) * plane];
+          MFN_COMPILER_FENCE();
+          MFN_UNROLL
+          for (int t = 0; t < T; ++t) vt[t] += old[t];
+        }
+        MFN_UNROLL
+        for (int t = 0; t < T; ++t) dst[(size_t)(2 * t) * plane] = vt[t];
+      } else {
+        MFN_UNROLL
+        for (int t = 0; t < T; ++t)
+          if (vt[t] != 0.f) atomicAdd(dst + (size_t)(2 * t) * plane, vt[t]);
+      }
     }
   }
   if (p.timeline) tk2 = MFN_CYCLES();
