@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
     MFN_UNROLL
     for (int t = 1; t < T; ++t) regular = regular && (q.off[2 * t] == oh) && (q.off[2 * t + 1] == ow);
     float a_y[3], b_y[3], a_x[3], b_x[3];
-    int iy[4], ix[4];
+    int iy[4], ix[4], c0x = 0;  // c0x: the neighbourhood's first column before clamping
     {
       int lo0 = 0;
       MFN_UNROLL
@@ -1165,6 +1165,7 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
       }
       MFN_UNROLL
       for (int m = 0; m < 4; ++m) ix[m] = min(max(w_in + lo0 + m, 0), W - 1);
+      c0x = w_in + lo0;
     }
     const bool fast = __all(regular || !q.px_valid) != 0;
     // every lane's four columns consecutive (not clamped at the image's left / right edge): one 16-byte load per row
@@ -1178,7 +1179,15 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
       }
       int *gi = reinterpret_cast<int *>(g);
       MFN_UNROLL
-      for (int m = 0; m < 4; ++m) { gi[(12 + m) * 32 + j] = iy[m] * W; gi[(16 + m) * 32 + j] = ix[m]; }
+      for (int m = 0; m < 4; ++m) gi[(12 + m) * 32 + j] = iy[m] * W;
+      // one 16-byte load per row at the base column (inside the row); where the image's edge clamps the columns, produce()
+      // picks column ix[m] - base out of the four loaded values (two bits per m)
+      const int cbase = min(max(c0x, 0), W - 4);
+      int shifts = 0;
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m) shifts |= (ix[m] - cbase) << (2 * m);
+      gi[16 * 32 + j] = cbase;
+      gi[17 * 32 + j] = shifts;
       gi[20 * 32 + j] = q.ho * W + q.wo;
       gi[21 * 32 + j] = q.px_valid ? 1 : 0;
       gi[22 * 32 + j] = q.ho;
@@ -1204,25 +1213,22 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
       MFN_UNROLL
       for (int k = 0; k < MTOT * 4; ++k) gvn[k] = gp[(size_t)min(osub + 8 * k, p.Cout - 1) * plane];
     }
-    if (mode != 0) {
-      int row[4], col[4];
+    {
+      // ONE unconditional path (tiles with consecutive columns, tiles the image's edge clamps, and -- their values unused --
+      // the tiles of the per-tap path): a load in a branch becomes "old or new value" at the join, hipcc copies the loaded
+      // registers there and waits for every load in flight to do so -- the requests were never ahead of anything
+      (void)mode;
+      int row[4];
       MFN_UNROLL
-      for (int m = 0; m < 4; ++m) { row[m] = gi[(12 + m) * 32 + j]; col[m] = gi[(16 + m) * 32 + j]; }
+      for (int m = 0; m < 4; ++m) row[m] = gi[(12 + m) * 32 + j];
+      const int cbase = gi[16 * 32 + j];
       MFN_UNROLL
       for (int k = 0; k < 4; ++k) {
         // channels past Cin (ragged last block) are written as zeros: any valid plane is read in their place
         const int c = min(cb + 2 * (4 * pw + k) + half, p.Cin - 1);
-        const float *pl = p.x + ((size_t)n * p.Cin + c) * plane;
-        if (mode == 2) {
-          MFN_UNROLL
-          for (int m = 0; m < 4; ++m) xv[k][m] = mfn_load4u(pl + row[m] + col[0]);
-        } else {
-          MFN_UNROLL
-          for (int m = 0; m < 4; ++m) {
-            xv[k][m].x = pl[row[m] + col[0]]; xv[k][m].y = pl[row[m] + col[1]];
-            xv[k][m].z = pl[row[m] + col[2]]; xv[k][m].w = pl[row[m] + col[3]];
-          }
-        }
+        const float *pl = p.x + ((size_t)n * p.Cin + c) * plane + cbase;
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m) xv[k][m] = mfn_load4u(pl + row[m]);
       }
     }
   };
@@ -1248,6 +1254,8 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
       for (int k = 0; k < 3; ++k) {
         a_y[k] = g[(0 + k) * 32 + j]; b_y[k] = g[(3 + k) * 32 + j]; a_x[k] = g[(6 + k) * 32 + j]; b_x[k] = g[(9 + k) * 32 + j];
       }
+      // columns clamped at the image's edge (mode 1): column m of the neighbourhood is loaded value (shifts >> 2m) & 3
+      const int shifts = mode == 1 ? gi[17 * 32 + j] : 0xE4;   // 0xE4: the identity (3, 2, 1, 0)
       MFN_UNROLL
       for (int k = 0; k < 4; ++k) {
         const int cl = 2 * (4 * pw + k) + half;   // channel of this lane inside the block
@@ -1255,9 +1263,15 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
         float tr[4][3];
         MFN_UNROLL
         for (int m = 0; m < 4; ++m) {
-          tr[m][0] = a_x[0] * xv[k][m].x + b_x[0] * xv[k][m].y;
-          tr[m][1] = a_x[1] * xv[k][m].y + b_x[1] * xv[k][m].z;
-          tr[m][2] = a_x[2] * xv[k][m].z + b_x[2] * xv[k][m].w;
+          f4u v = xv[k][m];
+          if (mode == 1) {  // uniform
+            const f4u u = v;
+            auto pick = [&](int sft) { return sft == 0 ? u.x : (sft == 1 ? u.y : (sft == 2 ? u.z : u.w)); };
+            v.x = pick(shifts & 3); v.y = pick((shifts >> 2) & 3); v.z = pick((shifts >> 4) & 3); v.w = pick((shifts >> 6) & 3);
+          }
+          tr[m][0] = a_x[0] * v.x + b_x[0] * v.y;
+          tr[m][1] = a_x[1] * v.y + b_x[1] * v.z;
+          tr[m][2] = a_x[2] * v.z + b_x[2] * v.w;
         }
         MFN_UNROLL
         for (int ii = 0; ii < 3; ++ii)
@@ -1295,12 +1309,20 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
   // one producer step: tile i into its buffer, then the requests for tile i + 1 (and, around every fourth tile, the
   // geometry of the next four)
   GeoIn gin;
+  // measurement only (p.timeline): shader cycles of wave 0 in produce / geometry / load issue / barrier, of wave 4 in MFMA / barrier
+  unsigned long long tq[6] = {0, 0, 0, 0, 0, 0};
   auto producer_step = [&](int i) {
     const bool next_group = ((i >> 2) + 1) * 4 < ntile;   // uniform: a group of tiles after this one
+    const unsigned long long c0 = MFN_CYCLES();
     produce(i);
+    const unsigned long long c1 = MFN_CYCLES();
     if ((i & 3) == 2 && next_group) geo_store(gin, ((i >> 2) + 1) & 1);   // visible after this step's barrier
-    if (i + 1 < ntile && ((i + 1) & 3) != 0) tile_loads(i + 1);   // (the first tile of a group: after that barrier, below)
+    const unsigned long long c2 = MFN_CYCLES();
+    tile_loads(max(min(i + 1, ntile - 1), 0));   // unconditional (past the last tile: the last one again, unused); a new group's
+                                         // geometry was parked one step ago
     if ((i & 3) == 1 && next_group) geo_load(t0 + ((i >> 2) + 1) * 4 + pw, gin);
+    const unsigned long long c3 = MFN_CYCLES();
+    tq[0] += c1 - c0; tq[1] += c2 - c1; tq[2] += c3 - c2;
   };
 
   // the slab of filter tile f: both kinds of waves store their half of it once the consumers have staged it
@@ -1330,13 +1352,16 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
     tile_loads(0);
     producer_step(0);
     MFN_LDS_BARRIER();
-    for (int i = 0; i < ntile; ++i) {
-      if (i + 1 < ntile) {
-        // the geometry of a new group became visible with the barrier above: its first tile's requests go out now
-        if (((i + 1) & 3) == 0) tile_loads(i + 1);
-        producer_step(i + 1);
-      }
+    for (int i = 0; i + 1 < ntile; ++i) {   // the consumers multiply tile i meanwhile
+      producer_step(i + 1);
+      const unsigned long long cb0 = MFN_CYCLES();
       MFN_LDS_BARRIER();  // tile i + 1 is complete, tile i's buffer is free
+      tq[3] += MFN_CYCLES() - cb0;
+    }
+    if (ntile > 0) MFN_LDS_BARRIER();    // the consumers' last tile
+    if (p.timeline && threadIdx.x == 0) {
+      unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+      b_[0] = tq[0]; b_[1] = tq[1]; b_[2] = tq[2]; b_[3] = tq[3];
     }
     // bias gradient: row sums of gout over this block's pixels (channel block 0)
     if (p.gbias && blockIdx.y == 0) {
@@ -1367,6 +1392,7 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
     for (int i = 0; i < ntile; ++i) {
       // ---- D[filter][channel] of tap t, filter tile f: accumulator tile u = t + 9 f, every fourth one is this wave's --------
       const float *colT = colB + (i & 1) * DCW_COL_F, *goutT = goutB + (i & 1) * GOUT_F;
+      const unsigned long long cm0 = MFN_CYCLES();
       MFN_UNROLL
       for (int ul = 0; ul < UMAX; ++ul) {
         const int u = pw + 4 * ul;
@@ -1386,7 +1412,13 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
           }
         }
       }
+      const unsigned long long cm1 = MFN_CYCLES();
       MFN_LDS_BARRIER();
+      tq[5] += MFN_CYCLES() - cm1; tq[4] += cm1 - cm0;
+    }
+    if (p.timeline && threadIdx.x == 256) {
+      unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+      b_[4] = tq[4]; b_[5] = tq[5]; b_[6] = (unsigned long long)ntile; b_[7] = 1;
     }
     // the sums leave as contiguous (c, t) rows: D reg r of lane (j, half) = filter (r&3)+8*(r>>2)+4*half, channel j
     for (int f = 0; f < MTOT; ++f) {
