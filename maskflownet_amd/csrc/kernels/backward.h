@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 3) void corr_bwd_lds_kernel(CorrBwdLdsParams p
       for (int ix = 0; ix < D; ++ix) {
         // the four source pixels x + q - dx of this displacement: one unaligned quad (it stays inside the tensor: a displacement
         // to the left never belongs to the first plane, one to the right never to the last); window index j = q + 4 - dx
-        const mfn_quad gl = mfn_load4_unaligned(go + (size_t)(iy * D + ix) * plane + (size_t)ys * W + x - (ix - MD));
+        const f4u gl = mfn_load4u(go + (size_t)(iy * D + ix) * plane + (size_t)ys * W + x - (ix - MD));
         constexpr int base = 4 + MD;
         float gq[4] = {gl.x, gl.y, gl.z, gl.w};
         MFN_UNROLL

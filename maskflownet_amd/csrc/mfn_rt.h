@@ -209,18 +209,6 @@ namespace mfn {
 // write-back L2 and the end-of-kernel release flushes all of it at once; `sc0 sc1` writes it through while the other
 // blocks still compute (level-2 correlation, 31.8 MB of stores: 18.8 -> 14.8 us; tools/corr_nt_time.py).
 // policy: 0 plain, 1 nt, 2 sc0 sc1 (default, tuning key store.policy), 3 sc0 sc1 nt.
-// four consecutive floats from a pointer that is only 4-byte aligned: one global_load_dwordx4 (global memory takes multi-dword
-// accesses at dword alignment on gfx950)
-struct mfn_quad { float x, y, z, w; };
-__device__ __forceinline__ mfn_quad mfn_load4_unaligned(const float *src) {
-#if defined(MFN_EMU)
-  return mfn_quad{src[0], src[1], src[2], src[3]};
-#else
-  typedef float mfn_v4f_u __attribute__((ext_vector_type(4), aligned(4)));
-  const mfn_v4f_u v = *reinterpret_cast<const mfn_v4f_u *>(src);
-  return mfn_quad{v.x, v.y, v.z, v.w};
-#endif
-}
 __device__ __forceinline__ void mfn_store4_stream(float *dst, float a, float b, float c, float d, int policy) {
 #if defined(MFN_EMU)
   (void)policy;

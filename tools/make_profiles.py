@@ -105,7 +105,7 @@ for name in ("bench_cfg5", "bench_cfg5_fused"):
             continue
         open(os.path.join(P, "%s_%s.json.log" % (tag, name)), "w").write(line + "\n")
         print("wrote", "%s_%s.json.log" % (tag, name))
-for name in ("atomic_patterns_ubench", "bwd_levels", "bwd_pix_phases", "bwd_wpix_phases", "corr_bwd_levels"):
+for name in ("atomic_patterns_ubench", "bwd_levels", "bwd_pix_phases", "bwd_wpix_phases", "bwd_wpc_phases", "corr_bwd_levels", "unaligned_loads_ubench"):
     src = os.path.join(G, name + ".txt")
     if os.path.exists(src):
         open(os.path.join(P, "%s_%s.txt" % (tag, name)), "w").write(open(src).read())
