@@ -44,6 +44,10 @@ constexpr int DCP_ROWS = 16, DCP_COLS = 24;      // source window of a 4x8 tile
 constexpr int DCP_XW_NI = 3;                     // 2 channels x 16 rows x 6 float4 = 192 slots = 3 wave DMA instructions
 constexpr int DCP_XW_F = DCP_XW_NI * 256;        // floats of a channel-pair source window
 constexpr int DCP_PR = 22, DCP_PC = 32;          // gx plane of the 8x16 region
+// row stride of a plane in LDS.  ds_read_b32 / ds_write_b32 serve a half-wave (one tile's 4 x 8 pixels on one channel plane) per
+// LDS cycle over 32 banks: with a stride of 32 the tile's four rows sit on the same banks (every access of the walk 4-way
+// conflicted), with 40 they sit 8 banks apart -- a regular tile touches 32 different banks
+constexpr int DCP_PS = 40;
 constexpr int DCP_FS = (DCP_PR * DCP_PC + 63) / 64;  // most 64-cell slices a plane's flush can take
 constexpr int DCP_EXCH = 32;                     // ints of the block's touched-box exchange
 // Three forms of the kernel.  <1, 1, 1> (default): both gradients from one pass over gout, one wave per SIMD (466 registers,
@@ -62,11 +66,11 @@ template <bool WX, bool WO, int OCC> struct DcpCfg {
   static constexpr int NSET = SPLIT ? 2 : 1;                 // plane sets walked one after the other
   static constexpr int NPL = 32 / NSET;                      // planes live at a time
   // plane stride: the two half-waves' planes (MFMA rows 4 apart) sit 32 banks apart
-  static constexpr int PLANE = DCP_PR * DCP_PC + (SPLIT ? 16 : 8);
+  static constexpr int PLANE = DCP_PR * DCP_PS + (SPLIT ? 16 : 8);
   static constexpr int STASH = WX ? 21 : 6;                  // words a lane parks in LDS (what only phase B / the end needs)
   // per wave next to the weight stages: its three source windows (offset gradient), or at least the scratch of the turn
   // assignment (one int per plane cell)
-  static constexpr int XW_WAVE = WO ? 3 * DCP_XW_F : DCP_PR * DCP_PC;
+  static constexpr int XW_WAVE = WO ? 3 * DCP_XW_F : DCP_PR * DCP_PS;
   static constexpr int LDS_A = 3 * STAGE_F + 4 * XW_WAVE, LDS_B = WX ? NPL * PLANE : 0;
   static constexpr int LDS_MAIN = LDS_A > LDS_B ? LDS_A : LDS_B;
   // K loop and phase A: weight stages + four x-window rings; phase B reuses the same memory for the planes
@@ -95,7 +99,7 @@ template <bool WX, bool WO, int OCC>
 __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams p) {
   using Cfg = DcpCfg<WX, WO, OCC>;
   constexpr int T = 9, KO = Cfg::KO, KS = KO / 2, NI = Cfg::NI, ROWS = DCP_ROWS, COLS = DCP_COLS, XW_NI = DCP_XW_NI;
-  constexpr int PR = DCP_PR, PC = DCP_PC, PL = Cfg::PLANE, RD = Cfg::RD, NSET = Cfg::NSET, CPG = 4 / NSET;
+  constexpr int PR = DCP_PR, PC = DCP_PC, PS = DCP_PS, PL = Cfg::PLANE, RD = Cfg::RD, NSET = Cfg::NSET, CPG = 4 / NSET;
   constexpr int DCP_STAGE_F = Cfg::STAGE_F, DCP_STASH = Cfg::STASH;
   if (!WX) p.req_x = 0;        // the form decides which gradients are formed
   if (!WO) p.req_offset = 0;
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
   int partner = -1, merged = 0;  // lane j' of the pixel whose contributions this lane adds to its own (or -1); any pair in the tile
   if (fast && p.req_x) {
     int *map = reinterpret_cast<int *>(xwin);
-    const int key = cry * PC + crx;
+    const int key = cry * PS + crx;
     bool pending = px_valid && inplane;
     while (__any(pending)) {
       if (pending) map[key] = j;   // both half-waves hold the same pixels: lane j and j + 32 write the same value
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
     }
     if (WX) {
       int *si = reinterpret_cast<int *>(stash);
-      si[18 * 64] = cry * PC + crx;
+      si[18 * 64] = cry * PS + crx;
       si[19 * 64] = (px_valid && !inplane) ? -2 : turn;   // -2: the neighbourhood leaves the plane -> straight to gx
       si[20 * 64] = partner;
     }
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
       if (col < 0) { --row; col += ncols; }
       if (col >= ncols) { ++row; col -= ncols; }
       const int yy = py0 + fy0 + row, xx = px0 + fx0 + col;
-      floff[sl] = min(max((fy0 + row) * PC + fx0 + col, 0), PR * PC - 1);
+      floff[sl] = min(max((fy0 + row) * PS + fx0 + col, 0), PR * PS - 1);
       fgoff[sl] = (e < ncells && yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
     }
   }
@@ -638,9 +642,9 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
               for (int v = 0; v < 4; ++v) {
                 float o[CPG];
                 MFN_UNROLL
-                for (int c = 0; c < CPG; ++c) o[c] = pl[c][u * PC + v];
+                for (int c = 0; c < CPG; ++c) o[c] = pl[c][u * PS + v];
                 MFN_UNROLL
-                for (int c = 0; c < CPG; ++c) pl[c][u * PC + v] = o[c] + G[c][u][v];
+                for (int c = 0; c < CPG; ++c) pl[c][u * PS + v] = o[c] + G[c][u][v];
                 // the next cell's reads are ISSUED after this cell's writes: another lane's cell (u, v) is this lane's
                 // cell (u', v'); the in-order LDS pipe then orders them
                 MFN_COMPILER_FENCE();
