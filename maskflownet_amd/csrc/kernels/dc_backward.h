@@ -505,12 +505,19 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
     }
     // the two half-waves hold the other 16 channels of the same pixel; half 0 writes d/dh, half 1 d/dw
     float vt[T], vsum = 0.f;
-    MFN_UNROLL
-    for (int t = 0; t < T; ++t) {
-      const float h2 = sh[t] + __shfl_xor(sh[t], 32), w2 = sw[t] + __shfl_xor(sw[t], 32);
-      const float m9 = stash[(0 + t / 3) * 64] * stash[(3 + t % 3) * 64];
-      vt[t] = (half ? w2 : h2) * m9;
-      vsum += vt[t];
+    {
+      // half 0 needs the other half's d/dh sums, half 1 its d/dw sums: ONE exchange per tap (each half sends what the other
+      // needs), all nine requested before the first is used
+      float mine[T], theirs[T];
+      MFN_UNROLL
+      for (int t = 0; t < T; ++t) { mine[t] = half ? sw[t] : sh[t]; theirs[t] = __shfl_xor(half ? sh[t] : sw[t], 32); }
+      MFN_COMPILER_FENCE();
+      MFN_UNROLL
+      for (int t = 0; t < T; ++t) {
+        const float m9 = stash[(0 + t / 3) * 64] * stash[(3 + t % 3) * 64];
+        vt[t] = (mine[t] + theirs[t]) * m9;
+        vsum += vt[t];
+      }
     }
     // one writer per value (no channel blocks, no filter slices): plain stores -- the buffer is zero-filled in write mode, so
     // only "add" reads it, all nine values requested before the first is used (`*dst += v` tap by tap was nine dependent
