@@ -265,6 +265,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   // ---- fast-path descriptors: regular floor pattern on both axes -----------------------------------
   DcAxis3 ay, ax;
   bool regular = shared && (p.dh == 1) && (p.dw == 1) && (p.allow_fast != 0);
+  int nb_c0 = 0;  // unclamped first column of the 4x4 neighbourhood (may lie outside the image at its left / right edge)
   {
     int lo0 = 0;
     MFN_UNROLL
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
     }
     MFN_UNROLL
     for (int m = 0; m < 4; ++m) ax.idx[m] = min(max(w_in + lo0 + m, 0), W - 1);
+    nb_c0 = w_in + lo0;
   }
   const bool fast = __all(regular || !px_valid) != 0;  // wave-uniform
 
@@ -351,27 +353,23 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
           acc[mt] = MFN_MFMA_32x32x2(ap[((i * 3 + q) * 2) * RL + mt * 32], cv, acc[mt]);
       }
   };
-  // second tier (window does not fit, e.g. a rough or discontinuous flow): gather each row of the 4x4
-  // neighbourhood with ONE dword-aligned global_load_dwordx4, straight from global memory, when the
-  // 4 columns are not clamped (consecutive) for every lane; uniform base + 32-bit lane offset.
-  const bool cols_consecutive = (ax.idx[1] - ax.idx[0] == 1) && (ax.idx[2] - ax.idx[1] == 1) && (ax.idx[3] - ax.idx[2] == 1);
+  // second tier (window does not fit: a rough or discontinuous flow, outliers): every row of the 4x4 neighbourhood is ONE
+  // dword-aligned 16-byte load straight from global memory, at the neighbourhood's first column clamped into [0, W - 4];
+  // the loads of pair k + 2 are in flight while pair k + 1 is interpolated and pair k multiplied (software pipeline
+  // below).  Lanes at the image's left / right edge see their columns shifted by `cshift` inside the loaded quad: their
+  // x pass runs on a general 3 x 4 weight matrix (zero where a column lies outside -- those carry weight 0 anyway), chosen
+  // per wave; everybody else keeps the banded two-term form.  Third tier (images narrower than four columns): 16 dword
+  // gathers at clamped columns.
   const bool small = (size_t)p.N * p.Cin * plane < ((size_t)1 << 30);
-  const bool rowgather = !staged && fast && small && __all(cols_consecutive || !px_valid) != 0;
-  const bool dwgather = !staged && fast && small && !rowgather;  // third tier: clamped columns, 16 dword gathers
+  const bool gtier = !staged && fast && small && W >= 4;
+  const bool dwgather = !staged && fast && small && !gtier;
+  const int cbase = min(max(nb_c0, 0), max(W - 4, 0));
+  const int cshift = nb_c0 - cbase;
+  const bool gbanded = __all(cshift == 0 || !px_valid) != 0;  // wave-uniform
   unsigned rowoff[4];
   MFN_UNROLL
   for (int m = 0; m < 4; ++m)
     rowoff[m] = (unsigned)(n * p.Cin * (int)plane + half * (int)plane + ay.idx[m] * W + ax.idx[0]);
-  auto rowgather_pair = [&](int cp, const float *ap) {
-    const float *base = p.x + (size_t)(2 * cp) * plane;  // uniform
-    float v[4][4];
-    MFN_UNROLL
-    for (int m = 0; m < 4; ++m) {
-      const f4u r = mfn_load4u(base + rowoff[m]);
-      v[m][0] = r.x; v[m][1] = r.y; v[m][2] = r.z; v[m][3] = r.w;
-    }
-    fast_pair(v, ap);
-  };
   auto dwgather_pair = [&](int cp, const float *ap) {
     const float *base = p.x + (size_t)(2 * cp) * plane;  // uniform
     float v[4][4];
@@ -539,21 +537,19 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       }
       w_in_flight = w_now;
       const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
-      if (k + 1 < nf) {
-        gather2(BN, vp);
-        mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
-        mfma_tap(ap, 1, cur[1]);
-        mfma_tap(ap, 2, cur[2]); interp_rows2(vp, trp, 1);
-        mfma_tap(ap, 3, cur[3]);
-        mfma_tap(ap, 4, cur[4]); interp_col2(trp, nxt, 0);
-        mfma_tap(ap, 5, cur[5]); interp_col2(trp, nxt, 1);
-        mfma_tap(ap, 6, cur[6]); interp_col2(trp, nxt, 2);
-        mfma_tap(ap, 7, cur[7]);
-        mfma_tap(ap, 8, cur[8]);
-      } else {
-        MFN_UNROLL
-        for (int t = 0; t < T; ++t) mfma_tap(ap, t, cur[t]);
-      }
+      // the gather / interpolation of pair k + 1 runs in the last step too (stale window values, results unused): with the
+      // MFMAs in two branches the accumulators lived in two register sets and hipcc copied all sixteen (after draining the
+      // MFMA pipe) at the end of EVERY step
+      gather2(BN, vp);
+      mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
+      mfma_tap(ap, 1, cur[1]);
+      mfma_tap(ap, 2, cur[2]); interp_rows2(vp, trp, 1);
+      mfma_tap(ap, 3, cur[3]);
+      mfma_tap(ap, 4, cur[4]); interp_col2(trp, nxt, 0);
+      mfma_tap(ap, 5, cur[5]); interp_col2(trp, nxt, 1);
+      mfma_tap(ap, 6, cur[6]); interp_col2(trp, nxt, 2);
+      mfma_tap(ap, 7, cur[7]);
+      mfma_tap(ap, 8, cur[8]);
       MFN_SCHED_BARRIER();
     };
     for (int k = 0; k < nf;) {
@@ -573,7 +569,127 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
     k_done = nf;
   }
 
-  // ---- everything else: waves whose window does not fit, the odd half pair, padding -------------------------
+  // ---- global-gather waves: the same flat pipeline, the 4x4 neighbourhood rows arriving in registers ----------------
+  // Pair p's four row quads live in register slot p % 2; step k multiplies pair k, interpolates pair k + 1 (requested one
+  // step ago) and requests pair k + 2.  The loads are counted by hand like the LDS-DMA transfers (mfn_gload4_async): vmcnt
+  // completes in order, every wait names how many NEWER operations may still be outstanding.
+  if (gtier) {
+    const int nf = MFN_UNIFORM(max(0, min(nchunks * KC, full_pairs - cp_base)));
+    unsigned boff[4];  // byte offset of the lane's four row quads inside channel 2*cp of image 0
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m)
+      boff[m] = (unsigned)(n * p.Cin * (int)plane + half * (int)plane + ay.idx[m] * W + cbase) * 4u;
+    f32x4 R[2][4];
+    auto fetch = [&](int cp, auto slot_c) {
+      constexpr int S = decltype(slot_c)::value;
+      const float *base = p.x + (size_t)(2 * cp) * plane;  // uniform
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m) mfn_gload4_async(R[S][m], base, boff[m]);
+    };
+    auto mfma_tap = [&](const float *ap, int t, float b) {
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], b, acc[mt]);
+    };
+    auto pipeline = [&](auto gen_c) {
+      constexpr bool GEN = decltype(gen_c)::value;
+      // x-pass weights: banded (two terms per tap column) or, for waves with edge lanes, the 3 x 4 matrix
+      float X[3][4];
+      if (GEN) {
+        MFN_UNROLL
+        for (int q = 0; q < 3; ++q)
+          MFN_UNROLL
+          for (int u = 0; u < 4; ++u)
+            X[q][u] = (u == q + cshift ? ax.a[q] : 0.f) + (u == q + cshift + 1 ? ax.b[q] : 0.f);
+      }
+      f32x2 trp[4];  // x pass of a neighbourhood row: columns 0 and 1 as a register pair (packed y pass), column 2 beside it
+      float tr2[4];
+      auto xrow = [&](const f32x4 &r, int m) {
+        float t[3];
+        MFN_UNROLL
+        for (int q = 0; q < 3; ++q) {
+          if (GEN) {
+            float a = X[q][0] * r[0];
+            a = fmaf(X[q][1], r[1], a);
+            a = fmaf(X[q][2], r[2], a);
+            t[q] = fmaf(X[q][3], r[3], a);
+          } else {
+            t[q] = fmaf(ax.b[q], r[q + 1], ax.a[q] * r[q]);
+          }
+        }
+        trp[m] = mfn_f2(t[0], t[1]);
+        tr2[m] = t[2];
+      };
+      auto ycol = [&](float (&cv)[9], int i) {
+        const f32x2 c01 = mfn_fma2(mfn_f2(ay.b[i], ay.b[i]), trp[i + 1], mfn_mul2(mfn_f2(ay.a[i], ay.a[i]), trp[i]));
+        cv[i * 3 + 0] = c01.x;
+        cv[i * 3 + 1] = c01.y;
+        cv[i * 3 + 2] = fmaf(ay.b[i], tr2[i + 1], ay.a[i] * tr2[i]);
+      };
+      float cv[9], cvn[9];
+      // every request is unconditional (past the last pair the last one is requested again and never used): a request
+      // inside a branch would make the slot registers phi values, see MFN_REGFENCE4
+      const int cp_last = cp_base + nf - 1;
+      if (nf > 0) {
+        fetch(cp_base, DcInt<0>{});
+        fetch(min(cp_base + 1, cp_last), DcInt<1>{});
+        MFN_LANDED4(R[0][0], R[0][1], R[0][2], R[0][3], 4);  // the first weight chunk is older than both
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m) xrow(R[0][m], m);
+        MFN_UNROLL
+        for (int i = 0; i < 3; ++i) ycol(cv, i);
+        MFN_REGFENCE9(cv);
+      }
+      bool w_in_flight = false;  // a weight chunk was requested in the previous step (behind that step's row quads)
+      auto step = [&](int k, auto sn_c, float (&cur)[9], float (&nxt)[9]) {
+        constexpr int SN = decltype(sn_c)::value;  // slot of pair k + 1 (read now); pair k + 2 goes to the other one
+        constexpr int SF = 1 - SN;
+        const int ch = k / KC, kk = k - ch * KC;
+        bool w_now = false;
+        if (kk == 0) {
+          // the weights of chunk ch landed: they are older than the quads of pair k + 1 unless every pair is a chunk
+          if (KC == 1) MFN_WAIT_VM(0); else MFN_WAIT_VM(4);
+          MFN_WAIT_LGKM0();
+          MFN_RAW_BARRIER();
+          if (k == 0) MFN_STAMP(p.timeline, 1);
+        }
+        fetch(min(cp_base + k + 2, cp_last), DcInt<SF>{});
+        if (kk == 0 && ch + 1 < nchunks) { issue(ch + 1); w_now = true; }
+        // pair k + 1 landed; newer: the request above and a weight chunk of this or the previous step
+        if (w_now || w_in_flight) MFN_WAIT_VM(NI + 4); else MFN_WAIT_VM(4);
+        MFN_REGFENCE4(R[SN][0], R[SN][1], R[SN][2], R[SN][3]);
+        w_in_flight = w_now;
+        const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
+        // the last step interpolates a repeated pair (results unused): one MFMA stream, no accumulator copies
+        mfma_tap(ap, 0, cur[0]); xrow(R[SN][0], 0);
+        mfma_tap(ap, 1, cur[1]); xrow(R[SN][1], 1);
+        mfma_tap(ap, 2, cur[2]); xrow(R[SN][2], 2);
+        mfma_tap(ap, 3, cur[3]); xrow(R[SN][3], 3);
+        mfma_tap(ap, 4, cur[4]); ycol(nxt, 0);
+        mfma_tap(ap, 5, cur[5]); ycol(nxt, 1);
+        mfma_tap(ap, 6, cur[6]); ycol(nxt, 2);
+        mfma_tap(ap, 7, cur[7]);
+        mfma_tap(ap, 8, cur[8]);
+        MFN_REGFENCE9(nxt);  // slot SN is read out: the next step's request may overwrite it
+        MFN_SCHED_BARRIER();
+      };
+      for (int k = 0; k < nf;) {
+        step(k, DcInt<1>{}, cv, cvn);
+        if (++k >= nf) break;
+        step(k, DcInt<0>{}, cvn, cv);
+        ++k;
+      }
+      // nothing may still be on its way into the slot registers when they are given to somebody else
+      if (nf > 0) {
+        MFN_WAIT_VM(0);
+        MFN_REGFENCE4(R[0][0], R[0][1], R[0][2], R[0][3]);
+        MFN_REGFENCE4(R[1][0], R[1][1], R[1][2], R[1][3]);
+      }
+    };
+    if (gbanded) pipeline(std::integral_constant<bool, false>{}); else pipeline(std::integral_constant<bool, true>{});
+    k_done = nf;
+  }
+
+  // ---- everything else: the odd half pair, padding, per-tap offsets, images narrower than four columns ----------
   for (int ch = k_done / KC; ch < nchunks; ++ch) {
     const bool resumed = ch * KC < k_done;  // chunk already opened (barrier passed, next chunk issued) above
     if (!resumed) {
@@ -586,11 +702,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
     const float *abuf = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j;
     const int cp0 = cp_base + ch * KC;
     int k = resumed ? k_done - ch * KC : 0;
-    if (rowgather) {
-      const int nrow = max(0, min(KC, full_pairs - cp0));
-      MFN_NOUNROLL
-      for (; k < nrow; ++k) rowgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
-    } else if (dwgather) {
+    if (dwgather) {
       const int nrow = max(0, min(KC, full_pairs - cp0));
       MFN_NOUNROLL
       for (; k < nrow; ++k) dwgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
@@ -601,6 +713,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   }
 
   MFN_STAMP(p.timeline, 2);
+  MFN_STAMP_INFO(p.timeline, (staged ? 1 : 0) | (gtier ? 2 : 0) | ((gtier && !gbanded) || dwgather ? 4 : 0) | (fast ? 8 : 0));
   // ---- in-block K-slice reduction through LDS ----------------------------------------------------------
   if (KW > 1) {
     MFN_WAIT_LGKM0();

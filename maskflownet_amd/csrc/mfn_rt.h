@@ -63,6 +63,13 @@ static inline void mfn_dma16(mfn_rsrc_t r, float *lds_wave_base, unsigned voff) 
 static inline void mfn_dma16_so(mfn_rsrc_t r, float *lds_wave_base, unsigned voff, unsigned soff) {
   mfn_dma16(r, lds_wave_base, voff > 0xFFFFFF00u - soff ? 0xFFFFFF00u : voff + soff);
 }
+// four consecutive floats at dword alignment from a wave-uniform base + a per-lane byte offset; synchronous here
+static inline void mfn_gload4_async(f32x4_emu &dst, const float *base_uniform, unsigned byteoff) {
+  memcpy(&dst, (const char *)base_uniform + byteoff, 16);
+}
+#define MFN_LANDED4(a, b, c, d, n) ((void)0)
+#define MFN_REGFENCE4(a, b, c, d) ((void)0)
+#define MFN_REGFENCE9(v) ((void)0)
 // emulated lanes are independent threads: a wave-private DMA hand-off needs a wave barrier where the
 // hardware needs only the issuing wave's vmcnt wait (lock-step lanes)
 #define MFN_WAIT_VM(n) (hipemu::wave().bar.arrive_and_wait())
@@ -71,6 +78,7 @@ static inline void mfn_dma16_so(mfn_rsrc_t r, float *lds_wave_base, unsigned vof
 #define MFN_LDS_BARRIER() __syncthreads()
 #define MFN_COMPILER_FENCE() ((void)0)
 #define MFN_STAMP(buf, k) ((void)0)
+#define MFN_STAMP_INFO(buf, val) ((void)0)
 #define MFN_CYCLES() 0ull
 #else
 #include <hip/hip_ext.h>
@@ -168,6 +176,28 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 }
 #define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// A register load hipcc neither counts nor waits for: four consecutive floats at dword alignment from a wave-uniform
+// base (SGPR pair) + a per-lane 32-bit byte offset.  It joins the same in-order vmcnt queue as the LDS-DMA transfers, so a
+// software pipeline can keep loads of later steps in flight across its counted waits (a load hipcc knows about would make
+// it wait for every LDS-DMA issued before the load's use as well).  The destination holds data only after MFN_LANDED4 on
+// it: that statement carries the wait and names the registers read-write, so no use is scheduled above it
+// (cdna_hip_programming.md 5.7, form (ii)).
+__device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_uniform, unsigned byteoff) {
+  const unsigned long long a = (unsigned long long)base_uniform;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+  // keep every request UNCONDITIONAL: a request inside a branch makes the destination a phi value, and the copies hipcc
+  // resolves those with can land between the request and its wait
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byteoff), "s"(sb) : "memory");
+}
+#define MFN_LANDED4(a, b, c, d, n) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n) : "memory")
+// the same in two parts, for waits whose count is chosen by a (uniform) branch: MFN_WAIT_VM(n) in the branches, then ONE
+// fence on the registers behind the join -- a LANDED4 per branch makes the destinations phi values, and hipcc resolved
+// those with register copies placed BEFORE the waits (copies of data that has not landed)
+#define MFN_REGFENCE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
+// nine values are COMPUTED here (hipcc otherwise sinks the arithmetic that forms them next to its use, one pipeline step
+// later, and keeps the registers it reads alive across the request that is about to overwrite them)
+#define MFN_REGFENCE9(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]), "+v"((v)[4]), "+v"((v)[5]), "+v"((v)[6]), "+v"((v)[7]), "+v"((v)[8]))
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
 // the compiler keeps memory accesses on their side of this point (no instruction): LDS accesses whose ORDER matters to other
 // lanes of the wave -- the in-order LDS pipe does the rest
@@ -185,7 +215,20 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 #endif
 #if !MFN_TIMELINE
 #define MFN_STAMP(buf, k) ((void)0)
+#define MFN_STAMP_INFO(buf, val) ((void)0)
 #else
+// one more word per block behind the stamps of 16384 blocks (tools/timeline_dc_blocks.py): bits 0..15 the caller's value,
+// 16..31 HW_ID (wave / SIMD / CU / SH / SE), 32..35 XCC_ID
+#define MFN_STAMP_INFO(buf, val)                                                                            \
+  do {                                                                                                      \
+    if ((buf) && threadIdx.x == 0) {                                                                        \
+      unsigned long long *b_ = (unsigned long long *)(((unsigned long long)(buf)) & ~1ull);                 \
+      const unsigned long long hw_ = (unsigned)__builtin_amdgcn_s_getreg(63492) & 0xFFFFu;                  \
+      const unsigned long long xcc_ = (unsigned)__builtin_amdgcn_s_getreg(63508) & 0xFu;                    \
+      b_[65536 + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =                 \
+          ((unsigned long long)(val) & 0xFFFFull) | (hw_ << 16) | (xcc_ << 32);                             \
+    }                                                                                                       \
+  } while (0)
 #define MFN_STAMP(buf, k)                                                                                   \
   do {                                                                                                      \
     if ((buf) && threadIdx.x == 0) {                                                                        \

@@ -104,16 +104,6 @@ def _tuple(s):
     return tuple(vals)
 
 
-_packed = {}   # (weight address, dims, tuning epoch) -> (buffer NDArray, nbytes, tag)
-
-
-def invalidate_packed():
-    """Forget the cached inference-time weight layouts.  The cache is keyed on the weight array's device
-    address, so call this after anything that rewrites parameters in place outside of training
-    (load_parameters / set_data -- /root/reference/network/pipeline.py:56-63)."""
-    _packed.clear()
-
-
 if mx is not None:
     class _Out:
         """Where a forward output goes for a given req: straight into MXNet's buffer ('write' / 'inplace'),
@@ -357,17 +347,6 @@ if mx is not None:
                 self.ws = mx.nd.empty(((need + 3) // 4,), ctx=ctx)
             return self.ws if need else None
 
-        def _pack(self, lib, w, dims):
-            key = (_ptr(w), dims, _lib.tuning_epoch())
-            hit = _packed.get(key)
-            if hit is None:
-                nbytes = lib.deform_conv_packed_weight_bytes(*dims)
-                buf = mx.nd.empty(((nbytes + 3) // 4,), ctx=w.context)
-                tag = ctypes.c_ulonglong()
-                _check(lib.deform_conv_pack_weights(_ptr(w), *dims, _ptr(buf), nbytes, ctypes.byref(tag), None))
-                hit = _packed[key] = (buf, nbytes, tag.value)
-            return hit
-
         def forward(self, is_train, req, in_data, out_data, aux):
             if req[0] == "null":
                 return
@@ -378,14 +357,12 @@ if mx is not None:
             ws = self._workspace(lib.deform_conv_workspace_bytes(*dims), x.context)
             out = _Out(self, out_data[0], req[0])
             wsp, wsn = (_ptr(ws), ws.size * 4) if ws is not None else (None, 0)
-            if is_train:
-                # the weights change every step: let the call lay them out in its workspace
-                _check(lib.deform_conv_fwd(_ptr(x), _ptr(off), _ptr(w), _ptr(b), _ptr(out.buf), *dims, wsp, wsn, None))
-            else:
-                # inference: constant parameters, laid out once per (weight buffer, shape, tuning)
-                buf, nbytes, tag = self._pack(lib, w, dims)
-                _check(lib.deform_conv_fwd_packed(_ptr(x), _ptr(off), _ptr(buf), nbytes, tag, _ptr(b), _ptr(out.buf),
-                                                  *dims, wsp, wsn, None))
+            # The call lays the weights out in its workspace every time, training or not.  A layout cached across calls
+            # would have to be keyed on the weight array's device address -- and Gluon's Trainer updates parameters in
+            # place at the same address while the reference validates between training steps (main.py:542-556): every
+            # validation after the first would run on the weights of the first.  MXNet arrays carry no version to key on;
+            # the pack kernel is ~3 us beside a call that synchronises the device anyway.
+            _check(lib.deform_conv_fwd(_ptr(x), _ptr(off), _ptr(w), _ptr(b), _ptr(out.buf), *dims, wsp, wsn, None))
             self._end()
             out.finish()
 

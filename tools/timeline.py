@@ -43,14 +43,14 @@ for l, cfgs in (((2, [(1, 4), (1, 2)]), (3, [(2, 2), (2, 1), (1, 4)]), (4, [(3, 
         _lib.set_tuning(dc_mt=mt, dc_pt=pt, dc_ksb=1)
         n, c, h, w = hotpath.level_shapes(wl.N, wl.H, wl.W)[l]
         nblk = ((n * h * w + 31) // 32 + pt - 1) // pt * ((c + 31) // 32 // mt)
-        tl = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+        tl = torch.zeros(5 * 16384, dtype=torch.int64, device="cuda")   # stamps + one info word per block (MFN_STAMP_INFO)
         fn = lambda: ops.deformable_convolution_shared(wl.t["c2_%d" % l], wl.t["flow_%d" % l], 20.0, hotpath.STRIDES[l], wl.t["w_%d" % l], wl.t["b_%d" % l], out=wl.o["deform%d" % l])
         for _ in range(3): fn()
         torch.cuda.synchronize()
         lib.debug_set_timeline(tl.data_ptr() | 1); fn(); torch.cuda.synchronize(); lib.debug_set_timeline(None)
-        cyc = tl.cpu().numpy().reshape(nblk, 4).astype(np.float64)
+        cyc = tl.cpu().numpy()[:nblk * 4].reshape(nblk, 4).astype(np.float64)
         lib.debug_set_timeline(tl.data_ptr()); fn(); torch.cuda.synchronize(); lib.debug_set_timeline(None)
-        t = tl.cpu().numpy().reshape(nblk, 4).astype(np.float64) * 0.01
+        t = tl.cpu().numpy()[:nblk * 4].reshape(nblk, 4).astype(np.float64) * 0.01
         t -= t[:, 0].min()
 
         print("deform L%d mt=%d pt=%d blocks %d" % (l, mt, pt, nblk))

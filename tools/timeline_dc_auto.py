@@ -15,17 +15,17 @@ wl.run_eager()
 MAXB = 16384
 for l in (5, 4, 3, 2):
     fn = calls["deform%d" % l]
-    tl = torch.zeros(MAXB * 4, dtype=torch.int64, device="cuda")
+    tl = torch.zeros(MAXB * 5, dtype=torch.int64, device="cuda")   # + one info word per block (MFN_STAMP_INFO)
     with torch.cuda.stream(wl.stream):
         for _ in range(3): fn()
         wl.stream.synchronize()
         lib.debug_set_timeline(tl.data_ptr() | 1); fn(); wl.stream.synchronize(); lib.debug_set_timeline(None)
-        cyc = tl.cpu().numpy().reshape(MAXB, 4).astype(np.float64)
+        cyc = tl.cpu().numpy()[:MAXB * 4].reshape(MAXB, 4).astype(np.float64)
         tl.zero_(); torch.cuda.synchronize()
         for _ in range(3): fn()
         wl.stream.synchronize()
         lib.debug_set_timeline(tl.data_ptr()); fn(); wl.stream.synchronize(); lib.debug_set_timeline(None)
-    t = tl.cpu().numpy().reshape(MAXB, 4).astype(np.float64) * 0.01
+    t = tl.cpu().numpy()[:MAXB * 4].reshape(MAXB, 4).astype(np.float64) * 0.01
     m = t[:, 0] > 0
     t, cyc = t[m], cyc[m]
     t -= t[:, 0].min()
