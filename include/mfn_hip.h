@@ -127,6 +127,14 @@ int mfn_grid_generator_warp(const float *flow_xy, float *grid, int N, int H, int
 int mfn_grid_generator_affine(const float *theta, float *grid, int N, int H, int W, void *stream);
 int mfn_bilinear_sampler_fwd(const float *data, const float *grid, float *out, int N, int C,
                              int iH, int iW, int oH, int oW, void *stream);
+/* Backward of the operator pair (what MXNet's autograd reaches where the reference differentiates a warp it built
+ * from the two operators: c40 of /root/reference/network/MaskFlownet.py:311, block_grad=False).  gdata: (N,C,iH,iW),
+ * ggrid: (N,2,oH,oW) channel 0 = x; gflow_xy = ggrid / ((size-1)/2).  req in {MFN_REQ_NULL, _WRITE, _ADD}. */
+int mfn_bilinear_sampler_bwd(const float *gout, const float *data, const float *grid, float *gdata,
+                             float *ggrid, int N, int C, int iH, int iW, int oH, int oW,
+                             int req_data, int req_grid, void *stream);
+int mfn_grid_generator_warp_bwd(const float *ggrid, float *gflow_xy, int N, int H, int W, int req,
+                                void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DeformableConvolution -- replaces F.contrib.DeformableConvolution(x, offset, weight[, bias],

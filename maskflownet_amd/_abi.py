@@ -25,6 +25,8 @@ SIGNATURES = {
     "grid_generator_warp": (_i, [_f, _f, _i, _i, _i, _s]),
     "grid_generator_affine": (_i, [_f, _f, _i, _i, _i, _s]),
     "bilinear_sampler_fwd": (_i, [_f, _f, _f] + [_i] * 6 + [_s]),
+    "bilinear_sampler_bwd": (_i, [_f] * 5 + [_i] * 8 + [_s]),
+    "grid_generator_warp_bwd": (_i, [_f, _f] + [_i] * 4 + [_s]),
     "deform_conv_out_shape": (_i, [_i] * 10 + [_pi, _pi]),
     "deform_conv_workspace_bytes": (C.c_size_t, [_i] * 15),
     "deform_conv_fwd": (_i, [_f] * 5 + [_i] * 15 + [C.c_void_p, C.c_size_t, _s]),

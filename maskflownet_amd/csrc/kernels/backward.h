@@ -458,6 +458,68 @@ __global__ __launch_bounds__(256) void warp_bwd_kernel(WarpBwdParams p) {
   }
 }
 
+// ---- BilinearSampler / GridGenerator('warp') backward on their own ---------------------------------------------
+// What MXNet's autograd reaches when the reference's operator PAIR (layer.py:17-18) is differentiated: the full model
+// trains through c40 = warp(c20, Upsample(4)(flow2) * scale) (MaskFlownet.py:311, block_grad=False).  Semantics:
+// oracle/mfn_ref_body.inc bilinear_sampler_bwd (BilinearSamplerBackward of bilinear_sampler.cc) and
+// grid_generator_warp_bwd.  One thread per output pixel, taps once for all channels; the data gradient is a scatter
+// (fp32 atomics, like MXNet's GPU kernel), the grid gradient a per-pixel sum over the channels.
+struct SamplerBwdParams {
+  const float *gout, *data, *grid;
+  float *gdata, *ggrid;
+  int N, C, iH, iW, oH, oW, req_data, req_grid;
+};
+__global__ __launch_bounds__(256) void bilinear_sampler_bwd_kernel(SamplerBwdParams p) {
+  const size_t oplane = (size_t)p.oH * p.oW, iplane = (size_t)p.iH * p.iW;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)p.N * oplane) return;
+  const size_t n = idx / oplane, pix = idx - n * oplane;
+  const float gxv = p.grid[n * 2 * oplane + pix], gyv = p.grid[n * 2 * oplane + oplane + pix];
+  const float y_real = (gyv + 1.f) * (float)(p.iH - 1) / 2.f, x_real = (gxv + 1.f) * (float)(p.iW - 1) / 2.f;
+  const float fyr = floorf(y_real), fxr = floorf(x_real);
+  const int ty = (int)fminf(fmaxf(fyr, -2.f), (float)p.iH + 1.f), tx = (int)fminf(fmaxf(fxr, -2.f), (float)p.iW + 1.f);
+  const float wy = 1.f - (y_real - fyr), wx = 1.f - (x_real - fxr);
+  const bool y0 = ty >= 0 && ty <= p.iH - 1, y1 = ty + 1 >= 0 && ty + 1 <= p.iH - 1;
+  const bool x0 = tx >= 0 && tx <= p.iW - 1, x1 = tx + 1 >= 0 && tx + 1 <= p.iW - 1;
+  const int cy0 = min(max(ty, 0), p.iH - 1), cy1 = min(max(ty + 1, 0), p.iH - 1);
+  const int cx0 = min(max(tx, 0), p.iW - 1), cx1 = min(max(tx + 1, 0), p.iW - 1);
+  const int i00 = cy0 * p.iW + cx0, i01 = cy0 * p.iW + cx1, i10 = cy1 * p.iW + cx0, i11 = cy1 * p.iW + cx1;
+  float gwy = 0.f, gwx = 0.f;
+  for (int c = 0; c < p.C; ++c) {
+    const float g = p.gout[(n * p.C + c) * oplane + pix];
+    const float *pl = p.data + (n * p.C + c) * iplane;
+    const float vtl = pl[i00], vtr = pl[i01], vbl = pl[i10], vbr = pl[i11];  // unconditional, masked by selects
+    const float tl = (y0 && x0) ? vtl : 0.f, tr = (y0 && x1) ? vtr : 0.f;
+    const float bl = (y1 && x0) ? vbl : 0.f, br = (y1 && x1) ? vbr : 0.f;
+    if (p.req_data) {
+      float *gp = p.gdata + (n * p.C + c) * iplane;
+      if (y0 && x0) atomicAdd(gp + i00, g * wy * wx);
+      if (y0 && x1) atomicAdd(gp + i01, g * wy * (1.f - wx));
+      if (y1 && x0) atomicAdd(gp + i10, g * (1.f - wy) * wx);
+      if (y1 && x1) atomicAdd(gp + i11, g * (1.f - wy) * (1.f - wx));
+    }
+    gwy -= g * (tr - br + (tl - tr - bl + br) * wx);
+    gwx -= g * (bl - br + (tl - tr - bl + br) * wy);
+  }
+  if (p.req_grid) {
+    float *ggx = p.ggrid + n * 2 * oplane + pix, *ggy = ggx + oplane;  // channel 0 = x
+    const float vx = gwx * (float)(p.iW - 1) / 2.f, vy = gwy * (float)(p.iH - 1) / 2.f;
+    *ggx = (p.req_grid == 3 ? *ggx : 0.f) + vx;
+    *ggy = (p.req_grid == 3 ? *ggy : 0.f) + vy;
+  }
+}
+
+struct GridWarpBwdParams { const float *ggrid; float *gflow; int N, H, W, req; };
+__global__ __launch_bounds__(256) void grid_warp_bwd_kernel(GridWarpBwdParams p) {
+  const size_t plane = (size_t)p.H * p.W;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over N*2*plane
+  if (idx >= (size_t)p.N * 2 * plane) return;
+  const bool is_y = ((idx / plane) & 1) != 0;
+  const float nrm = is_y ? (float)((p.H - 1) / 2.0) : (float)((p.W - 1) / 2.0);
+  const float v = p.ggrid[idx] / nrm;
+  p.gflow[idx] = (p.req == 3 ? p.gflow[idx] : 0.f) + v;
+}
+
 // ---- deformable convolution -------------------------------------------------------------------------------
 struct DcBwdParams {
   const float *gout, *x, *offset, *w;

@@ -537,10 +537,13 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       }
       w_in_flight = w_now;
       const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
-      // the gather / interpolation of pair k + 1 runs in the last step too (stale window values, results unused): with the
-      // MFMAs in two branches the accumulators lived in two register sets and hipcc copied all sixteen (after draining the
-      // MFMA pipe) at the end of EVERY step
-      gather2(BN, vp);
+      // The interpolation of pair k + 1 runs in the last step too (on the previous step's window values, results unused):
+      // with the MFMAs in two branches the accumulators lived in two register sets and hipcc copied all sixteen (after
+      // draining the MFMA pipe) at the end of EVERY step.  The LDS reads themselves must NOT run there: left in flight when
+      // the loop ends, they land in registers that are dead from the compiler's point of view -- it had handed them to the
+      // epilogue without a wait, and one pass in two came back with a wrong 4x8 tile somewhere (tools/r03_det.py; every
+      // comparison with the oracle had passed).
+      if (k + 1 < nf) gather2(BN, vp);
       mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
       mfma_tap(ap, 1, cur[1]);
       mfma_tap(ap, 2, cur[2]); interp_rows2(vp, trp, 1);
@@ -571,8 +574,12 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
 
   // ---- global-gather waves: the same flat pipeline, the 4x4 neighbourhood rows arriving in registers ----------------
   // Pair p's four row quads live in register slot p % 2; step k multiplies pair k, interpolates pair k + 1 (requested one
-  // step ago) and requests pair k + 2.  The loads are counted by hand like the LDS-DMA transfers (mfn_gload4_async): vmcnt
-  // completes in order, every wait names how many NEWER operations may still be outstanding.
+  // step ago) and requests pair k + 2.  The loads are counted by hand like the LDS-DMA transfers (mfn_gload4_async).  The
+  // waits rely on in-order completion only AMONG the register loads and AMONG the LDS-DMA transfers, never between the two
+  // kinds: with "the weight chunk is older than the four quads still allowed in flight" as the argument for vmcnt(4) at a
+  // chunk boundary, one pass in a dozen came back with a block of wrong values at level 3 (tools/r03_det.py) -- a
+  // register load can complete before an older LDS-DMA.  So: a chunk boundary drains everything (vmcnt(0)), and "pair
+  // k + 1 landed" is vmcnt(4): pair k + 1 outstanding would need all four quads of pair k + 2 outstanding as well.
   if (gtier) {
     const int nf = MFN_UNIFORM(max(0, min(nchunks * KC, full_pairs - cp_base)));
     unsigned boff[4];  // byte offset of the lane's four row quads inside channel 2*cp of image 0
@@ -639,25 +646,20 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         for (int i = 0; i < 3; ++i) ycol(cv, i);
         MFN_REGFENCE9(cv);
       }
-      bool w_in_flight = false;  // a weight chunk was requested in the previous step (behind that step's row quads)
       auto step = [&](int k, auto sn_c, float (&cur)[9], float (&nxt)[9]) {
         constexpr int SN = decltype(sn_c)::value;  // slot of pair k + 1 (read now); pair k + 2 goes to the other one
         constexpr int SF = 1 - SN;
         const int ch = k / KC, kk = k - ch * KC;
-        bool w_now = false;
         if (kk == 0) {
-          // the weights of chunk ch landed: they are older than the quads of pair k + 1 unless every pair is a chunk
-          if (KC == 1) MFN_WAIT_VM(0); else MFN_WAIT_VM(4);
+          MFN_WAIT_VM(0);  // this wave's part of weight chunk ch landed (and the quads of pair k + 1 with it)
           MFN_WAIT_LGKM0();
           MFN_RAW_BARRIER();
           if (k == 0) MFN_STAMP(p.timeline, 1);
         }
         fetch(min(cp_base + k + 2, cp_last), DcInt<SF>{});
-        if (kk == 0 && ch + 1 < nchunks) { issue(ch + 1); w_now = true; }
-        // pair k + 1 landed; newer: the request above and a weight chunk of this or the previous step
-        if (w_now || w_in_flight) MFN_WAIT_VM(NI + 4); else MFN_WAIT_VM(4);
+        if (kk == 0 && ch + 1 < nchunks) issue(ch + 1);
+        MFN_WAIT_VM(4);  // pair k + 1 landed (see above; a weight chunk requested in this or the last step is waited for too)
         MFN_REGFENCE4(R[SN][0], R[SN][1], R[SN][2], R[SN][3]);
-        w_in_flight = w_now;
         const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
         // the last step interpolates a repeated pair (results unused): one MFMA stream, no accumulator copies
         mfma_tap(ap, 0, cur[0]); xrow(R[SN][0], 0);

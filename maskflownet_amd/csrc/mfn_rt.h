@@ -188,7 +188,9 @@ __device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_u
   const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
   // keep every request UNCONDITIONAL: a request inside a branch makes the destination a phi value, and the copies hipcc
   // resolves those with can land between the request and its wait
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byteoff), "s"(sb) : "memory");
+  // s_nop 4: the base may have been written by a v_readfirstlane just before (VALU-written SGPR -> VMEM: 5 wait states,
+  // and hipcc pads nothing inside an asm statement)
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byteoff), "s"(sb) : "memory");
 }
 #define MFN_LANDED4(a, b, c, d, n) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n) : "memory")
 // the same in two parts, for waits whose count is chosen by a (uniform) branch: MFN_WAIT_VM(n) in the branches, then ONE

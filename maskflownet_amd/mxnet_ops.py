@@ -263,9 +263,17 @@ if mx is not None:
             out.finish()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
-            if _REQ[req[0]]:
-                raise NotImplementedError("mfn_grid_generator has no backward: the reference never differentiates its "
-                                          "grids (BlockGrad / image warp, MaskFlownet.py:311); use mfn_warp to train through a warp")
+            r = _REQ[req[0]]
+            if not r:
+                return
+            if self.kind != "warp":
+                raise NotImplementedError("mfn_grid_generator(affine) has no backward: the augmentation grids "
+                                          "(augmentation.py:306-321) are never differentiated")
+            # the full model trains through c40 = warp(c20, Upsample(4)(flow2) * scale) (MaskFlownet.py:311, block_grad=False)
+            n, _, h, w = out_grad[0].shape
+            lib = self._begin(out_grad[0])
+            _check(lib.grid_generator_warp_bwd(_ptr(out_grad[0]), _ptr(in_grad[0]), n, h, w, r, None))
+            self._end()
 
     @mx.operator.register("mfn_grid_generator")
     class _GridGeneratorProp(mx.operator.CustomOpProp):
@@ -291,6 +299,9 @@ if mx is not None:
                 raise ValueError("GridGenerator(affine): data must be (N,6) and target_shape=(H,W) positive")
             return in_shape, [(s[0], 2, self.target[0], self.target[1])], []
 
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return list(out_grad)
+
         def create_operator(self, ctx, shapes, dtypes):
             return _GridGenerator(self.kind)
 
@@ -307,8 +318,16 @@ if mx is not None:
             out.finish()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
-            if _REQ[req[0]] or _REQ[req[1]]:
-                raise NotImplementedError("mfn_bilinear_sampler has no backward; use mfn_warp to train through a warp")
+            rd, rg = _REQ[req[0]], _REQ[req[1]]
+            if not (rd or rg):
+                return
+            n, c, ih, iw = in_data[0].shape
+            _, _, oh, ow = in_data[1].shape
+            lib = self._begin(in_data[0])
+            _check(lib.bilinear_sampler_bwd(_ptr(out_grad[0]), _ptr(in_data[0]), _ptr(in_data[1]),
+                                            _ptr(in_grad[0]) if rd else None, _ptr(in_grad[1]) if rg else None,
+                                            n, c, ih, iw, oh, ow, rd, rg, None))
+            self._end()
 
     @mx.operator.register("mfn_bilinear_sampler")
     class _BilinearSamplerProp(mx.operator.CustomOpProp):
@@ -326,6 +345,9 @@ if mx is not None:
             if len(d) != 4 or len(g) != 4 or g[1] != 2 or g[0] != d[0]:
                 raise ValueError("BilinearSampler: data (N,C,H,W) and grid (N,2,H',W') expected")
             return in_shape, [(d[0], d[1], g[2], g[3])], []
+
+        def declare_backward_dependency(self, out_grad, in_data, out_data):
+            return list(out_grad) + list(in_data)
 
         def create_operator(self, ctx, shapes, dtypes):
             return _BilinearSampler()

@@ -182,6 +182,37 @@ class OpSet:
                                                 oW, self.ad.stream(d)))
         return out
 
+    def BilinearSampler_backward(self, out_grad, data, grid, req_data="write", req_grid="write", gdata=None, ggrid=None):
+        """Gradients of BilinearSampler w.r.t. data and grid (BilinearSamplerBackward of MXNet's bilinear_sampler.cc)."""
+        go, d, g = self._in(out_grad, data, grid)
+        N, C, iH, iW = self.ad.shape(d)
+        _, _, oH, oW = self.ad.shape(g)
+        rd, rg = _REQ[req_data], _REQ[req_grid]
+        if gdata is None and rd:
+            gdata = self.ad.empty(d, (N, C, iH, iW))
+        if ggrid is None and rg:
+            ggrid = self.ad.empty(d, (N, 2, oH, oW))
+        self.check(self.ns.bilinear_sampler_bwd(self.ad.ptr(go), self.ad.ptr(d), self.ad.ptr(g),
+                                                self.ad.ptr(gdata) if rd else None, self.ad.ptr(ggrid) if rg else None,
+                                                N, C, iH, iW, oH, oW, rd, rg, self.ad.stream(d)))
+        return gdata, ggrid
+
+    def GridGenerator_backward(self, out_grad, transform_type="warp", req="write", gdata=None):
+        """Gradient of GridGenerator('warp') w.r.t. its flow input: grad / ((size - 1) / 2) per channel."""
+        if transform_type != "warp":
+            raise NotImplementedError("GridGenerator backward: only transform_type='warp' (the affine grids of "
+                                      "augmentation.py are never differentiated)")
+        (go,) = self._in(out_grad)
+        N, two, H, W = self.ad.shape(go)
+        if two != 2:
+            raise ValueError("GridGenerator(warp) backward: out_grad must be (N,2,H,W)")
+        r = _REQ[req]
+        if gdata is None and r:
+            gdata = self.ad.empty(go, (N, 2, H, W))
+        self.check(self.ns.grid_generator_warp_bwd(self.ad.ptr(go), self.ad.ptr(gdata) if r else None, N, H, W, r,
+                                                   self.ad.stream(go)))
+        return gdata
+
     # ---- DeformableConvolution -----------------------------------------------------------------------
     @staticmethod
     def _pair(v):

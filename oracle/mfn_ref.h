@@ -59,6 +59,9 @@ extern "C" {
                                      int is_multiply);                                              \
   /* GridGenerator(transform_type='warp'): flow_xy (N,2,H,W) ch0 = x -> grid (N,2,H,W). */          \
   int mfn_ref##SFX##_grid_generator_warp(const REAL *flow_xy, REAL *grid, int N, int H, int W);     \
+  /* backward of the above: gflow_xy = ggrid / ((size - 1) / 2) per channel. */                     \
+  int mfn_ref##SFX##_grid_generator_warp_bwd(const REAL *ggrid, REAL *gflow_xy, int N, int H,       \
+                                             int W);                                                \
   /* GridGenerator(transform_type='affine'): theta (N,6) -> grid (N,2,H,W). */                      \
   int mfn_ref##SFX##_grid_generator_affine(const REAL *theta, REAL *grid, int N, int H, int W);     \
   int mfn_ref##SFX##_bilinear_sampler_fwd(const REAL *data, const REAL *grid, REAL *out, int N,     \

@@ -112,6 +112,15 @@ def grid_generator_warp(flow_xy, dtype=np.float32):
     return grid
 
 
+def grid_generator_warp_backward(ggrid, dtype=np.float32):
+    g = _c(ggrid, dtype)
+    N, two, H, W = g.shape
+    assert two == 2
+    out = np.empty_like(g)
+    _check(_fn("grid_generator_warp_bwd", dtype)(_p(g), _p(out), N, H, W), "grid_generator_warp_bwd")
+    return out
+
+
 def grid_generator_affine(theta, target_shape, dtype=np.float32):
     t = _c(theta, dtype).reshape(-1, 6)
     H, W = target_shape

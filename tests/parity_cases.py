@@ -264,6 +264,38 @@ def case_warp_bwd(ops, oracle, to_dev, to_host, shape, clip, seed=0):
     return max(check_close(to_host(gx), wx, what="warp gx"), check_close(to_host(gf), wf, tol=5e-5, what="warp gflow"))
 
 
+def case_sampler_pair_bwd(ops, oracle, to_dev, to_host, shape, oshape=None, seed=0):
+    """Backward of the operator PAIR of layer.py:17-18 on its own: BilinearSampler (d/ddata, d/dgrid) and
+    GridGenerator('warp') (d/dflow), incl. req 'add' -- what MXNet's autograd calls when the full model trains through
+    c40 (MaskFlownet.py:311)."""
+    rng = np.random.default_rng(43 + seed)
+    N, C, H, W = shape
+    oH, oW = oshape if oshape is not None else (H, W)
+    x = rng.standard_normal(shape).astype(np.float32)
+    flow_xy = (flow_field(rng, N, oH, oW, sigma=2.0)[:, ::-1]).copy()
+    if (oH, oW) == (H, W):
+        grid = oracle.grid_generator_warp(flow_xy)
+    else:   # a free grid (affine augmentation shape): target grid != data shape
+        grid = rng.uniform(-1.1, 1.1, (N, 2, oH, oW)).astype(np.float32)
+    go = rng.standard_normal((N, C, oH, oW)).astype(np.float32)
+    wd, wg = oracle.bilinear_sampler_backward(go, x, grid)
+    gd, gg = ops.BilinearSampler_backward(to_dev(go), to_dev(x), to_dev(grid))
+    e = max(check_close(to_host(gd), wd, what="sampler gdata"), check_close(to_host(gg), wg, tol=5e-5, what="sampler ggrid"))
+    wf = oracle.grid_generator_warp_backward(wg)
+    gf = ops.GridGenerator_backward(to_dev(wg), "warp")
+    e = max(e, check_close(to_host(gf), wf, what="grid generator gflow"))
+    # req 'add' on all three
+    base_d, base_g = np.full_like(wd, 0.25), np.full_like(wg, -0.5)
+    bd, bg = to_dev(base_d.copy()), to_dev(base_g.copy())
+    ops.BilinearSampler_backward(to_dev(go), to_dev(x), to_dev(grid), req_data="add", req_grid="add", gdata=bd, ggrid=bg)
+    e = max(e, check_close(to_host(bd) - base_d, wd, tol=2e-5, what="sampler gdata (add)"),
+            check_close(to_host(bg) - base_g, wg, tol=5e-5, what="sampler ggrid (add)"))
+    bf = to_dev(base_g.copy())
+    ops.GridGenerator_backward(to_dev(wg), "warp", req="add", gdata=bf)
+    e = max(e, check_close(to_host(bf) - base_g, wf, tol=2e-5, what="grid generator gflow (add)"))
+    return e
+
+
 def shared_offsets(rng, N, H, W, kind):
     """(N,18,H,W) offsets with ONE (dy,dx) per pixel repeated over the nine taps (MaskFlownet.py:230) -- what the
     shared-offset backward kernel takes in one pass.  kind: smooth (sub-pixel field + global shift), integer (floors

@@ -309,6 +309,11 @@ def test_warp_backward(ops, oracle, clip):
     pc.case_warp_bwd(ops, oracle, ident, ident, (2, 3, 8, 11), clip)
 
 
+def test_sampler_and_grid_generator_backward(ops, oracle):
+    pc.case_sampler_pair_bwd(ops, oracle, ident, ident, (2, 3, 8, 11))
+    pc.case_sampler_pair_bwd(ops, oracle, ident, ident, (1, 2, 6, 9), oshape=(5, 7), seed=1)
+
+
 @pytest.mark.parametrize("kw", [dict(kernel=(3, 3), pad=(1, 1)), dict(kernel=(3, 3), pad=(1, 1), stride=(2, 2)),
                                 dict(kernel=(3, 3), pad=(2, 2), dilate=(2, 2)), dict(kernel=(3, 3), pad=(1, 1), num_group=2),
                                 dict(kernel=(3, 3), pad=(1, 1), num_deformable_group=2), dict(kernel=(1, 1), pad=(0, 0))])

@@ -306,6 +306,18 @@ def test_warp_backward(ops, oracle, dev, clip):
     pc.case_warp_bwd(ops, oracle, dev, host, (2, 3, 96, 128), clip)
 
 
+@pytest.mark.parametrize("clip", [False, True])
+def test_warp_backward_bench_size(ops, oracle, dev, clip):
+    """The full-resolution image warp of BASELINE configs[1] (8 x 3 x 384 x 512), both gradients."""
+    pc.case_warp_bwd(ops, oracle, dev, host, (8, 3, 384, 512), clip, seed=3)
+
+
+def test_sampler_and_grid_generator_backward(ops, oracle, dev):
+    """The operator pair's own backward (MaskFlownet.py:311 trained through): level-2 feature shape and a free grid."""
+    pc.case_sampler_pair_bwd(ops, oracle, dev, host, (2, 32, 96, 128))
+    pc.case_sampler_pair_bwd(ops, oracle, dev, host, (2, 3, 40, 56), oshape=(32, 48), seed=1)
+
+
 @pytest.mark.parametrize("C,H,W", [(128, 12, 16), (64, 24, 32), (32, 48, 64)])
 def test_deform_conv_backward_levels(ops, oracle, dev, C, H, W):
     pc.case_deform_bwd(ops, oracle, dev, host, 2, C, C, H, W, kernel=(3, 3), pad=(1, 1))
@@ -726,6 +738,30 @@ def test_hot_path_pass_graph_replay_matches_eager(T):
     T.cuda.synchronize()
     for a, b in zip(outs_eager, wl.outputs()):
         assert T.equal(a, b)
+
+
+@pytest.mark.parametrize("cfg,flow", [("cfg2", "smooth"), ("cfg2", "rough"), ("cfg3", "smooth")])
+def test_hot_path_pass_is_run_to_run_deterministic(T, cfg, flow):
+    """30 eager passes and 30 graph replays give the bits of the first pass, every output.  A single eager-vs-replay
+    comparison (above) let a sporadic fault through in round 3: LDS reads still in flight when a loop was left landed in
+    registers the epilogue already used -- one pass in two had a wrong 4x8 tile somewhere, every oracle comparison passed."""
+    from maskflownet_amd import hotpath
+    wl = hotpath.HotPathWorkload(cfg, device="cuda", flow_model=flow)
+    ref = [o.clone() for o in wl.run_eager()]
+    T.cuda.synchronize()
+
+    def check(tag):
+        T.cuda.synchronize()
+        for nm, a, b in zip(wl.output_names(), ref, wl.outputs()):
+            assert T.equal(a, b), "%s differs in %s" % (nm, tag)
+    for i in range(30):
+        wl.run_eager()
+        check("eager pass %d" % i)
+    wl.capture()
+    for i in range(30):
+        wl.replay()
+        wl.synchronize()
+        check("replay %d" % i)
 
 
 def test_hot_path_three_batches_in_flight_match_single_stream(T):

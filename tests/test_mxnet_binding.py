@@ -287,6 +287,33 @@ def test_gluon_conv_kwargs_route_to_the_convolution_kernels(cpu_binding, oracle)
         y.backward()
 
 
+def _pair_backward(mx, oracle, ctx, shape, seed=0):
+    """layer.py:14-18 with block_grad=False through install(): flow -> flip -> GridGenerator('warp') -> BilinearSampler;
+    gradients into the image AND the flow (what the full model's c40 needs, MaskFlownet.py:311)."""
+    rng = np.random.default_rng(61 + seed)
+    N, C, H, W = shape
+    img = rng.standard_normal(shape).astype(np.float32)
+    flow = pc.flow_field(rng, N, H, W, sigma=2.0)
+    gout = rng.standard_normal(shape).astype(np.float32)
+    X, FLXY = mx.nd.array(img, ctx=ctx), mx.nd.array(flow[:, ::-1].copy(), ctx=ctx)
+    X.attach_grad()
+    FLXY.attach_grad()
+    with mx.autograd.record():
+        grid = mx.nd.GridGenerator(data=FLXY, transform_type="warp")
+        out = mx.nd.BilinearSampler(X, grid)
+    pc.check_close(out.asnumpy(), oracle.warp(img, flow))
+    out.backward(mx.nd.array(gout, ctx=ctx))
+    gx, gf = oracle.warp_backward(gout, img, flow)
+    pc.check_close(X.grad.asnumpy(), gx, tol=2e-5, what="pair backward: d/dimage")
+    pc.check_close(FLXY.grad.asnumpy(), gf[:, ::-1], tol=5e-5, what="pair backward: d/dflow (x, y order)")
+
+
+def test_operator_pair_backward_through_custom_ops(cpu_binding, oracle):
+    mx, m = cpu_binding
+    m.install()
+    _pair_backward(mx, oracle, mx.cpu(), (2, 3, 8, 12))
+
+
 def test_forward_only_ops_raise_in_backward(cpu_binding, oracle):
     mx, m = cpu_binding
     x = mx.nd.array(np.ones((1, 2, 4, 8), np.float32))
@@ -379,6 +406,13 @@ def test_gpu_deform_conv_custom_op_no_bias_and_add(gpu_binding, oracle):
     m.install()
     _deform_fwd_bwd(mx, oracle, mx.gpu(0), 2, 64, 24, 32, use_bias=False, seed=7)
     _deform_fwd_bwd(mx, oracle, mx.gpu(0), 1, 32, 24, 32, use_bias=True, grad_req="add", seed=8)
+
+
+@pytest.mark.gpu
+def test_gpu_operator_pair_backward(gpu_binding, oracle):
+    mx, m = gpu_binding
+    m.install()
+    _pair_backward(mx, oracle, mx.gpu(0), (2, 16, 96, 128), seed=1)
 
 
 @pytest.mark.gpu
