@@ -56,6 +56,7 @@ def parse():
                     help="flow fields of the synthetic batch: smooth = Upsample(2)-recursive fields as inside the network "
                          "(default); rough = SURVEY.md 8(d)'s i.i.d. N(0, 2 px) + 2%% outliers per pixel")
     ap.add_argument("--no-e2e", action="store_true", help="skip the informational end-to-end network forward")
+    ap.add_argument("--no-side-configs", action="store_true", help="skip the cfg3 / fused / train sub-objects of the default line")
     ap.add_argument("--no-epe", action="store_true",
                     help="skip the network-level EPE delta (MaskFlownet-S end to end, HIP hot path vs the CPU reference path)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -206,6 +207,7 @@ def roofline_of_dominant_kernel(wl, iters, torch):
         return best or (None, 0, 0.0)
     kname, cnt_v, ms_v = pick("corr2")
     lib.profile_reset()
+    wl._per_op_profile = per_op   # the same profiled pass also prices the warp (roofline_warp) and the other calls
     if cnt_v == 0:
         return None, compute_roofline(wl, per_op, hotpath)
     cnt, ms = ctypes.c_int(cnt_v), ctypes.c_double(ms_v)
@@ -257,6 +259,55 @@ def compute_roofline(wl, per_op, hotpath):
             "achieved": round(tot_f / tot_s / 1e12, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tot_f / tot_s / 1e12 / FP32_PEAK_TFLOPS, 3), "us_per_pass": round(tot_s * 1e6, 1), "levels": levels,
             "note": "fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: bit-exact fmaf chain); interpolation flops not counted"}
+
+
+def warp_roofline(wl, hotpath):
+    """The full-resolution image warp (gather-bound, SURVEY.md 8d: 4*N*H*W*(2C+2) bytes, C = 3) inside the profiled pass."""
+    recs = getattr(wl, "_per_op_profile", {}).get("warp", [])
+    if not recs:
+        return None
+    launches = max(r[1] for r in recs)
+    sec = sum(r[2] for r in recs) / launches * 1e-3
+    nbytes = hotpath.algorithmic_bytes(wl.N, wl.H, wl.W)["warp"]
+    return {"bound": "hbm", "kernel": "%s (N=%d C=3 %dx%d, flow-warped image of MaskFlownet.py:311)" % (recs[0][0], wl.N, wl.H, wl.W),
+            "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(sec * 1e6, 3), "launches_timed": launches,
+            "timed_where": "inside the operator sequence of the pass (eager, HIP events)"}
+
+
+def side_config(cfg, mode, steps, torch, hotpath, want_roofline=False, want_dominant=False):
+    """Another BASELINE configuration timed the same way as the headline (hipGraph replay, one stream, `steps` steps after
+    a warm-up) -- sub-objects of the default line so that the driver's run carries them."""
+    wl = hotpath.HotPathWorkload(cfg, device="cuda:%d" % torch.cuda.current_device(), mode=mode).capture()
+    for _ in range(50):
+        wl.step()
+    wl.synchronize()
+    dt = timed_steps([wl], steps, None, torch)
+    out = {"config": "%s (%s), batch=%d synthetic %dx%d" % (cfg, {"S": "MaskFlownet-S forward", "full": "full MaskFlownet forward",
+                                                                  "train": "MaskFlownet-S train step"}[wl.kind], wl.N, wl.H, wl.W),
+           "mode": mode, "value": round(wl.N * steps / dt, 2), "unit": "image-pairs/s", "ms_per_step": round(dt / steps * 1e3, 4),
+           "steps": steps}
+    if want_roofline:
+        r, rc = roofline_of_dominant_kernel(wl, 60, torch)
+        if r:
+            out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                 "algorithmic_bytes_per_launch") if k in r}
+            out["roofline"]["hbm_rotated_frac"] = (r.get("hbm_rotated") or {}).get("frac")
+        if rc:
+            out["roofline_compute"] = {k: rc[k] for k in ("achieved", "peak", "unit", "frac", "us_per_pass")}
+    if want_dominant:
+        kb = per_kernel_breakdown(wl, 10, torch)
+        tot = sum(v["us_per_pass"] for v in kb.values())
+        name, rec = max(kb.items(), key=lambda kv: kv[1]["us_per_pass"])
+        dom = {"kernel": name, "us_per_pass": rec["us_per_pass"], "launches_per_pass": rec["launches_per_pass"],
+               "share_of_kernel_time": round(rec["us_per_pass"] / max(tot, 1e-9), 3)}
+        if name.startswith("dc_bwd_input"):   # column-gradient GEMM of the four levels (the forward's flop count) against the fp32 peak
+            fl = sum(2.0 * n * h * w * c * c * 9 for l, (n, c, h, w) in hotpath.level_shapes(wl.N, wl.H, wl.W).items() if l != 6)
+            dom.update({"bound": "mfma", "achieved": round(fl / (rec["us_per_pass"] * 1e-6) / 1e12, 1), "peak": FP32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(fl / (rec["us_per_pass"] * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, 3)})
+        out["dominant_kernel"] = dom
+    del wl
+    return out
 
 
 def per_kernel_breakdown(wl, iters, torch):
@@ -585,11 +636,23 @@ def main():
     if gpu:
         try:
             res["roofline"], res["roofline_compute"] = roofline_of_dominant_kernel(wl, args.roofline_iters, torch)
+            res["roofline_warp"] = warp_roofline(wl, hotpath)
             res["kernels"] = per_kernel_breakdown(wl, 20, torch)
             res["ops_in_graph_us"] = per_op_graph_cost(wl, torch)
         except Exception as e:  # the headline number must survive a profiler problem
             res["roofline"] = None
             res["roofline_error"] = repr(e)
+    if gpu and world == 1 and not args.no_graph and not args.no_side_configs and args.config == "cfg2" and args.mode == "dropin" \
+            and args.flow == "smooth" and len(wls) == 1:
+        # the other configurations north_star names, in the driver's own run: 448x1024 (configs[2]), the fused operator
+        # forms on the headline batch, and the training step (configs[4]) -- 200 steps each
+        for key, (cfg_, mode_, kw_) in (("cfg3", ("cfg3", "dropin", dict(want_roofline=True))),
+                                        ("fused", ("cfg2", "fused", {})),
+                                        ("train", ("cfg5", "dropin", dict(want_dominant=True)))):
+            try:
+                res[key] = side_config(cfg_, mode_, 200, torch, hotpath, **kw_)
+            except Exception as e:
+                res[key] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1 and gpu:  # rank 0 at N=1 only: other ranks would idle in the barrier meanwhile
         res["cpu_baseline"], want = cpu_baseline(wl, args.cpu_seconds)
         res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)

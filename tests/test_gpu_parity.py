@@ -48,9 +48,11 @@ def test_correlation_md4_all_levels(ops, oracle, dev, shape):
     pc.case_correlation(ops, oracle, dev, host, shape, 4)
 
 
-@pytest.mark.parametrize("shape", [(2,) + s[1:] for s in CFG2])
+@pytest.mark.parametrize("shape", CFG2 + CFG3)
 def test_correlation_md2_cascade_levels(ops, oracle, dev, shape):
-    pc.case_correlation(ops, oracle, dev, host, shape, 2)  # full MaskFlownet, MaskFlownet.py:322
+    """The cascade's 25-channel cost volumes (full MaskFlownet, MaskFlownet.py:322, :440-441) at every level shape of
+    configs[1] and configs[2] at their full batch sizes."""
+    pc.case_correlation(ops, oracle, dev, host, shape, 2)
 
 
 @pytest.mark.parametrize("variant", range(24))
@@ -857,6 +859,20 @@ def test_conv_full_batch_matches_torch_and_concat_slice(ops, T):
     got = ops.Deconvolution(xd, wd, None, no_bias=True, num_filter=16)
     want = F.conv_transpose2d(xd, wd, None, stride=2, padding=1)
     assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("cfg,mode", [("cfg4", "dropin"), ("cfg4", "fused"), ("cfg5", "dropin"), ("cfg5", "fused")])
+def test_cascade_and_training_passes_at_bench_size_against_the_oracle(T, cfg, mode):
+    """BASELINE configs[3] (full MaskFlownet: S pass + cascade, 8 pairs per GPU) and configs[4] (S training step: forward +
+    backward of every correlation / deformable conv, 8 pairs per GPU) at their full size, every output against the
+    oracle's pass over the same synthetic batch (the oracle takes ~2 s and ~10 s)."""
+    from maskflownet_amd import hotpath
+    from oracle import hotpath_ref
+    wl = hotpath.HotPathWorkload(cfg, device="cuda", mode=mode)
+    outs = wl.run_eager()
+    want = hotpath_ref.oracle_pass(wl.host, wl.N, kind=wl.kind, mode=mode)
+    for name, got in zip(wl.output_names(), outs):
+        pc.check_close(host(got), want[name], tol=5e-5 if name.startswith("g") else 1e-5, what="%s %s %s" % (cfg, mode, name))
 
 
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
