@@ -884,7 +884,7 @@ struct DcBwdIParams {
   int T, tiles_x, tiles_y;
   int req_x, req_offset;
   unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, scatter, total} shader cycles
-  const int *skip;               // per (tile, strip): non-zero = already done by dc_bwd_input_shared_kernel; may be NULL
+  const int *skip;               // per (tile, strip): non-zero = already done by dc_bwd_input_pix_kernel (dc_backward.h); may be NULL
   int skip_tiles;                // 1: `skip` holds one flag per 4x8-pixel tile [n][cdiv(H,4)][cdiv(W,8)] (dc_bwd_input_pix_kernel)
   // flow mode (mfn_deform_conv_shared_bwd; dc_backward.h: DcBwdPParams): offsets from flow[n][dir][pixel], d/dflow instead of goffset
   const float *flow;
@@ -1141,55 +1141,11 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
 }
 
 
-// ---- shared-offset fast path of the input / offset gradient (3x3, dilation 1; the only form the reference uses:
-// MaskFlownet.py:230 feeds one (dy,dx) to all nine taps) ----------------------------------------------------------------
-// dc_bwd_input_tile_kernel above walks the nine taps one by one: nine GEMMs that each re-read gout, nine geometry
-// tables, 36 read-add-writes and 36 strided x loads per (pixel, channel) -- 534 us at level 2 where the arithmetic
-// needs ~12.  With ONE offset per pixel the nine taps sample a 4x4 neighbourhood with separable weights (the
-// forward's "regular" fast path, deform_conv.h), so here, per 2x16 strip and 32 channels:
-//   * one pass over gout: the column gradients of all nine taps are accumulated together (nine fp32-MFMA accumulator
-//     tiles, 144 registers; the block runs one wave per SIMD anyway because of its LDS windows), the weights of a lane's
-//     channel are nine consecutive floats;
-//   * cg is folded onto the 4x4 neighbourhood (42 FMAs, row weights then column weights) and added to the lane's
-//     private window plane in ONE round trip of 16 reads + 16 writes per turn instead of nine of 4 + 4;
-//   * the 4x4 x neighbourhood is loaded once (four 16-byte loads) and serves all 18 offset-gradient terms.
-// A strip qualifies when every pixel's nine offsets are bit-identical and the floor pattern is regular on both axes
-// (forward weights and deformable_col2im_coord's absolute-coordinate floors agree with floor(off)+i); otherwise its flag
-// stays 0 and dc_bwd_input_tile_kernel (launched next with the flags as its skip list) does that strip tap by tap.
-// Strips (waves) per block NS: 2 = a 4x16-pixel sub-tile, two blocks per CU (one can flush while the other computes; levels
-// 5 / 4: 76 -> 70, 97 -> 88 us, levels 3 / 2 unchanged); 4 = the tile kernel's 8x16 tile, fewer halo cells to flush (1.63
-// against 2.08 atomics per pixel and channel) but one block per CU.  At level 2 the gx flush is what the launch waits for:
-// gx alone 215 us, goffset alone 107 us, both 242 us, although a block's instructions take 71 k / 59 k cycles (~90 / ~75 us of
-// three rounds) -- 6.5 M fp32 atomics at the device's ~55 G/s.
-constexpr int DCS_WR = 10, DCS_GS = 40;
-constexpr int DCS_OS = 18;  // offset-gradient sums of a pixel (9 taps x {dh, dw}), staged per strip and flushed coalesced
-constexpr int dcs_wc(int ns) { return ns == 4 ? 26 : 24; }
-constexpr int dcs_plane(int ns) { return DCS_WR * dcs_wc(ns) + 1; }  // odd plane stride: the 32 lanes (channels) hit distinct banks
-constexpr size_t dc_bwd_shared_lds_bytes(int ns) { return (size_t)ns * 32 * (dcs_plane(ns) + DCS_GS + DCS_OS) * sizeof(float); }
+// ---- geometry record of a pixel whose nine taps share one offset (used by the lane = pixel kernels of dc_backward.h) ------------
+constexpr int DCS_GS = 40;
 // words of a pixel's geometry record
 enum { DCS_AY = 0, DCS_BY = 3, DCS_AX = 6, DCS_BX = 9, DCS_M9 = 12, DCS_FH0 = 21, DCS_FH1 = 24, DCS_FW0 = 27, DCS_FW1 = 30,
-       DCS_CELL = 36, DCS_LY0 = 37, DCS_LX0 = 38, DCS_FL = 39 };  // the four ints: one 16-byte read
-// Hand-over of the gx windows (r02, tuning key dc.bwdscratch, NOT the default): instead of flushing its merged 32-channel x 12 x 24 window into gx with ~2 atomics per
-// (pixel, channel) -- 6.5 M device-scope fp32 atomics at level 2, the launch's bound -- a two-strip block stores the window
-// to its slot of a global scratch (plain coalesced stores) and its origin to a table; dc_bwd_gx_gather_kernel then adds, for
-// every gx element, the cells of the windows that cover it (each element has one owner: no atomics).  Measured on the
-// cfg5 pass: shared kernel 547 -> 492 us, gather pass +50 us, step 1.229 -> 1.240 ms -- the flush was not the bound (round
-// 1's reading of the req-by-req timings was wrong: the blocks' per-pixel instructions are).  Blocks whose window
-// follows an offset of more than DCS_FMAX pixels keep the atomic flush (origin = DCS_NO_WINDOW): the gather pass only looks
-// at the windows of tiles at most DCS_RY rows / DCS_RX columns of tiles away.
-constexpr int DCS_FMAX = 8, DCS_RY = 5, DCS_RX = 2, DCS_NO_WINDOW = (int)0x80000000;
-struct DcBwdSParams {
-  const float *gout, *x, *offset, *w;
-  float *gx, *goffset;
-  int *flags;  // per (tile, strip): 1 = finished here, 0 = left to dc_bwd_input_tile_kernel
-  int N, Cin, H, W, Cout, ph, pw;
-  int tiles_x, tiles_y;
-  int req_x, req_offset;
-  unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, per-pixel phase, total} shader cycles
-  float *scratch;                // [block][channel block][32][BR][WC] window slots, or NULL: flush with atomics
-  int *origins;                  // [block][2]: window origin (row, column) or DCS_NO_WINDOW
-};
-
+       DCS_CELL = 36, DCS_LY0 = 37, DCS_LX0 = 38, DCS_FL = 39 };
 // one axis of the record: forward weights of tap row i on lines i / i+1 (dc_axis), validity, and the weights of
 // deformable_col2im_coord's absolute-coordinate interpolation; *ok is cleared when the floors leave the regular pattern
 __device__ __forceinline__ void dcs_axis(float off, int in0, int dim, int lo0, float *g, int a_, int b_, int f0_, int f1_,
@@ -1208,374 +1164,6 @@ __device__ __forceinline__ void dcs_axis(float off, int in0, int dim, int lo0, f
     if (v && cl != min(max(in0 + lo0 + i, 0), dim - 1)) ok = false;
     g[f0_ + i] = (float)(cl + 1) - a;
     g[f1_ + i] = a - (float)cl;
-  }
-}
-
-template <int NS>
-__global__ __launch_bounds__(64 * NS) void dc_bwd_input_shared_kernel(DcBwdSParams p) {
-  constexpr int SB = 4 / NS, NT = 64 * NS;  // SB sub-tiles of 2*NS rows per 8-row tile of the tile kernel
-  constexpr int TW = DCI_TW, WR = DCS_WR, WC = dcs_wc(NS), GS = DCS_GS, PL = dcs_plane(NS), T = 9;
-  MFN_DYN_SHARED(float, lds);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = MFN_UNIFORM(tid >> 6);
-  float *win = lds + (size_t)wave * 32 * PL;                         // [32 channels][WR][WC] (+1), this wave's strip
-  float *geom = lds + (size_t)NS * 32 * PL + (size_t)wave * 32 * GS;  // [32 pixels][GS]
-  float *gsum = lds + (size_t)NS * 32 * (PL + GS) + (size_t)wave * 32 * DCS_OS;  // [32 pixels][18]
-  const int j = lane & 31, half = lane >> 5;
-  const int H = p.H, W = p.W;
-  const size_t plane = (size_t)H * W;
-  const int tpi = p.tiles_x * p.tiles_y;
-  const int bx = gridDim.y == 1 ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // neighbours share an L2
-  // block -> (image, 8-row tile row, sub-tile, tile column); the strip's flag sits where the tile kernel looks for it
-  const int n = bx / (tpi * SB), rt = bx - n * (tpi * SB);
-  const int ty8 = rt / (SB * p.tiles_x), r2 = rt - ty8 * (SB * p.tiles_x);
-  const int sb = r2 / p.tiles_x, txi = r2 - sb * p.tiles_x;
-  const int ty0 = ty8 * DCI_TH + sb * 2 * NS, tx0 = txi * TW;
-  const size_t flag_idx = ((size_t)(n * tpi + ty8 * p.tiles_x + txi)) * 4 + sb * NS + wave;
-  const int cb = blockIdx.y * 32;
-  int wy0, wx0;  // window origin: follows the offset of the sub-tile's centre pixel; strip w sits 2w rows lower
-  bool far_window;  // the window sits more than DCS_FMAX pixels from its tile: outside the gather pass's search range
-  {
-    const int cy = min(ty0 + NS, H - 1), cx = min(tx0 + TW / 2, W - 1);
-    const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)cy * W + cx;
-    const float oh = op[(size_t)8 * plane], ow = op[(size_t)9 * plane];
-    const float fh = fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), fw = fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
-    wy0 = MFN_UNIFORM(ty0 - p.ph + (int)fh - (WR - 5) / 2 + 2 * wave);
-    wx0 = MFN_UNIFORM(tx0 - p.pw + (int)fw - (WC - (TW + 3)) / 2);
-    far_window = MFN_UNIFORM((int)(fabsf(fh) > (float)DCS_FMAX || fabsf(fw) > (float)DCS_FMAX)) != 0;
-  }
-  for (int e = lane; e < 32 * PL; e += 64) win[e] = 0.f;
-
-  // this lane as a PIXEL of the strip (geometry record, MFMA A operand) ...
-  const int py = ty0 + 2 * wave + (j >> 4), px = tx0 + (j & 15);
-  const bool pix_ok = py < H && px < W;
-  const int pyc = min(py, H - 1), pxc = min(px, W - 1);
-  const size_t pix = (size_t)pyc * W + pxc;
-  // ... and as a CHANNEL (MFMA B operand, D column, owner of one window plane)
-  const int c = cb + j;
-  const bool c_ok = c < p.Cin;
-  float *wpl = win + (size_t)j * PL;
-  int half_o = half;
-  MFN_OPAQUE(half_o);
-  float *gim = p.gx + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
-  const float *im = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
-
-  // scalar base + 32-bit lane offset (the launch checks that an image's gout and the weights stay below 2^29 floats):
-  // the filter index of a k-step is uniform but for `half`, so its two candidate offsets are scalar
-  const float *ga = p.gout + (size_t)n * p.Cout * plane;
-  const int ga_lane = (int)pix, wb_lane = (c_ok ? c : 0) * T;
-  const int iplane = (int)plane, wstep = p.Cin * T;
-  // four k-steps (eight filters) per trip, 16 unconditional loads into one of three register sets (see the K loop)
-  float a[3][4], b[3][4][T];
-  auto ld = [&](const int buf, int s2) {
-    MFN_UNROLL
-    for (int u = 0; u < 4; ++u) {
-      const int oc0 = min(s2 + 2 * u, p.Cout - 1), oc1 = min(s2 + 2 * u + 1, p.Cout - 1);
-      const int oc = half ? oc1 : oc0;
-      a[buf][u] = ga[ga_lane + oc * iplane];
-      const float *wr = p.w + (wb_lane + oc * wstep);  // nine consecutive floats at 4-byte alignment
-      const f4u q0 = mfn_load4u(wr), q1 = mfn_load4u(wr + 4);
-      b[buf][u][0] = q0.x; b[buf][u][1] = q0.y; b[buf][u][2] = q0.z; b[buf][u][3] = q0.w;
-      b[buf][u][4] = q1.x; b[buf][u][5] = q1.y; b[buf][u][6] = q1.z; b[buf][u][7] = q1.w;
-      b[buf][u][8] = wr[8];
-    }
-  };
-  ld(0, 0);  // the first two trips travel while the geometry records are built (they do not depend on them)
-  ld(1, 8);
-
-  // ---- geometry records of the strip's 32 pixels (lanes 0..31 write, everyone reads them back as broadcasts)
-  const unsigned long long tk0 = MFN_CYCLES();
-  unsigned long long tk1 = tk0, tk2 = tk0, tk3 = tk0;
-  bool ok = true;
-  if (half == 0) {
-    const float *op = p.offset + (size_t)n * 2 * T * plane + pix;
-    const float oh = op[0], ow = op[plane];
-    MFN_UNROLL
-    for (int t = 1; t < T; ++t) ok = ok && (op[(size_t)(2 * t) * plane] == oh) && (op[(size_t)(2 * t + 1) * plane] == ow);
-    const int h_in = pyc - p.ph, w_in = pxc - p.pw;
-    const int lo0y = (int)fminf(fmaxf(floorf(oh), -1.0e6f), 1.0e6f), lo0x = (int)fminf(fmaxf(floorf(ow), -1.0e6f), 1.0e6f);
-    float *g = geom + (size_t)j * GS;
-    int *gi = reinterpret_cast<int *>(g);
-    float vyf[3], vxf[3];
-    dcs_axis(oh, h_in, H, lo0y, g, DCS_AY, DCS_BY, DCS_FH0, DCS_FH1, vyf, ok);
-    dcs_axis(ow, w_in, W, lo0x, g, DCS_AX, DCS_BX, DCS_FW0, DCS_FW1, vxf, ok);
-    MFN_UNROLL
-    for (int t = 0; t < T; ++t) g[DCS_M9 + t] = pix_ok ? vyf[t / 3] * vxf[t % 3] : 0.f;
-    const int ly0 = h_in + lo0y, lx0 = w_in + lo0x;
-    const int ry = ly0 - wy0, rx = lx0 - wx0;
-    gi[DCS_CELL] = (ry >= 0 && ry <= WR - 4 && rx >= 0 && rx <= WC - 4) ? ry * WC + rx : -1;
-    gi[DCS_LY0] = ly0;
-    gi[DCS_LX0] = lx0;
-    gi[DCS_FL] = (lx0 >= 0 && lx0 + 3 <= W - 1) ? 1 : 0;  // the neighbourhood's rows are four contiguous in-image floats
-    ok = ok || !pix_ok;
-  }
-  const bool fast = __all(ok) != 0;  // wave-uniform: the whole strip or nothing
-  if (lane == 0) p.flags[flag_idx] = fast ? 1 : 0;  // every channel block writes the same value
-  MFN_WAIT_LGKM0();
-  if (p.timeline) tk1 = tk2 = tk3 = MFN_CYCLES();
-
-  if (fast) {
-    // ---- D_t[pixel][channel] = sum_o gout[o][pixel] * W[o][channel][t], all nine taps in one pass over gout
-    f32x16 acc[T];
-    MFN_UNROLL
-    for (int t = 0; t < T; ++t)
-      MFN_UNROLL
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    auto mm = [&](const int buf, int s2) {
-      MFN_UNROLL
-      for (int u = 0; u < 4; ++u) {
-        // only the filter tail needs a zero: rows of pixels outside the image and columns of channels >= Cin hold
-        // finite values from clamped addresses and are dropped below (m9 = 0 / c_ok), so the nine MFMAs of a k-step
-        // issue back to back from the loaded registers
-        const float av = (s2 + 2 * u + half < p.Cout) ? a[buf][u] : 0.f;
-        MFN_UNROLL
-        for (int t = 0; t < T; ++t) acc[t] = MFN_MFMA_32x32x2(av, b[buf][u][t], acc[t]);
-      }
-    };
-    // three register sets: the loads of trip i+2 are issued before the MFMAs of trip i (one wave per SIMD: nobody else
-    // hides the ~1.5 us a strided weight load takes; with two sets a trip cost 3.7 k cycles against 2.3 k of MFMA).
-    // Loads past Cout are clamped and unused; the first two trips' loads were issued before the geometry records.
-    for (int s2 = 0; s2 < p.Cout; s2 += 24) {
-      ld(2, s2 + 16);
-      mm(0, s2);
-      ld(0, s2 + 24);
-      if (s2 + 8 < p.Cout) mm(1, s2 + 8);
-      ld(1, s2 + 32);
-      if (s2 + 16 < p.Cout) mm(2, s2 + 16);
-    }
-    if (p.timeline) { MFN_OPAQUE(acc[0][0]); MFN_OPAQUE(acc[8][15]); tk2 = tk3 = MFN_CYCLES(); }
-    // ---- per pixel of the strip: D reg r of lane (j, half) = pixel (r&3)+8*(r>>2)+4*half, channel j
-    // the 4x4 x neighbourhood of pixel r at the clamped lines (clamped duplicates carry zero weight)
-    auto loadX = [&](const int r, float (&X)[4][4]) {
-      const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float4 gq = *reinterpret_cast<const float4 *>(geom + (size_t)pp * GS + DCS_CELL);
-      const int ly0 = mfn_f2i(gq.y), lx0 = mfn_f2i(gq.z);
-      int ro[4];
-      MFN_UNROLL
-      for (int m = 0; m < 4; ++m) ro[m] = min(max(ly0 + m, 0), H - 1) * W;
-      if (mfn_f2i(gq.w)) {
-        MFN_UNROLL
-        for (int m = 0; m < 4; ++m) {
-          const f4u q = mfn_load4u(im + ro[m] + lx0);
-          X[m][0] = q.x; X[m][1] = q.y; X[m][2] = q.z; X[m][3] = q.w;
-        }
-      } else {
-        int co[4];
-        MFN_UNROLL
-        for (int m = 0; m < 4; ++m) co[m] = min(max(lx0 + m, 0), W - 1);
-        MFN_UNROLL
-        for (int m = 0; m < 4; ++m)
-          MFN_UNROLL
-          for (int v = 0; v < 4; ++v) X[m][v] = im[ro[m] + co[v]];
-      }
-    };
-    auto loadG = [&](const int r, float (&gq)[GS]) {
-      const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float4 *g4 = reinterpret_cast<const float4 *>(geom + (size_t)pp * GS);
-      MFN_UNROLL
-      for (int q = 0; q < GS / 4; ++q) {
-        const float4 v = g4[q];
-        gq[4 * q] = v.x; gq[4 * q + 1] = v.y; gq[4 * q + 2] = v.z; gq[4 * q + 3] = v.w;
-      }
-    };
-    float Xn[4][4];
-    if (p.req_offset) loadX(0, Xn);
-    MFN_UNROLL
-    for (int r = 0; r < 16; ++r) {
-      const int pp = (r & 3) + 8 * (r >> 2) + 4 * half;
-      float g[GS];  // the pixel's record: ten 16-byte broadcast reads issued together, one wait
-      loadG(r, g);
-      float cg[T];
-      MFN_UNROLL
-      for (int t = 0; t < T; ++t) cg[t] = (c_ok ? acc[t][r] : 0.f) * g[DCS_M9 + t];  // invalid taps contribute nothing
-      const int ly0 = mfn_f2i(g[DCS_LY0]), lx0 = mfn_f2i(g[DCS_LX0]);
-      if (p.req_offset) {
-        float X[4][4];
-        MFN_UNROLL
-        for (int m = 0; m < 4; ++m)
-          MFN_UNROLL
-          for (int v = 0; v < 4; ++v) X[m][v] = Xn[m][v];
-        if (r + 1 < 16) loadX(r + 1, Xn);  // the next pixel's neighbourhood travels while this one is reduced
-        float sh_[T], sw_[T];
-        MFN_UNROLL
-        for (int i = 0; i < 3; ++i)
-          MFN_UNROLL
-          for (int jj = 0; jj < 3; ++jj) {
-            const int t = 3 * i + jj;
-            // d/dh: fw0*(v21-v11) + fw1*(v22-v12);  d/dw: fh0*(v12-v11) + fh1*(v22-v21)
-            const float th = g[DCS_FW0 + jj] * (X[i + 1][jj] - X[i][jj]) + g[DCS_FW1 + jj] * (X[i + 1][jj + 1] - X[i][jj + 1]);
-            const float tw = g[DCS_FH0 + i] * (X[i][jj + 1] - X[i][jj]) + g[DCS_FH1 + i] * (X[i + 1][jj + 1] - X[i + 1][jj]);
-            sh_[t] = mfn_half_sum_top(th * cg[t]);
-            sw_[t] = mfn_half_sum_top(tw * cg[t]);
-          }
-        if (j == 31) {  // the half-wave's top lane holds the sums over its 32 channels
-          float2 *os = reinterpret_cast<float2 *>(gsum + (size_t)pp * DCS_OS);
-          MFN_UNROLL
-          for (int t = 0; t < T; ++t) os[t] = make_float2(sh_[t], sw_[t]);
-        }
-      }
-      if (p.req_x) {
-        // fold the nine taps onto the 4x4 neighbourhood: along x first, then along y
-        float G[4][4];
-        {
-          float R[3][4];
-          MFN_UNROLL
-          for (int i = 0; i < 3; ++i) {
-            R[i][0] = cg[3 * i] * g[DCS_AX];
-            R[i][1] = fmaf(cg[3 * i], g[DCS_BX], cg[3 * i + 1] * g[DCS_AX + 1]);
-            R[i][2] = fmaf(cg[3 * i + 1], g[DCS_BX + 1], cg[3 * i + 2] * g[DCS_AX + 2]);
-            R[i][3] = cg[3 * i + 2] * g[DCS_BX + 2];
-          }
-          MFN_UNROLL
-          for (int v = 0; v < 4; ++v) {
-            G[0][v] = g[DCS_AY] * R[0][v];
-            G[1][v] = fmaf(g[DCS_BY], R[0][v], g[DCS_AY + 1] * R[1][v]);
-            G[2][v] = fmaf(g[DCS_BY + 1], R[1][v], g[DCS_AY + 2] * R[2][v]);
-            G[3][v] = g[DCS_BY + 2] * R[2][v];
-          }
-        }
-        const int cell = mfn_f2i(g[DCS_CELL]);
-        if (cell < 0) {  // neighbourhood outside the window (rough flow): straight to global memory
-          MFN_UNROLL
-          for (int u = 0; u < 4; ++u)
-            MFN_UNROLL
-            for (int v = 0; v < 4; ++v) {
-              const int yy = ly0 + u, xx = lx0 + v;
-              if (G[u][v] != 0.f && yy >= 0 && yy < H && xx >= 0 && xx < W) atomicAdd(gim + (size_t)yy * W + xx, G[u][v]);
-            }
-        }
-        // The two half-waves hold different pixels of the SAME channel plane and take turns (see the tile kernel): the
-        // 16 cells of a turn are distinct (unclamped lines), so all reads go out together -- one LDS round trip per turn.
-        MFN_UNROLL
-        for (int hs = 0; hs < 2; ++hs) {
-          if (half_o == hs && cell >= 0) {
-            float o[4][4];
-            MFN_UNROLL
-            for (int u = 0; u < 4; ++u)
-              MFN_UNROLL
-              for (int v = 0; v < 4; ++v) o[u][v] = wpl[cell + u * WC + v];
-            MFN_UNROLL
-            for (int u = 0; u < 4; ++u)
-              MFN_UNROLL
-              for (int v = 0; v < 4; ++v) wpl[cell + u * WC + v] = o[u][v] + G[u][v];
-          }
-          MFN_WAVE_SYNC_EMU();
-        }
-      }
-    }
-    if (p.req_offset) {  // the strip's 32 x 18 sums: one coalesced pass of atomics (other channel blocks add to the same)
-      MFN_WAIT_LGKM0();
-      MFN_UNROLL
-      for (int i = 0; i < DCS_OS / 2; ++i) {
-        const int t2 = 2 * i + half;  // lanes 0..31: channel 2i of the record, lanes 32..63: channel 2i+1; lane = pixel
-        const float v = gsum[(size_t)j * DCS_OS + t2];
-        float *dst = p.goffset + ((size_t)n * 2 * T + t2) * plane + pix;
-        if (gridDim.y == 1) {  // one channel block: this strip is the only writer of its entries (the tile kernel skips it)
-          if (pix_ok) *dst += v;  // zero-filled (write) or the caller's values (add)
-        } else if (pix_ok && v != 0.f) {
-          atomicAdd(dst, v);    // device-wide fp32 atomics are the scarce resource of this kernel (~57 G/s)
-        }
-      }
-    }
-    if (p.timeline) { MFN_WAIT_LGKM0(); tk3 = MFN_CYCLES(); }
-  }
-  if (p.req_x) __syncthreads();
-  const unsigned long long tk4 = p.timeline ? MFN_CYCLES() : 0ull;  // after the block barrier
-  if (p.req_x) {
-  // ---- merge the strips' windows (strip w covers block-window rows 2w .. 2w+WR-1) and flush once
-  const int bwy0 = wy0 - 2 * wave;
-  constexpr int BR = WR + 2 * (NS - 1);     // rows of the block window
-  constexpr int CELLS = 32 * BR * WC;
-  static_assert(CELLS % (4 * NT) == 0, "merge loop: four cells per thread per trip");
-  const bool hand_over = NS == 2 && p.scratch != nullptr && !far_window;   // uniform
-  if (NS == 2 && p.origins && blockIdx.y == 0 && tid == 0) {
-    p.origins[2 * bx] = hand_over ? bwy0 : DCS_NO_WINDOW;
-    p.origins[2 * bx + 1] = wx0;
-  }
-  float *slot = hand_over ? p.scratch + ((size_t)bx * gridDim.y + blockIdx.y) * CELLS : nullptr;
-  for (int e0 = tid; e0 < CELLS; e0 += 4 * NT) {  // four cells per trip, their LDS reads issued together (no branches)
-    float v[4];
-    int cl[4], R[4], cc[4];
-    MFN_UNROLL
-    for (int q = 0; q < 4; ++q) {
-      const int e = e0 + NT * q;
-      cl[q] = e / (BR * WC);
-      const int rem = e - cl[q] * (BR * WC);
-      R[q] = rem / WC;
-      cc[q] = rem - R[q] * WC;
-      float s_ = 0.f;
-      MFN_UNROLL
-      for (int w2 = 0; w2 < NS; ++w2) {
-        const int rr = R[q] - 2 * w2;
-        const bool in = rr >= 0 && rr < WR;
-        const float val = lds[(size_t)w2 * 32 * PL + (size_t)cl[q] * PL + (in ? rr : 0) * WC + cc[q]];
-        s_ += in ? val : 0.f;
-      }
-      v[q] = s_;
-    }
-    if (hand_over) {   // the window as it is: consecutive threads, consecutive cells
-      MFN_UNROLL
-      for (int q = 0; q < 4; ++q) slot[e0 + NT * q] = v[q];
-      continue;
-    }
-    MFN_UNROLL
-    for (int q = 0; q < 4; ++q) {
-      const int yy = bwy0 + R[q], xx = wx0 + cc[q];
-      if (v[q] != 0.f && cb + cl[q] < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        atomicAdd(p.gx + ((size_t)n * p.Cin + cb + cl[q]) * plane + (size_t)yy * W + xx, v[q]);
-    }
-  }
-  }
-  if (p.timeline && tid == 0) {
-    unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-    // low halves as the tile kernel's record; high half of [0]: wave 0's wait at the block barrier
-    b_[0] = ((tk1 - tk0) & 0xffffffffull) | ((tk4 - tk3) << 32); b_[1] = tk2 - tk1; b_[2] = tk3 - tk2; b_[3] = MFN_CYCLES() - tk0;
-  }
-}
-
-// ---- gather pass of the window hand-over: gx[n][c][y][x] += sum over the windows that cover (y, x) ------------------
-// One block per 4x16-pixel tile and 32-channel block (the shared kernel's two-strip tiling): thread = (pixel, group of 8
-// channels).  Candidate windows: the tiles within DCS_RY tile rows / DCS_RX tile columns (a window is 12 x 24 cells placed
-// at most DCS_FMAX pixels from its tile); a uniform box test rejects the ones that do not reach this tile.
-struct DcBwdGatherParams {
-  const float *scratch;
-  const int *origins;
-  float *gx;
-  int N, Cin, H, W, tiles_x, tiles_y4, cblocks;
-};
-__global__ __launch_bounds__(256) void dc_bwd_gx_gather_kernel(DcBwdGatherParams p) {
-  constexpr int BR = DCS_WR + 2, WC = 24, PLC = BR * WC, CELLS = 32 * PLC;
-  const int tid = threadIdx.x;
-  const int px = tid & 63, cg = tid >> 6;
-  const int bt = (int)mfn_xcd_remap(blockIdx.x, gridDim.x);
-  const int tpi = p.tiles_x * p.tiles_y4;
-  const int n = bt / tpi, rt = bt - n * tpi;
-  const int ty = rt / p.tiles_x, tx = rt - ty * p.tiles_x;
-  const int y0 = ty * 4, x0 = tx * 16;
-  const int y = y0 + (px >> 4), x = x0 + (px & 15);
-  const int cbi = blockIdx.y;
-  float acc[8];
-  MFN_UNROLL
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  const int ylo = max(ty - DCS_RY, 0), yhi = min(ty + DCS_RY, p.tiles_y4 - 1);
-  const int xlo = max(tx - DCS_RX, 0), xhi = min(tx + DCS_RX, p.tiles_x - 1);
-  for (int sy = ylo; sy <= yhi; ++sy)
-    for (int sx = xlo; sx <= xhi; ++sx) {
-      const int b = (n * p.tiles_y4 + sy) * p.tiles_x + sx;
-      const int oy = p.origins[2 * b], ox = p.origins[2 * b + 1];                      // uniform
-      if (oy == DCS_NO_WINDOW || oy >= y0 + 4 || oy + BR <= y0 || ox >= x0 + 16 || ox + WC <= x0) continue;
-      const int ry = y - oy, rx = x - ox;
-      if ((unsigned)ry < (unsigned)BR && (unsigned)rx < (unsigned)WC) {
-        const float *src = p.scratch + ((size_t)b * p.cblocks + cbi) * CELLS + (size_t)(cg * 8) * PLC + ry * WC + rx;
-        MFN_UNROLL
-        for (int k = 0; k < 8; ++k) acc[k] += src[(size_t)k * PLC];
-      }
-    }
-  if (y < p.H && x < p.W) {
-    float *dst = p.gx + ((size_t)n * p.Cin + cbi * 32 + cg * 8) * ((size_t)p.H * p.W) + (size_t)y * p.W + x;
-    MFN_UNROLL
-    for (int k = 0; k < 8; ++k)
-      if (cbi * 32 + cg * 8 + k < p.Cin && acc[k] != 0.f) dst[(size_t)k * p.H * p.W] += acc[k];
   }
 }
 

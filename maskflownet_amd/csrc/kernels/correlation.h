@@ -23,6 +23,11 @@
 #pragma once
 #include "../mfn_rt.h"
 
+// measurement builds only (tools/corr_ablate_build.py): bit mask -- 1 no output stores, 2 no global loads, 4 no LDS reads / FMAs
+#ifndef MFN_CORR_ABLATE_MASK
+#define MFN_CORR_ABLATE_MASK 0
+#endif
+
 namespace mfn {
 
 // ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, and the
@@ -71,14 +76,10 @@ struct CorrParams {
   int nt_store;        // cache policy of the output stores (mfn_store4_stream; LDS-DMA kernel)
   int xcd_swizzle;     // 1: remap blockIdx so that neighbouring tiles share an XCD's L2
   int leaky;           // fused epilogue (f-1): LeakyReLU(0.1) on the output (MaskFlownet.py:217)
-  int ablate;          // measurement only: 1 = drop the output stores, 2 = drop the global loads
-  int stagger;         // LDS-DMA kernel: the k-th resident block of a CU (dispatch round k) starts k * stagger shader
-                       // cycles late, so that the blocks of a CU do not walk their stages in lockstep (0 = off)
   // channel slicing for levels with few pixels and many channels: blockIdx.y = slice, each slice
   // reduces `slice_channels` channels and writes RAW partial sums to partial + slice*N*D*D*H*W;
   // corr_reduce_kernel then sums the slices in a fixed order and normalises (deterministic).
   int nslices, slice_channels;
-  int lanemap;         // 0: ds_read_b128 service-group order (guide), 1: natural lane order
   unsigned long long *timeline;  // measurement only: 4 wall-clock stamps (100 MHz) per block, or NULL
   float *partial;
 };
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
 
   // ---- lane geometry ------------------------------------------------------------------------
   int row, gx;
-  G::map(p.lanemap == 0 ? b128_service_pos(lane) : lane, row, gx);
+  G::map(b128_service_pos(lane), row, gx);
   const int f1_off = row * RS + 4 * gx;          // chunk plane 0; plane k adds k*RPC*RS
   const int f2_off = (row + dy0) * RS + 4 * gx;  // window row = row + dy + MD; row e adds e*RS
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
     goff2[i] = ok ? c * (int)plane + y * W + x : -1;
     lofc2[i] = (c * F2_PER_C + r * RS + 4 * q) | (c << 20);
   }
-  const bool loads_on = p.ablate != 2;
+  const bool loads_on = MFN_CORR_ABLATE_MASK != 2;
 
   auto fetch = [&](int c0) {
     const float *b1 = f1n + (size_t)c0 * plane;  // wave-uniform
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(((D + DYW - 1) / DYW) * 64, WPE) void corr_tiled_ke
               float v[4];
               MFN_UNROLL
               for (int q = 0; q < 4; ++q) { const float r = ACC(e, k, d, q) * scale; v[q] = fmaxf(r, slope * r); }
-              if (p.ablate != 1 || v[0] != v[0])  // ablation keeps the value live but never stores
+              if (MFN_CORR_ABLATE_MASK != 1 || v[0] != v[0])  // ablation keeps the value live but never stores
                 *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
             }
           }
@@ -349,30 +350,16 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
                 corr_tiled_lds_bytes<D, TW, NCH, CK>(), stream, p);
 }
 
-// Named variants (corr.variant tuning key).  Each is one point of (NCH, CK, DYW, PF, WPE).
-//   0: 1 dy/wave, 1 chunk,  CK=8, no prefetch, >=3 waves/SIMD   (9-wave blocks)
-//   1: 1 dy/wave, 1 chunk,  CK=4, prefetch,    >=4 waves/SIMD
-//   2: 1 dy/wave, 2 chunks, CK=4, prefetch,    >=2 waves/SIMD   (512-px tiles)
-//   3: 3 dy/wave, 1 chunk,  CK=4, prefetch,    >=2 waves/SIMD   (3-wave blocks)
-//   4: 3 dy/wave, 1 chunk,  CK=8, no prefetch, >=1 wave/SIMD
-//   5: 2 dy/wave, 1 chunk,  CK=4, prefetch,    >=3 waves/SIMD   (5-wave blocks)
-//   6: 1 dy/wave, 1 chunk,  CK=4, no prefetch, >=4 waves/SIMD
-//   7: 3 dy/wave, 1 chunk,  CK=4, no prefetch, >=2 waves/SIMD
-constexpr int kCorrVariants = 28;  // 0-7: corr_tiled_kernel; 8-11: corr_hw_kernel; 12-23: corr_dma_kernel (20-23: channel groups)
+// The one point of (NCH, CK, DYW, PF, WPE) that is still built: one displacement row per wave, one 4-px chunk per lane,
+// 4-channel stages, no register prefetch, >= 4 waves per SIMD -- the kernel of images narrower than 32 columns
+// (corr.variant 6).  Rounds 1 / 2 swept eight points and a half-wave form (corr_hw_kernel); none of them is selected by a plan.
+constexpr int kCorrVariants = 23;  // valid values of corr.variant: 6 (corr_tiled_kernel), 16 / 20 / 22 (corr_dma_kernel: 1 / 2 / 3 channel groups)
+inline bool corr_variant_known(int v) { return v == 6 || v == 16 || v == 20 || v == 22; }
 template <int D, int TW>
-inline int corr_tiled_variant(const CorrParams &p, int variant, hipStream_t s) {
-  switch (variant) {
-    case 0: return corr_tiled_launch<D, TW, 1, 8, 1, false, 3>(p, s, "corr_tiled_v0");
-    case 1: return corr_tiled_launch<D, TW, 1, 4, 1, true, 4>(p, s, "corr_tiled_v1");
-    case 2: return corr_tiled_launch<D, TW, 2, 4, 1, true, 2>(p, s, "corr_tiled_v2");
-    case 3: return corr_tiled_launch<D, TW, 1, 4, 3, true, 2>(p, s, "corr_tiled_v3");
-    case 4: return corr_tiled_launch<D, TW, 1, 8, 3, false, 1>(p, s, "corr_tiled_v4");
-    case 5: return corr_tiled_launch<D, TW, 1, 4, 2, true, 3>(p, s, "corr_tiled_v5");
-    case 6: return corr_tiled_launch<D, TW, 1, 4, 1, false, 4>(p, s, "corr_tiled_v6");
-    default: return corr_tiled_launch<D, TW, 1, 4, 3, false, 2>(p, s, "corr_tiled_v7");
-  }
+inline int corr_tiled_variant(const CorrParams &p, int /*variant*/, hipStream_t s) {
+  return corr_tiled_launch<D, TW, 1, 4, 1, false, 4>(p, s, "corr_tiled_v6");
 }
-inline int corr_variant_tile_h(int tw, int variant) { return variant >= 8 ? 4 : (256 / tw) * (variant == 2 ? 2 : 1); }
+inline int corr_variant_tile_h(int tw, int variant) { return variant >= 8 ? 4 : (256 / tw); }
 
 #ifndef MFN_CORR_ABLATE
 #define MFN_CORR_ABLATE 0  // tools/corr_ablate_build.py: 1 no LDS operand reads, 2 no FMAs (single-buffered consume only)
@@ -450,192 +437,11 @@ __device__ __forceinline__ void corr_hw_consume(const float *f1p, const float *f
   }
 }
 
-// ---- corr_hw_kernel: 32x4-pixel tiles, two displacement rows per wave (one per half-wave) ----------
-// Measured on MI355X (profiles/): the 256-px/9-wave blocks above leave one block per CU, so each
-// CU walks its channel stages serially and the kernel is bound by global-load latency, not by HBM,
-// LDS (conflict-free) or VALU.  This variant trades tile size for residency:
-//   * tile = 32 x 4 px (128 px): lanes 0-31 own the 32 four-pixel groups for displacement row
-//     2*wave, lanes 32-63 the same groups for row 2*wave+1 -> ceil(D/2) waves per block (5 for D=9);
-//   * 768 blocks for the level-2 shape = 3 per CU, all resident (<= 80 VGPRs, 12 KB LDS per stage);
-//   * LDS row stride 48 floats: the two rows {r, r+2} of one ds_read_b128 service group land on
-//     16 distinct 16-byte slots (2*12 = 24 = 8 mod 16) -> conflict-free.
-template <int D, int CK, bool PF, int WPE>
-__global__ __launch_bounds__(((D + 1) / 2) * 64, WPE) void corr_hw_kernel(CorrParams p) {
-  constexpr int MD = (D - 1) / 2;
-  constexpr int NW = (D + 1) / 2;
-  constexpr int NT = NW * 64;
-  constexpr int TW = 32, TH = 4, RS = 48, CW4 = 10;  // window = 40 floats of each 48-float row
-  constexpr int ROWS2 = TH + 2 * MD;
-  constexpr int F1_PER_C = TH * RS;
-  constexpr int F2_PER_C = ROWS2 * RS;
-  constexpr int ITEMS1 = CK * TH * (TW / 4);
-  constexpr int ITEMS2 = CK * ROWS2 * CW4;
-  constexpr int NI1 = (ITEMS1 + NT - 1) / NT;
-  constexpr int NI2 = (ITEMS2 + NT - 1) / NT;
-  constexpr int OFF = 4 - MD;
-
-  MFN_DYN_SHARED(float, lds);
-  float *f1s = lds;
-  float *f2s = lds + CK * F1_PER_C;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int dyi = MFN_UNIFORM(tid >> 6) * 2 + (lane >> 5);  // displacement row of this half-wave
-  const bool live = dyi < D;                                // upper half of the last wave idles
-
-  int bid = blockIdx.x;
-  const int nblk = gridDim.x;
-  if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)nblk);
-  const int tiles_per_img = p.tiles_x * p.tiles_y;
-  const int n = bid / tiles_per_img;
-  const int t = bid - n * tiles_per_img;
-  const int ty = t / p.tiles_x;
-  const int tx = t - ty * p.tiles_x;
-  const int y0 = ty * TH, x0 = tx * TW;
-  const int H = p.H, W = p.W, C = p.C;
-  const size_t plane = (size_t)H * W;
-  const int c_begin = blockIdx.y * p.slice_channels;
-  const int c_end = min(C, c_begin + p.slice_channels);
-  const float *f1n = p.f1 + (size_t)n * C * plane;
-  const float *f2n = p.f2 + (size_t)n * C * plane;
-
-  // half-wave lane -> (row, group): service-group order of ds_read_b128 inside each 32-lane half
-  const int pos = b128_service_pos(lane) & 31;
-  const int sg = pos >> 4, wi = pos & 15;
-  const int row = sg + 2 * (wi >> 3), gx = wi & 7;
-  const int f1_off = row * RS + 4 * gx;
-  const int f2_off = (row + (live ? dyi : 0)) * RS + 4 * gx;
-
-  f32x2 accp[D - 1][2];
-  float accs[4];
-  MFN_UNROLL
-  for (int d = 0; d < D - 1; ++d) { accp[d][0] = mfn_f2(0.f, 0.f); accp[d][1] = mfn_f2(0.f, 0.f); }
-  MFN_UNROLL
-  for (int q = 0; q < 4; ++q) accs[q] = 0.f;
-
-  // staging plan (see corr_tiled_kernel)
-  float4 pre1[NI1], pre2[NI2];
-  int goff1[NI1], goff2[NI2], lofc1[NI1], lofc2[NI2];
-  MFN_UNROLL
-  for (int i = 0; i < NI1; ++i) {
-    const int it = tid + i * NT;
-    const int c = it / (TH * (TW / 4));
-    const int rem = it - c * (TH * (TW / 4));
-    const int r = rem / (TW / 4);
-    const int q = rem - r * (TW / 4);
-    const int y = y0 + r, x = x0 + 4 * q;
-    const bool ok = (i < NI1 - 1 || ITEMS1 % NT == 0 || it < ITEMS1) && y < H && x < W;
-    goff1[i] = ok ? c * (int)plane + y * W + x : -1;
-    lofc1[i] = (c * F1_PER_C + r * RS + 4 * q) | (c << 20);
-  }
-  MFN_UNROLL
-  for (int i = 0; i < NI2; ++i) {
-    const int it = tid + i * NT;
-    const int c = it / (ROWS2 * CW4);
-    const int rem = it - c * (ROWS2 * CW4);
-    const int r = rem / CW4;
-    const int q = rem - r * CW4;
-    const int y = y0 - MD + r, x = x0 - 4 + 4 * q;
-    const bool ok = (i < NI2 - 1 || ITEMS2 % NT == 0 || it < ITEMS2) && y >= 0 && y < H && x >= 0 && x < W;
-    goff2[i] = ok ? c * (int)plane + y * W + x : -1;
-    lofc2[i] = (c * F2_PER_C + r * RS + 4 * q) | (c << 20);
-  }
-  const bool loads_on = p.ablate != 2;
-  auto fetch = [&](int c0) {
-    const float *b1 = f1n + (size_t)c0 * plane;
-    const float *b2 = f2n + (size_t)c0 * plane;
-    const int cleft = c_end - c0;
-    MFN_UNROLL
-    for (int i = 0; i < NI1; ++i) {
-      const bool ok = goff1[i] >= 0 && (lofc1[i] >> 20) < cleft && loads_on;
-      pre1[i] = zero_unless(ok, *reinterpret_cast<const float4 *>(b1 + (ok ? goff1[i] : 0)));
-    }
-    MFN_UNROLL
-    for (int i = 0; i < NI2; ++i) {
-      const bool ok = goff2[i] >= 0 && (lofc2[i] >> 20) < cleft && loads_on;
-      pre2[i] = zero_unless(ok, *reinterpret_cast<const float4 *>(b2 + (ok ? goff2[i] : 0)));
-    }
-  };
-  auto stash = [&]() {
-    MFN_UNROLL
-    for (int i = 0; i < NI1; ++i)
-      if (i < NI1 - 1 || ITEMS1 % NT == 0 || tid + i * NT < ITEMS1)
-        *reinterpret_cast<float4 *>(f1s + (lofc1[i] & 0xFFFFF)) = pre1[i];
-    MFN_UNROLL
-    for (int i = 0; i < NI2; ++i)
-      if (i < NI2 - 1 || ITEMS2 % NT == 0 || tid + i * NT < ITEMS2)
-        *reinterpret_cast<float4 *>(f2s + (lofc2[i] & 0xFFFFF)) = pre2[i];
-  };
-  auto consume = [&]() { corr_hw_consume<D, CK, F1_PER_C, F2_PER_C>(f1s + f1_off, f2s + f2_off, accp, accs); };
-
-  const int nchunks = (c_end - c_begin + CK - 1) / CK;
-  if (PF) {
-    fetch(c_begin);
-    for (int ch = 0; ch < nchunks; ++ch) {
-      stash();
-      __syncthreads();
-      if (ch + 1 < nchunks) fetch(c_begin + (ch + 1) * CK);
-      consume();
-      __syncthreads();
-    }
-  } else {
-    for (int ch = 0; ch < nchunks; ++ch) {
-      fetch(c_begin + ch * CK);
-      if (ch) __syncthreads();
-      stash();
-      __syncthreads();
-      consume();
-    }
-  }
-
-#define ACC1(d, q)                                                                        \
-  (((q) & 1) ? ((d) < D - 1 ? accp[(d) < D - 1 ? (d) : 0][((q) - 1) / 2].x : accs[2 + ((q) - 1) / 2]) \
-             : ((d) > 0 ? accp[(d) > 0 ? (d) - 1 : 0][(q) / 2].y : accs[(q) / 2]))
-  const bool raw = p.nslices > 1;
-  float *outn = raw ? p.partial + ((size_t)blockIdx.y * p.N + n) * (D * D) * plane : p.out + (size_t)n * p.out_nstride;
-  const bool use_div = p.exact_div && !raw;
-  const float scale = raw ? 1.f : p.inv_sumelems;
-  const float slope = (p.leaky && !raw) ? 0.1f : 1.f;
-  const int y = y0 + row, x = x0 + 4 * gx;
-  if (live && y < H && x < W) {
-    float *dst = outn + (size_t)(dyi * D) * plane + (size_t)y * W + x;
-    MFN_UNROLL
-    for (int d = 0; d < D; ++d) {
-      float v[4];
-      MFN_UNROLL
-      for (int q = 0; q < 4; ++q) {
-        const float r = use_div ? ACC1(d, q) / p.sumelems : ACC1(d, q) * scale;
-        v[q] = fmaxf(r, slope * r);
-      }
-      if (p.ablate != 1 || v[0] != v[0])
-        *reinterpret_cast<float4 *>(dst + (size_t)d * plane) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  }
-#undef ACC1
-}
-
-template <int D, int CK, bool PF, int WPE>
-inline int corr_hw_launch(CorrParams p, hipStream_t stream, const char *name) {
-  constexpr int MD = (D - 1) / 2;
-  p.tiles_x = cdiv(p.W, 32);
-  p.tiles_y = cdiv(p.H, 4);
-  const int nblk = p.N * p.tiles_x * p.tiles_y;
-  if (nblk <= 0) return 0;
-  const size_t lds = (size_t)CK * (4 * 48 + (4 + 2 * MD) * 48) * sizeof(float);
-  return launch(name, corr_hw_kernel<D, CK, PF, WPE>, dim3(nblk, p.nslices), dim3(((D + 1) / 2) * 64), lds, stream, p);
-}
-// variants 8..11 of corr.variant
-template <int D>
-inline int corr_hw_variant(const CorrParams &p, int variant, hipStream_t s) {
-  switch (variant) {
-    case 8: return corr_hw_launch<D, 4, false, 4>(p, s, "corr_hw_v8");
-    case 9: return corr_hw_launch<D, 4, true, 4>(p, s, "corr_hw_v9");
-    case 10: return corr_hw_launch<D, 8, false, 4>(p, s, "corr_hw_v10");
-    default: return corr_hw_launch<D, 8, true, 4>(p, s, "corr_hw_v11");
-  }
-}
-
-// ---- corr_dma_kernel: corr_hw_kernel's tile/lane geometry fed by an LDS-DMA staging ring -----------
+// ---- corr_dma_kernel: 32x4-pixel tiles, two displacement rows per wave (one per half-wave), LDS-DMA staging ring ----
+//   * tile = 32 x 4 px (128 px): lanes 0-31 own the 32 four-pixel groups for displacement row 2*wave, lanes 32-63 the same
+//     groups for row 2*wave+1 -> ceil(D/2) waves per block (5 for D=9); 768 blocks for the level-2 shape = 3 per CU, all resident;
+//   * LDS row stride 48 floats: the two rows {r, r+2} of one ds_read_b128 service group land on 16 distinct 16-byte slots
+//     (2*12 = 24 = 8 mod 16) -> conflict-free.
 // The register-staged kernels pay one full global-load latency per channel stage (measured: ~1.2-1.5
 // us per stage, 8-16 stages per block).  Here the loads of NS-1 stages are always in flight:
 //   * a stage = CK channels of the f1 tile (4 x 48-float rows) and the f2 window (12 rows), laid
@@ -676,15 +482,6 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
 
   int bid = blockIdx.x;
   const int nblk = gridDim.x;
-#if !defined(MFN_EMU)
-  if (p.stagger) {  // dispatch round of this block: blocks go round-robin over 8 XCDs x 32 CUs
-    const int round = (int)(blockIdx.x >> 8);
-    if (round) {
-      const unsigned long long t_end = __builtin_readcyclecounter() + (unsigned long long)round * (unsigned)p.stagger;
-      while (__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-#endif
   if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)nblk);
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int n = bid / tiles_per_img;
@@ -742,7 +539,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
     const int y = ybase + r, x = xbase + 4 * q;
     const bool ok = first < ITEMS && q < qmax && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
     const unsigned v = (unsigned)(c * (int)plane + y * W + x) * 4u;
-    voff[i] = (ok && !(p.ablate & 2)) ? v : INVALID;
+    voff[i] = (ok && !(MFN_CORR_ABLATE_MASK & 2)) ? v : INVALID;
   }
 
   auto issue = [&](int ch) {  // stage ch -> ring slot ch % NS
@@ -778,7 +575,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
     MFN_RAW_BARRIER();     // stage ch landed for every wave; slot (ch-1)%NS is free
     if (ch == 0) MFN_STAMP(p.timeline, 1);
     if (ch + NS - 1 < nchunks) issue(ch + NS - 1);
-    if (!(p.ablate & 4)) consume(ch);
+    if (!(MFN_CORR_ABLATE_MASK & 4)) consume(ch);
   }
   MFN_STAMP(p.timeline, 2);
   if (G > 1) {  // add the groups' accumulators in index order (deterministic); group 0 owns the epilogue
@@ -819,7 +616,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
   const int y = y0 + row, x = x0 + 4 * gx;
   // the normalisation / activation choice is uniform: one straight-line copy of the 9 stores per case instead of
   // a branch per element (the epilogue, like the prologue, runs on every wave of the CU at the same time)
-  if (live && y < H && x < W && !(p.ablate & 1)) {
+  if (live && y < H && x < W && !(MFN_CORR_ABLATE_MASK & 1)) {
     float *dst = outn + (size_t)(dyi * D) * plane + (size_t)y * W + x;
     auto emit = [&](auto div_c, auto leaky_c) {
       constexpr bool DIV = decltype(div_c)::value, LEAKY = decltype(leaky_c)::value;
@@ -865,26 +662,15 @@ inline int corr_dma_launch(CorrParams p, hipStream_t stream, const char *name) {
   return launch(name, corr_dma_kernel<D, CK, NS, WPE, DBUF, G>, dim3(nblk, p.nslices), dim3(NT * G), ring > red ? ring : red,
                 stream, p);
 }
-// variants 12..19 of corr.variant: (CK, ring stages, min waves/SIMD, double-buffered operands)
+// corr.variant 16 / 20 / 22: (CK, ring stages, min waves/SIMD, double-buffered operands, channel groups) as the plans pick
+// them (api_impl.inc corr_plan: >= 400 tiles / 128-399 / fewer).  Rounds 1 / 2 measured sixteen more points (deeper rings,
+// 8- and 16-channel stages, operand double buffering at level 2, staggered block starts): DESIGN.md 4.1.
 template <int D>
 inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
-    case 12: return corr_dma_launch<D, 4, 3, 4, true>(p, s, "corr_dma_v12");
-    case 13: return corr_dma_launch<D, 4, 2, 5, true>(p, s, "corr_dma_v13");
-    case 14: return corr_dma_launch<D, 8, 3, 4, true>(p, s, "corr_dma_v14");
-    case 15: return corr_dma_launch<D, 8, 2, 4, true>(p, s, "corr_dma_v15");
-    case 16: return corr_dma_launch<D, 4, 2, 5, false>(p, s, "corr_dma_v16");
-    case 17: return corr_dma_launch<D, 8, 2, 5, false>(p, s, "corr_dma_v17");
-    case 18: return corr_dma_launch<D, 4, 3, 5, false>(p, s, "corr_dma_v18");
-    case 19: return corr_dma_launch<D, 4, 3, 5, true>(p, s, "corr_dma_v19");
-    case 20: return corr_dma_launch<D, 8, 2, 2, true, 2>(p, s, "corr_dma_v20");   // 15 with two channel groups
-    case 21: return corr_dma_launch<D, 8, 2, 2, false, 2>(p, s, "corr_dma_v21");  // 17 with two channel groups
-    case 22: return corr_dma_launch<D, 8, 2, 1, true, 3>(p, s, "corr_dma_v22");   // 15 with three channel groups
-    case 24: return corr_dma_launch<D, 4, 4, 5, false>(p, s, "corr_dma_v24");     // 16 with a 4-stage ring (3 stages in flight)
-    case 25: return corr_dma_launch<D, 8, 3, 5, false>(p, s, "corr_dma_v25");     // 17 with a 3-stage ring
-    case 26: return corr_dma_launch<D, 8, 2, 5, true>(p, s, "corr_dma_v26");      // 15 held to five waves per SIMD
-    case 27: return corr_dma_launch<D, 16, 2, 5, true>(p, s, "corr_dma_v27");     // two 16-channel stages (C = 32: one barrier pair)
-    default: return corr_dma_launch<D, 4, 2, 1, false, 3>(p, s, "corr_dma_v23");  // 16 with three channel groups
+    case 20: return corr_dma_launch<D, 8, 2, 2, true, 2>(p, s, "corr_dma_v20");   // two channel groups
+    case 22: return corr_dma_launch<D, 8, 2, 1, true, 3>(p, s, "corr_dma_v22");   // three channel groups
+    default: return corr_dma_launch<D, 4, 2, 5, false>(p, s, "corr_dma_v16");     // level 2: every block of the launch resident
   }
 }
 

@@ -736,9 +736,6 @@ constexpr int DCW_RS = 36;                       // row stride of the column / g
 constexpr int DCW_XW_F = 512;                    // pair window: 2 x 12 x 20 = 480 used
 constexpr int DCW_STG = 292;                     // row stride of the flush staging [32 filters][288 (c, t)]
 constexpr int DCW_COL_F = 9 * 32 * DCW_RS;
-constexpr size_t dc_bwd_weight_pix_lds_bytes(int mtot) {
-  return ((size_t)8 * DCW_SLOT + DCW_COL_F + (size_t)mtot * 32 * DCW_RS + 4 * 8 * DCW_XW_F) * sizeof(float);
-}
 struct DcBwdWPParams {
   const float *gout, *x, *offset;
   float *gw, *gbias;             // gbias NULL: not requested (the channel-block-0 blocks add it)
@@ -754,332 +751,8 @@ struct DcBwdWPParams {
   float flow_scale, flow_stride;
 };
 
-template <int MTOT>
-__global__ __launch_bounds__(256, 1) void dc_bwd_weight_pix_kernel(DcBwdWPParams p) {
-  constexpr int T = 9, UN = 9 * MTOT, UMAX = (UN + 3) / 4, RS = DCW_RS, ROWS = 12, COLS = 20, XW_NI = 2;
-  MFN_DYN_SHARED(float, lds);
-  float *geom = lds;                                   // [2 sets][4 slots][DCW_SLOT]
-  float *colT = lds + 8 * DCW_SLOT;                    // [9 taps][32 channels][RS]: B operand, pixel-contiguous rows
-  float *goutT = colT + DCW_COL_F;                     // [MTOT * 32 filters][RS]: A operand
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = MFN_UNIFORM(tid >> 6);
-  const int half = lane >> 5, j = lane & 31;
-  float *xwin = goutT + MTOT * 32 * RS + wave * (8 * DCW_XW_F);  // two sets of four pair windows
-  const int H = p.H, W = p.W;
-  const size_t plane = (size_t)H * W;
-  const int cb = blockIdx.y * 32;
-  const int t0 = blockIdx.x * p.tiles_per_block, t1 = min(t0 + p.tiles_per_block, p.ntiles);
-  const int ntile = t1 - t0;
-  const mfn_rsrc_t xrsrc = mfn_make_rsrc(p.x, (unsigned)((size_t)p.N * p.Cin * plane * 4));
-
-  f32x16 acc[UMAX];
-  MFN_UNROLL
-  for (int u = 0; u < UMAX; ++u)
-    MFN_UNROLL
-    for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
-  float bsum[MTOT * 4];  // thread (filter row tid >> 5, pixel tid & 31): filters (tid >> 5) + 8 i
-  MFN_UNROLL
-  for (int i = 0; i < MTOT * 4; ++i) bsum[i] = 0.f;
-
-  // ---- geometry of one tile per wave (deform_conv.h's fast-path descriptors), parked in LDS for all four waves: the loads
-  // go out one pixel tile before the values are used
-  struct GeoIn { float off[2 * T]; int n, ho, wo; bool px_valid; };
-  auto geo_load = [&](int tile, GeoIn &q) {
-    const bool tile_ok = tile < t1;
-    const int tpi = p.tiles_y * p.tiles_x;
-    const int tl = min(tile, p.ntiles - 1);
-    auto divmod = [](int a, int b, float inv_b, int &qq, int &r) {
-      qq = (int)((float)a * inv_b);
-      r = a - qq * b;
-      if (r < 0) { --qq; r += b; }
-      if (r >= b) { ++qq; r -= b; }
-    };
-    int rt, ty, tx;
-    divmod(tl, tpi, p.inv_tpi, q.n, rt);
-    divmod(rt, p.tiles_x, p.inv_tiles_x, ty, tx);
-    q.ho = ty * 4 + (j >> 3);
-    q.wo = tx * 8 + (j & 7);
-    q.px_valid = tile_ok && q.ho < H && q.wo < W;
-    q.ho = min(q.ho, H - 1);
-    q.wo = min(q.wo, W - 1);
-    const float *op = p.offset + (size_t)q.n * 2 * T * plane + (size_t)q.ho * W + q.wo;
-    MFN_UNROLL
-    for (int t = 0; t < 2 * T; ++t) q.off[t] = op[(size_t)t * plane];
-  };
-  auto geo_store = [&](const GeoIn &q, int set) {
-    const int h_in = q.ho - p.ph, w_in = q.wo - p.pw;
-    const float oh = q.off[0], ow = q.off[1];
-    bool regular = true;
-    MFN_UNROLL
-    for (int t = 1; t < T; ++t) regular = regular && (q.off[2 * t] == oh) && (q.off[2 * t + 1] == ow);
-    float a_y[3], b_y[3], a_x[3], b_x[3];
-    int iy[4], ix[4];
-    {
-      int lo0 = 0;
-      MFN_UNROLL
-      for (int i = 0; i < 3; ++i) {
-        bool v; int lo, hi; float l;
-        dc_axis(oh, h_in, i, H, v, lo, hi, l);
-        v = v && q.px_valid;
-        const int ulo = (int)fminf(fmaxf(floorf((float)i + oh), -1.0e6f), 1.0e6f);  // unclamped floor
-        if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i);
-        a_y[i] = v ? 1.f - l : 0.f;
-        b_y[i] = v ? l : 0.f;
-      }
-      MFN_UNROLL
-      for (int m = 0; m < 4; ++m) iy[m] = min(max(h_in + lo0 + m, 0), H - 1);
-      MFN_UNROLL
-      for (int i = 0; i < 3; ++i) {
-        bool v; int lo, hi; float l;
-        dc_axis(ow, w_in, i, W, v, lo, hi, l);
-        v = v && q.px_valid;
-        const int ulo = (int)fminf(fmaxf(floorf((float)i + ow), -1.0e6f), 1.0e6f);
-        if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i);
-        a_x[i] = v ? 1.f - l : 0.f;
-        b_x[i] = v ? l : 0.f;
-      }
-      MFN_UNROLL
-      for (int m = 0; m < 4; ++m) ix[m] = min(max(w_in + lo0 + m, 0), W - 1);
-    }
-    const bool fast = __all(regular || !q.px_valid) != 0;
-    // lanes outside the image / past the last tile duplicate a valid pixel: they take part in the box
-    const int wr0 = mfn_wave_min_i32(iy[0]), rhi = mfn_wave_max_i32(iy[3]);
-    const int wc0 = mfn_wave_min_i32(ix[0]) & ~3, chi = mfn_wave_max_i32(ix[3]);
-    const bool staged = fast && (W % 4 == 0) && (rhi - wr0 < ROWS) && (chi - wc0 < COLS);
-    float *g = geom + (set * 4 + wave) * DCW_SLOT;
-    if (half == 0) {
-      MFN_UNROLL
-      for (int i = 0; i < 3; ++i) {
-        g[(0 + i) * 32 + j] = a_y[i]; g[(3 + i) * 32 + j] = b_y[i];
-        g[(6 + i) * 32 + j] = a_x[i]; g[(9 + i) * 32 + j] = b_x[i];
-      }
-      int *gi = reinterpret_cast<int *>(g);
-      MFN_UNROLL
-      for (int m = 0; m < 4; ++m) { gi[(12 + m) * 32 + j] = (iy[m] - wr0) * COLS; gi[(16 + m) * 32 + j] = ix[m] - wc0; }
-      gi[20 * 32 + j] = q.ho * W + q.wo;
-      gi[21 * 32 + j] = q.px_valid ? 1 : 0;
-      gi[22 * 32 + j] = q.ho;
-      gi[23 * 32 + j] = q.wo;
-    }
-    if (lane == 0) {
-      int *hd = reinterpret_cast<int *>(g + DCW_GWD * 32);
-      hd[0] = wr0; hd[1] = wc0; hd[2] = q.n; hd[3] = staged ? 1 : 0;
-    }
-  };
-  // ---- what a tile needs from memory, requested one tile ahead: its gout values (registers) and, when its window is
-  // staged, the four pair windows of this wave's eight channels (window set i & 1)
-  float gvn[MTOT * 4];
-  auto tile_loads = [&](int i) {
-    const float *g = geom + (((i >> 2) & 1) * 4 + (i & 3)) * DCW_SLOT;
-    const int *gi = reinterpret_cast<const int *>(g);
-    const int *hd = reinterpret_cast<const int *>(g + DCW_GWD * 32);
-    const int wr0 = MFN_UNIFORM(hd[0]), wc0 = MFN_UNIFORM(hd[1]), n = MFN_UNIFORM(hd[2]);
-    const bool staged = MFN_UNIFORM(hd[3]) != 0;
-    {
-      const int px = tid & 31, osub = tid >> 5;
-      const float *gp = p.gout + (size_t)n * p.Cout * plane + gi[20 * 32 + px];
-      MFN_UNROLL
-      for (int k = 0; k < MTOT * 4; ++k) gvn[k] = gp[(size_t)min(osub + 8 * k, p.Cout - 1) * plane];
-    }
-    if (staged) {
-      float *ring = xwin + (i & 1) * 4 * DCW_XW_F;
-      MFN_UNROLL
-      for (int q = 0; q < XW_NI; ++q) {
-        const int slot = q * 64 + lane;               // float4 slots: [channel 0/1][12 rows][5 float4]
-        const int chs = slot / 60, rem = slot - chs * 60;
-        const int row = rem / 5, c4 = rem - row * 5;
-        const int r = wr0 + row, c = wc0 + 4 * c4;
-        const unsigned xvoff = (chs < 2 && r <= H - 1 && c <= W - 4)
-                                   ? (unsigned)(((size_t)n * p.Cin * plane + (size_t)chs * plane + (size_t)r * W + c) * 4)
-                                   : 0xFFFFFF00u;
-        MFN_UNROLL
-        for (int k = 0; k < 4; ++k) {
-          // channels past Cin (ragged last block): whatever lies there (the next image, or zeros past the end of the
-          // buffer) is fetched and dropped
-          const int c0 = min(cb + 2 * (4 * wave + k), p.Cin - 1);
-          mfn_dma16_so(xrsrc, ring + k * DCW_XW_F + q * 256, xvoff, (unsigned)((size_t)c0 * plane * 4));
-        }
-      }
-    }
-  };
-
-  unsigned long long tq[6] = {0, 0, 0, 0, 0, 0};
-  const unsigned long long tq0 = MFN_CYCLES();
-  GeoIn gin;
-  geo_load(t0 + wave, gin);
-  geo_store(gin, 0);
-  MFN_LDS_BARRIER();
-  tile_loads(0);
-
-  for (int i = 0; i < ntile; ++i) {
-    const float *g = geom + (((i >> 2) & 1) * 4 + (i & 3)) * DCW_SLOT;
-    const int *gi = reinterpret_cast<const int *>(g);
-    const int *hd = reinterpret_cast<const int *>(g + DCW_GWD * 32);
-    const int n = MFN_UNIFORM(hd[2]);
-    const bool staged = MFN_UNIFORM(hd[3]) != 0;
-    const bool next_group = ((i >> 2) + 1) * 4 < ntile;   // uniform: a group of tiles after this one
-    // everything requested during the previous tile has landed: this tile's gout values and windows (and, every fourth
-    // tile, the next group's offsets)
-    unsigned long long ta = p.timeline ? MFN_CYCLES() : 0ull, tb;
-#define DCW_LAP(k) if (p.timeline) { tb = MFN_CYCLES(); tq[k] += tb - ta; ta = tb; }
-    MFN_WAIT_VM(0);
-    {
-      const int px = tid & 31, osub = tid >> 5;
-      const bool pvx = gi[21 * 32 + px] != 0;
-      MFN_UNROLL
-      for (int k = 0; k < MTOT * 4; ++k) {
-        const float v = (pvx && osub + 8 * k < p.Cout) ? gvn[k] : 0.f;
-        goutT[(osub + 8 * k) * RS + px] = v;
-        bsum[k] += v;
-      }
-    }
-    DCW_LAP(0)
-    if ((i & 3) == 2 && next_group) geo_store(gin, ((i >> 2) + 1) & 1);   // visible after this tile's barriers
-    if (i + 1 < ntile) tile_loads(i + 1);
-    if ((i & 3) == 1 && next_group) geo_load(t0 + ((i >> 2) + 1) * 4 + wave, gin);
-    DCW_LAP(1)
-    // ---- columns of this wave's eight channels -------------------------------------------------------------------------------
-    const bool pv = gi[21 * 32 + j] != 0;
-    if (staged) {
-      float a_y[3], b_y[3], a_x[3], b_x[3];
-      MFN_UNROLL
-      for (int k = 0; k < 3; ++k) {
-        a_y[k] = g[(0 + k) * 32 + j]; b_y[k] = g[(3 + k) * 32 + j]; a_x[k] = g[(6 + k) * 32 + j]; b_x[k] = g[(9 + k) * 32 + j];
-      }
-      int lrow[4], lcol[4];
-      MFN_UNROLL
-      for (int m = 0; m < 4; ++m) { lrow[m] = half * (ROWS * COLS) + gi[(12 + m) * 32 + j]; lcol[m] = gi[(16 + m) * 32 + j]; }
-      const float *ring = xwin + (i & 1) * 4 * DCW_XW_F;
-      MFN_UNROLL
-      for (int k = 0; k < 4; ++k) {
-        const float *xb = ring + k * DCW_XW_F;
-        float v[4][4];
-        MFN_UNROLL
-        for (int m = 0; m < 4; ++m)
-          MFN_UNROLL
-          for (int q = 0; q < 4; ++q) v[m][q] = xb[lrow[m] + lcol[q]];
-        const int cl = 2 * (4 * wave + k) + half;   // channel of this lane inside the block
-        const bool c_ok = cb + cl < p.Cin;
-        float tr[4][3];
-        MFN_UNROLL
-        for (int m = 0; m < 4; ++m)
-          MFN_UNROLL
-          for (int q = 0; q < 3; ++q) tr[m][q] = a_x[q] * v[m][q] + b_x[q] * v[m][q + 1];
-        MFN_UNROLL
-        for (int ii = 0; ii < 3; ++ii)
-          MFN_UNROLL
-          for (int q = 0; q < 3; ++q) {
-            const float cv = a_y[ii] * tr[ii][q] + b_y[ii] * tr[ii + 1][q];
-            colT[((ii * 3 + q) * 32 + cl) * RS + j] = c_ok ? cv : 0.f;
-          }
-      }
-    } else {
-      // per-tap geometry (dc_make_tap) and four global loads per value: arbitrary offsets, irregular floors, windows
-      // that do not fit
-      const int ho = gi[22 * 32 + j], wo = gi[23 * 32 + j];
-      const float *op = p.offset + (size_t)n * 2 * T * plane + (size_t)ho * W + wo;
-      MFN_NOUNROLL
-      for (int k = 0; k < 4; ++k) {
-        const int cl = 2 * (4 * wave + k) + half;
-        const bool c_ok = cb + cl < p.Cin;
-        const float *pl = p.x + ((size_t)n * p.Cin + (c_ok ? cb + cl : 0)) * plane;
-        MFN_NOUNROLL
-        for (int t = 0; t < T; ++t) {
-          const int ti = t / 3, tj = t - 3 * ti;
-          const DcTap tp = dc_make_tap(op[(size_t)(2 * t) * plane], op[(size_t)(2 * t + 1) * plane], ho - p.ph, wo - p.pw, ti, tj, H, W,
-                                       pv && c_ok);
-          const int bb = tp.base & 0x3FFFFFFF, dwi = (tp.base >> 30) & 1;
-          const float cv = tp.w1 * pl[bb] + tp.w2 * pl[bb + dwi] + tp.w3 * pl[bb + tp.dhW] + tp.w4 * pl[bb + tp.dhW + dwi];
-          colT[(t * 32 + cl) * RS + j] = cv;
-        }
-      }
-    }
-    if (p.timeline) MFN_WAIT_LGKM0();
-    DCW_LAP(2)
-    MFN_LDS_BARRIER();
-    DCW_LAP(3)
-    // ---- D[filter][channel] of tap t, filter tile f: accumulator tile u = t + 9 f, every fourth one is this wave's ----------
-    MFN_UNROLL
-    for (int ul = 0; ul < UMAX; ++ul) {
-      const int u = wave + 4 * ul;
-      if (u < UN) {  // uniform
-        const int t = u % 9, f = u / 9;
-        const float4 *bp = reinterpret_cast<const float4 *>(colT + (t * 32 + j) * RS + half * 16);
-        const float4 *ap = reinterpret_cast<const float4 *>(goutT + (f * 32 + j) * RS + half * 16);
-        float4 a4[4], b4[4];
-        MFN_UNROLL
-        for (int q = 0; q < 4; ++q) { a4[q] = ap[q]; b4[q] = bp[q]; }
-        MFN_UNROLL
-        for (int q = 0; q < 4; ++q) {
-          acc[ul] = MFN_MFMA_32x32x2(a4[q].x, b4[q].x, acc[ul]);
-          acc[ul] = MFN_MFMA_32x32x2(a4[q].y, b4[q].y, acc[ul]);
-          acc[ul] = MFN_MFMA_32x32x2(a4[q].z, b4[q].z, acc[ul]);
-          acc[ul] = MFN_MFMA_32x32x2(a4[q].w, b4[q].w, acc[ul]);
-        }
-      }
-    }
-    if (p.timeline) { MFN_OPAQUE(acc[0][0]); MFN_OPAQUE(acc[UMAX - 1][15]); }
-    DCW_LAP(4)
-    MFN_LDS_BARRIER();  // the tiles are free for the next pixel tile
-    DCW_LAP(5)
-#undef DCW_LAP
-  }
-  const unsigned long long tq1 = MFN_CYCLES();
-
-  // ---- bias gradient: row sums of gout over this block's pixels (channel block 0 only) ---------------------------------------
-  if (p.gbias && blockIdx.y == 0) {
-    MFN_UNROLL
-    for (int i = 0; i < MTOT * 4; ++i) {
-      float v = bsum[i];
-      for (int sft = 16; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 32);
-      const int o = (tid >> 5) + 8 * i;
-      if ((tid & 31) == 0 && o < p.Cout) {
-        // (256 blocks adding to the same 32 values with atomics: ~25 k cycles per block, and the slab stores queue behind them)
-        if (p.bias_slabs) p.bias_slabs[(size_t)blockIdx.x * (MTOT * 32) + o] = v;
-        else if (v != 0.f) atomicAdd(p.gbias + o, v);
-      }
-    }
-  }
-  // ---- the sums leave as contiguous (c, t) rows: D reg r of lane (j, half) = filter (r&3)+8*(r>>2)+4*half, channel j ---------
-  float *stg = colT;  // [32 filters][DCW_STG]
-  for (int f = 0; f < MTOT; ++f) {
-    MFN_UNROLL
-    for (int ul = 0; ul < UMAX; ++ul) {
-      const int u = wave + 4 * ul;
-      if (u < UN && u / 9 == f) {  // uniform
-        const int t = u % 9;
-        MFN_UNROLL
-        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * half) * DCW_STG + j * 9 + t] = acc[ul][r];
-      }
-    }
-    MFN_LDS_BARRIER();
-    if (p.slabs) {
-      // this block's slab: plain coalesced stores; dc_bwd_weight_reduce_kernel adds the slabs (256 blocks adding to the
-      // same 32 x 288 values with atomics queue up behind each other: 41 k cycles per block at level 2, measured)
-      float *slab = p.slabs + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * MTOT + f) * (32 * 288);
-      for (int e = tid; e < 32 * 288; e += 256) {
-        const int ol = e / 288, col = e - ol * 288;
-        slab[e] = stg[ol * DCW_STG + col];
-      }
-    } else {
-      for (int e = tid; e < 32 * 288; e += 256) {
-        const int ol = e / 288, col = e - ol * 288;
-        const int o = f * 32 + ol, c = cb + col / 9;
-        const float v = stg[ol * DCW_STG + col];
-        if (o < p.Cout && c < p.Cin && v != 0.f) atomicAdd(p.gw + ((size_t)o * p.Cin + cb) * 9 + col, v);
-      }
-    }
-    MFN_LDS_BARRIER();
-  }
-  if (p.timeline && tid == 0) {
-    unsigned long long *b_ = p.timeline + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
-    b_[0] = (tq[0] & 0xffffffffull) | (tq[1] << 32); b_[1] = (tq[2] & 0xffffffffull) | (tq[3] << 32);
-    b_[2] = (tq[4] & 0xffffffffull) | (tq[5] << 32); b_[3] = ((tq1 - tq0) & 0xffffffffull) | ((MFN_CYCLES() - tq1) << 32);
-  }
-}
-
-// ---- the same with producer and consumer waves (default) ----------------------------------------------------------------------
-// dc_bwd_weight_pix_kernel's waves all produce, then all multiply: per tile 2.6 k cycles of producing (LDS / memory round
+// ---- producer and consumer waves ------------------------------------------------------------------------------------------
+// With four waves that all produce, then all multiply (round 2's first form, removed in round 3): per tile 2.6 k cycles of producing (LDS / memory round
 // trips, little arithmetic) + 3.5 k of MFMA + two barriers.  Here a block is EIGHT waves: waves 0-3 produce the columns of
 // tile i + 1 into one half of a double buffer while waves 4-7 multiply tile i out of the other half; a SIMD holds one wave
 // of each kind, so the producer's round trips run under the consumer's MFMAs.  One barrier per tile.  With the LDS taken by

@@ -179,74 +179,13 @@ __global__ __launch_bounds__(256) void warp_fwd_fast_kernel(WarpParams p, unsign
   for (; c < p.C; ++c) mfn_store1_stream(o + (size_t)c * plane, sample_pairs(xin + (size_t)c * plane, t), p.st_policy);
 }
 
-// PX pixels per thread, `stride` pixels apart (every load / store of a wave still covers 64 adjacent pixels): more
-// bytes in flight per thread in both round trips.  Measured no faster than one pixel per thread on MI355X (the
-// grid of the fast kernel already keeps every CU full), kept behind warp.vec = 2 | 8 for experiments.
-template <int PX>
-__global__ __launch_bounds__(256) void warp_fwd_ilp_kernel(WarpParams p, unsigned total, unsigned stride) {
-  const unsigned W = (unsigned)p.W, H = (unsigned)p.H;
-  const size_t plane = (size_t)H * W;
-  const unsigned idx0 = blockIdx.x * 256u + threadIdx.x;
-  if (idx0 >= stride) return;
-  size_t base[PX];
-  unsigned pix[PX];
-  float fy[PX], fx[PX];
-  bool ok[PX];
-  unsigned xs[PX], ys[PX];
-  MFN_UNROLL
-  for (int k = 0; k < PX; ++k) {
-    const unsigned idx = idx0 + (unsigned)k * stride;
-    ok[k] = idx < total;
-    const unsigned id = ok[k] ? idx : idx0;  // clamped: loads stay unconditional, the store is predicated
-    const unsigned row = id / W, n = row / H;
-    xs[k] = id - row * W;
-    ys[k] = row - n * H;
-    pix[k] = ys[k] * W + xs[k];
-    base[k] = (size_t)n * p.C * plane;
-    const float *fl = p.flow + (size_t)n * 2 * plane + pix[k];
-    fy[k] = fl[0];
-    fx[k] = fl[plane];
-  }
-  Taps t[PX];
-  MFN_UNROLL
-  for (int k = 0; k < PX; ++k) {
-    float gx, gy;
-    warp_grid(fx[k], fy[k], (int)xs[k], (int)ys[k], p.H, p.W, p.clip, gx, gy);
-    t[k] = sampler_taps(gx, gy, p.H, p.W);
-  }
-  for (int c = 0; c < p.C; ++c) {
-    f2u a[PX], b[PX];
-    MFN_UNROLL
-    for (int k = 0; k < PX; ++k) {
-      const float *pl = p.x + base[k] + (size_t)c * plane;
-      a[k] = mfn_load2u(pl + t[k].p0);
-      b[k] = mfn_load2u(pl + t[k].p1);
-    }
-    MFN_UNROLL
-    for (int k = 0; k < PX; ++k)
-      if (ok[k]) p.out[base[k] + (size_t)c * plane + pix[k]] = combine_pairs(a[k], b[k], t[k]);
-  }
-}
-
-inline int warp_fwd_launch(WarpParams p, hipStream_t stream, int vec_pref = 0) {
-  // one pixel per thread keeps the 4 gathers of a wave on adjacent addresses (measured 28 us vs 46 us
-  // for 4 px/thread on 8x3x384x512 with noisy flow); the 4-px form is kept behind warp.vec=4
-  const bool vec4 = vec_pref == 4 && (p.W % 4 == 0) && (((uintptr_t)p.flow | (uintptr_t)p.out) % 16 == 0);
-  const size_t total = (size_t)p.N * p.H * (vec4 ? p.W / 4 : p.W);
+inline int warp_fwd_launch(WarpParams p, hipStream_t stream) {
+  // one pixel per thread keeps the gathers of a wave on adjacent addresses (measured 28 us vs 46 us for 4 px / thread on
+  // 8x3x384x512 with noisy flow; 2 / 4 strided pixels per thread were no faster either: both forms removed in round 3)
+  const size_t total = (size_t)p.N * p.H * p.W;
   if (total == 0) return 0;
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (vec4) return launch("warp_fwd_v4", warp_fwd_kernel<4>, grid, dim3(256), 0, stream, p);
-  // warp.vec: 0 = auto (the fast kernel when its 32-bit indices and 8-byte tap pairs apply), 1 = the general
-  // kernel, 2 | 8 = 2 | 4 strided pixels per thread
-  const bool small = total < ((size_t)1 << 32) - 256 && p.W >= 2;
-  if (small && (vec_pref == 2 || vec_pref == 8)) {
-    const int px = vec_pref == 2 ? 2 : 4;
-    const unsigned stride = (unsigned)((((total + px - 1) / px) + 63) / 64 * 64);
-    const dim3 g((stride + 255) / 256);
-    if (px == 2) return launch("warp_fwd_p2", warp_fwd_ilp_kernel<2>, g, dim3(256), 0, stream, p, (unsigned)total, stride);
-    return launch("warp_fwd_p4", warp_fwd_ilp_kernel<4>, g, dim3(256), 0, stream, p, (unsigned)total, stride);
-  }
-  if (small && vec_pref != 1) {
+  if (total < ((size_t)1 << 32) - 256 && p.W >= 2) {   // the fast kernel's 32-bit indices and 8-byte tap pairs apply
     if (p.C % 4 != 0 && p.C % 3 == 0) return launch("warp_fwd_fast", warp_fwd_fast_kernel<3>, grid, dim3(256), 0, stream, p, (unsigned)total);
     return launch("warp_fwd_fast", warp_fwd_fast_kernel<4>, grid, dim3(256), 0, stream, p, (unsigned)total);
   }

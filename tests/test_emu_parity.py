@@ -17,21 +17,25 @@ def ops():
     return emu_ops.emu_ops()
 
 
+DEFAULT_TUNING = dict(corr_variant=-1, corr_band=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0,
+                      dc_nw=0, dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0)
+
+
 @pytest.fixture(autouse=True)
 def _reset_tuning():
     yield
-    emu_ops.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1,
-                       dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdshared=1, dc_bwdstrips=0, dc_bwdscratch=0, dc_bwdpix=1, dc_bwdwpix=1, dc_bwdwblocks=0, dc_bwdwpc=1, dc_bwdsplit2=0, dc_bwdksplit=0, dc_bwdflow=1, corr_bwdlds=1, corr_bwdsplit=1)
+    emu_ops.set_tuning(**DEFAULT_TUNING)
 
 
-@pytest.mark.parametrize("variant", range(24))
+@pytest.mark.parametrize("variant", [6, 16, 20, 22])
 def test_correlation_variants_md4(ops, oracle, variant):
-    emu_ops.set_tuning(corr_variant=variant)
-    # ragged tiles in both directions: H=10 is not a multiple of any tile height, W=72 > TW=64
-    pc.case_correlation(ops, oracle, ident, ident, (1, 6, 10, 72), 4)
+    """corr.variant: 6 = corr_tiled_kernel (the plan's choice below 32 columns), 16 / 20 / 22 = corr_dma_kernel with one / two /
+    three channel groups.  Ragged tiles in both directions: H = 10 is not a multiple of any tile height, W = 72 / 20."""
+    emu_ops.set_tuning(corr_variant=variant, corr_band=2, corr_direct=2)
+    pc.case_correlation(ops, oracle, ident, ident, (1, 6, 10, 20 if variant == 6 else 72), 4)
 
 
-@pytest.mark.parametrize("variant", [20, 21, 22, 23])
+@pytest.mark.parametrize("variant", [20, 22])
 @pytest.mark.parametrize("C", [20, 48])
 def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     # two / three channel groups per block, ragged last group (20 = 16+4 or 8+8+4), added through LDS in index order
@@ -40,34 +44,34 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 32), 2, seed=2)
 
 
-@pytest.mark.parametrize("tw,shape", [(32, (2, 5, 9, 36)), (16, (1, 9, 18, 20)), (8, (1, 3, 6, 8)), (64, (1, 4, 5, 64))])
+@pytest.mark.parametrize("shape", [(1, 9, 18, 20), (1, 3, 6, 8), (2, 5, 9, 28)])
 @pytest.mark.parametrize("md", [4, 2])
-def test_correlation_tile_widths(ops, oracle, tw, shape, md):
-    emu_ops.set_tuning(corr_tw=tw, corr_variant=1)
+def test_correlation_tile_widths(ops, oracle, shape, md):
+    """Images narrower than 32 columns: corr_tiled_kernel with 16- and 8-column tiles."""
+    emu_ops.set_tuning(corr_band=2, corr_direct=2)
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
 
 
-@pytest.mark.parametrize("variant", [3, 5, 6, 8, 11, 12, 15, 16, 19])
+@pytest.mark.parametrize("variant", [16, 20, 22])
 def test_correlation_md2_variants(ops, oracle, variant):
     emu_ops.set_tuning(corr_variant=variant)
-    pc.case_correlation(ops, oracle, ident, ident, (2, 7, 6, 16), 2)
     pc.case_correlation(ops, oracle, ident, ident, (1, 5, 7, 36), 2, seed=1)
+    pc.case_correlation(ops, oracle, ident, ident, (2, 7, 6, 64), 2)
 
 
 def test_correlation_xcd_swizzle_is_a_permutation(ops, oracle):
-    emu_ops.set_tuning(corr_variant=6, corr_tw=16, corr_xcd=1)
+    emu_ops.set_tuning(corr_band=2, corr_direct=2)
     pc.case_correlation(ops, oracle, ident, ident, (4, 4, 32, 16), 4)  # 8 blocks -> swizzle active
 
 
-@pytest.mark.parametrize("slices,C", [(2, 16), (3, 20), (4, 13), (8, 9)])
-def test_correlation_channel_slices_and_reduce(ops, oracle, slices, C):
-    # partial sums per slice + fixed-order reduce; ragged last slice; slice count clipped to C/4
-    emu_ops.set_tuning(corr_slices=slices, corr_variant=6, corr_tw=16)
+@pytest.mark.parametrize("C", [16, 20, 32, 64])
+def test_correlation_channel_slices_and_reduce(ops, oracle, C):
+    """Few tiles and many channels outside the band / direct kernels' range: partial sums per channel slice + fixed-order
+    reduce kernel; ragged last slice; slice count clipped by the channel count."""
+    emu_ops.set_tuning(corr_band=2, corr_direct=2)
+    assert ops.ns.correlation_workspace_bytes(2, C, 7, 16, 4, 1, 1, 1, 4, 1) > 0
     pc.case_correlation(ops, oracle, ident, ident, (2, C, 7, 16), 4)
-    emu_ops.set_tuning(corr_variant=3)
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 16), 2, seed=3)
-    emu_ops.set_tuning(corr_variant=9, corr_tw=0)
-    pc.case_correlation(ops, oracle, ident, ident, (1, C, 6, 32), 4, seed=4)
 
 
 @pytest.mark.parametrize("shape,md", [((2, 20, 6, 8), 4),      # level-6 like: whole image in one band
@@ -102,20 +106,20 @@ def test_correlation_band_is_the_default_for_coarse_levels(ops, oracle):
     assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) > 0     # sliced + reduce path
 
 
-@pytest.mark.parametrize("tune,shape", [(dict(corr_variant=6, corr_tw=16), (1, 6, 7, 16)),          # tiled kernel
-                                        (dict(corr_variant=15), (1, 8, 6, 36)),                     # LDS-DMA tile kernel
-                                        (dict(corr_variant=6, corr_tw=16, corr_slices=2), (1, 16, 5, 16)),  # reduce kernel
-                                        (dict(corr_band=1), (2, 20, 6, 8)),                         # band kernel
-                                        (dict(corr_generic=1), (1, 3, 6, 7))])                      # generic kernel
+@pytest.mark.parametrize("tune,shape", [(dict(corr_band=2, corr_direct=2), (1, 6, 7, 16)),               # tiled kernel
+                                        (dict(corr_variant=16), (1, 8, 6, 36)),                       # LDS-DMA tile kernel
+                                        (dict(corr_band=2, corr_direct=2), (1, 32, 5, 16)),           # reduce kernel
+                                        (dict(corr_band=1), (2, 20, 6, 8)),                           # band kernel
+                                        (dict(corr_generic=1), (1, 3, 6, 7))])                        # generic kernel
 def test_correlation_fused_leaky_relu(ops, oracle, tune, shape):
     emu_ops.set_tuning(**tune)
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, 4)
 
 
-@pytest.mark.parametrize("tune,shape,c0", [(dict(corr_variant=6, corr_tw=16), (2, 6, 7, 16), 4),          # tiled kernel
-                                           (dict(corr_variant=15), (2, 8, 6, 36), 4),                     # LDS-DMA tile kernel
+@pytest.mark.parametrize("tune,shape,c0", [(dict(corr_band=2, corr_direct=2), (2, 6, 7, 16), 4),            # tiled kernel
+                                           (dict(corr_variant=16), (2, 8, 6, 36), 4),                     # LDS-DMA tile kernel
                                            (dict(corr_variant=22), (2, 12, 6, 32), 8),                    # ... with channel groups
-                                           (dict(corr_variant=6, corr_tw=16, corr_slices=2), (3, 16, 5, 16), 4),  # reduce kernel
+                                           (dict(corr_band=2, corr_direct=2), (3, 32, 5, 16), 4),         # reduce kernel
                                            (dict(corr_band=1), (2, 20, 6, 8), 4),                         # band kernel
                                            (dict(corr_direct=1), (2, 30, 6, 8), 4),                       # direct kernel
                                            (dict(), (2, 5, 6, 8), 3),                                     # slice not 16-byte aligned -> generic
@@ -157,17 +161,6 @@ def test_warp(ops, oracle, shape, clip):
     pc.case_warp(ops, oracle, ident, ident, shape, clip)
 
 
-@pytest.mark.parametrize("vec", [1, 2, 4, 8])
-def test_warp_kernel_forms(ops, oracle, vec):
-    """warp.vec: 1 = general kernel (64-bit indices), 2 / 8 = strided pixels per thread, 4 = 4 adjacent pixels; the
-    default (0) is the fast kernel of test_warp.  1x2x5x7 has a ragged last stride, 3x6x8x12 crosses batch items
-    inside one thread and has a ragged channel group."""
-    emu_ops.set_tuning(warp_vec=vec)
-    for shape in ((1, 2, 5, 7), (3, 6, 8, 12)):
-        pc.case_warp(ops, oracle, ident, ident, shape, False)
-        pc.case_warp(ops, oracle, ident, ident, shape, True)
-
-
 @pytest.mark.parametrize("shape,factor", [((2, 2, 6, 8), 2), ((1, 3, 5, 7), 2), ((1, 2, 4, 6), 4), ((1, 1, 3, 5), 3), ((1, 2, 4, 4), 1)])
 def test_upsample(ops, oracle, shape, factor):
     pc.case_upsample(ops, oracle, ident, ident, shape, factor)
@@ -186,12 +179,12 @@ def test_grid_generator_and_sampler(ops, oracle):
     pc.check_close(ops.BilinearSampler(x, ga), oracle.bilinear_sampler(x, ga), what="sampler affine")
 
 
-@pytest.mark.parametrize("mt,pt,ksb", [(1, 1, 1), (1, 4, 1), (2, 2, 1), (1, 2, 2), (2, 1, 2), (1, 1, 0)])
+@pytest.mark.parametrize("pt,ksb", [(1, 1), (4, 1), (2, 1), (2, 2), (1, 2), (1, 0)])
 @pytest.mark.parametrize("fused", [True, False])
-def test_deform_shared_offsets(ops, oracle, mt, pt, ksb, fused):
+def test_deform_shared_offsets(ops, oracle, pt, ksb, fused):
     # pt pixel tiles per block, 4/pt in-block K slices, ksb cross-block K slices (partials + reduce)
-    emu_ops.set_tuning(dc_mt=mt, dc_pt=pt, dc_ksb=ksb)
-    pc.case_deform_shared(ops, oracle, ident, ident, 1, 64 if mt == 2 else 32, 6, 7, fused=fused)
+    emu_ops.set_tuning(dc_pt=pt, dc_ksb=ksb)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 7, fused=fused)
 
 
 @pytest.mark.parametrize("opt", [dict(), dict(mask=False), dict(tradeoff=False, leaky=False), dict(mask=False, tradeoff=False)])
@@ -206,17 +199,16 @@ def test_deform_matching_epilogue(ops, oracle, opt):
 
 def test_deform_eight_wave_blocks(ops, oracle):
     # 8 waves = 8 in-block K slices of one pixel tile (the coarsest-level plan), even and ragged channel counts
-    emu_ops.set_tuning(dc_nw=8, dc_mt=1, dc_pt=1)
+    emu_ops.set_tuning(dc_nw=8, dc_pt=1)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 64, 4, 8)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 40, 5, 8, seed=2, fused=False)
     pc.case_deform_pertap(ops, oracle, ident, ident, 1, 36, 33, 4, 8, kernel=(3, 3), pad=(1, 1))
 
 
-def test_deform_three_filter_tiles_and_two_mgroups(ops, oracle):
-    emu_ops.set_tuning(dc_mt=3)
-    pc.case_deform_shared(ops, oracle, ident, ident, 1, 96, 4, 5)      # MT=3, one M-group
-    emu_ops.set_tuning(dc_mt=2)
-    pc.case_deform_shared(ops, oracle, ident, ident, 1, 72, 3, 4)      # 3 filter tiles as 2 M-groups of MT=2
+def test_deform_several_filter_groups(ops, oracle):
+    """One 32-filter tile per wave, the filter tiles spread over blockIdx.z: three full groups, and 72 filters = two full + one ragged."""
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 96, 4, 5)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 72, 3, 4)
 
 
 def test_deform_shared_odd_channels_and_padding_of_filters(ops, oracle):
@@ -231,11 +223,9 @@ def test_deform_window_staging_and_per_tap_fallback(ops, oracle, stage):
     pc.case_deform_shared(ops, oracle, ident, ident, 2, 8, 12, 16, seed=3)
 
 
-@pytest.mark.parametrize("tile", [0, 16, 1])
-@pytest.mark.parametrize("hw", [(6, 32), (5, 20), (3, 18), (9, 12)])
-def test_deform_pixel_tile_shapes(ops, oracle, tile, hw):
-    # 2x16 / 4x8 / flattened pixel tiles, full and ragged (partial tiles at the right and bottom edges)
-    emu_ops.set_tuning(dc_tile=tile)
+@pytest.mark.parametrize("hw", [(6, 32), (5, 20), (3, 18), (9, 12), (5, 6)])
+def test_deform_pixel_tile_shapes(ops, oracle, hw):
+    # 4x8 pixel tiles, full and ragged (partial tiles at the right and bottom edges); 32 flattened pixels below 8 columns
     pc.case_deform_shared(ops, oracle, ident, ident, 2, 8, hw[0], hw[1], seed=hw[1])
 
 
@@ -270,7 +260,7 @@ def test_deform_stale_pack_is_refused(ops, oracle):
     w = rng.standard_normal((64, 64, 3, 3)).astype(np.float32)
     with pytest.raises(ValueError, match="laid out for"):        # host-side shape key
         ops.DeformableConvolution(x[:, :, :5], off[:, :, :5], w, None, kernel=(3, 3), pad=(1, 1), no_bias=True, packed=pk)
-    emu_ops.set_tuning(dc_mt=2)                                   # same shape, different tiling: the C ABI refuses
+    emu_ops.set_tuning(dc_pt=4)                                   # same shape, different tiling: the C ABI refuses
     with pytest.raises(Exception, match="do not match this shape/tuning"):
         ops.DeformableConvolution(x, off, w, None, kernel=(3, 3), pad=(1, 1), no_bias=True, packed=pk)
 
@@ -353,59 +343,25 @@ def test_deform_conv_backward_lane_is_pixel_channel_blocks_and_requests(ops, ora
     # one gradient at a time, and accumulation into the caller's buffers
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "outside", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "rough", seed=1, req=("null", "write", "null", "null"))
-    emu_ops.set_tuning(dc_bwdpix=0)   # the lane = channel kernel gives the same gradients
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "smooth", seed=2, req=("write", "write", "null", "null"))
-
-
-@pytest.mark.parametrize("kind", ["smooth", "rough"])
-def test_deform_conv_backward_lane_is_pixel_split_launches(ops, oracle, kind):
-    """dc.bwdsplit2=1: one launch per gradient, the forms with 8-filter weight chunks, three source windows in flight and two
-    sets of 16 planes (two blocks per CU on the GPU; measured slower there, kept as a tested variant); three filter
-    slices (blockIdx.z)."""
-    emu_ops.set_tuning(dc_bwdsplit2=1)
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 12, 9, 16, kind, req=("write", "write", "null", "null"))
-    if kind == "smooth":
-        emu_ops.set_tuning(dc_bwdsplit2=1, dc_bwdksplit=3)
-        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 40, 5, 16, kind, seed=1, req=("write", "write", "null", "null"))
 
 
 @pytest.mark.parametrize("kind", ["smooth", "outside", "mixed"])
 def test_deform_conv_backward_weight_lane_is_pixel(ops, oracle, kind):
-    """dc_bwd_weight_pix_kernel + dc_bwd_weight_reduce_kernel: ragged tiles, staged windows ('smooth'), the per-tap
-    producer ('outside' windows that do not fit, 'mixed' per-tap offsets); then a long tile pipeline (two blocks walk 16
-    tiles each: geometry of the next four tiles one tile ahead, two window sets) and the kernel it replaced."""
+    """dc_bwd_weight_pc_kernel + dc_bwd_weight_reduce_kernel: ragged tiles, regular neighbourhoods ('smooth'), the per-tap
+    producer ('outside', 'mixed' per-tap offsets); ragged channel / filter tiles; more than 96 filters (per-tap MFMA kernel)."""
     req = ("null", "null", "write", "write")
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 11, 20, kind, req=req)
-    emu_ops.set_tuning(dc_bwdwblocks=2)
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 8, 8, 13, 28, kind, seed=1, req=req)
     if kind == "smooth":
-        emu_ops.set_tuning(dc_bwdwblocks=0)
         pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 40, 5, 16, kind, seed=2, req=req)   # ragged channel / filter tiles
-        emu_ops.set_tuning(dc_bwdwpix=2)
         pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 100, 5, 8, kind, seed=4, req=req)   # four filter tiles
-        emu_ops.set_tuning(dc_bwdwpix=1, dc_bwdwpc=0, dc_bwdwblocks=2)   # four waves that produce, then multiply
-        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 8, 8, 9, 24, kind, seed=5, req=req)
-        emu_ops.set_tuning(dc_bwdwpix=0, dc_bwdwpc=1, dc_bwdwblocks=0)
-        pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 11, 20, kind, seed=3, req=req)
-
-
-@pytest.mark.parametrize("kind", ["smooth", "outside", "rough"])
-def test_deform_conv_backward_gx_window_hand_over(ops, oracle, kind):
-    """dc.bwdscratch=1 (measured, not the default): the gx windows go through the workspace and a gather pass adds them;
-    windows that follow a far offset ('outside') and neighbourhoods that leave their window ('rough') keep the atomics."""
-    emu_ops.set_tuning(dc_bwdscratch=1, dc_bwdpix=0)
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 2, 34 if kind == "smooth" else 4, 4, 9, 35, kind,
-                              req=("write", "null", "null", "null"))
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 5, 16, kind, seed=2, req=("write", "null", "null", "null"))
 
 
 def test_deform_conv_backward_shared_offsets_partial_requests_and_switch(ops, oracle):
-    emu_ops.set_tuning(dc_bwdpix=0)   # the lane = channel kernel and its block shapes
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", req=("null", "write", "null", "null"))
-    emu_ops.set_tuning(dc_bwdstrips=4)   # four-strip blocks
-    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 2, 4, 9, 17, "smooth", seed=4, req=("write", "write", "null", "null"))
-    emu_ops.set_tuning(dc_bwdstrips=0, dc_bwdshared=0)   # the tap-by-tap kernel alone gives the same gradients
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 2, 4, 9, 17, "smooth", seed=4, req=("write", "write", "null", "null"))   # W % 4 != 0: tile kernel
+    emu_ops.set_tuning(dc_bwdshared=0)   # the tap-by-tap kernel alone gives the same gradients
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", seed=3, req=("write", "write", "null", "null"))
 
 
@@ -535,16 +491,13 @@ def test_conv_generic_parameter_space(ops, oracle, kw):
 
 
 @pytest.mark.parametrize("pt", [1, 4])
-@pytest.mark.parametrize("shuffle", [1, 0])
-def test_deconv4x4_mfma(ops, oracle, pt, shuffle):
-    """shuffle=1: as a 3x3 convolution with four pseudo-filters per filter (one per output parity) on the input grid;
-    shuffle=0: the masked-tap transposed kernel."""
-    emu_ops.set_tuning(conv_pt=pt, conv_shuffle=shuffle)
-    try:
-        pc.case_deconv(ops, oracle, ident, ident, 2, 9, 16, 5, 8, leaky=True)       # upfeat: Cout = 16, odd Cin
-        pc.case_deconv(ops, oracle, ident, ident, 1, 4, 10, 6, 9, bias=False)       # ragged tiles, filters not a multiple of 8
-    finally:
-        emu_ops.set_tuning(conv_pt=0, conv_shuffle=1)
+def test_deconv4x4_mfma(ops, oracle, pt):
+    """4x4 / stride 2 / pad 1: a 3x3 convolution with four pseudo-filters per filter (one per output parity) on the input grid;
+    other transposed geometries: the generic kernel."""
+    emu_ops.set_tuning(conv_pt=pt)
+    pc.case_deconv(ops, oracle, ident, ident, 2, 9, 16, 5, 8, leaky=True)       # upfeat: Cout = 16, odd Cin
+    pc.case_deconv(ops, oracle, ident, ident, 1, 4, 10, 6, 9, bias=False)       # ragged tiles, filters not a multiple of 8
+    emu_ops.set_tuning(conv_pt=0)
     pc.case_deconv(ops, oracle, ident, ident, 1, 4, 6, 4, 5, kernel=(3, 3), stride=(2, 2), pad=(1, 1), adj=(1, 1))   # generic kernel
 
 

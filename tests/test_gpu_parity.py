@@ -35,7 +35,8 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_tw=0, corr_variant=-1, corr_xcd=1, corr_generic=0, corr_slices=0, corr_band=0, corr_direct=0, warp_vec=0, store_policy=-1, dc_mt=0, dc_pt=0, dc_ksb=0, dc_fast=1, dc_stage=1, dc_generic=0, dc_tile=0, dc_nw=0, dc_bwdscratch=0, dc_bwdflow=1, corr_bwdlds=1)
+    _lib.set_tuning(corr_variant=-1, corr_band=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0,
+                    dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -55,8 +56,9 @@ def test_correlation_md2_cascade_levels(ops, oracle, dev, shape):
     pc.case_correlation(ops, oracle, dev, host, shape, 2)
 
 
-@pytest.mark.parametrize("variant", range(24))
+@pytest.mark.parametrize("variant", [16, 20, 22])
 def test_correlation_every_variant(ops, oracle, dev, variant):
+    """corr_dma_kernel with one / two / three channel groups at shapes the plan would give to another of them."""
     from maskflownet_amd import _lib
     _lib.set_tuning(corr_variant=variant)
     pc.case_correlation(ops, oracle, dev, host, (2, 32, 96, 128), 4)
@@ -79,13 +81,12 @@ def test_correlation_band_kernel_and_sliced_path(ops, oracle, dev, shape, band):
     pc.case_correlation(ops, oracle, dev, host, shape[:1] + (shape[1] // 2,) + shape[2:], 2, seed=5)
 
 
-@pytest.mark.parametrize("slices", [1, 2, 4, 16, 32])
-def test_correlation_channel_slices(ops, oracle, dev, slices):
+def test_correlation_channel_slices_are_deterministic(ops, oracle, dev):
+    """Narrow coarse levels outside the band / direct kernels: channel slices + fixed-order reduce launch."""
     from maskflownet_amd import _lib
-    _lib.set_tuning(corr_slices=slices)
+    _lib.set_tuning(corr_band=2, corr_direct=2)
     pc.case_correlation(ops, oracle, dev, host, (8, 196, 6, 8), 4)
-    pc.case_correlation(ops, oracle, dev, host, (8, 96, 24, 32), 4, seed=1)
-    # deterministic: the slice reduction has a fixed order
+    pc.case_correlation(ops, oracle, dev, host, (8, 128, 12, 16), 4, seed=1)
     import torch
     g = torch.Generator(device="cuda").manual_seed(7)
     f1 = torch.randn(8, 128, 12, 16, device="cuda", generator=g)
@@ -127,10 +128,7 @@ def test_correlation_properties_at_full_size(ops, T):
 
 @pytest.mark.parametrize("shape", [(8, 3, 384, 512), (4, 3, 448, 1024), (2, 16, 40, 52), (1, 3, 37, 53)])
 @pytest.mark.parametrize("clip", [False, True])
-@pytest.mark.parametrize("vec", [0, 1, 2, 4, 8])
-def test_warp(ops, oracle, dev, shape, clip, vec):
-    from maskflownet_amd import _lib
-    _lib.set_tuning(warp_vec=vec)
+def test_warp(ops, oracle, dev, shape, clip):
     pc.case_warp(ops, oracle, dev, host, shape, clip)
 
 
@@ -212,11 +210,10 @@ def test_deform_conv_sintel_level_and_full_model_l6(ops, oracle, dev):
     pc.case_deform_shared(ops, oracle, dev, host, 2, 196, 6, 8, stride=64.0)  # full model deform6, C=196 -> 224 padded
 
 
-@pytest.mark.parametrize("mt,pt,ksb", [(1, 1, 1), (1, 2, 1), (1, 4, 1), (2, 1, 2), (2, 4, 4), (4, 1, 1), (4, 4, 8),
-                                        (3, 2, 1), (4, 1, 0)])
-def test_deform_conv_every_tiling(ops, oracle, dev, mt, pt, ksb):
+@pytest.mark.parametrize("pt,ksb,nw", [(1, 1, 0), (2, 1, 0), (4, 1, 0), (1, 2, 0), (4, 4, 0), (1, 1, 8), (4, 8, 0), (1, 0, 0)])
+def test_deform_conv_every_tiling(ops, oracle, dev, pt, ksb, nw):
     from maskflownet_amd import _lib
-    _lib.set_tuning(dc_mt=mt, dc_pt=pt, dc_ksb=ksb)
+    _lib.set_tuning(dc_pt=pt, dc_ksb=ksb, dc_nw=nw)
     pc.case_deform_shared(ops, oracle, dev, host, 2, 128, 12, 16, stride=32.0)
 
 
@@ -333,18 +330,6 @@ def test_deform_conv_backward_shared_offsets(ops, oracle, dev, kind, N, C, H, W)
     pc.case_deform_bwd_shared(ops, oracle, dev, host, N, C, C if C != 40 else 36, H, W, kind)
 
 
-@pytest.mark.parametrize("kind", ["smooth", "rough", "mixed"])
-def test_deform_conv_backward_shared_offsets_lane_is_channel(ops, oracle, dev, kind):
-    """dc.bwdpix=0: dc_bwd_input_shared_kernel (lane = channel), what the shapes above ran on before dc_backward.h."""
-    from maskflownet_amd import _lib
-    _lib.set_tuning(dc_bwdpix=0)
-    try:
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 96, 96, 24, 32, kind)
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 96, 128, kind)
-    finally:
-        _lib.set_tuning(dc_bwdpix=1)
-
-
 def test_deform_conv_backward_lane_is_pixel_requests_and_accumulation(ops, oracle, dev):
     """dc_bwd_input_pix_kernel with one gradient requested at a time, with ragged channel / filter blocks, at the full
     bench batch of level 4, and adding into the caller's buffers (req 'add')."""
@@ -364,31 +349,17 @@ def test_deform_conv_backward_lane_is_pixel_requests_and_accumulation(ops, oracl
     pc.check_close(host(got[1]), want[1] + base[1], tol=5e-5, what="lane = pixel goffset, req add")
 
 
-@pytest.mark.parametrize("kind", ["smooth", "outside", "rough", "mixed"])
-def test_deform_conv_backward_gx_window_hand_over(ops, oracle, dev, kind):
-    """dc.bwdscratch=1: gx windows handed over through the workspace + gather pass instead of the atomic flush."""
-    from maskflownet_amd import _lib
-    _lib.set_tuning(dc_bwdscratch=1, dc_bwdpix=0)
-    try:
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 64, 64, 48, 64, kind)
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 40, 36, 27, 45, kind, seed=1)
-    finally:
-        _lib.set_tuning(dc_bwdscratch=0, dc_bwdpix=1)
-
-
 def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracle, dev, T):
     from maskflownet_amd import _lib
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth", req=("null", "write", "write", "write"))
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 40, 36, 27, 45, "smooth")   # W % 4 != 0: the tile kernel takes every strip
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "mixed")
     try:
-        for strips in (2, 4):   # both block shapes of the lane = channel kernel, whatever the heuristic would pick
-            _lib.set_tuning(dc_bwdstrips=strips, dc_bwdpix=0)
-            pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 40, 36, 27, 45, "smooth")
-            pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "mixed")
         _lib.set_tuning(dc_bwdshared=0)
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth")
     finally:
-        _lib.set_tuning(dc_bwdshared=1, dc_bwdstrips=0, dc_bwdpix=1)
+        _lib.set_tuning(dc_bwdshared=1)
     # straight through the C ABI with workspace = NULL: tap-by-tap kernel only, same gradients
     rng = np.random.default_rng(1)
     N, C, H, W = 1, 8, 16, 16
@@ -414,37 +385,13 @@ def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracl
 
 @pytest.mark.parametrize("kind", ["smooth", "rough", "mixed"])
 def test_deform_conv_backward_weight_gradient_kernels(ops, oracle, dev, kind):
-    """dc_bwd_weight_pix_kernel (columns produced as the forward kernel does, slabs + deterministic reduce) at a shape with
-    several tiles per block, two channel blocks and three filter tiles; with few blocks (long tile pipelines); and the
-    per-tap kernel it replaced (dc.bwdwpix=0)."""
-    from maskflownet_amd import _lib
+    """dc_bwd_weight_pc_kernel (columns produced as the forward kernel does, slabs + deterministic reduce) at a shape with
+    several tiles per block, two channel blocks and three filter tiles; at one block of channels; and the per-tap kernel
+    that keeps the shapes with more than three filter tiles (level 5)."""
     req = ("null", "null", "write", "write")
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 4, 64, 96, 48, 64, kind, req=req)
-    try:
-        _lib.set_tuning(dc_bwdwblocks=16)
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 32, 32, 48, 64, kind, seed=1, req=req)
-        _lib.set_tuning(dc_bwdwblocks=0, dc_bwdwpix=0)
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 32, 32, 48, 64, kind, seed=1, req=req)
-        _lib.set_tuning(dc_bwdwpix=2)   # four filter tiles per block (by default level 5 keeps the per-tap kernel)
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 128, 128, 12, 16, kind, seed=2, req=req)
-        _lib.set_tuning(dc_bwdwpix=1, dc_bwdwpc=0)   # four waves that produce, then multiply (before the producer / consumer split)
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 64, 64, 48, 64, kind, seed=3, req=req)
-    finally:
-        _lib.set_tuning(dc_bwdwblocks=0, dc_bwdwpix=1, dc_bwdwpc=1)
-
-
-@pytest.mark.parametrize("kind", ["smooth", "outside", "rough"])
-def test_deform_conv_backward_lane_is_pixel_split_launches(ops, oracle, dev, kind):
-    """dc.bwdsplit2=1: one launch per gradient at two blocks per CU (measured slower than the one-launch form, kept as a
-    tested variant); dc.bwdksplit: filter slices over blockIdx.z."""
-    from maskflownet_amd import _lib
-    try:
-        _lib.set_tuning(dc_bwdsplit2=1)
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 64, 64, 48, 64, kind, req=("write", "write", "null", "null"))
-        _lib.set_tuning(dc_bwdsplit2=0, dc_bwdksplit=3)
-        pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 96, 96, 24, 32, kind, seed=1, req=("write", "write", "null", "null"))
-    finally:
-        _lib.set_tuning(dc_bwdsplit2=0, dc_bwdksplit=0)
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 32, 32, 48, 64, kind, seed=1, req=req)
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 128, 128, 12, 16, kind, seed=2, req=req)
 
 
 def test_deform_conv_backward_weight_gradient_is_deterministic(ops, dev):
@@ -616,7 +563,7 @@ def test_layer_packed_weight_cache_follows_the_parameter(oracle, T):
         dc.load_state_dict({"weight": T.from_numpy(pc.msra_weight(rng, C, C)), "bias": T.zeros(C)})
         pc.check_close(host(dc(xt, ot)), ref(), what="after load_state_dict")
         second = dc._pack
-        _lib.set_tuning(dc_mt=1)
+        _lib.set_tuning(dc_pt=1)
         pc.check_close(host(dc(xt, ot)), ref(), what="after set_tuning")
         assert dc._pack is not second
         pc.check_close(host(dc(xt[:, :, :20], ot[:, :, :20])),
