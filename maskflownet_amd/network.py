@@ -1,4 +1,4 @@
-"""MaskFlownet-S forward, end to end on libmfn_hip.so (inference).
+"""MaskFlownet-S and the full MaskFlownet forward, end to end on libmfn_hip.so (inference).
 
 The caller of the hot path: /root/reference/network/MaskFlownet.py:66-315 (`MaskFlownet_S`).  Every layer with
 arithmetic in it is one of this package's HIP operators -- Convolution / Deconvolution, Correlation,
@@ -8,6 +8,11 @@ every densely connected decoder stage writes its output channels straight into t
 stage reads the buffer's channel suffix in place (x = concat(conv(x), x), MaskFlownet.py:219-223, without a concat copy),
 the cost volume, the up-sampled features and the skip features land in that buffer directly, and one forward is a fixed,
 allocation-free launch sequence that can be captured into a hipGraph (capture() / replay()).
+
+`MaskFlownet` (the full model, MaskFlownet.py:318-545) runs the S head and then the cascade in the same launch sequence:
+a second pyramid over (image 1 | zeros) and (warped image 2 | occlusion mask - 0.5), per level a deformable warp by the
+cascade's flow, two md = 2 cost volumes and the decoder; its parameters are keyed 'MaskFlownet_S.<block>' for the head
+and '<block>' for the cascade, as in the reference's checkpoints.
 
 Parameters use the reference's block names ('conv1a', 'conv6_0', 'pred_flow5', 'upfeat4', 'deform3', 'conv2f',
 'dc_conv7', ... with '.weight' / '.bias'); a Gluon checkpoint's structural keys carry an extra sequence index
@@ -30,13 +35,18 @@ CONTEXT = ((128, 1), (128, 2), (128, 4), (96, 8), (64, 16), (32, 1))   # dc_conv
 DEC_SUM = sum(DECODER)                                   # 448 channels a decoder prepends to its input
 
 
+MD_CASCADE = 2                                           # MaskFlownet.py:322
+HEAD = "MaskFlownet_S."                                  # the head's structural key inside the full model, :328
+
+
 def from_reference_keys(params):
-    """{'conv1a.0.weight': ...} (Gluon save_parameters, network/pipeline.py:52-54) -> {'conv1a.weight': ...}."""
+    """{'conv1a.0.weight': ...} (Gluon save_parameters, network/pipeline.py:52-54) -> {'conv1a.weight': ...};
+    'MaskFlownet_S.conv1a.0.weight' -> 'MaskFlownet_S.conv1a.weight'."""
     out = {}
     for k, v in params.items():
         parts = k.split(".")
-        if len(parts) == 3 and parts[1].isdigit():
-            k = parts[0] + "." + parts[2]
+        if len(parts) >= 3 and parts[-2].isdigit():
+            k = ".".join(parts[:-2] + parts[-1:])
         out[k] = v
     return out
 
@@ -70,11 +80,45 @@ def layer_shapes():
     return out
 
 
-def random_params(seed=0, slope=0.1):
+def cascade_input_channels(l):
+    """Channels of the cascade decoder's input at level l: level 6 concat(corr_u, corr_v, flow) (MaskFlownet.py:466);
+    below, concat(c1, upfeat, corr_u, corr_v, flow, head flow) (:480)."""
+    nd = (2 * MD_CASCADE + 1) ** 2
+    return 2 * nd + 2 if l == 6 else PYRAMID[l] + UPFEAT + 2 * nd + 4
+
+
+def layer_shapes_full():
+    """MaskFlownet's parametrised layers (MaskFlownet.py:328-407): the head's 71 under 'MaskFlownet_S.', then the
+    cascade's 18 pyramid convolutions over 4-channel inputs, 5 deformable convolutions (level 6 included), 25 decoder
+    convolutions, 5 flow heads, 4 feature deconvolutions and the 7-layer context network."""
+    out = [(HEAD + n, w, b) for n, w, b in layer_shapes()]
+    cin = 4
+    for l in range(1, 7):
+        for k in "xyz":
+            out.append(("conv%d%s" % (l, k), (PYRAMID[l], cin, 3, 3), (PYRAMID[l],)))
+            cin = PYRAMID[l]
+    for l in (6, 5, 4, 3, 2):
+        c = cascade_input_channels(l)
+        out.append(("deform%d" % l, (PYRAMID[l], PYRAMID[l], 3, 3), (PYRAMID[l],)))
+        for k, ch in enumerate(DECODER):
+            out.append(("conv%d_%d" % (l, k), (ch, c, 3, 3), (ch,)))
+            c += ch
+        out.append(("pred_flow%d" % l, (2, c, 3, 3), (2,)))
+        if l > 2:
+            out.append(("upfeat%d" % (l - 1), (c, UPFEAT, 4, 4), (UPFEAT,)))
+        else:
+            for i, (ch, _) in enumerate(CONTEXT):
+                out.append(("dc_conv%d" % (i + 1), (ch, c, 3, 3), (ch,)))
+                c = ch
+            out.append(("dc_conv7", (2, c, 3, 3), (2,)))
+    return out
+
+
+def random_params(seed=0, slope=0.1, full=False):
     """Seeded MSRAPrelu(factor_type='avg', slope=0.1) weights and zero biases (network/pipeline.py:26) for every layer."""
     rng = np.random.default_rng(seed)
     params = {}
-    for name, ws, bs in layer_shapes():
+    for name, ws, bs in (layer_shapes_full() if full else layer_shapes()):
         hw = ws[2] * ws[3]
         std = np.sqrt(2.0 / (1.0 + slope ** 2) / ((ws[0] * hw + ws[1] * hw) / 2.0))
         params[name + ".weight"] = (rng.standard_normal(ws) * std).astype(np.float32)
@@ -202,14 +246,15 @@ class MaskFlownetS:
         ops.warp(b["im"][N:], b["flow_up0"], clip_grid=False, out=b["warped"])
         t.sigmoid(b["mask_up2"], out=b["occlusion"])                       # :309
 
-    def _dpack(self, l, x):
+    def _dpack(self, l, x, scope="", corr_channels=81):
         C, hw = x.shape[1], x.shape[2] * x.shape[3]
-        self._flops["deform%d" % l] = 2.0 * x.shape[0] * hw * C * C * 9
-        self._flops["corr%d" % l] = 2.0 * x.shape[0] * hw * C * 81
-        key = ("deform%d" % l, tuple(x.shape))
+        name = "%sdeform%d" % (scope, l)
+        self._flops[name] = 2.0 * x.shape[0] * hw * C * C * 9
+        self._flops["%scorr%d" % (scope, l)] = 2.0 * x.shape[0] * hw * C * corr_channels
+        key = (name, tuple(x.shape))
         pk = self._packed.get(key)
         if pk is None:
-            pk = self._packed[key] = self.ops.pack_deform_weights(self.P["deform%d.weight" % l], tuple(x.shape), kernel=(3, 3), pad=(1, 1))
+            pk = self._packed[key] = self.ops.pack_deform_weights(self.P[name + ".weight"], tuple(x.shape), kernel=(3, 3), pad=(1, 1))
         return pk
 
     # ---- running it ------------------------------------------------------------------------------------------------------
@@ -271,3 +316,106 @@ class MaskFlownetS:
                 self.lib.graph_destroy(self.graph)
         except Exception:
             pass
+
+
+CASCADE = "cascade/"      # scope of the cascade's parameters and buffers inside the object (the head keeps the bare names)
+
+
+class MaskFlownet(MaskFlownetS):
+    """The full model (MaskFlownet.hybrid_forward, /root/reference/network/MaskFlownet.py:436-545): `params` holds the head
+    under 'MaskFlownet_S.<block>.weight|bias' and the cascade under '<block>.weight|bias'.  One forward = the head's launch
+    sequence followed by the cascade's, on one stream, capturable as one hipGraph."""
+
+    def __init__(self, params, batch, H, W, device="cuda:0"):
+        head = {k[len(HEAD):]: v for k, v in params.items() if k.startswith(HEAD)}
+        if not head:
+            raise ValueError("MaskFlownet: no 'MaskFlownet_S.*' parameters (is this an S checkpoint? use MaskFlownetS)")
+        super().__init__(head, batch, H, W, device)
+        torch, N = self.torch, self.N
+        with torch.cuda.stream(self.stream):
+            for k, v in params.items():
+                if not k.startswith(HEAD):
+                    self.P[CASCADE + k] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.dev)
+            e = lambda *shape: torch.empty(*shape, device=self.dev)
+            b = self.b
+            b["im4"] = torch.zeros(2 * N, 4, H, W, device=self.dev)     # [:N] = (image 1 | 0), [N:] = (warped image 2 | mask0)
+            b["mask0"] = e(N, 1, H, W)
+            h, w = H, W
+            for l in range(1, 7):
+                h, w = h // 2, w // 2
+                for k in "xyz":
+                    b["d%d%s" % (l, k)] = e(2 * N, PYRAMID[l], h, w)
+            for l in (6, 5, 4, 3, 2):
+                h, w = H // STRIDES[l], W // STRIDES[l]
+                b["y%d" % l] = e(N, DEC_SUM + cascade_input_channels(l), h, w)
+                b["gflow%d" % l] = e(N, 2, h, w)
+                b["gdflow%d" % l] = e(N, 2, h, w)
+                b["gwarp%d" % l] = e(N, PYRAMID[l], h, w)
+                if l < 6:
+                    b["gflow_up%d" % l] = e(N, 2, h, w)
+            h, w = H // 4, W // 4
+            for i, (ch, _) in enumerate(CONTEXT):
+                b["gdc%d" % (i + 1)] = e(N, ch, h, w)
+            b["gdc7"] = e(N, 2, h, w)
+            b["gpred2"] = e(N, 2, h, w)
+            b["gflow_full"] = e(N, 2, H, W)
+        self.stream.synchronize()
+        torch.cuda.synchronize(self.dev)
+
+    def _forward(self):
+        super()._forward()
+        t, b, ops, N = self.torch, self.b, self.ops, self.N
+        nd = (2 * MD_CASCADE + 1) ** 2
+        # c30 = (image 1 | zeros), c40 = (warp(image 2, Upsample(4)(flow2) * scale) | sigmoid(Upsample(4)(mask2)) - 0.5), :309-314
+        im4 = b["im4"]
+        im4[:N, :3].copy_(b["im"][:N])
+        im4[N:, :3].copy_(b["warped"])
+        ops.Upsample(b["mask_up2"], 4, out=b["mask0"])
+        b["mask0"].sigmoid_().sub_(0.5)
+        im4[N:, 3:].copy_(b["mask0"])
+        x = im4
+        for l in range(1, 7):                       # c3* = [:N], c4* = [N:]
+            for k, s in (("x", 2), ("y", 1), ("z", 1)):
+                x = self._conv(CASCADE + "conv%d%s" % (l, k), x, b["d%d%s" % (l, k)], stride=s)
+        for l in (6, 5, 4, 3, 2):
+            C = PYRAMID[l]
+            c1 = b["c%dc" % l][:N]
+            c2 = c1 if l in (2, 3) else b["c%dc" % l][N:]     # c2s = [c21, c12, c13, c24, c25, c26] (:307)
+            c3, c4 = b["d%dz" % l][:N], b["d%dz" % l][N:]
+            yb = b["y%d" % l]
+            if l == 6:
+                flow_in, o = b["flow6"], DEC_SUM              # the head's coarsest flow starts the cascade (:457)
+            else:
+                flow_in, o = b["gflow_up%d" % l], DEC_SUM + C + UPFEAT
+                ops.Upsample(b["gflow%d" % (l + 1)], 2, out=flow_in)
+                yb[:, DEC_SUM:DEC_SUM + C].copy_(c1)
+                yb[:, o + 2 * nd + 2:].copy_(b["flow%d" % l])  # the head's flow at this level
+            ops.deformable_matching(c2, flow_in, SCALE, float(STRIDES[l]), self.P[CASCADE + "deform%d.weight" % l],
+                                    self.P[CASCADE + "deform%d.bias" % l], leaky=True, out=b["gwarp%d" % l],
+                                    packed=self._dpack(l, c2, CASCADE, 2 * nd))
+            ops.Correlation(c1, b["gwarp%d" % l], 1, MD_CASCADE, 1, 1, MD_CASCADE, True, out=yb[:, o:o + nd], activation="leaky")
+            ops.Correlation(c3, c4, 1, MD_CASCADE, 1, 1, MD_CASCADE, True, out=yb[:, o + nd:o + 2 * nd], activation="leaky")
+            yb[:, o + 2 * nd:o + 2 * nd + 2].copy_(flow_in)
+            off = DEC_SUM
+            for k, ch in enumerate(DECODER):
+                self._conv(CASCADE + "conv%d_%d" % (l, k), yb[:, off:], yb[:, off - ch:off])
+                off -= ch
+            self._conv(CASCADE + "pred_flow%d" % l, yb, b["gdflow%d" % l], act=False)
+            t.add(flow_in, b["gdflow%d" % l], out=b["gflow%d" % l])
+            if l > 2:
+                nxt, Cn = b["y%d" % (l - 1)], PYRAMID[l - 1]
+                self._conv(CASCADE + "upfeat%d" % (l - 1), yb, nxt[:, DEC_SUM + Cn:DEC_SUM + Cn + UPFEAT], transposed=True)
+        y = b["y2"]
+        for i, (ch, dil) in enumerate(CONTEXT):
+            y = self._conv(CASCADE + "dc_conv%d" % (i + 1), y, b["gdc%d" % (i + 1)], dilation=dil)
+        self._conv(CASCADE + "dc_conv7", y, b["gdc7"], act=False)
+        b["gflow2"].add_(b["gdc7"])
+        t.mul(b["gflow2"], SCALE, out=b["gpred2"])
+        ops.Upsample(b["gpred2"], 4, out=b["gflow_full"])                  # pipeline.py:136
+
+    def __call__(self, im1, im2):
+        """-> dict(flow_full, predictions [5], visual = flow2[:, :1] (`visuals`, :543), head = the S head's outputs)."""
+        head = super().__call__(im1, im2)
+        b = self.b
+        return {"flow_full": b["gflow_full"], "predictions": [b["gflow%d" % l] * SCALE for l in (6, 5, 4, 3, 2)],
+                "visual": b["gflow2"][:, :1], "head": head}

@@ -64,8 +64,8 @@ class OracleMatching:
     """Correlation / deformable conv / warp / Upsample from the CPU oracle (numpy in, numpy out)."""
     name = "oracle"
 
-    def corr(self, a, b):
-        return oracle.correlation(a, b, kernel_size=1, max_displacement=MD, stride1=1, stride2=1, pad_size=MD)
+    def corr(self, a, b, md=MD):
+        return oracle.correlation(a, b, kernel_size=1, max_displacement=md, stride1=1, stride2=1, pad_size=md)
 
     def deform(self, x, offset, w, b):
         return oracle.deformable_convolution(x, offset, w, b, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(1, 1))
@@ -90,9 +90,9 @@ class HipMatching:
         t = self.torch
         return a.to(self.device) if isinstance(a, t.Tensor) else t.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
-    def corr(self, a, b):
-        return self.ops.Correlation(self._d(a), self._d(b), kernel_size=1, max_displacement=MD, stride1=1, stride2=1,
-                                    pad_size=MD, is_multiply=True)
+    def corr(self, a, b, md=MD):
+        return self.ops.Correlation(self._d(a), self._d(b), kernel_size=1, max_displacement=md, stride1=1, stride2=1,
+                                    pad_size=md, is_multiply=True)
 
     def deform(self, x, offset, w, b):
         return self.ops.DeformableConvolution(self._d(x), self._d(offset), self._d(w), self._d(b), kernel=(3, 3),
@@ -109,11 +109,13 @@ class Net:
     """forward(im1, im2) -> dict(flow_full, predictions[5], occlusion, warped).  `matching` supplies the hot-path
     operators; everything else (convolutions, activations, concat) is torch on `conv_device`."""
 
-    def __init__(self, params, matching, conv_device="cpu"):
+    def __init__(self, params, matching, conv_device="cpu", prefix=""):
         import torch
         self.P, self.M, self.torch = params, matching, torch
         self.dev = torch.device(conv_device)
+        self.prefix = prefix   # "MaskFlownet_S." when this is the head of the full model (Gluon's structural key of the child block)
         self.calls = []   # (operator, shape) of every hot-path call, in order
+        self.srcs = None  # what MaskFlownet_S hands to the cascade (MaskFlownet.py:305-314), kept by forward()
 
     # ---- plumbing between the glue (torch on conv_device) and the matching operators ---------------------------
     def _to_m(self, t):
@@ -124,11 +126,12 @@ class Net:
         return (a if isinstance(a, t.Tensor) else t.from_numpy(np.ascontiguousarray(a))).to(self.dev)
 
     def _w(self, name, shape):
-        return self.torch.from_numpy(self.P.get(name, shape)).to(self.dev)
+        return self.torch.from_numpy(self.P.get(self.prefix + name, shape)).to(self.dev)
 
     # ---- layers (nn.Conv2D / Conv2DTranspose / LeakyReLU(0.1) of the reference's conv(), deconv(), predict_*()) --
     def conv(self, name, x, cout, stride=1, dilation=1, act=True):
         F = self.torch.nn.functional
+        x = x.contiguous()
         w = self._w(name + ".weight", (cout, x.shape[1], 3, 3))
         b = self._w(name + ".bias", (cout,))
         y = F.conv2d(x, w, b, stride=stride, padding=dilation, dilation=dilation)
@@ -149,16 +152,16 @@ class Net:
         return feats
 
     # ---- hot-path operators ------------------------------------------------------------------------------------
-    def corr(self, a, b):
-        self.calls.append(("correlation", tuple(a.shape)))
-        return self._from_m(self.M.corr(self._to_m(a), self._to_m(b)))
+    def corr(self, a, b, md=MD):
+        self.calls.append(("correlation", tuple(a.shape)) if md == MD else ("correlation_md%d" % md, tuple(a.shape)))
+        return self._from_m(self.M.corr(self._to_m(a.contiguous()), self._to_m(b.contiguous()), md))
 
     def deform(self, l, x, flow_l):
         c = x.shape[1]
         # offset = repeat(expand_dims(flow * scale / stride, 1), 9, 1).reshape((0, -3, -2)): one (dy, dx) for all taps
         off = (flow_l * SCALE / STRIDES[l]).unsqueeze(1).repeat(1, 9, 1, 1, 1).reshape(x.shape[0], 18, *x.shape[2:])
-        w = self.P.get("deform%d.weight" % l, (c, c, 3, 3))
-        b = self.P.get("deform%d.bias" % l, (c,))
+        w = self.P.get(self.prefix + "deform%d.weight" % l, (c, c, 3, 3))
+        b = self.P.get(self.prefix + "deform%d.bias" % l, (c,))
         self.calls.append(("deformable_conv", tuple(x.shape)))
         return self._from_m(self.M.deform(self._to_m(x), self._to_m(off.contiguous()), w, b))
 
@@ -205,8 +208,77 @@ class Net:
             flow_full = self.upsample(preds[-1], 4)                       # pipeline.py:136
             self.calls.append(("warp", tuple(im2.shape)))
             warped = self._from_m(self.M.warp(self._to_m(im2), self._to_m((self.upsample(flows[2], 4) * SCALE).contiguous())))
+            # srcs (MaskFlownet.py:305-314).  c2s = [c21, c12, c13, c24, c25, c26]: levels 2 and 3 of the "second image" list
+            # are IMAGE-1 features -- the released full-model weights were trained with that aliasing
+            mask0 = t.sigmoid(self.upsample(mask, 4)) - 0.5
+            self.srcs = {"c1": c1, "c2": {l: (c1[l] if l in (2, 3) else c2[l]) for l in range(1, 7)}, "flows": dict(flows),
+                         "c30": t.cat([im1, t.zeros_like(mask0)], dim=1), "c40": t.cat([warped, mask0], dim=1)}
             return {"flow_full": flow_full.cpu().numpy(), "predictions": [p.cpu().numpy() for p in preds],
                     "occlusion": t.sigmoid(mask).cpu().numpy(), "warped": warped.cpu().numpy()}
+
+
+MD_CASCADE = 2                                 # MaskFlownet.py:322
+PYRAMID_X = "xyz"                              # conv{l}x / y / z: the second (4-channel) pyramid, :332-349
+
+
+class NetFull:
+    """The full MaskFlownet (MaskFlownet.hybrid_forward, /root/reference/network/MaskFlownet.py:436-545): the S head, a second
+    pyramid over (image 1 | zeros) and (warped image 2 | occlusion mask - 0.5), and per level 6..2 a deformable warp of the
+    head's features by the cascade's own flow (LeakyReLU, no gating: :460-461), two md = 2 cost volumes (u: c1 vs the warp,
+    v: the two new pyramids), a densely connected decoder and a flow head; the dilated context network at level 2.
+    Parameters: the head's under 'MaskFlownet_S.<block>', the cascade's under the reference's block names."""
+
+    def __init__(self, params, matching, conv_device="cpu"):
+        self.head = Net(params, matching, conv_device, prefix="MaskFlownet_S.")
+        self.body = Net(params, matching, conv_device, prefix="")     # layer helpers with the cascade's parameter names
+        self.P, self.M, self.torch, self.dev = params, matching, self.head.torch, self.head.dev
+        self.calls = self.body.calls
+
+    def pyramid4(self, x):
+        feats = {}
+        for l in range(1, 7):
+            for k, s_ in zip(PYRAMID_X, (2, 1, 1)):
+                x = self.body.conv("conv%d%s" % (l, k), x, PYRAMID[l], stride=s_)
+            feats[l] = x
+        return feats
+
+    def forward(self, im1, im2):
+        t = self.torch
+        F = t.nn.functional
+        B = self.body
+        with t.no_grad():
+            head_out = self.head.forward(im1, im2)
+            S = self.head.srcs
+            self.calls[:0] = self.head.calls
+            c1, c2 = S["c1"], S["c2"]
+            c3, c4 = self.pyramid4(S["c30"]), self.pyramid4(S["c40"])
+            flows, flow, x = {}, None, None
+            for l in (6, 5, 4, 3, 2):
+                flow = S["flows"][6] if l == 6 else B.upsample(flow, 2)
+                self.calls.append(("deform_source", "c1" if c2[l] is c1[l] else "c2"))
+                warp_u = F.leaky_relu(B.deform(l, c2[l], flow), SLOPE)
+                corr_u = F.leaky_relu(B.corr(c1[l], warp_u, MD_CASCADE), SLOPE)
+                corr_v = F.leaky_relu(B.corr(c3[l], c4[l], MD_CASCADE), SLOPE)
+                if l == 6:
+                    x = t.cat([corr_u, corr_v, flow], dim=1)
+                else:
+                    feat = B.deconv("upfeat%d" % l, x, UPFEAT)
+                    x = t.cat([c1[l], feat, corr_u, corr_v, flow, S["flows"][l]], dim=1)
+                for k, ch in enumerate(DECODER):
+                    x = t.cat([B.conv("conv%d_%d" % (l, k), x, ch), x], dim=1)
+                flow = flow + B.conv("pred_flow%d" % l, x, 2, act=False)
+                flows[l] = flow
+            y = x
+            for i, (ch, dil) in enumerate(CONTEXT[:4]):
+                y = B.conv("dc_conv%d" % (i + 1), y, ch, dilation=dil)
+            for i, (ch, dil) in enumerate(CONTEXT[4:]):
+                y = B.conv("dc_conv%d" % (i + 5), y, ch, dilation=dil)
+            flows[2] = flows[2] + B.conv("dc_conv7", y, 2, act=False)
+            preds = [flows[l] * SCALE for l in (6, 5, 4, 3, 2)]
+            flow_full = B.upsample(preds[-1], 4)                          # pipeline.py:136
+            return {"flow_full": flow_full.cpu().numpy(), "predictions": [p.cpu().numpy() for p in preds],
+                    "visual": flows[2][:, :1].cpu().numpy(),               # `visuals` (:543), what do_batch up-samples as "occ_mask"
+                    "head": head_out}
 
 
 def synthetic_pair(N=1, H=384, W=512, seed=20260925, shift=(3, -5)):

@@ -19,8 +19,8 @@ class _EmuMatching:
         from tests.emu import emu_ops
         self.ops = emu_ops.emu_ops()
 
-    def corr(self, a, b):
-        return self.ops.Correlation(a, b, kernel_size=1, max_displacement=4, stride1=1, stride2=1, pad_size=4)
+    def corr(self, a, b, md=4):
+        return self.ops.Correlation(a, b, kernel_size=1, max_displacement=md, stride1=1, stride2=1, pad_size=md)
 
     def deform(self, x, offset, w, b):
         return self.ops.DeformableConvolution(x, offset, w, b, kernel=(3, 3), pad=(1, 1), num_filter=w.shape[0])
@@ -72,6 +72,47 @@ def test_emulated_kernels_through_the_network():
     assert d["epe_delta_rel"] <= 1e-4, d
 
 
+def test_full_model_harness_has_the_references_structure():
+    """MaskFlownet (the full model, MaskFlownet.py:318-545): head + cascade.  The cascade warps c2s = [.., c12, c13, ..]:
+    IMAGE-1 features at levels 3 and 2 (:307), runs two md = 2 cost volumes per level and has its own deform6."""
+    from maskflownet_amd import network
+    im1, im2 = nr.synthetic_pair(1, 64, 128, seed=3)
+    P = nr.Params(seed=0)
+    net = nr.NetFull(P, nr.OracleMatching(), "cpu")
+    out = net.forward(im1, im2)
+    shapes = network.layer_shapes_full()
+    assert len(shapes) == 71 + 18 + 5 + 25 + 5 + 4 + 7 and len(P.store) == 2 * len(shapes)
+    assert {n + ".weight": w for n, w, _ in shapes} == {k: v.shape for k, v in P.store.items() if k.endswith(".weight")}
+    assert P.count() == sum(int(np.prod(w)) + int(np.prod(b)) for _, w, b in shapes) == 20655716
+    assert sum(1 for n, _, _ in shapes if n.startswith("MaskFlownet_S.")) == 71
+    ops_called = [c[0] for c in net.calls if c[0] != "deform_source"]
+    assert ops_called == ["correlation"] + ["deformable_conv", "correlation"] * 4 + ["warp"] + ["deformable_conv", "correlation_md2", "correlation_md2"] * 5
+    assert [c[1] for c in net.calls if c[0] == "deform_source"] == ["c2", "c2", "c2", "c1", "c1"]
+    assert [c[1][1] for c in net.calls if c[0] == "correlation_md2"] == [196, 196, 128, 128, 96, 96, 64, 64, 32, 32]
+    assert out["flow_full"].shape == (1, 2, 64, 128) and [p.shape[2] for p in out["predictions"]] == [1, 2, 4, 8, 16]
+    assert out["visual"].shape == (1, 1, 16, 32)
+    assert all(np.isfinite(v).all() for v in [out["flow_full"]] + out["predictions"])
+    # the head inside the full model is the S network: same seeds under the prefixed names give another draw, so compare
+    # against an S harness fed the head's own parameters
+    Ps = nr.Params(seed=0)
+    Ps.store = {k[len("MaskFlownet_S."):]: v for k, v in P.store.items() if k.startswith("MaskFlownet_S.")}
+    s_only = nr.Net(Ps, nr.OracleMatching(), "cpu").forward(im1, im2)
+    np.testing.assert_array_equal(s_only["flow_full"], out["head"]["flow_full"])
+    assert nr.epe_delta(out, out["head"])["epe_delta_rel"] > 1e-3          # the cascade does change the flow
+    rp = network.random_params(seed=3, full=True)
+    assert set(rp) == set(P.store) and all(rp[k].shape == P.store[k].shape for k in rp)
+    assert network.from_reference_keys({"MaskFlownet_S.conv1a.0.weight": 1, "conv1x.0.bias": 2, "deform6.weight": 3}) == \
+        {"MaskFlownet_S.conv1a.weight": 1, "conv1x.bias": 2, "deform6.weight": 3}
+
+
+def test_emulated_kernels_through_the_full_network():
+    im1, im2 = nr.synthetic_pair(1, 64, 64, seed=4)
+    ref = nr.NetFull(nr.Params(seed=2), nr.OracleMatching(), "cpu").forward(im1, im2)
+    got = nr.NetFull(nr.Params(seed=2), _EmuMatching(), "cpu").forward(im1, im2)
+    d = nr.epe_delta(got, ref)
+    assert d["epe_delta_rel"] <= 1e-4, d
+
+
 @pytest.mark.gpu
 def test_gpu_network_epe_delta_vs_cpu_reference():
     """(i) ops only: both runs use the same torch-ROCm convolutions, the hot path comes from libmfn_hip.so vs the
@@ -116,3 +157,33 @@ def test_gpu_network_end_to_end_on_hip_kernels():
     again = net(im1, im2)
     assert torch.equal(again["flow_full"], out["flow_full"])             # the graph replays the same launches
     assert net.flops() > 7.5e10 * 2                                       # ~40 GFLOP per pair
+
+
+@pytest.mark.gpu
+def test_gpu_full_network_end_to_end_on_hip_kernels():
+    """maskflownet_amd.network.MaskFlownet: the full model (head + cascade: 135 parametrised layers, 15 deformable /
+    cost-volume calls on top of the head's ten) on libmfn_hip.so, eager and as one hipGraph, against the CPU reference
+    path; and the hot path only (torch-ROCm convolutions both sides) through the harness."""
+    import torch
+    from maskflownet_amd import network
+    im1, im2 = nr.synthetic_pair(1, 384, 512)
+    P = nr.Params(seed=11)
+    cpu = nr.NetFull(P, nr.OracleMatching(), "cpu").forward(im1, im2)
+    hip = nr.NetFull(nr.Params(seed=11), nr.HipMatching("cuda:0"), "cuda:0").forward(im1, im2)
+    d_ops = nr.epe_delta(hip, cpu)
+    net = network.MaskFlownet(P.store, 1, 384, 512)
+    out = net(im1, im2)
+    got = {"flow_full": out["flow_full"].cpu().numpy(), "predictions": [p.cpu().numpy() for p in out["predictions"]]}
+    d = nr.epe_delta(got, cpu)
+    print("full model: harness (HIP hot path) vs CPU reference path %r; end-to-end HIP network %r" % (d_ops, d))
+    assert d_ops["epe_delta_rel"] <= 1e-4, d_ops
+    assert d["epe_delta_rel"] <= 1e-4, d
+    for a, b in zip(got["predictions"], cpu["predictions"]):
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
+    assert np.abs(out["visual"].cpu().numpy() - cpu["visual"]).max() <= 2e-4 * np.abs(cpu["visual"]).max()
+    np.testing.assert_allclose(out["head"]["flow_full"].cpu().numpy(), cpu["head"]["flow_full"],
+                               atol=2e-4 * np.abs(cpu["head"]["flow_full"]).max())
+    net.capture()
+    again = net(im1, im2)
+    assert torch.equal(again["flow_full"], out["flow_full"])
+    assert net.flops() > 1.2 * 4.0e10
