@@ -449,11 +449,15 @@ def network_epe_delta(H, W, device):
             "seconds": round(time.perf_counter() - t0, 1)}
 
 
-def end_to_end(N, H, W, device, torch, steps=30):
+def end_to_end(N, H, W, device, torch, steps=30, full=False):
     """Informational: the whole MaskFlownet-S forward (71 convolutions / deconvolutions + the hot path) on libmfn_hip.so
-    as one hipGraph -- maskflownet_amd/network.py; seeded MSRAPrelu weights, random images."""
+    as one hipGraph -- maskflownet_amd/network.py; seeded MSRAPrelu weights, random images.  full=True: the full
+    MaskFlownet (head + cascade, 135 layers, MaskFlownet.py:318-545)."""
     from maskflownet_amd import network
-    net = network.MaskFlownetS(network.random_params(seed=1), N, H, W, device=device)
+    if full:
+        net = network.MaskFlownet(network.random_params(seed=1, full=True), N, H, W, device=device)
+    else:
+        net = network.MaskFlownetS(network.random_params(seed=1), N, H, W, device=device)
     g = torch.Generator(device="cpu").manual_seed(3)
     net.set_input(torch.rand(N, 3, H, W, generator=g) - 0.5, torch.rand(N, 3, H, W, generator=g) - 0.5)
     net.capture()
@@ -465,7 +469,13 @@ def end_to_end(N, H, W, device, torch, steps=30):
         net.replay()
     net.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    ok = bool(torch.isfinite(net.b["flow_full"]).all().item())
+    ok = bool(torch.isfinite(net.b["gflow_full" if full else "flow_full"]).all().item())
+    if full:
+        return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_forward": round(dt * 1e3, 3), "batch": N,
+                "GFLOP_per_forward": round(net.flops() / 1e9, 1), "achieved_TFLOPs": round(net.flops() / dt / 1e12, 1),
+                "frac_of_fp32_peak": round(net.flops() / dt / 1e12 / FP32_PEAK_TFLOPS, 3), "finite": ok,
+                "what": "full MaskFlownet forward %dx%d (S head + cascade: second pyramid, 5 deformable warps, 10 md=2 cost "
+                        "volumes, decoders, context), every layer a libmfn_hip.so kernel, fp32, one hipGraph replay" % (H, W)}
     return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_forward": round(dt * 1e3, 3), "batch": N,
             "GFLOP_per_forward": round(net.flops() / 1e9, 1), "achieved_TFLOPs": round(net.flops() / dt / 1e12, 1),
             "frac_of_fp32_peak": round(net.flops() / dt / 1e12 / FP32_PEAK_TFLOPS, 3), "finite": ok,
@@ -668,6 +678,10 @@ def main():
             res["e2e"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch)
         except Exception as e:
             res["e2e"] = {"error": repr(e)}
+        try:
+            res["e2e_full"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch, full=True)
+        except Exception as e:
+            res["e2e_full"] = {"error": repr(e)}
     if gpu and world == 1 and not args.no_epe and wl.kind != "train":
         try:
             res["epe"] = network_epe_delta(wl.H, wl.W, "cuda:%d" % torch.cuda.current_device())

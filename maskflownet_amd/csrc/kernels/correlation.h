@@ -371,16 +371,36 @@ template <int D, int CK, int F1_PER_C, int F2_PER_C, bool DBUF = true>
 __device__ __forceinline__ void corr_hw_consume(const float *f1p, const float *f2p, f32x2 (&accp)[D - 1][2],
                                                 float (&accs)[4]) {
   constexpr int MD = (D - 1) / 2, OFF = 4 - MD;
+  // one channel: pairs {out(d,2h+1), out(d+1,2h)} += {a[2h+1], a[2h]} * b[2h+1+d+OFF]; the four corner products stay scalar
+  auto channel = [&](f32x4v a, f32x4v b0, f32x4v b1, f32x4v b2) {
+    const f32x2 ap[2] = {mfn_lo2(a), mfn_hi2(a)};
+    const f32x2 bp[6] = {mfn_lo2(b0), mfn_hi2(b0), mfn_lo2(b1), mfn_hi2(b1), mfn_lo2(b2), mfn_hi2(b2)};
+    const float av[4] = {a.x, a.y, a.z, a.w};
+    const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+    mfn_fmac_inorder(accs[0], av[0], bv[0 + OFF]);   // operands in read order: b0 first, b2 last
+    mfn_fmac_inorder(accs[1], av[2], bv[2 + OFF]);
+    MFN_UNROLL
+    for (int d = 0; d < D - 1; ++d)
+      MFN_UNROLL
+      for (int h = 0; h < 2; ++h) {
+        const int i = 2 * h + 1 + d + OFF;
+        if (i & 1) mfn_pk_fma_swbc<true>(accp[d][h], ap[h], bp[i >> 1]);
+        else mfn_pk_fma_swbc<false>(accp[d][h], ap[h], bp[i >> 1]);
+      }
+    mfn_fmac_inorder(accs[2], av[1], bv[1 + (D - 1) + OFF]);
+    mfn_fmac_inorder(accs[3], av[3], bv[3 + (D - 1) + OFF]);
+  };
   if (!DBUF) {  // single operand set: ~16 fewer VGPRs (one more resident block per CU); LDS latency is hidden by TLP
     MFN_UNROLL
     for (int c = 0; c < CK; ++c) {
 #if MFN_CORR_ABLATE & 1  // measurement build: operands without LDS traffic (loop-carried, so nothing folds)
-      const float4 a = make_float4(accs[0], accs[1], accs[2], accs[3]), b0 = a, b1 = a, b2 = a;
+      f32x4v a; a.x = accs[0]; a.y = accs[1]; a.z = accs[2]; a.w = accs[3];
+      const f32x4v b0 = a, b1 = a, b2 = a;
 #else
-      const float4 a = *reinterpret_cast<const float4 *>(f1p + c * F1_PER_C);
-      const float4 b0 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C);
-      const float4 b1 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C + 4);
-      const float4 b2 = *reinterpret_cast<const float4 *>(f2p + c * F2_PER_C + 8);
+      const f32x4v a = mfn_lds_read4(f1p + c * F1_PER_C);
+      const f32x4v b0 = mfn_lds_read4(f2p + c * F2_PER_C);
+      const f32x4v b1 = mfn_lds_read4(f2p + c * F2_PER_C + 4);
+      const f32x4v b2 = mfn_lds_read4(f2p + c * F2_PER_C + 8);
 #endif
 #if MFN_CORR_ABLATE & 2  // measurement build: the four reads stay live, the 36 FMAs are gone
       accs[0] += a.x + b0.x;
@@ -388,51 +408,25 @@ __device__ __forceinline__ void corr_hw_consume(const float *f1p, const float *f
       MFN_SCHED_BARRIER();
       continue;
 #endif
-      const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-      const f32x2 asw[2] = {mfn_f2(a.y, a.x), mfn_f2(a.w, a.z)};
-      MFN_UNROLL
-      for (int d = 0; d < D - 1; ++d)
-        MFN_UNROLL
-        for (int h = 0; h < 2; ++h) {
-          const float bb = bv[2 * h + 1 + d + OFF];
-          accp[d][h] = mfn_fma2(asw[h], mfn_f2(bb, bb), accp[d][h]);
-        }
-      accs[0] = fmaf(a.x, bv[0 + OFF], accs[0]);
-      accs[1] = fmaf(a.z, bv[2 + OFF], accs[1]);
-      accs[2] = fmaf(a.y, bv[1 + (D - 1) + OFF], accs[2]);
-      accs[3] = fmaf(a.w, bv[3 + (D - 1) + OFF], accs[3]);
+      channel(a, b0, b1, b2);
       MFN_SCHED_BARRIER();
     }
     return;
   }
-  float4 A[2], B[2][3];
-  A[0] = *reinterpret_cast<const float4 *>(f1p);
-  B[0][0] = *reinterpret_cast<const float4 *>(f2p);
-  B[0][1] = *reinterpret_cast<const float4 *>(f2p + 4);
-  B[0][2] = *reinterpret_cast<const float4 *>(f2p + 8);
+  f32x4v A[2], B[2][3];
+  A[0] = mfn_lds_read4(f1p);
+  B[0][0] = mfn_lds_read4(f2p);
+  B[0][1] = mfn_lds_read4(f2p + 4);
+  B[0][2] = mfn_lds_read4(f2p + 8);
   MFN_UNROLL
   for (int c = 0; c < CK; ++c) {
     if (c + 1 < CK) {
-      A[(c + 1) & 1] = *reinterpret_cast<const float4 *>(f1p + (c + 1) * F1_PER_C);
-      B[(c + 1) & 1][0] = *reinterpret_cast<const float4 *>(f2p + (c + 1) * F2_PER_C);
-      B[(c + 1) & 1][1] = *reinterpret_cast<const float4 *>(f2p + (c + 1) * F2_PER_C + 4);
-      B[(c + 1) & 1][2] = *reinterpret_cast<const float4 *>(f2p + (c + 1) * F2_PER_C + 8);
+      A[(c + 1) & 1] = mfn_lds_read4(f1p + (c + 1) * F1_PER_C);
+      B[(c + 1) & 1][0] = mfn_lds_read4(f2p + (c + 1) * F2_PER_C);
+      B[(c + 1) & 1][1] = mfn_lds_read4(f2p + (c + 1) * F2_PER_C + 4);
+      B[(c + 1) & 1][2] = mfn_lds_read4(f2p + (c + 1) * F2_PER_C + 8);
     }
-    const float4 a = A[c & 1];
-    const float4 b0 = B[c & 1][0], b1 = B[c & 1][1], b2 = B[c & 1][2];
-    const float bv[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
-    const f32x2 asw[2] = {mfn_f2(a.y, a.x), mfn_f2(a.w, a.z)};
-    MFN_UNROLL
-    for (int d = 0; d < D - 1; ++d)
-      MFN_UNROLL
-      for (int h = 0; h < 2; ++h) {
-        const float bb = bv[2 * h + 1 + d + OFF];
-        accp[d][h] = mfn_fma2(asw[h], mfn_f2(bb, bb), accp[d][h]);
-      }
-    accs[0] = fmaf(a.x, bv[0 + OFF], accs[0]);
-    accs[1] = fmaf(a.z, bv[2 + OFF], accs[1]);
-    accs[2] = fmaf(a.y, bv[1 + (D - 1) + OFF], accs[2]);
-    accs[3] = fmaf(a.w, bv[3 + (D - 1) + OFF], accs[3]);
+    channel(A[c & 1], B[c & 1][0], B[c & 1][1], B[c & 1][2]);
     MFN_SCHED_BARRIER();
   }
 }
@@ -618,14 +612,29 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
   // a branch per element (the epilogue, like the prologue, runs on every wave of the CU at the same time)
   if (live && y < H && x < W && !(MFN_CORR_ABLATE_MASK & 1)) {
     float *dst = outn + (size_t)(dyi * D) * plane + (size_t)y * W + x;
-    auto emit = [&](auto div_c, auto leaky_c) {
+    // POL: the store policy as a constant for the two the plans use (2 = written through for >= 4 MB outputs, 0 = plain);
+    // -1 = whatever the store.policy key asked for, decided per store
+    auto emit = [&](auto div_c, auto leaky_c, auto pol_c) {
       constexpr bool DIV = decltype(div_c)::value, LEAKY = decltype(leaky_c)::value;
+      constexpr int POL = decltype(pol_c)::value;
       if (!DIV) {  // packed multiplies on the accumulator pairs
         const f32x2 s2 = mfn_f2(scale, scale);
         MFN_UNROLL
         for (int d = 0; d < D - 1; ++d) { accp[d][0] = mfn_mul2(accp[d][0], s2); accp[d][1] = mfn_mul2(accp[d][1], s2); }
         MFN_UNROLL
         for (int q = 0; q < 4; ++q) accs[q] *= scale;
+        if (LEAKY) {  // LeakyReLU(0.1)(r) = max(r, 0.1 r): the products packed as well
+          const f32x2 k2 = mfn_f2(0.1f, 0.1f);
+          MFN_UNROLL
+          for (int d = 0; d < D - 1; ++d)
+            MFN_UNROLL
+            for (int h = 0; h < 2; ++h) {
+              const f32x2 t = mfn_mul2(accp[d][h], k2);
+              accp[d][h] = mfn_f2(fmaxf(accp[d][h].x, t.x), fmaxf(accp[d][h].y, t.y));
+            }
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q) accs[q] = fmaxf(accs[q], 0.1f * accs[q]);
+        }
       }
       MFN_UNROLL
       for (int d = 0; d < D; ++d) {
@@ -633,15 +642,20 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
         MFN_UNROLL
         for (int q = 0; q < 4; ++q) {
           const float r = DIV ? ACC1(d, q) / p.sumelems : ACC1(d, q);
-          v[q] = LEAKY ? fmaxf(r, 0.1f * r) : r;
+          v[q] = (DIV && LEAKY) ? fmaxf(r, 0.1f * r) : r;
         }
-        mfn_store4_stream(dst + (size_t)d * plane, v[0], v[1], v[2], v[3], p.nt_store);
+        mfn_store4_stream(dst + (size_t)d * plane, v[0], v[1], v[2], v[3], POL < 0 ? p.nt_store : POL);
       }
     };
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
-    if (use_div) { if (leaky) emit(T_{}, T_{}); else emit(T_{}, F_{}); }
-    else { if (leaky) emit(F_{}, T_{}); else emit(F_{}, F_{}); }
+    auto emit_pol = [&](auto pol_c) {
+      if (use_div) { if (leaky) emit(T_{}, T_{}, pol_c); else emit(T_{}, F_{}, pol_c); }
+      else { if (leaky) emit(F_{}, T_{}, pol_c); else emit(F_{}, F_{}, pol_c); }
+    };
+    if (p.nt_store == 2) emit_pol(std::integral_constant<int, 2>{});
+    else if (p.nt_store == 0) emit_pol(std::integral_constant<int, 0>{});
+    else emit_pol(std::integral_constant<int, -1>{});
   }
   MFN_STAMP(p.timeline, 3);
 #undef ACC1

@@ -22,6 +22,16 @@ static inline f2u mfn_load2u(const float *p) { f2u v; memcpy(&v, p, 8); return v
 struct f32x2 { float x, y; };
 static inline f32x2 mfn_f2(float x, float y) { return f32x2{x, y}; }
 static inline f32x2 mfn_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+// acc = {a.y, a.x} * b[HI] + acc (see the device definition)
+template <bool HI> static inline void mfn_pk_fma_swbc(f32x2 &acc, f32x2 a, f32x2 b) {
+  const float bb = HI ? b.y : b.x;
+  acc = f32x2{fmaf(a.y, bb, acc.x), fmaf(a.x, bb, acc.y)};
+}
+static inline void mfn_fmac_inorder(float &acc, float a, float b) { acc = fmaf(a, b, acc); }
+struct f32x4v { float x, y, z, w; };
+static inline f32x4v mfn_lds_read4(const float *p) { return f32x4v{p[0], p[1], p[2], p[3]}; }
+static inline f32x2 mfn_lo2(f32x4v v) { return f32x2{v.x, v.y}; }
+static inline f32x2 mfn_hi2(f32x4v v) { return f32x2{v.z, v.w}; }
 static inline f32x2 mfn_mul2(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
 #define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_shared())
 #define MFN_MFMA_32x32x2(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
@@ -100,6 +110,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 mfn_f2(float x, float y) { return (f32x2){x, y}; }
 #define mfn_fma2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
 #define mfn_mul2(a, b) ((a) * (b))
+// acc = {a.y, a.x} * b[HI] + acc as ONE v_pk_fma_f32 with the swizzles spelled out in op_sel / op_sel_hi.  hipcc folds most
+// but not all of them from the generic form (the cost volume's channel loop kept 4 v_mov_b32 per 20 FMA instructions); a and b
+// are the aligned halves of a ds_read_b128 result, so nothing has to move.
+template <bool HI> __device__ __forceinline__ void mfn_pk_fma_swbc(f32x2 &acc, f32x2 a, f32x2 b) {
+  if (HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+// a scalar FMA that stays where it is written among the packed ones (the scheduler otherwise hoists it above them and with it
+// the wait for the LAST operand read)
+__device__ __forceinline__ void mfn_fmac_inorder(float &acc, float a, float b) { asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b)); }
+typedef f32x4 f32x4v;
+__device__ __forceinline__ f32x4v mfn_lds_read4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x2 mfn_lo2(f32x4v v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 mfn_hi2(f32x4v v) { return __builtin_shufflevector(v, v, 2, 3); }
 // all dynamic LDS hangs off ONE 16-byte aligned symbol (cdna_hip_programming.md G17)
 extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
 #define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(mfn_lds_raw)
@@ -261,9 +285,12 @@ __device__ __forceinline__ void mfn_store4_stream(float *dst, float a, float b, 
 #else
   typedef float mfn_v4f __attribute__((ext_vector_type(4)));
   const mfn_v4f v = {a, b, c, d};
-  if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-  else if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
-  else if (policy == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(v) : "memory");
+  // s_nop 1: a store of more than 64 bits reads its data registers after issue, and gfx940+ wants 2 wait states before a VALU
+  // instruction overwrites them; the compiler's hazard recognizer does not look inside an asm statement (seen: straight-line
+  // epilogues re-filling the same four registers for the next store -> ~1 % wrong elements)
+  if (policy == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+  else if (policy == 1) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+  else if (policy == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
   else *reinterpret_cast<mfn_v4f *>(dst) = v;
 #endif
 }

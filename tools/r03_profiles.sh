@@ -1,0 +1,29 @@
+#!/bin/bash
+# Profile session: rocprofv3 kernel stats of the bench command, HBM traffic passes and SQ counter sets of the level-2
+# correlation, kernel stats of the training-step pass; summaries are turned into profiles/ by tools/make_profiles.py <tag>.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+G=gpurun_out
+rm -rf $G/prof_bench $G/prof_cfg5 $G/pmc_FETCH_SIZE $G/pmc_WRITE_SIZE
+mkdir -p $G/r03p
+python bench.py > $G/bench.log 2> $G/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $G/prof_bench -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe > $G/r03p/prof_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $G/prof_cfg5 -o cfg5 -- python bench.py --config cfg5 --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-e2e > $G/r03p/prof_cfg5.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --pmc $c --kernel-trace -d $G/pmc_$c -o r -- python tools/prof_one.py corr 2 > $G/r03p/pmc_$c.log 2>&1
+done
+i=0
+: > $G/r03p/corr_pmc.txt
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
+           "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAVES" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+  i=$((i+1))
+  rm -rf $G/r03p/pmc_$i
+  timeout 200 rocprofv3 --pmc $set --kernel-trace -d $G/r03p/pmc_$i -o r -- python tools/prof_one.py corr 2 > $G/r03p/pmc_$i.log 2>&1
+  echo "set $i: $set" >> $G/r03p/corr_pmc.txt
+  python tools/pmc_read.py $G/r03p/pmc_$i/r_results.db 2>&1 | grep -v "^==" >> $G/r03p/corr_pmc.txt
+  rm -rf $G/r03p/pmc_$i
+done
+tail -30 $G/r03p/corr_pmc.txt
+ls -la $G/prof_bench $G/prof_cfg5 | head
