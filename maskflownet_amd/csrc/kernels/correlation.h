@@ -353,8 +353,8 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
 // The one point of (NCH, CK, DYW, PF, WPE) that is still built: one displacement row per wave, one 4-px chunk per lane,
 // 4-channel stages, no register prefetch, >= 4 waves per SIMD -- the kernel of images narrower than 32 columns
 // (corr.variant 6).  Rounds 1 / 2 swept eight points and a half-wave form (corr_hw_kernel); none of them is selected by a plan.
-constexpr int kCorrVariants = 23;  // valid values of corr.variant: 6 (corr_tiled_kernel), 16 / 20 / 22 (corr_dma_kernel: 1 / 2 / 3 channel groups)
-inline bool corr_variant_known(int v) { return v == 6 || v == 16 || v == 20 || v == 22; }
+constexpr int kCorrVariants = 32;  // valid values of corr.variant: 6 (corr_tiled_kernel), 16 / 20 / 22 / 26 / 31 (corr_dma_kernel)
+inline bool corr_variant_known(int v) { return v == 6 || v == 16 || v == 20 || v == 22 || v == 26 || v == 31; }
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int /*variant*/, hipStream_t s) {
   return corr_tiled_launch<D, TW, 1, 4, 1, false, 4>(p, s, "corr_tiled_v6");
@@ -447,13 +447,17 @@ __device__ __forceinline__ void corr_hw_consume(const float *f1p, const float *f
 //   * G > 1: G channel groups inside the block (each its own ring over 1/G of the channels), accumulators added
 //     through LDS at the end -- for levels whose tile count leaves CUs idle (level 3: 192 tiles), no workspace and
 //     no second launch.
-template <int D, int CK, int NS, int WPE, bool DBUF, int G = 1>
-__global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(CorrParams p) {
+//   * NWB < ceil(D/2): the displacement rows of a tile are split over blockIdx.z -- a block runs NWB of the ceil(D/2)
+//     row-pair waves (per channel group) and stages only the TH + 2*NWB - 1 window rows they read.  For the coarse levels
+//     (48 / 192 tiles on 256 CUs) the work of a tile is what ONE CU can pull through its LDS and VALU; split five ways it
+//     runs on five CUs, at the price of staging the f1 tile five times.
+template <int D, int CK, int NS, int WPE, bool DBUF, int G = 1, int NWB = (D + 1) / 2>
+__global__ __launch_bounds__(NWB * 64 * G, WPE) void corr_dma_kernel(CorrParams p) {
   constexpr int MD = (D - 1) / 2;
-  constexpr int NW = (D + 1) / 2;
+  constexpr int NW = NWB;                   // row-pair waves of this block (per channel group)
   constexpr int NT = NW * 64;
   constexpr int TH = 4, RS = 48, R4 = 12;  // 12 float4 per LDS row (f1 uses 8, f2 uses 10)
-  constexpr int ROWS2 = TH + 2 * MD;
+  constexpr int ROWS2 = (TH + 2 * NWB - 1) < (TH + 2 * MD) ? (TH + 2 * NWB - 1) : (TH + 2 * MD);
   constexpr int F1_PER_C = TH * RS, F2_PER_C = ROWS2 * RS;
   constexpr int ITEMS1 = CK * TH * R4;     // multiple of 64 for CK % 4 == 0 (CK*48)
   constexpr int ITEMS2 = CK * ROWS2 * R4;
@@ -471,7 +475,9 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
   const int tid = wave * 64 + lane;                // thread inside the group
   float *lds = lds_all + (size_t)grp * NS * STAGE_F;
   MFN_STAMP(p.timeline, 0);
-  const int dyi = wave * 2 + (lane >> 5);
+  const int dy_first = (int)blockIdx.z * (2 * NWB);   // first displacement row of this block
+  const int dyl = wave * 2 + (lane >> 5);             // displacement row inside the block's window
+  const int dyi = dy_first + dyl;
   const bool live = dyi < D;
 
   int bid = blockIdx.x;
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
   const int sg = pos >> 4, wi = pos & 15;
   const int row = sg + 2 * (wi >> 3), gx = wi & 7;
   const int f1_off = row * RS + 4 * gx;
-  const int f2_off = ITEMS1 * 4 + (row + (live ? dyi : 0)) * RS + 4 * gx;
+  const int f2_off = ITEMS1 * 4 + (row + (live ? dyl : 0)) * RS + 4 * gx;
 
   f32x2 accp[D - 1][2];
   float accs[4];
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
       c = it2 / (ROWS2 * R4);
       const int rem = it2 - c * (ROWS2 * R4);
       r = rem / R4; q = rem - r * R4;
-      ybase = y0 - MD; xbase = x0 - 4; qmax = 10;
+      ybase = y0 - MD + dy_first; xbase = x0 - 4; qmax = 10;
     }
     const int y = ybase + r, x = xbase + 4 * q;
     const bool ok = first < ITEMS && q < qmax && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
@@ -661,20 +667,22 @@ __global__ __launch_bounds__(((D + 1) / 2) * 64 * G, WPE) void corr_dma_kernel(C
 #undef ACC1
 }
 
-template <int D, int CK, int NS, int WPE, bool DBUF, int G = 1>
+template <int D, int CK, int NS, int WPE, bool DBUF, int G = 1, int NWB = (D + 1) / 2>
 inline int corr_dma_launch(CorrParams p, hipStream_t stream, const char *name) {
   constexpr int MD = (D - 1) / 2;
-  constexpr int NT = ((D + 1) / 2) * 64;
-  constexpr int ITEMS = CK * (4 + 4 + 2 * MD) * 12;
+  constexpr int NT = NWB * 64;
+  constexpr int ROWS2 = (4 + 2 * NWB - 1) < (4 + 2 * MD) ? (4 + 2 * NWB - 1) : (4 + 2 * MD);
+  constexpr int ITEMS = CK * (4 + ROWS2) * 12;
   constexpr int NI = (ITEMS + NT - 1) / NT;
+  constexpr int DS = ((D + 1) / 2 + NWB - 1) / NWB;   // blocks per tile along the displacement rows
   p.tiles_x = cdiv(p.W, 32);
   p.tiles_y = cdiv(p.H, 4);
   const int nblk = p.N * p.tiles_x * p.tiles_y;
   if (nblk <= 0) return 0;
   const size_t ring = (size_t)G * NS * NI * NT * 16;
   const size_t red = (size_t)(G - 1) * (4 * (D - 1) + 4) * NT * sizeof(float);
-  return launch(name, corr_dma_kernel<D, CK, NS, WPE, DBUF, G>, dim3(nblk, p.nslices), dim3(NT * G), ring > red ? ring : red,
-                stream, p);
+  return launch(name, corr_dma_kernel<D, CK, NS, WPE, DBUF, G, NWB>, dim3(nblk, p.nslices, DS), dim3(NT * G),
+                ring > red ? ring : red, stream, p);
 }
 // corr.variant 16 / 20 / 22: (CK, ring stages, min waves/SIMD, double-buffered operands, channel groups) as the plans pick
 // them (api_impl.inc corr_plan: >= 400 tiles / 128-399 / fewer).  Rounds 1 / 2 measured sixteen more points (deeper rings,
@@ -683,7 +691,8 @@ template <int D>
 inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
     case 20: return corr_dma_launch<D, 8, 2, 2, true, 2>(p, s, "corr_dma_v20");   // two channel groups
-    case 22: return corr_dma_launch<D, 8, 2, 1, true, 3>(p, s, "corr_dma_v22");   // three channel groups
+    case 26: return corr_dma_launch<D, 4, 2, 2, true, 4, 1>(p, s, "corr_dma_v26");  // one row pair per block (blockIdx.z), 4 channel groups
+    case 31: return corr_dma_launch<D, 4, 2, 2, true, 2, 2>(p, s, "corr_dma_v31");  // two row pairs per block, 2 channel groups
     default: return corr_dma_launch<D, 4, 2, 5, false>(p, s, "corr_dma_v16");     // level 2: every block of the launch resident
   }
 }

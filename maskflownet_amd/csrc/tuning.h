@@ -1,11 +1,11 @@
 // tuning.h -- kernel-selection knobs behind mfn_set_tuning()/mfn_get_tuning() (include/mfn_hip.h).
-// 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 17 that
+// 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 16 that
 // select between code paths the library ships (tests force every path through them); the measurement knobs of rounds 1 / 2
 // (tilings, ring depths, cache policies per kernel family, staggering, ablation masks) are gone with the variants they chose
 // between -- DESIGN.md records what each of them measured.
-//   corr.variant  6: corr_tiled_kernel (images narrower than 32 columns), 16 / 20 / 22: corr_dma_kernel with 1 / 2 / 3 channel
-//                 groups; -1 = the plan (api_impl.inc corr_plan)
-//   corr.band     one-launch row-band kernel of the coarse levels: 0 auto (180 .. 512 px images), 1 always, 2 never
+//   corr.variant  6: corr_tiled_kernel (images narrower than 16 columns), 16 / 20 / 22: corr_dma_kernel with 1 / 2 / 3 channel
+//                 groups, 26 / 31: the same with a tile's displacement rows spread over 5 / 3 blocks (coarse levels); -1 = the
+//                 plan (api_impl.inc corr_plan)
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   corr.generic  1: force the generic one-thread-per-output kernel
 //   corr.bwdlds   0: corr_bwd_block_kernel at every level; 1 (default): corr_bwd_lds_kernel where W is 8, 16, ... 256
@@ -27,13 +27,12 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_variant = -1, corr_band = 0, corr_direct = 0, corr_generic = 0, corr_bwdlds = 1;
+  int corr_variant = -1, corr_direct = 0, corr_generic = 0, corr_bwdlds = 1;
   int store_policy = -1;
   int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_stage = 1, dc_fast = 1, dc_generic = 0, dc_bwdshared = 1, dc_bwdflow = 1;
   int conv_generic = 0, conv_mt = 0, conv_pt = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.variant")) return &corr_variant;
-    if (!strcmp(key, "corr.band")) return &corr_band;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
     if (!strcmp(key, "corr.generic")) return &corr_generic;
     if (!strcmp(key, "corr.bwdlds")) return &corr_bwdlds;

@@ -17,7 +17,7 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(corr_variant=-1, corr_band=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0,
+DEFAULT_TUNING = dict(corr_variant=-1, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0,
                       dc_nw=0, dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0)
 
 
@@ -27,15 +27,15 @@ def _reset_tuning():
     emu_ops.set_tuning(**DEFAULT_TUNING)
 
 
-@pytest.mark.parametrize("variant", [6, 16, 20, 22])
+@pytest.mark.parametrize("variant", [6, 16, 20, 22, 26, 31])
 def test_correlation_variants_md4(ops, oracle, variant):
     """corr.variant: 6 = corr_tiled_kernel (the plan's choice below 32 columns), 16 / 20 / 22 = corr_dma_kernel with one / two /
     three channel groups.  Ragged tiles in both directions: H = 10 is not a multiple of any tile height, W = 72 / 20."""
-    emu_ops.set_tuning(corr_variant=variant, corr_band=2, corr_direct=2)
+    emu_ops.set_tuning(corr_variant=variant, corr_direct=2)
     pc.case_correlation(ops, oracle, ident, ident, (1, 6, 10, 20 if variant == 6 else 72), 4)
 
 
-@pytest.mark.parametrize("variant", [20, 22])
+@pytest.mark.parametrize("variant", [20, 22, 26, 31])
 @pytest.mark.parametrize("C", [20, 48])
 def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     # two / three channel groups per block, ragged last group (20 = 16+4 or 8+8+4), added through LDS in index order
@@ -48,11 +48,11 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
 @pytest.mark.parametrize("md", [4, 2])
 def test_correlation_tile_widths(ops, oracle, shape, md):
     """Images narrower than 32 columns: corr_tiled_kernel with 16- and 8-column tiles."""
-    emu_ops.set_tuning(corr_band=2, corr_direct=2)
+    emu_ops.set_tuning(corr_variant=6, corr_direct=2)
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
 
 
-@pytest.mark.parametrize("variant", [16, 20, 22])
+@pytest.mark.parametrize("variant", [16, 20, 22, 26, 31])
 def test_correlation_md2_variants(ops, oracle, variant):
     emu_ops.set_tuning(corr_variant=variant)
     pc.case_correlation(ops, oracle, ident, ident, (1, 5, 7, 36), 2, seed=1)
@@ -60,29 +60,32 @@ def test_correlation_md2_variants(ops, oracle, variant):
 
 
 def test_correlation_xcd_swizzle_is_a_permutation(ops, oracle):
-    emu_ops.set_tuning(corr_band=2, corr_direct=2)
+    emu_ops.set_tuning(corr_variant=6, corr_direct=2)
     pc.case_correlation(ops, oracle, ident, ident, (4, 4, 32, 16), 4)  # 8 blocks -> swizzle active
 
 
 @pytest.mark.parametrize("C", [16, 20, 32, 64])
 def test_correlation_channel_slices_and_reduce(ops, oracle, C):
-    """Few tiles and many channels outside the band / direct kernels' range: partial sums per channel slice + fixed-order
+    """Few tiles and many channels outside the one-launch kernels' range: partial sums per channel slice + fixed-order
     reduce kernel; ragged last slice; slice count clipped by the channel count."""
-    emu_ops.set_tuning(corr_band=2, corr_direct=2)
+    emu_ops.set_tuning(corr_variant=6, corr_direct=2)
     assert ops.ns.correlation_workspace_bytes(2, C, 7, 16, 4, 1, 1, 1, 4, 1) > 0
     pc.case_correlation(ops, oracle, ident, ident, (2, C, 7, 16), 4)
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 16), 2, seed=3)
 
 
-@pytest.mark.parametrize("shape,md", [((2, 20, 6, 8), 4),      # level-6 like: whole image in one band
-                                      ((1, 37, 12, 16), 4),    # ragged channel groups, several bands
-                                      ((1, 9, 7, 32), 4),      # H not a multiple of the band height
-                                      ((2, 8, 5, 12), 2),      # md=2 (25 channels), one group only
-                                      ((1, 70, 3, 4), 4),      # one quad per row, 16 groups
-                                      ((1, 16, 24, 32), 4)])   # level-4 plane
-def test_correlation_band_kernel(ops, oracle, shape, md):
-    emu_ops.set_tuning(corr_band=1)
+@pytest.mark.parametrize("variant", [26, 31])
+@pytest.mark.parametrize("shape,md", [((1, 37, 12, 16), 4),    # half-filled tiles (16 columns), ragged channel groups
+                                      ((1, 9, 7, 32), 4),      # H not a multiple of the tile height, fewer channels than groups x stage
+                                      ((2, 8, 5, 16), 2),      # md=2 (25 channels): 3 row-pair waves
+                                      ((1, 16, 24, 32), 4),    # level-4 plane
+                                      ((1, 12, 9, 44), 4)])    # ragged second tile column
+def test_correlation_displacement_rows_over_blocks(ops, oracle, variant, shape, md):
+    """corr.variant 26 / 31: a tile's displacement rows are spread over blockIdx.z (one / two row pairs per block), each
+    block stages only the window rows its rows read."""
+    emu_ops.set_tuning(corr_variant=variant, corr_direct=2)
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
+    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
 
 
 @pytest.mark.parametrize("shape,md", [((2, 30, 6, 8), 4),      # level-6 like, several channel slices
@@ -96,31 +99,31 @@ def test_correlation_direct_kernel(ops, oracle, shape, md):
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
 
 
-def test_correlation_band_is_the_default_for_coarse_levels(ops, oracle):
+def test_correlation_coarse_levels_run_in_one_launch(ops, oracle):
     pc.case_correlation(ops, oracle, ident, ident, (1, 24, 12, 16), 4)
-    assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) == 0    # level 5: band kernel, no partials
-    assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) == 0     # level 4: in-block channel groups
+    assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) == 0    # level 5: rows over blocks, channel groups
+    assert ops.ns.correlation_workspace_bytes(8, 96, 24, 32, 4, 1, 1, 1, 4, 1) == 0     # level 4: the same
     assert ops.ns.correlation_workspace_bytes(8, 64, 48, 64, 4, 1, 1, 1, 4, 1) == 0     # level 3: in-block channel groups
     assert ops.ns.correlation_workspace_bytes(8, 196, 6, 8, 4, 1, 1, 1, 4, 1) == 0      # level 6: direct kernel
-    emu_ops.set_tuning(corr_band=2)
+    emu_ops.set_tuning(corr_variant=6)
     assert ops.ns.correlation_workspace_bytes(8, 128, 12, 16, 4, 1, 1, 1, 4, 1) > 0     # sliced + reduce path
 
 
-@pytest.mark.parametrize("tune,shape", [(dict(corr_band=2, corr_direct=2), (1, 6, 7, 16)),               # tiled kernel
+@pytest.mark.parametrize("tune,shape", [(dict(corr_variant=6, corr_direct=2), (1, 6, 7, 16)),               # tiled kernel
                                         (dict(corr_variant=16), (1, 8, 6, 36)),                       # LDS-DMA tile kernel
-                                        (dict(corr_band=2, corr_direct=2), (1, 32, 5, 16)),           # reduce kernel
-                                        (dict(corr_band=1), (2, 20, 6, 8)),                           # band kernel
+                                        (dict(corr_variant=6, corr_direct=2), (1, 32, 5, 16)),           # reduce kernel
+                                        (dict(corr_variant=26), (2, 20, 6, 16)),                      # rows over blocks
                                         (dict(corr_generic=1), (1, 3, 6, 7))])                        # generic kernel
 def test_correlation_fused_leaky_relu(ops, oracle, tune, shape):
     emu_ops.set_tuning(**tune)
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, 4)
 
 
-@pytest.mark.parametrize("tune,shape,c0", [(dict(corr_band=2, corr_direct=2), (2, 6, 7, 16), 4),            # tiled kernel
+@pytest.mark.parametrize("tune,shape,c0", [(dict(corr_variant=6, corr_direct=2), (2, 6, 7, 16), 4),            # tiled kernel
                                            (dict(corr_variant=16), (2, 8, 6, 36), 4),                     # LDS-DMA tile kernel
                                            (dict(corr_variant=22), (2, 12, 6, 32), 8),                    # ... with channel groups
-                                           (dict(corr_band=2, corr_direct=2), (3, 32, 5, 16), 4),         # reduce kernel
-                                           (dict(corr_band=1), (2, 20, 6, 8), 4),                         # band kernel
+                                           (dict(corr_variant=6, corr_direct=2), (3, 32, 5, 16), 4),         # reduce kernel
+                                           (dict(corr_variant=26), (2, 20, 6, 16), 4),                    # rows over blocks
                                            (dict(corr_direct=1), (2, 30, 6, 8), 4),                       # direct kernel
                                            (dict(), (2, 5, 6, 8), 3),                                     # slice not 16-byte aligned -> generic
                                            (dict(corr_generic=1), (2, 3, 6, 7), 3)])                      # generic kernel

@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_variant=-1, corr_band=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0,
+    _lib.set_tuning(corr_variant=-1, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0,
                     dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0)
 
 
@@ -56,7 +56,7 @@ def test_correlation_md2_cascade_levels(ops, oracle, dev, shape):
     pc.case_correlation(ops, oracle, dev, host, shape, 2)
 
 
-@pytest.mark.parametrize("variant", [16, 20, 22])
+@pytest.mark.parametrize("variant", [16, 20, 22, 26, 31])
 def test_correlation_every_variant(ops, oracle, dev, variant):
     """corr_dma_kernel with one / two / three channel groups at shapes the plan would give to another of them."""
     from maskflownet_amd import _lib
@@ -68,23 +68,23 @@ def test_correlation_every_variant(ops, oracle, dev, variant):
 
 @pytest.mark.parametrize("shape", [(8, 196, 6, 8), (8, 128, 12, 16), (8, 96, 24, 32), (8, 64, 48, 64), (4, 196, 7, 16),
                                    (4, 128, 14, 32), (2, 33, 9, 20)])
-@pytest.mark.parametrize("band", [1, 2, 3])
-def test_correlation_band_kernel_and_sliced_path(ops, oracle, dev, shape, band):
-    # coarse levels: 1 = the one-launch row-band kernel, 2 = channel slices + reduce launch, 3 = the direct kernel of the
-    # tiniest levels (all against the oracle)
+@pytest.mark.parametrize("path", ["plan", "sliced", "direct"])
+def test_correlation_coarse_level_paths(ops, oracle, dev, shape, path):
+    # coarse levels: the plan's choice (displacement rows over blocks / in-block channel groups / direct kernel), channel
+    # slices + reduce launch, the direct kernel of the tiniest levels (all against the oracle)
     from maskflownet_amd import _lib
-    if band == 3:
+    if path == "direct":
         _lib.set_tuning(corr_direct=1)
-    else:
-        _lib.set_tuning(corr_band=band, corr_direct=2)
+    elif path == "sliced":
+        _lib.set_tuning(corr_variant=6, corr_direct=2)
     pc.case_correlation(ops, oracle, dev, host, shape, 4)
     pc.case_correlation(ops, oracle, dev, host, shape[:1] + (shape[1] // 2,) + shape[2:], 2, seed=5)
 
 
 def test_correlation_channel_slices_are_deterministic(ops, oracle, dev):
-    """Narrow coarse levels outside the band / direct kernels: channel slices + fixed-order reduce launch."""
+    """Narrow coarse levels on the tiled kernel: channel slices + fixed-order reduce launch."""
     from maskflownet_amd import _lib
-    _lib.set_tuning(corr_band=2, corr_direct=2)
+    _lib.set_tuning(corr_variant=6, corr_direct=2)
     pc.case_correlation(ops, oracle, dev, host, (8, 196, 6, 8), 4)
     pc.case_correlation(ops, oracle, dev, host, (8, 128, 12, 16), 4, seed=1)
     import torch

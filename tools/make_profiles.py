@@ -19,7 +19,7 @@ if os.path.exists(db):
         f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe`\n\n" % tag)
         f.write("MI355X (gfx950), ROCm 7.2.  Source: gpurun_out/prof_bench/bench_results.db (top_kernels view); durations in "
                 "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (level 6: direct "
-                "kernel; level 5: band / tiled kernel; levels 4/3: LDS-DMA tile kernel with in-block channel groups; level 2: "
+                "kernel; levels 5/4: LDS-DMA tile kernel, displacement rows over 5 blocks x 4 channel groups; level 3: two channel groups; level 2: "
                 "LDS-DMA tile kernel), 4 x (offsets + deformable conv `dc_lds_kernel`), 1 warp.  bench.py also runs the pass on two more "
                 "streams for its informational `pipelined` figure, the level-2 correlation ~420 more times for `roofline` "
                 "(hot loop, in-pass, rotated buffers), the rough-flow batch, and one end-to-end network forward (`e2e`: the "
