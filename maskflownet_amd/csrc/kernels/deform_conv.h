@@ -168,6 +168,9 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   const int wave = MFN_UNIFORM(tid >> 6);
   const int half = lane >> 5, j = lane & 31;
   MFN_STAMP(p.timeline, 0);
+#ifdef MFN_DC_STAGGER  // measurement build: the launch's thirds (= the three resident blocks of a CU) start MFN_DC_STAGGER x 64 x k cycles apart
+  for (int i = 0, nsl = (int)((blockIdx.x * 3u) / gridDim.x); i < nsl; ++i) __builtin_amdgcn_s_sleep(MFN_DC_STAGGER);
+#endif
   const int pt = wave / KW, kw = wave % KW;
   // neighbouring tiles stage overlapping source windows: keep them on one XCD's L2
   const int bx = p.xcd ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
