@@ -251,6 +251,14 @@ int mfn_offsets_from_flow_bwd(const float *goffset, float *gflow_yx, int N, int 
  * 1-|f-1-a|/f, kernel 2f-1, stride f, pad f-1, last row/column dropped; call sites :228-229 ... :311).
  * x: (N,C,H,W) -> out: (N,C,H*factor,W*factor); factor 1 copies.  Bit-identical to the fp32 oracle. */
 int mfn_upsample_fwd(const float *x, float *out, int N, int C, int H, int W, int factor, void *stream);
+/* Its backward (the block is linear; on the gradient path of every level: flow5 = Upsample(2)(flow6), MaskFlownet.py:228):
+ * gout: (N,C,H*factor,W*factor) -> gx: (N,C,H,W); req: MFN_REQ_*.  What MXNet's autograd computes through the
+ * pad / Deconvolution / slice chain of :51-62. */
+int mfn_upsample_bwd(const float *gout, float *gx, int N, int C, int H, int W, int factor, int req, void *stream);
+/* LeakyReLU(slope) backward from the forward OUTPUT y: gin = gout * (y > 0 ? 1 : slope) -- the gradient side of the fused
+ * activations (mfn_correlation_fwd_act, mfn_conv2d_fwd activation = MFN_ACT_LEAKY_0_1; nn.LeakyReLU(0.1) of
+ * /root/reference/network/MaskFlownet.py:76,217).  gin may alias gout. */
+int mfn_leaky_relu_bwd(const float *gout, const float *y, float *gin, size_t n, float slope, void *stream);
 /* Offset builder of /root/reference/network/MaskFlownet.py:230:
  *   offset[n, 2k+t, y, x] = flow_yx[n, t, y, x] * scale / stride   for k < taps. */
 int mfn_offsets_from_flow(const float *flow_yx, float *offset, int N, int H, int W, int taps,
@@ -288,6 +296,20 @@ int mfn_conv2d_fwd(const float *x, long long in_batch_stride, const float *w_or_
                    long long out_batch_stride, int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
                    int dw, int groups, int transposed, int adj_h, int adj_w, int activation, void *workspace,
                    size_t workspace_bytes, void *stream);
+
+/* Backward of mfn_conv2d_fwd (num_group == 1): what autograd runs for the Conv2D / Conv2DTranspose blocks of
+ * /root/reference/network/MaskFlownet.py:79-163 in network/pipeline.py:112-113.  gout: (N,Cout,Ho,Wo); y: the forward output
+ * (only read when activation = MFN_ACT_LEAKY_0_1, NULL otherwise); gx: (N,Cin,H,W); gw: the weight's own layout; gbias: (Cout).
+ * req_*: MFN_REQ_NULL / WRITE / ADD per gradient.  workspace: mfn_conv2d_bwd_workspace_bytes (16-byte aligned).
+ * The weight gradient runs on the deformable convolution's weight-gradient kernels with zero offsets; where those sum
+ * through fp32 atomics (filters > 96 per call or widths that are no multiple of 4) its last bits vary from run to run. */
+size_t mfn_conv2d_bwd_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                      int pw, int dh, int dw, int groups, int transposed, int adj_h, int adj_w,
+                                      int activation);
+int mfn_conv2d_bwd(const float *gout, const float *x, const float *w, const float *y_or_null, float *gx, float *gw,
+                   float *gbias, int N, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                   int dh, int dw, int groups, int transposed, int adj_h, int adj_w, int activation, int req_x, int req_w,
+                   int req_bias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stream plumbing for the host side (no reference equivalent: MXNet's engine does this).

@@ -52,6 +52,10 @@ SIGNATURES = {
     "conv2d_packed_weight_bytes": (C.c_size_t, [_i] * 15),
     "conv2d_pack_weights": (_i, [_f] + [_i] * 15 + [C.c_void_p, C.c_size_t, C.POINTER(C.c_ulonglong), _s]),
     "conv2d_fwd": (_i, [_f, C.c_longlong, _f, C.c_void_p, C.c_size_t, C.c_ulonglong, _f, _f, C.c_longlong] + [_i] * 18 + [C.c_void_p, C.c_size_t, _s]),
+    "upsample_bwd": (_i, [_f, _f] + [_i] * 6 + [_s]),
+    "leaky_relu_bwd": (_i, [_f, _f, _f, C.c_size_t, C.c_float, _s]),
+    "conv2d_bwd_workspace_bytes": (C.c_size_t, [_i] * 18),
+    "conv2d_bwd": (_i, [_f] * 7 + [_i] * 21 + [C.c_void_p, C.c_size_t, _s]),
     "set_tuning": (_i, [C.c_char_p, _i]),
     "get_tuning": (_i, [C.c_char_p, _pi]),
 }

@@ -67,6 +67,93 @@ inline int fill_zero4_launch(float *const ptr[4], const size_t cnt[4], hipStream
   return launch("fill_zero4", fill_zero4_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, f);
 }
 
+// ---- elementwise helpers of the f-row backward passes (round 3) -------------------------------------------
+// LeakyReLU(0.1) backward from the forward OUTPUT y (sign(y) = sign of the pre-activation): gin = gout * (y > 0 ? 1 : 0.1),
+// as MXNet's LeakyReLU (xelu_grad: x > 0 ? 1 : slope)
+struct LeakyBwdParams { const float *gout, *y; float *gin; size_t n; float slope; };
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(LeakyBwdParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < p.n) p.gin[i] = p.y[i] > 0.f ? p.gout[i] : p.gout[i] * p.slope;
+}
+inline int leaky_bwd_launch(LeakyBwdParams p, hipStream_t s) {
+  if (!p.n) return 0;
+  return launch("leaky_bwd", leaky_bwd_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, s, p);
+}
+struct AccumParams { float *dst; const float *src; size_t n; };
+__global__ __launch_bounds__(256) void accumulate_kernel(AccumParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < p.n) p.dst[i] += p.src[i];
+}
+inline int accumulate_launch(float *dst, const float *src, size_t n, hipStream_t s) {
+  if (!n) return 0;
+  return launch("accumulate", accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, AccumParams{dst, src, n});
+}
+// data gradient of a stride-1 convolution = convolution of gout with wf[c][o][i][j] = w[o][c][kh-1-i][kw-1-j]
+struct FlipParams { const float *w; float *wf; int Cout, Cin, kh, kw; };
+__global__ __launch_bounds__(256) void conv_flip_weights_kernel(FlipParams p) {
+  const size_t total = (size_t)p.Cout * p.Cin * p.kh * p.kw;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx % p.kw), i = (int)((idx / p.kw) % p.kh);
+  const int o = (int)((idx / ((size_t)p.kw * p.kh)) % p.Cout), c = (int)(idx / ((size_t)p.kw * p.kh * p.Cout));
+  p.wf[idx] = p.w[(((size_t)o * p.Cin + c) * p.kh + (p.kh - 1 - i)) * p.kw + (p.kw - 1 - j)];
+}
+inline int conv_flip_weights_launch(FlipParams p, hipStream_t s) {
+  const size_t total = (size_t)p.Cout * p.Cin * p.kh * p.kw;
+  if (!total) return 0;
+  return launch("conv_flip_weights", conv_flip_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+}
+// per-channel sum over (n, pixel) of a (N, C, plane) tensor (bias gradient)
+struct ChanSumParams { const float *g; float *out; int N, C; size_t plane; int add; };
+__global__ __launch_bounds__(256) void channel_sum_kernel(ChanSumParams p) {
+  MFN_DYN_SHARED(float, red);
+  const int o = blockIdx.x;
+  float s = 0.f;
+  for (size_t q = threadIdx.x; q < (size_t)p.N * p.plane; q += 256) {
+    const size_t n = q / p.plane, pix = q - n * p.plane;
+    s += p.g[(n * p.C + o) * p.plane + pix];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.out[o] = (p.add ? p.out[o] : 0.f) + red[0];
+}
+// Upsample(factor) backward (MaskFlownet.py:35-62 is linear: its adjoint).  One thread per INPUT pixel gathers the at most
+// (2f-1)^2 outputs it fed, with the forward's weights (upsample.h): row i receives weight ka0(r) from output rows i*f + r and
+// ka1(r) from rows whose lower neighbour min(iy0 + 1, H - 1) is i (the edge pad makes the last row its own neighbour).
+struct UpsampleBwdParams { const float *gout; float *gx; int N, C, H, W, f, add; };
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(UpsampleBwdParams p) {
+  const size_t total = (size_t)p.N * p.C * p.H * p.W;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int f = p.f, cc = f - 1;
+  const int ix = (int)(idx % p.W), iy = (int)((idx / p.W) % p.H);
+  const size_t nc = idx / ((size_t)p.W * p.H);
+  const int Hout = p.H * f, Wout = p.W * f;
+  const float *g = p.gout + nc * (size_t)Hout * Wout;
+  auto tri = [&](int a) { return 1.f - fabsf((float)(cc - a)) / (float)(cc + 1); };
+  // weight of input line `i` (of `n` lines) in output line `o`
+  auto wline = [&](int o, int i, int n) {
+    const int i0 = o / f, r = o - i0 * f;
+    float w = 0.f;
+    if (i0 == i) w += tri(r + f - 1);
+    if (r && min(i0 + 1, n - 1) == i) w += tri(r - 1);
+    return w;
+  };
+  float s = 0.f;
+  const int oy_lo = max((iy - 1) * f + 1, 0), oy_hi = min((iy + 1) * f - 1, Hout - 1);
+  const int ox_lo = max((ix - 1) * f + 1, 0), ox_hi = min((ix + 1) * f - 1, Wout - 1);
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float wy = wline(oy, iy, p.H);
+    if (wy == 0.f) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) s += g[(size_t)oy * Wout + ox] * (wy * wline(ox, ix, p.W));
+  }
+  p.gx[idx] = p.add ? p.gx[idx] + s : s;
+}
+
 // ---- correlation -----------------------------------------------------------------------------------
 struct CorrBwdParams {
   const float *gout, *f1, *f2;

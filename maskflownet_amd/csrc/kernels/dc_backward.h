@@ -749,6 +749,10 @@ struct DcBwdWPParams {
   // flow mode (mfn_deform_conv_shared_bwd; DcBwdPParams): offsets from flow[n][dir][pixel]; dc_bwd_weight_pc_kernel only
   const float *flow;
   float flow_scale, flow_stride;
+  // write-mode gradients of the call's other kernels (gx, goffset / gflow) that this launch clears on its way in (it then runs
+  // first): every thread of the grid zeroes a strided share with 16-byte stores; NULL / 0 = nothing to clear
+  float *zero_p[2];
+  size_t zero_n[2];
 };
 
 // ---- producer and consumer waves ------------------------------------------------------------------------------------------
@@ -778,6 +782,20 @@ __global__ __launch_bounds__(512, 1) void dc_bwd_weight_pc_kernel(DcBwdWPParams 
   const int cb = blockIdx.y * 32;
   const int t0 = blockIdx.x * p.tiles_per_block, t1 = min(t0 + p.tiles_per_block, p.ntiles);
   const int ntile = t1 - t0;
+
+  MFN_UNROLL
+  for (int k = 0; k < 2; ++k) {
+    float *z = p.zero_p[k];
+    if (!z) continue;  // uniform
+    const size_t n = p.zero_n[k];
+    const size_t gthreads = (size_t)gridDim.x * gridDim.y * 512, gtid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 512 + threadIdx.x;
+    if ((reinterpret_cast<size_t>(z) & 15) == 0) {
+      for (size_t q = gtid; q * 4 + 3 < n; q += gthreads) *reinterpret_cast<float4 *>(z + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (size_t i = (n & ~(size_t)3) + gtid; i < n; i += gthreads) z[i] = 0.f;
+    } else {
+      for (size_t i = gtid; i < n; i += gthreads) z[i] = 0.f;
+    }
+  }
 
   float bsum[MTOT * 4];  // producer thread (filter row tid >> 5, pixel tid & 31): filters (tid >> 5) + 8 i
   MFN_UNROLL

@@ -149,15 +149,17 @@ if mx is not None:
             out.finish()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
-            if self.act:
-                raise NotImplementedError("mfn_correlation(activation='leaky') is the fused inference form; train with "
-                                          "the separate LeakyReLU (MaskFlownet.py:217)")
             r1, r2 = _REQ[req[0]], _REQ[req[1]]
             if not (r1 or r2):
                 return
             n, c, h, w = in_data[0].shape
             lib = self._begin(in_data[0])
-            _check(lib.correlation_bwd(_ptr(out_grad[0]), _ptr(in_data[0]), _ptr(in_data[1]),
+            gout = out_grad[0]
+            if self.act:   # fused LeakyReLU(0.1) (MaskFlownet.py:217): its gradient from the forward output, then the cost volume's
+                gpre = mx.nd.empty(gout.shape, ctx=gout.context)
+                _check(lib.leaky_relu_bwd(_ptr(gout), _ptr(out_data[0]), _ptr(gpre), gout.size, 0.1, None))
+                gout = gpre
+            _check(lib.correlation_bwd(_ptr(gout), _ptr(in_data[0]), _ptr(in_data[1]),
                                        _ptr(in_grad[0]) if r1 else None, _ptr(in_grad[1]) if r2 else None,
                                        n, c, h, w, *self.a, r1, r2, None))
             self._end()
@@ -192,7 +194,7 @@ if mx is not None:
             return in_shape, [(n, tc.value, th.value, tw.value)], []
 
         def declare_backward_dependency(self, out_grad, in_data, out_data):
-            return list(out_grad) + list(in_data)
+            return list(out_grad) + list(in_data) + (list(out_data) if self.act else [])   # the fused LeakyReLU's sign
 
         def create_operator(self, ctx, shapes, dtypes):
             return _Correlation(self.a, self.act)
@@ -451,6 +453,7 @@ if mx is not None:
         def __init__(self, p, transposed):
             self.p, self.transposed = p, transposed
             self.ws = None
+            self.bws = None   # backward workspace (mfn_conv2d_bwd_workspace_bytes)
 
         def forward(self, is_train, req, in_data, out_data, aux):
             if req[0] == "null":
@@ -473,9 +476,23 @@ if mx is not None:
             out.finish()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
-            if any(_REQ[r] for r in req):
-                raise NotImplementedError("mfn_convolution / mfn_deconvolution are forward-only (SURVEY.md 8 f-4b): keep "
-                                          "MXNet's own operators where gradients flow")
+            rq = [_REQ[r] for r in req] + [0] * (3 - len(req))   # no_bias: two inputs
+            if not any(rq):
+                return
+            x, w = in_data[:2]
+            n, cin, h, wd = x.shape
+            cout = out_data[0].shape[1]
+            p = self.p
+            dims = (n, cin, h, wd, cout, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"], p["dh"], p["dw"], p["g"],
+                    int(self.transposed), p["ah"], p["aw"], 0)
+            lib = self._begin(x)
+            need = lib.conv2d_bwd_workspace_bytes(*dims)
+            if need and (self.bws is None or self.bws.size * 4 < need or self.bws.context != x.context):
+                self.bws = mx.nd.empty(((need + 3) // 4,), ctx=x.context)
+            g = [_ptr(in_grad[i]) if i < len(in_grad) and rq[i] else None for i in range(3)]
+            _check(lib.conv2d_bwd(_ptr(out_grad[0]), _ptr(x), _ptr(w), None, g[0], g[1], g[2], *dims, rq[0], rq[1], rq[2],
+                                  _ptr(self.bws) if need else None, self.bws.size * 4 if need else 0, None))
+            self._end()
 
     class _ConvPropBase(mx.operator.CustomOpProp):
         TRANSPOSED = False
@@ -520,7 +537,7 @@ if mx is not None:
     class _DeconvolutionProp(_ConvPropBase):
         TRANSPOSED = True
 
-    # ---- Upsample(factor) (MaskFlownet.py:35-62), forward / inference ----------------------------------
+    # ---- Upsample(factor) (MaskFlownet.py:35-62) ---------------------------------------------------------
     class _Upsample(_Op):
         def __init__(self, factor):
             self.factor = factor
@@ -536,9 +553,13 @@ if mx is not None:
             out.finish()
 
         def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
-            if _REQ[req[0]]:
-                raise NotImplementedError("mfn_upsample is forward-only (SURVEY.md 8 f-2); keep the reference's Upsample "
-                                          "block where gradients flow through it")
+            r = _REQ[req[0]]
+            if not r:
+                return
+            n, c, h, w = in_data[0].shape
+            lib = self._begin(in_data[0])
+            _check(lib.upsample_bwd(_ptr(out_grad[0]), _ptr(in_grad[0]), n, c, h, w, self.factor, r, None))
+            self._end()
 
     @mx.operator.register("mfn_upsample")
     class _UpsampleProp(mx.operator.CustomOpProp):

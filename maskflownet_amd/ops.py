@@ -443,6 +443,91 @@ class OpSet:
         self.check(self.ns.upsample_fwd(self.ad.ptr(x), self.ad.ptr(out), N, C, H, W, factor, self.ad.stream(x)))
         return out
 
+    def Upsample_backward(self, out_grad, factor, req="write", out=None):
+        """Adjoint of Upsample(factor): (N,C,H*f,W*f) -> (N,C,H,W) (mfn_upsample_bwd)."""
+        (go,) = self._in(out_grad)
+        factor = int(factor)
+        N, C, Hf, Wf = self.ad.shape(go)
+        if factor < 1 or Hf % factor or Wf % factor:
+            raise ValueError("Upsample_backward: out_grad %s is no multiple of factor %d" % ((Hf, Wf), factor))
+        if _REQ[req] == _REQ["add"] and out is None:
+            raise ValueError("Upsample_backward: req 'add' needs the buffer to add into")
+        out = self._out(out, go, (N, C, Hf // factor, Wf // factor), "Upsample_backward")
+        self.check(self.ns.upsample_bwd(self.ad.ptr(go), self.ad.ptr(out), N, C, Hf // factor, Wf // factor, factor, _REQ[req],
+                                        self.ad.stream(go)))
+        return out
+
+    def LeakyReLU_backward(self, out_grad, output, slope=0.1, out=None):
+        """gin = gout * (y > 0 ? 1 : slope) from the forward OUTPUT y (the fused activations' gradient side)."""
+        go, y = self._in(out_grad, output)
+        if self.ad.shape(go) != self.ad.shape(y):
+            raise ValueError("LeakyReLU_backward: out_grad %s vs output %s" % (self.ad.shape(go), self.ad.shape(y)))
+        out = self._out(out, go, self.ad.shape(go), "LeakyReLU_backward")
+        n = 1
+        for d in self.ad.shape(go):
+            n *= d
+        self.check(self.ns.leaky_relu_bwd(self.ad.ptr(go), self.ad.ptr(y), self.ad.ptr(out), n, float(slope), self.ad.stream(go)))
+        return out
+
+    def _conv_backward(self, what, transposed, out_grad, data, weight, output, kernel, stride, dilate, pad, adj, num_group,
+                       no_bias, activation, req, out):
+        if activation not in (None, "leaky"):
+            raise ValueError("%s: activation must be None or 'leaky'" % what)
+        if activation == "leaky" and output is None:
+            raise ValueError("%s: the forward output is needed for activation='leaky'" % what)
+        go, x, w = self._in(out_grad, data, weight)
+        y = self._in(output)[0] if output is not None else None
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw), (ah, aw) = map(self._pair, (kernel, stride, pad, dilate, adj))
+        N, Cin, H, W = self.ad.shape(x)
+        g = int(num_group)
+        Cout = self.ad.shape(w)[1] * g if transposed else self.ad.shape(w)[0]
+        Ho, Wo = self.conv_out_shape(H, W, (kh, kw), (sh, sw), (ph, pw), (dh, dw), transposed, (ah, aw))
+        if self.ad.shape(go) != (N, Cout, Ho, Wo):
+            raise ValueError("%s: out_grad has shape %s, expected %s" % (what, self.ad.shape(go), (N, Cout, Ho, Wo)))
+        rq = [_REQ[r] for r in req]
+        if no_bias:
+            rq[2] = 0
+        want = (self.ad.shape(x), self.ad.shape(w), (Cout,))
+        given = tuple(out) if out is not None else (None, None, None)
+        if len(given) != 3:
+            raise ValueError("%s: out must be (gx, gweight, gbias)" % what)
+        grads = []
+        for i, (gbuf, shp) in enumerate(zip(given, want)):
+            if not rq[i]:
+                grads.append(None)
+            elif gbuf is None:
+                if rq[i] == _REQ["add"]:
+                    raise ValueError("%s: req 'add' needs the buffer to add into (out[%d])" % (what, i))
+                grads.append(self.ad.empty(x, shp))
+            else:
+                self.ad.require_destination(gbuf, x, what)
+                if self.ad.shape(gbuf) != tuple(shp):
+                    raise ValueError("%s: out[%d] has shape %s, expected %s" % (what, i, self.ad.shape(gbuf), tuple(shp)))
+                grads.append(gbuf)
+        gx, gw, gb = grads
+        act = 1 if activation == "leaky" else 0
+        dims = (N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, g, int(bool(transposed)), ah, aw, act)
+        nbytes = self.ns.conv2d_bwd_workspace_bytes(*dims)
+        ws = self._workspace(x, nbytes) if nbytes else None
+        p = lambda a: self.ad.ptr(a) if a is not None else None
+        self.check(self.ns.conv2d_bwd(self.ad.ptr(go), self.ad.ptr(x), self.ad.ptr(w), p(y), p(gx), p(gw), p(gb), *dims,
+                                      rq[0], rq[1], rq[2], p(ws), self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(x)))
+        return gx, gw, gb
+
+    def Convolution_backward(self, out_grad, data, weight, output=None, kernel=(3, 3), stride=(1, 1), dilate=(1, 1), pad=(0, 0),
+                             num_group=1, no_bias=False, activation=None, req=("write", "write", "write"), out=None):
+        """Gradients of Convolution w.r.t. (data, weight, bias) -- mfn_conv2d_bwd; `output` = the forward result, needed when
+        the forward fused activation='leaky'."""
+        return self._conv_backward("Convolution_backward", False, out_grad, data, weight, output, kernel, stride, dilate, pad,
+                                   (0, 0), num_group, no_bias, activation, req, out)
+
+    def Deconvolution_backward(self, out_grad, data, weight, output=None, kernel=(4, 4), stride=(2, 2), dilate=(1, 1),
+                               pad=(1, 1), adj=(0, 0), num_group=1, no_bias=False, activation=None,
+                               req=("write", "write", "write"), out=None):
+        """Gradients of Deconvolution w.r.t. (data, weight, bias)."""
+        return self._conv_backward("Deconvolution_backward", True, out_grad, data, weight, output, kernel, stride, dilate, pad,
+                                   adj, num_group, no_bias, activation, req, out)
+
     def deformable_matching(self, data, flow, flow_scale, flow_stride, weight, bias=None, mask=None, tradeoff=None,
                             leaky=True, kernel=(3, 3), dilate=(1, 1), pad=(1, 1), num_group=1, out=None, packed=None):
         """MaskFlownet.py:230-233 in one launch: LeakyReLU(0.1)(deform(data, repeat9(flow*scale/stride)) *

@@ -413,3 +413,86 @@ def case_deconv(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, bias=T
     got = ops.Deconvolution(to_dev(x), to_dev(w), to_dev(b) if bias else None, num_filter=Cout, no_bias=not bias,
                             activation="leaky" if leaky else None, **kw)
     return check_close(to_host(got), want, what="deconv %s %s" % ((N, Cin, Cout, H, W), kw))
+
+
+# ---- backward of the f rows (round 3): reference = torch autograd (fp64) of the same operators ------------------------------
+def _torch_conv_backward(x, w, b, go, transposed, leaky, stride, pad, dilate, adj):
+    import torch
+    F = torch.nn.functional
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tw = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    tb = torch.tensor(b, dtype=torch.float64, requires_grad=True) if b is not None else None
+    if transposed:
+        y = F.conv_transpose2d(tx, tw, tb, stride=stride, padding=pad, output_padding=adj, dilation=dilate)
+    else:
+        y = F.conv2d(tx, tw, tb, stride=stride, padding=pad, dilation=dilate)
+    if leaky:
+        y = F.leaky_relu(y, 0.1)
+    y.backward(torch.tensor(go, dtype=torch.float64))
+    return tx.grad.numpy(), tw.grad.numpy(), tb.grad.numpy() if tb is not None else None
+
+
+def case_conv_backward(ops, to_dev, to_host, N, Cin, Cout, H, W, transposed=False, leaky=False, bias=True, seed=0, tol=2e-5,
+                       kernel=(3, 3), stride=(1, 1), pad=(1, 1), dilate=(1, 1), adj=(0, 0), req=("write", "write", "write")):
+    """Convolution / Deconvolution backward (mfn_conv2d_bwd: nn.Conv2D / nn.Conv2DTranspose of MaskFlownet.py:79-163 under
+    pipeline.py:112-113) against torch's fp64 autograd of conv2d / conv_transpose2d [+ leaky_relu]."""
+    rng = np.random.default_rng(4100 + seed)
+    x = feat(rng, (N, Cin, H, W))
+    wshape = (Cin, Cout) + tuple(kernel) if transposed else (Cout, Cin) + tuple(kernel)
+    w = (rng.standard_normal(wshape) * np.sqrt(2.0 / (1.01 * Cin * kernel[0] * kernel[1]))).astype(np.float32)
+    b = (rng.standard_normal(Cout) * 0.1).astype(np.float32) if bias else None
+    fwd = ops.Deconvolution if transposed else ops.Convolution
+    bwd = ops.Deconvolution_backward if transposed else ops.Convolution_backward
+    kw = dict(kernel=kernel, stride=stride, pad=pad, dilate=dilate)
+    if transposed:
+        kw["adj"] = adj
+    y = fwd(to_dev(x), to_dev(w), to_dev(b) if bias else None, no_bias=not bias, activation="leaky" if leaky else None, **kw)
+    go = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    want = _torch_conv_backward(x, w, b, go, transposed, leaky, stride, pad, dilate, adj)
+    base = [rng.standard_normal(a.shape).astype(np.float32) if (r == "add" and a is not None) else None
+            for r, a in zip(req, want)]
+    out = tuple(to_dev(a.copy()) if a is not None else None for a in base)
+    got = bwd(to_dev(go), to_dev(x), to_dev(w), output=y if leaky else None, no_bias=not bias, activation="leaky" if leaky else None,
+              req=req, out=out if any(o is not None for o in out) else None, **kw)
+    names = ("gx", "gw", "gb")
+    for g, wnt, r, b0, nm in zip(got, want, req, base, names):
+        if r == "null" or wnt is None:
+            assert g is None or wnt is None
+            continue
+        ref = wnt + (b0 if b0 is not None else 0.0)
+        check_close(to_host(g), ref, tol=tol, what="%s %s %s" % ("deconv" if transposed else "conv", nm, (N, Cin, Cout, H, W, kw)))
+    return got
+
+
+def case_upsample_backward(ops, oracle, to_dev, to_host, shape, factor, seed=0, req="write"):
+    """Upsample(factor) backward: the adjoint of the (linear) forward.  Reference: the oracle's forward applied to the basis
+    would be exact but slow; instead <Upsample(x), g> == <x, Upsample_backward(g)> in fp64 for several x, plus an explicit
+    transposed-matrix check on a tiny plane."""
+    rng = np.random.default_rng(4200 + seed)
+    N, C, H, W = shape
+    g = rng.standard_normal((N, C, H * factor, W * factor)).astype(np.float32)
+    base = rng.standard_normal(shape).astype(np.float32) if req == "add" else None
+    got = to_host(ops.Upsample_backward(to_dev(g), factor, req=req, out=to_dev(base.copy()) if base is not None else None))
+    if base is not None:
+        got = got - base
+    # dense adjoint from the oracle's forward on the basis vectors of ONE plane (the operator acts per plane)
+    eye = np.eye(H * W, dtype=np.float64).reshape(H * W, 1, H, W)
+    A = oracle.upsample(eye, factor, dtype=np.float64).reshape(H * W, -1)          # [input cell][output cell]
+    want = (g.reshape(N * C, -1).astype(np.float64) @ A.T).reshape(shape)
+    check_close(got, want, tol=1e-5, what="upsample backward %s x%d" % (shape, factor))
+    return got
+
+
+def case_leaky_corr_backward(ops, oracle, to_dev, to_host, shape, md=4, seed=0):
+    """Correlation(activation='leaky') backward = LeakyReLU_backward on the forward output, then Correlation_backward."""
+    rng = np.random.default_rng(4300 + seed)
+    f1, f2 = feat(rng, shape), feat(rng, shape)
+    y = ops.Correlation(to_dev(f1), to_dev(f2), 1, md, 1, 1, md, True, activation="leaky")
+    go = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    gpre = ops.LeakyReLU_backward(to_dev(go), y)
+    g1, g2 = ops.Correlation_backward(gpre, to_dev(f1), to_dev(f2), 1, md, 1, 1, md, True)
+    pre = oracle.correlation(f1, f2, kernel_size=1, max_displacement=md, stride1=1, stride2=1, pad_size=md)
+    gpre_ref = np.where(pre > 0, go, np.float32(0.1) * go).astype(np.float32)
+    w1, w2 = oracle.correlation_backward(gpre_ref, f1, f2, kernel_size=1, max_displacement=md, stride1=1, stride2=1, pad_size=md)
+    check_close(to_host(g1), w1, tol=2e-5, what="leaky corr g1 %s" % (shape,))
+    check_close(to_host(g2), w2, tol=2e-5, what="leaky corr g2 %s" % (shape,))

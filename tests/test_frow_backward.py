@@ -1,0 +1,106 @@
+"""Backward of the f rows (round 3): Upsample, the fused LeakyReLU of the cost volume, Convolution / Deconvolution --
+what pipeline.py:112-113 needs beyond the hot path so that training can leave MXNet's operators.  CPU: the real kernel
+sources on the emulation (tests/emu); `-m gpu`: libmfn_hip.so.  References: torch fp64 autograd (convolutions), the
+oracle's forward as a dense matrix (Upsample), the oracle's correlation backward."""
+import numpy as np
+import pytest
+
+from oracle import ref as oracle
+from tests import parity_cases as pc
+
+ident = lambda a: a
+
+CONV_CASES = [
+    dict(N=1, Cin=8, Cout=32, H=8, W=16),                                              # 3x3 / stride 1 / pad 1
+    dict(N=2, Cin=6, Cout=5, H=9, W=12, leaky=True),                                   # ragged channels + fused LeakyReLU
+    dict(N=1, Cin=8, Cout=16, H=12, W=16, stride=(2, 2)),                              # the pyramid's stride-2 layers
+    dict(N=1, Cin=4, Cout=8, H=12, W=16, dilate=(2, 2), pad=(2, 2), leaky=True),       # the context network's dilations
+    dict(N=1, Cin=8, Cout=2, H=8, W=8, bias=False),                                    # a flow head
+    dict(N=1, Cin=8, Cout=4, H=4, W=8, transposed=True, kernel=(4, 4), stride=(2, 2), pad=(1, 1), leaky=True),   # upfeat
+    dict(N=2, Cin=4, Cout=8, H=8, W=8, req=("add", "add", "add")),
+    dict(N=1, Cin=4, Cout=4, H=8, W=8, req=("null", "write", "null")),
+]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests.emu import emu_ops
+    return emu_ops.emu_ops()
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_backward_emulated(emu, case):
+    pc.case_conv_backward(emu, ident, ident, **case)
+
+
+@pytest.mark.parametrize("shape,factor", [((1, 2, 3, 4), 2), ((2, 1, 4, 5), 4), ((1, 1, 1, 1), 2), ((1, 2, 5, 3), 1)])
+def test_upsample_backward_emulated(emu, shape, factor):
+    pc.case_upsample_backward(emu, oracle, ident, ident, shape, factor)
+    pc.case_upsample_backward(emu, oracle, ident, ident, shape, factor, req="add", seed=1)
+
+
+def test_leaky_correlation_backward_emulated(emu):
+    pc.case_leaky_corr_backward(emu, oracle, ident, ident, (1, 8, 8, 16), md=4)
+    pc.case_leaky_corr_backward(emu, oracle, ident, ident, (2, 4, 6, 8), md=2, seed=1)
+
+
+def test_conv_backward_argument_errors(emu):
+    x = np.zeros((1, 4, 8, 8), np.float32)
+    w = np.zeros((8, 4, 3, 3), np.float32)
+    go = np.zeros((1, 8, 8, 8), np.float32)
+    with pytest.raises(ValueError):
+        emu.Convolution_backward(go, x, w, activation="leaky", pad=(1, 1))          # the forward output is missing
+    with pytest.raises(ValueError):
+        emu.Convolution_backward(go[:, :4], x, w, pad=(1, 1))                        # out_grad of the wrong shape
+    with pytest.raises(ValueError):
+        emu.Convolution_backward(go, x, w, pad=(1, 1), req=("add", "write", "write"))   # nothing to add into
+    with pytest.raises(RuntimeError):
+        emu.Convolution_backward(np.zeros((1, 8, 8, 8), np.float32), np.zeros((1, 4, 8, 8), np.float32),
+                                 np.zeros((8, 2, 3, 3), np.float32), pad=(1, 1), num_group=2)   # groups: refused, not wrong
+
+
+# ---- the same on the GPU, at the network's shapes -----------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gpu_ops():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from maskflownet_amd import ops as o
+    return o.default_ops()
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _host(t):
+    return t.detach().cpu().numpy()
+
+
+GPU_CONV_CASES = CONV_CASES + [
+    dict(N=2, Cin=64, Cout=32, H=48, W=64, leaky=True),                                          # decoder-like, weight gradient on slabs
+    dict(N=2, Cin=81 + 64 + 18, Cout=128, H=24, W=32, leaky=True),                               # conv4_0-like: odd channels, 128 filters
+    dict(N=2, Cin=32, Cout=64, H=48, W=64, stride=(2, 2), leaky=True),                           # conv3a-like
+    dict(N=1, Cin=128, Cout=128, H=24, W=32, dilate=(4, 4), pad=(4, 4), leaky=True),             # dc_conv3-like
+    dict(N=2, Cin=96, Cout=16, H=12, W=16, transposed=True, kernel=(4, 4), stride=(2, 2), pad=(1, 1), leaky=True),   # upfeat
+    dict(N=2, Cin=64, Cout=3, H=24, W=32, bias=True),                                            # pred_flow + pred_mask heads
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_CONV_CASES)
+def test_conv_backward_gpu(gpu_ops, case):
+    pc.case_conv_backward(gpu_ops, _dev, _host, **case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,factor", [((8, 2, 12, 16), 2), ((8, 1, 48, 64), 2), ((2, 2, 24, 32), 4), ((1, 2, 7, 5), 2)])
+def test_upsample_backward_gpu(gpu_ops, shape, factor):
+    pc.case_upsample_backward(gpu_ops, oracle, _dev, _host, shape, factor)
+    pc.case_upsample_backward(gpu_ops, oracle, _dev, _host, shape, factor, req="add", seed=2)
+
+
+@pytest.mark.gpu
+def test_leaky_correlation_backward_gpu(gpu_ops):
+    pc.case_leaky_corr_backward(gpu_ops, oracle, _dev, _host, (2, 32, 24, 32), md=4)
+    pc.case_leaky_corr_backward(gpu_ops, oracle, _dev, _host, (2, 64, 12, 16), md=2, seed=3)

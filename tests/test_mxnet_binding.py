@@ -279,12 +279,29 @@ def test_gluon_conv_kwargs_route_to_the_convolution_kernels(cpu_binding, oracle)
     out = mx.nd.Deconvolution(mx.nd.array(x), mx.nd.array(wd), name="fwd", **kwd)
     assert out.shape == (1, 16, 16, 32)
     pc.check_close(out.asnumpy(), oracle.deconvolution(x, wd, None))
-    X = mx.nd.array(x)
-    X.attach_grad()
+    # round 3: the blocks train through the same routing (mfn_conv2d_bwd) -- against torch's fp64 autograd
+    import torch
+    X, Wt, B = mx.nd.array(x), mx.nd.array(w), mx.nd.array(b)
+    for a in (X, Wt, B):
+        a.attach_grad()
     with mx.autograd.record():
-        y = mx.nd.Convolution(X, mx.nd.array(w), mx.nd.array(b), name="fwd", **kw)
-    with pytest.raises(NotImplementedError):
-        y.backward()
+        y = mx.nd.Convolution(X, Wt, B, name="fwd", **kw)
+    go = rng.standard_normal(y.shape).astype(np.float32)
+    y.backward(mx.nd.array(go))
+    want = pc._torch_conv_backward(x, w, b, go, False, False, (2, 2), (1, 1), (1, 1), (0, 0))
+    for got, ref, nm in zip((X.grad, Wt.grad, B.grad), want, ("gx", "gw", "gb")):
+        pc.check_close(got.asnumpy(), ref, tol=2e-5, what="Convolution backward through install(): " + nm)
+    del mx.autograd._tape[:]
+    X, Wd = mx.nd.array(x), mx.nd.array(wd)
+    X.attach_grad()
+    Wd.attach_grad()
+    with mx.autograd.record():
+        y = mx.nd.Deconvolution(X, Wd, name="fwd", **kwd)
+    go = rng.standard_normal(y.shape).astype(np.float32)
+    y.backward(mx.nd.array(go))
+    want = pc._torch_conv_backward(x, wd, None, go, True, False, (2, 2), (1, 1), (1, 1), (0, 0))
+    pc.check_close(X.grad.asnumpy(), want[0], tol=2e-5, what="Deconvolution backward: gx")
+    pc.check_close(Wd.grad.asnumpy(), want[1], tol=2e-5, what="Deconvolution backward: gw")
 
 
 def _pair_backward(mx, oracle, ctx, shape, seed=0):
@@ -314,22 +331,43 @@ def test_operator_pair_backward_through_custom_ops(cpu_binding, oracle):
     _pair_backward(mx, oracle, mx.cpu(), (2, 3, 8, 12))
 
 
-def test_forward_only_ops_raise_in_backward(cpu_binding, oracle):
+def test_upsample_and_fused_leaky_correlation_train(cpu_binding, oracle):
+    """Round 3: mfn_upsample and mfn_correlation(activation='leaky') have a backward (they raised before); only the affine
+    grid generator stays forward-only."""
     mx, m = cpu_binding
-    x = mx.nd.array(np.ones((1, 2, 4, 8), np.float32))
+    rng = np.random.default_rng(77)
+    xv = rng.standard_normal((1, 2, 4, 8)).astype(np.float32)
+    x = mx.nd.array(xv)
     x.attach_grad()
     with mx.autograd.record():
         up = mx.nd.Custom(x, op_type="mfn_upsample", factor=2)
-    np.testing.assert_array_equal(up.asnumpy(), oracle.upsample(np.ones((1, 2, 4, 8), np.float32), 2))
-    with pytest.raises(NotImplementedError):
-        up.backward()
+    np.testing.assert_array_equal(up.asnumpy(), oracle.upsample(xv, 2))
+    go = rng.standard_normal(up.shape).astype(np.float32)
+    up.backward(mx.nd.array(go))
+    eye = np.eye(32, dtype=np.float64).reshape(32, 1, 4, 8)
+    A = oracle.upsample(eye, 2, dtype=np.float64).reshape(32, -1)
+    pc.check_close(x.grad.asnumpy(), (go.reshape(2, -1).astype(np.float64) @ A.T).reshape(1, 2, 4, 8), tol=1e-5, what="mfn_upsample backward")
     del mx.autograd._tape[:]
-    f = mx.nd.array(np.ones((1, 4, 4, 8), np.float32))
-    f.attach_grad()
+    f1v, f2v = pc.feat(rng, (1, 4, 4, 8)), pc.feat(rng, (1, 4, 4, 8))
+    f1, f2 = mx.nd.array(f1v), mx.nd.array(f2v)
+    f1.attach_grad()
+    f2.attach_grad()
     with mx.autograd.record():
-        c = mx.nd.Custom(f, f, op_type="mfn_correlation", pad_size=4, max_displacement=4, activation="leaky")
+        c = mx.nd.Custom(f1, f2, op_type="mfn_correlation", pad_size=4, max_displacement=4, activation="leaky")
+    go = rng.standard_normal(c.shape).astype(np.float32)
+    c.backward(mx.nd.array(go))
+    pre = oracle.correlation(f1v, f2v, max_displacement=4, pad_size=4)
+    w1, w2 = oracle.correlation_backward(np.where(pre > 0, go, np.float32(0.1) * go).astype(np.float32), f1v, f2v,
+                                         max_displacement=4, pad_size=4)
+    pc.check_close(f1.grad.asnumpy(), w1, tol=2e-5, what="leaky correlation backward g1")
+    pc.check_close(f2.grad.asnumpy(), w2, tol=2e-5, what="leaky correlation backward g2")
+    del mx.autograd._tape[:]
+    th = mx.nd.array(np.tile(np.array([[1, 0, 0, 0, 1, 0]], np.float32), (1, 1)))
+    th.attach_grad()
+    with mx.autograd.record():
+        g = mx.nd.Custom(th, op_type="mfn_grid_generator", transform_type="affine", target_shape=(4, 8))
     with pytest.raises(NotImplementedError):
-        c.backward()
+        g.backward()
 
 
 # ---- the reference's own source files, unmodified, through install() ---------------------------------------------
