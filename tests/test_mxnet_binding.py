@@ -325,6 +325,50 @@ def _pair_backward(mx, oracle, ctx, shape, seed=0):
     pc.check_close(FLXY.grad.asnumpy(), gf[:, ::-1], tol=5e-5, what="pair backward: d/dflow (x, y order)")
 
 
+def test_one_process_drives_several_devices(cpu_binding, oracle, monkeypatch):
+    """network/pipeline.py:95 split_and_load()s a batch over a ctx LIST and runs the network on every shard from ONE
+    process: every operator call must select the device its arrays live on (hipSetDevice(ctx.device_id)), and scratch
+    kept by an operator instance must follow the context.  Emulated here with host memory behind gpu(0) / gpu(2)."""
+    mx, m = cpu_binding
+    import torch
+    monkeypatch.setattr(mx.context.Context, "torch_device", lambda self: torch.device("cpu"))
+    entered = []
+
+    class _Recording(_HostRuntime):
+        def enter(self, ctx):
+            assert ctx.device_type == "gpu"
+            entered.append(ctx.device_id)
+
+    m._rt = _Recording()
+    m.install()
+    for dev in (0, 2, 0):
+        ctx = mx.gpu(dev)
+        n0 = len(entered)
+        _deform_fwd_bwd(mx, oracle, ctx, 1, 8, 6, 8, seed=dev)          # forward + backward, workspaces on `ctx`
+        rng = np.random.default_rng(5 + dev)
+        f1, f2 = pc.feat(rng, (1, 8, 6, 8)), pc.feat(rng, (1, 8, 6, 8))
+        c = mx.nd.Correlation(mx.nd.array(f1, ctx=ctx), mx.nd.array(f2, ctx=ctx), kernel_size=1, max_displacement=4, stride1=1,
+                              stride2=1, pad_size=4, is_multiply=1)
+        assert c.context == ctx
+        pc.check_close(c.asnumpy(), oracle.correlation(f1, f2, max_displacement=4, pad_size=4))
+        assert len(entered) - n0 >= 3 and set(entered[n0:]) == {dev}, entered[n0:]
+        del mx.autograd._tape[:]
+    # one operator INSTANCE called on two devices in turn (what a cached CustomOp sees): its scratch follows the context
+    prop = mx.operator.get_registered("mfn_deform_conv")(**{k: str(v) for k, v in reference_deform_kwargs(8).items()})
+    op = prop.create_operator(mx.gpu(0), None, None)
+    rng = np.random.default_rng(9)
+    x, off, w, b = _inputs(rng, 1, 8, 6, 8)
+    want = oracle.deformable_convolution(x, off, w, b, pad=(1, 1))
+    for dev in (0, 3):
+        ctx = mx.gpu(dev)
+        ins = [mx.nd.array(a, ctx=ctx) for a in (x, off, w, b)]
+        out = mx.nd.empty(want.shape, ctx=ctx)
+        op.forward(False, ["write"], ins, [out], [])
+        pc.check_close(out.asnumpy(), want)
+        assert op.ws is None or op.ws.context == ctx
+    assert entered[-1] == 3
+
+
 def test_operator_pair_backward_through_custom_ops(cpu_binding, oracle):
     mx, m = cpu_binding
     m.install()
