@@ -183,7 +183,8 @@ def roofline_of_dominant_kernel(wl, iters, torch):
             wl.stream.synchronize()
             lib.profile_reset()
             lib.profile_enable(1)
-            for it in range(max(iters, 3 * nsets)):
+            for it in range(3 * nsets):   # three rounds over the sets: enough for a mean, few enough not to skew the
+                                          # rocprofv3 average of this kernel (profiles/*_bench_kernel_stats.md)
                 i = it % nsets
                 wl.ops.Correlation(f1s[i], f2s[i], 1, 4, 1, 1, 4, True, out=outs[i])
             lib.profile_enable(0)

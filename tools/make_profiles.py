@@ -16,14 +16,13 @@ if os.path.exists(db):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     with open(os.path.join(P, "%s_bench_kernel_stats.md" % tag), "w") as f:
-        f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe`\n\n" % tag)
+        f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-side-configs --no-e2e`\n\n" % tag)
         f.write("MI355X (gfx950), ROCm 7.2.  Source: gpurun_out/prof_bench/bench_results.db (top_kernels view); durations in "
                 "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (level 6: direct "
                 "kernel; levels 5/4: LDS-DMA tile kernel, displacement rows over 5 blocks x 4 channel groups; level 3: two channel groups; level 2: "
                 "LDS-DMA tile kernel), 4 x (offsets + deformable conv `dc_lds_kernel`), 1 warp.  bench.py also runs the pass on two more "
-                "streams for its informational `pipelined` figure, the level-2 correlation ~420 more times for `roofline` "
-                "(hot loop, in-pass, rotated buffers), the rough-flow batch, and one end-to-end network forward (`e2e`: the "
-                "conv3x3 / deconv rows).\n"
+                "streams for its informational `pipelined` figure, the level-2 correlation 200 more times back to back, 200 eager "
+                "passes with every kernel timed (`roofline`, `kernels`), 18 launches on rotated buffers, and the rough-flow batch.\n"
                 "Only `mfn::` kernels belong to the pass; the `at::native` rows are bench.py's checksum.\n\n")
         f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows:
@@ -83,10 +82,10 @@ if os.path.exists(db5):
         f.write("MI355X (gfx950), ROCm 7.2.  Source: rocprofv3 rocpd database (top_kernels view); durations in microseconds.\n"
                 "Training-step pass (BASELINE configs[4], 8 pairs of 384x512 per GPU): the S forward pass, then corr_bwd -> deform_bwd per "
                 "level.  `dc_bwd_input_pix_kernel` = input + offset gradient of the deformable conv in the forward's orientation "
-                "(kernels/dc_backward.h); `dc_bwd_input_tile_kernel` only sees its skip list here; `dc_bwd_weight_pix_kernel<MTOT>` + "
+                "(kernels/dc_backward.h); `dc_bwd_input_tile_kernel` only sees its skip list here; `dc_bwd_weight_pc_kernel<MTOT>` + "
                 "`dc_bwd_weight_reduce_kernel` = weight + bias gradient (columns as the forward produces them, per-block slabs, "
-                "fixed-order sum); `corr_bwd_lds_kernel` computes g1 and g2 in separate blocks (the other feature map's rows through LDS); `fill_zero4_kernel` zeroes the "
-                "write-mode gradients of a call.  bench.py also runs the pass on two more streams (`pipelined`) and eager passes for "
+                "fixed-order sum; its blocks also clear gx / goffset on their way in); `corr_bwd_lds_kernel` computes g1 and g2 in separate blocks (the other feature map's rows through LDS); `fill_zero4_kernel` zeroes the "
+                "write-mode gradients of a call where no slab launch does it (level 5).  bench.py also runs the pass on two more streams (`pipelined`) and eager passes for "
                 "`roofline` / `kernels`.\n\n")
         f.write("| kernel | calls | total us | avg us | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows:
@@ -105,7 +104,7 @@ for name in ("bench_cfg5", "bench_cfg5_fused"):
             continue
         open(os.path.join(P, "%s_%s.json.log" % (tag, name)), "w").write(line + "\n")
         print("wrote", "%s_%s.json.log" % (tag, name))
-for name in ("atomic_patterns_ubench", "bwd_levels", "bwd_pix_phases", "bwd_wpix_phases", "bwd_wpc_phases", "corr_bwd_levels", "unaligned_loads_ubench"):
+for name in ("bwd_levels", "corr_bwd_levels"):
     src = os.path.join(G, name + ".txt")
     if os.path.exists(src):
         open(os.path.join(P, "%s_%s.txt" % (tag, name)), "w").write(open(src).read())
