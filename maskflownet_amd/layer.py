@@ -247,6 +247,9 @@ class DeformableConv2D(nn.Module):
         kw = self._kwargs
         if kw["stride"] != (1, 1) or kw["num_deformable_group"] != 1:
             raise ValueError("forward_matching needs stride 1 and one deformable group")
+        if self.act is not None:
+            raise ValueError("forward_matching is the reference's warp step (MaskFlownet.py:230-233): no activation between the "
+                             "deformable convolution and the gating -- build the block with activation=None")
         if _any_grad(x, flow, mask, tradeoff, self.weight, self.bias):
             # differentiable form of the same arithmetic (MaskFlownet.py:230-233), elementwise part in torch
             out = self.forward_shared(x, flow, flow_scale, flow_stride)

@@ -41,11 +41,19 @@ class OpSet:
         if ws is None or self.ad.nbytes(ws) < nbytes:
             if ws is not None:
                 # a hipGraph captured earlier (hotpath.capture, or a user's own capture) still holds the old
-                # pointer: the superseded buffer must outlive it, so it is parked instead of freed
+                # pointer: the superseded buffer must outlive it, so it is parked instead of freed -- until the owner of
+                # those graphs says they are gone (release_retired)
                 self._retired.append(ws)
             ws = self.ad.empty_bytes(like, max(int(nbytes), 1 << 20))
             self._ws[key] = ws
         return ws
+
+    def release_retired(self):
+        """Free the workspaces superseded by larger ones.  Call it when no hipGraph captured BEFORE the growth is alive any
+        more (such a graph holds the old pointer); returns how many buffers were dropped."""
+        n = len(self._retired)
+        del self._retired[:]
+        return n
 
     def _out(self, out, like, shape, what):
         """A caller-supplied destination goes to the kernel as it is: it must already be what the kernel writes --
@@ -325,7 +333,7 @@ class OpSet:
                     raise ValueError("DeformableConvolution_backward: req 'add' needs the buffer to add into (out[%d])" % i)
                 grads.append(self.ad.empty(x, shp))
             else:
-                (g,) = self._in(g)
+                self.ad.require_destination(g, x, "DeformableConvolution_backward")   # written in place: no silent copy
                 if self.ad.shape(g) != tuple(shp):
                     raise ValueError("DeformableConvolution_backward: out[%d] has shape %s, expected %s"
                                      % (i, self.ad.shape(g), tuple(shp)))
@@ -371,7 +379,7 @@ class OpSet:
                     raise ValueError("deformable_convolution_shared_backward: req 'add' needs the buffer to add into (out[%d])" % i)
                 grads.append(self.ad.empty(x, shp))
             else:
-                (g,) = self._in(g)
+                self.ad.require_destination(g, x, "deformable_convolution_shared_backward")   # written in place: no silent copy
                 if self.ad.shape(g) != tuple(shp):
                     raise ValueError("deformable_convolution_shared_backward: out[%d] has shape %s, expected %s"
                                      % (i, self.ad.shape(g), tuple(shp)))

@@ -104,3 +104,21 @@ def test_upsample_backward_gpu(gpu_ops, shape, factor):
 def test_leaky_correlation_backward_gpu(gpu_ops):
     pc.case_leaky_corr_backward(gpu_ops, oracle, _dev, _host, (2, 32, 24, 32), md=4)
     pc.case_leaky_corr_backward(gpu_ops, oracle, _dev, _host, (2, 64, 12, 16), md=2, seed=3)
+
+
+def test_superseded_workspaces_are_parked_until_released(emu):
+    """OpSet keeps a workspace that a larger one replaced (a hipGraph captured earlier still points at it) until its owner
+    calls release_retired(); gradient destinations are never silently copied."""
+    x = np.zeros((1, 4, 8, 8), np.float32)
+    emu._workspace(x, 1 << 20)
+    n0 = len(emu._retired)
+    emu._workspace(x, (emu.ad.nbytes(emu._ws[emu.ad.device_key(x)])) * 2)
+    assert len(emu._retired) == n0 + 1
+    assert emu.release_retired() == n0 + 1 and emu._retired == []
+    go = np.zeros((1, 4, 8, 8), np.float32)
+    off = np.zeros((1, 18, 8, 8), np.float32)
+    w = np.zeros((4, 4, 3, 3), np.float32)
+    strided = np.zeros((1, 4, 8, 16), np.float32)[:, :, :, ::2]      # right shape, not contiguous
+    with pytest.raises(ValueError, match="contiguous"):
+        emu.DeformableConvolution_backward(go, x, off, w, pad=(1, 1), req=("add", "null", "null", "null"),
+                                           out=(strided, None, None, None))
