@@ -1,7 +1,9 @@
 """mxnet.ndarray (mx.nd) of the stub: NDArray over a torch tensor, and nd.Custom with MXNet's CustomOp protocol.
 
 Only plumbing lives here (allocation, copies, the flip / clip / slicing the reference applies around its operator
-calls): every operator result comes from a registered CustomOp.
+calls): every operator result comes from a registered CustomOp -- except the shape / element-wise GLUE of
+network/MaskFlownet.py (concat, repeat, reshape codes, sigmoid, pad, scalar arithmetic ...), which `_glue.py` states in
+torch, forward only, so that the reference's whole hybrid_forward can run through the stub (tests/test_reference_network.py).
 """
 import ctypes
 import itertools
@@ -78,7 +80,29 @@ class NDArray:
         return NDArray(torch.clamp(self._tensor, a_min, a_max), self._ctx)
 
     def reshape(self, shape):
-        return NDArray(self._tensor.reshape(shape), self._ctx)
+        from ._glue import reshape as _reshape   # MXNet's special codes (0, -2, -3) included
+        return _reshape(self, shape)
+
+    def slice_axis(self, axis, begin, end):
+        import builtins
+        idx = [builtins.slice(None)] * self._tensor.dim()
+        idx[axis] = builtins.slice(begin, end)
+        return NDArray(self._tensor[tuple(idx)], self._ctx)
+
+    # forward-only arithmetic glue (MaskFlownet.py: flow * self.scale / stride, flow + pred_flow(x), sigmoid(m) - 0.5 ...)
+    def _bin(self, other, fn):
+        o = other._tensor if isinstance(other, NDArray) else other
+        return NDArray(fn(self._tensor, o), self._ctx)
+
+    def __add__(self, o): return self._bin(o, lambda a, b: a + b)
+    def __radd__(self, o): return self._bin(o, lambda a, b: b + a)
+    def __sub__(self, o): return self._bin(o, lambda a, b: a - b)
+    def __rsub__(self, o): return self._bin(o, lambda a, b: b - a)
+    def __mul__(self, o): return self._bin(o, lambda a, b: a * b)
+    def __rmul__(self, o): return self._bin(o, lambda a, b: b * a)
+    def __truediv__(self, o): return self._bin(o, lambda a, b: a / b)
+    def __rtruediv__(self, o): return self._bin(o, lambda a, b: b / a)
+    def __neg__(self): return NDArray(-self._tensor, self._ctx)
 
     def __getitem__(self, key):
         return NDArray(self._tensor[key], self._ctx)
@@ -177,3 +201,5 @@ def Custom(*inputs, op_type=None, name=None, **kwargs):
 
 
 contrib = SimpleNamespace()  # mx.nd.contrib: the binding's install() puts DeformableConvolution here
+
+from ._glue import *  # noqa: E402,F401,F403  (concat, expand_dims, repeat, reshape, sigmoid, pad, ... : forward-only glue)
