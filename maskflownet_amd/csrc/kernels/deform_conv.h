@@ -57,6 +57,7 @@ struct DeformParams {
   float *partial;                             // ksb > 1: raw partial sums [ksb][N][Cout][Ho][Wo]
 };
 
+constexpr int DC_PAIR_W_BF16 = 3 * 2 * 32 * 8 / 2 + 2 * 32;   // words of a channel pair's weights in the bf16 x 3 form (832; 576 in fp32)
 // weights (Cout, Cin, 9) -> wt[mg][cp][t][half][RL]: filter o = mg*RL + r, channel c = 2*cp + half; zero padded
 // in c (odd Cin, rows up to ncp_pad) and o (Cout not a multiple of RL).  One M-group is one linear
 // array, so a K-chunk of it is one contiguous LDS-DMA transfer.
@@ -72,6 +73,28 @@ __global__ __launch_bounds__(256) void dc_pack_weights_kernel(PackParams p) {
   const int mg = (int)(idx / ((size_t)2 * p.RL * p.T * p.ncp_pad));
   const int c = 2 * cp + half, o = mg * p.RL + r;
   p.wt[idx] = (c < p.Cin && o < p.Cout) ? p.w[((size_t)o * p.Cin + c) * p.T + t] : 0.f;
+}
+
+// the same filters for the bf16 x 3 split (DcGeom<.., MMA = 1>): one thread per (M-group, pair, channel of the pair, filter)
+struct PackBf16Params { const float *w; float *wt; int Cin, Cout, mgroups, ncp_pad; };
+__global__ __launch_bounds__(256) void dc_pack_weights_bf16_kernel(PackBf16Params p) {
+  const size_t total = (size_t)p.mgroups * p.ncp_pad * 2 * 32;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int m = (int)(idx & 31), kb = (int)((idx >> 5) & 1);
+  const int cp = (int)((idx >> 6) % p.ncp_pad), mg = (int)((idx >> 6) / p.ncp_pad);
+  const int c = 2 * cp + kb, o = mg * 32 + m;
+  const bool ok = c < p.Cin && o < p.Cout;
+  float x[8];
+  MFN_UNROLL
+  for (int e = 0; e < 8; ++e) x[e] = ok ? p.w[((size_t)o * p.Cin + c) * 9 + e] : 0.f;
+  mfn_bf16x8 h, mm, l;
+  mfn_split3x8(x, h, mm, l);
+  float *base = p.wt + ((size_t)mg * p.ncp_pad + cp) * DC_PAIR_W_BF16;
+  mfn_write_bf16x8(base + ((0 * 2 + kb) * 32 + m) * 4, h);
+  mfn_write_bf16x8(base + ((1 * 2 + kb) * 32 + m) * 4, mm);
+  mfn_write_bf16x8(base + ((2 * 2 + kb) * 32 + m) * 4, l);
+  base[768 + kb * 32 + m] = ok ? p.w[((size_t)o * p.Cin + c) * 9 + 8] : 0.f;
 }
 
 // the matching module's epilogue on one output value (bias already added): v * sigmoid(mask) + add, LeakyReLU(0.1)
@@ -133,10 +156,14 @@ constexpr int dc_kc(int mt, int kw) {
   return q >= 4 ? 4 : (q >= 2 ? 2 : 1);
 }
 template <int V> struct DcInt { static constexpr int value = V; };
-template <int MT, int KW> struct DcGeom {
+// MMA = 1 (dc.mma, one filter tile per wave only): the weights of a channel pair are stored for the bf16 x 3 split --
+// [split hi|mid|lo][channel of the pair][filter][taps 0..7] as bf16 (16 bytes per lane and split: the A operand of one
+// v_mfma_f32_32x32x16_bf16) followed by [channel][filter] fp32 for tap 8, which stays on the exact fp32 MFMA.
+template <int MT, int KW, int MMA = 0> struct DcGeom {
   static constexpr int RL = 32 * MT;
   static constexpr int KC = dc_kc(MT, KW);
-  static constexpr int CHUNK_F = KC * 18 * RL;  // floats
+  static constexpr int PAIR_W = MMA ? DC_PAIR_W_BF16 : 18 * RL;   // words of one channel pair's weights
+  static constexpr int CHUNK_F = KC * PAIR_W;   // floats
   static constexpr int CH4 = CHUNK_F / 4;       // float4 items
 };
 
@@ -147,15 +174,18 @@ constexpr int dc_min_waves(int mt, int pt, int nw = 4) {
 }
 
 // NW = waves per block (4, or 8 for the coarsest level: twice the in-block K slices, half the channel-pair chain per wave)
-template <int MT, int PT, int NW = 4>
+template <int MT, int PT, int NW = 4, int MMA = 0>
 __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kernel(DeformParams p) {
+  static_assert(MMA == 0 || MT == 1, "the bf16 x 3 form is built for one filter tile per wave");
   constexpr int T = 9;
   constexpr int NTH = NW * 64;
   constexpr int KW = NW / PT;  // K-slices handled inside the block (one wave each per pixel tile)
-  using G = DcGeom<MT, KW>;
+  using G = DcGeom<MT, KW, MMA>;
   constexpr int RL = G::RL, KC = G::KC, CH4 = G::CH4;
   constexpr int NI = (KW * CH4 + NTH - 1) / NTH;  // DMA instructions per thread per stage
-  constexpr int STAGE_F = NI * NTH * 4;           // floats per stage buffer
+  // floats per stage buffer.  MMA: whole wave transfers only (the instructions that carry nothing go to a 1 KB dump behind
+  // the windows), so that the larger bf16 x 3 blocks still fit three workgroups into a CU's LDS
+  constexpr int STAGE_F = MMA ? ((KW * CH4 + 63) / 64) * 256 : NI * NTH * 4;
   MFN_DYN_SHARED(float, lds);                 // 2 weight stage buffers + x windows (all reused for the K-slice reduction)
   // staged source window per wave and channel: 10 rows x 24 floats under a 2x16 pixel tile, 12 rows x 20 floats
   // under a 4x8 tile -- 60 float4 slots per channel, one channel pair = 2 wave DMA instructions (120 of 128 lanes)
@@ -221,21 +251,25 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   const int h_in = ho * p.sh - p.ph, w_in = wo * p.sw - p.pw;
 
   // ---- weight staging plan: item -> byte offset inside this M-group's packed array -----------------
-  const size_t mg_floats = (size_t)p.ncp_pad * 18 * RL;
+  const size_t mg_floats = (size_t)p.ncp_pad * G::PAIR_W;
   const mfn_rsrc_t wrsrc = mfn_make_rsrc(p.wt + (size_t)mg * mg_floats, (unsigned)(mg_floats * 4));
   unsigned voff[NI];
   MFN_UNROLL
   for (int i = 0; i < NI; ++i) {
     const int it = (i * NW + wave) * 64 + lane;
     const int k = it / CH4, idx = it - k * CH4;
-    voff[i] = k < KW ? (unsigned)(((size_t)(blockIdx.y * KW + k) * p.cps_per_slice * 18 * RL + (size_t)idx * 4) * 4)
+    voff[i] = k < KW ? (unsigned)(((size_t)(blockIdx.y * KW + k) * p.cps_per_slice * G::PAIR_W + (size_t)idx * 4) * 4)
                      : 0xFFFFFF00u;
   }
   auto issue = [&](int ch) {
     float *buf = lds + (ch & 1) * STAGE_F;
     const unsigned soff = (unsigned)((size_t)ch * G::CHUNK_F * 4);
     MFN_UNROLL
-    for (int i = 0; i < NI; ++i) mfn_dma16_so(wrsrc, buf + (i * NW + wave) * 256, voff[i], soff);
+    for (int i = 0; i < NI; ++i) {
+      float *dst = buf + (i * NW + wave) * 256;
+      if (MMA && (i * NW + wave) * 64 >= KW * CH4) dst = lds + 2 * STAGE_F + NW * (3 * XW_F);   // nothing to carry: the dump
+      mfn_dma16_so(wrsrc, dst, voff[i], soff);
+    }
   };
 
   issue(0);  // the first weight chunk lands while the tap geometry below is computed
@@ -337,10 +371,39 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   const int cp_base = gs * p.cps_per_slice;
   const int nchunks = p.cps_per_slice / KC;  // cps_per_slice is a multiple of KC
 
+  // this lane's weight of tap t inside a channel pair's block `pw` (wave-uniform pointer): the filter (j) x channel (half)
+  // element the fp32 MFMA wants as A.  MMA: rebuilt exactly from its three bf16 terms (the tiers that are not hot use this).
+  auto a_of = [&](const float *pw, int t, int mt) -> float {
+    if (!MMA) return pw[(t * 2 + half) * RL + mt * 32 + j];
+    if (t == 8) return pw[768 + half * 32 + j];
+    const int e = ((0 * 2 + half) * 32 + j) * 8 + t;   // bf16 index of the hi term; mid / lo follow 2 * 32 * 8 further
+    return mfn_bf16_at(pw, e) + mfn_bf16_at(pw, e + 512) + mfn_bf16_at(pw, e + 1024);
+  };
+  // MMA: the nine column values of a pair against its filters -- taps 0..7 as three bf16 terms each, six products on the
+  // matrix cores (smallest terms first); tap 8 on the fp32 MFMA.  prepare = split + operand reads, issue(i) = product i
+  struct MmaOps { mfn_bf16x8 ah, am, al, bh, bm, bl; float a8, b8; };
+  auto mma_prepare = [&](const float *pw, const float (&cv)[9], MmaOps &o) {
+    const float x8[8] = {cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7]};
+    mfn_split3x8(x8, o.bh, o.bm, o.bl);
+    o.ah = mfn_read_bf16x8(pw + ((0 * 2 + half) * 32 + j) * 4);
+    o.am = mfn_read_bf16x8(pw + ((1 * 2 + half) * 32 + j) * 4);
+    o.al = mfn_read_bf16x8(pw + ((2 * 2 + half) * 32 + j) * 4);
+    o.a8 = pw[768 + half * 32 + j];
+    o.b8 = cv[8];
+  };
+  auto mma_issue = [&](const MmaOps &o, int i) {
+    if (i == 0) acc[0] = MFN_MFMA_32x32x16_BF16(o.al, o.bh, acc[0]);
+    else if (i == 1) acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bl, acc[0]);
+    else if (i == 2) acc[0] = MFN_MFMA_32x32x16_BF16(o.am, o.bm, acc[0]);
+    else if (i == 3) acc[0] = MFN_MFMA_32x32x16_BF16(o.am, o.bh, acc[0]);
+    else if (i == 4) acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bm, acc[0]);
+    else if (i == 5) acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bh, acc[0]);
+    else acc[0] = MFN_MFMA_32x32x2(o.a8, o.b8, acc[0]);
+  };
   const int full_pairs = p.Cin / 2;  // pairs whose two channels both exist; an odd Cin adds one half pair
   // one channel pair on the fast path: separable bilinear interpolation of the 4x4 neighbourhood into
   // the 9 column values, which ARE the B operands of the 9 k-steps
-  auto fast_pair = [&](const float (&v)[4][4], const float *ap) {
+  auto fast_pair = [&](const float (&v)[4][4], const float *pw) {
     float tr[4][3];
     MFN_UNROLL
     for (int m = 0; m < 4; ++m)
@@ -353,7 +416,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         const float cv = ay.a[i] * tr[i][q] + ay.b[i] * tr[i + 1][q];
         MFN_UNROLL
         for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = MFN_MFMA_32x32x2(ap[((i * 3 + q) * 2) * RL + mt * 32], cv, acc[mt]);
+          acc[mt] = MFN_MFMA_32x32x2(a_of(pw, i * 3 + q, mt), cv, acc[mt]);
       }
   };
   // second tier (window does not fit: a rough or discontinuous flow, outliers): every row of the 4x4 neighbourhood is ONE
@@ -373,19 +436,19 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   MFN_UNROLL
   for (int m = 0; m < 4; ++m)
     rowoff[m] = (unsigned)(n * p.Cin * (int)plane + half * (int)plane + ay.idx[m] * W + ax.idx[0]);
-  auto dwgather_pair = [&](int cp, const float *ap) {
+  auto dwgather_pair = [&](int cp, const float *pw) {
     const float *base = p.x + (size_t)(2 * cp) * plane;  // uniform
     float v[4][4];
     MFN_UNROLL
     for (int m = 0; m < 4; ++m)
       MFN_UNROLL
       for (int q = 0; q < 4; ++q) v[m][q] = base[rowoff[m] + (unsigned)(ax.idx[q] - ax.idx[0])];
-    fast_pair(v, ap);
+    fast_pair(v, pw);
   };
   // per-tap path (arbitrary offsets, and the half pair of an odd Cin; never hot in the reference
   // network).  Deliberately lean in registers, not fast: a rolled tap loop that re-reads its offset,
   // rebuilds the tap geometry and feeds the MFMA at once, so the fast path sets the VGPR budget.
-  auto slow_pair = [&](int cp, const float *ap) {
+  auto slow_pair = [&](int cp, const float *pw) {
     const int c = 2 * cp + half;
     const bool cvalid = c < p.Cin;
     const float *pl = xn + (size_t)(cvalid ? c : 0) * plane;
@@ -406,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       const float v1 = pl[bb], v2 = pl[bb + dwi], v3 = pl[bb + tp.dhW], v4 = pl[bb + tp.dhW + dwi];
       const float cv = tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4;
       MFN_UNROLL
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(ap[(t * 2) * RL + mt * 32], cv, acc[mt]);
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(a_of(pw, t, mt), cv, acc[mt]);
     }
   };
 
@@ -431,7 +494,8 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
     for (int m = 0; m < 4; ++m)
       MFN_UNROLL
       for (int q = 0; q < 4; ++q)
-        loff[m][q] = half * (XW_ROWS * XW_COLS) + (ay.idx[m] - wr0) * XW_COLS + (ax.idx[q] - wc0);
+        loff[m][q] = px_valid ? half * (XW_ROWS * XW_COLS) + (ay.idx[m] - wr0) * XW_COLS + (ax.idx[q] - wc0) : 0;  // lanes past
+        // the image read slot 0 (their weights are zero): their own neighbourhood may lie anywhere relative to the window
   }
   auto issue_x = [&](int cp, int buf) {
     const unsigned soff = (unsigned)((size_t)(2 * cp) * plane * 4);
@@ -539,23 +603,48 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         }
       }
       w_in_flight = w_now;
-      const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
+      const float *pw = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + (size_t)kk * G::PAIR_W;   // this pair's weights (uniform)
+      const float *ap = pw + half * RL + j;
       // The interpolation of pair k + 1 runs in the last step too (on the previous step's window values, results unused):
       // with the MFMAs in two branches the accumulators lived in two register sets and hipcc copied all sixteen (after
       // draining the MFMA pipe) at the end of EVERY step.  The LDS reads themselves must NOT run there: left in flight when
       // the loop ends, they land in registers that are dead from the compiler's point of view -- it had handed them to the
       // epilogue without a wait, and one pass in two came back with a wrong 4x8 tile somewhere (tools/r03_det.py; every
       // comparison with the oracle had passed).
-      if (k + 1 < nf) gather2(BN, vp);
-      mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
-      mfma_tap(ap, 1, cur[1]);
-      mfma_tap(ap, 2, cur[2]); interp_rows2(vp, trp, 1);
-      mfma_tap(ap, 3, cur[3]);
-      mfma_tap(ap, 4, cur[4]); interp_col2(trp, nxt, 0);
-      mfma_tap(ap, 5, cur[5]); interp_col2(trp, nxt, 1);
-      mfma_tap(ap, 6, cur[6]); interp_col2(trp, nxt, 2);
-      mfma_tap(ap, 7, cur[7]);
-      mfma_tap(ap, 8, cur[8]);
+      // MMA: the reads are unconditional (the last step re-reads a stale window, results unused) and MFN_REGFENCE_P8 after
+      // the loop keeps their destination registers alive until they have landed -- no branch, no phi copies of the results
+      if (MMA || k + 1 < nf) gather2(BN, vp);
+      if (MMA) {   // six matrix-core products + tap 8, the next pair's interpolation between them
+        MmaOps o;
+        mma_prepare(pw, cur, o);
+        mma_issue(o, 0); interp_rows2(vp, trp, 0);
+        mma_issue(o, 1); interp_rows2(vp, trp, 1);
+        mma_issue(o, 2); interp_col2(trp, nxt, 0);
+        mma_issue(o, 3); interp_col2(trp, nxt, 1);
+        mma_issue(o, 4); interp_col2(trp, nxt, 2);
+        mma_issue(o, 5);
+        mma_issue(o, 6);
+        // the order the scheduler is asked for: the split (VALU) and the operand reads first, then one matrix instruction per
+        // five VALU instructions of the next pair's interpolation
+        MFN_SCHED_GROUP(0x002, 40); MFN_SCHED_GROUP(0x100, 4);
+        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
+        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
+        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
+        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
+        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
+        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
+        MFN_SCHED_GROUP(0x008, 1);
+      } else {
+        mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
+        mfma_tap(ap, 1, cur[1]);
+        mfma_tap(ap, 2, cur[2]); interp_rows2(vp, trp, 1);
+        mfma_tap(ap, 3, cur[3]);
+        mfma_tap(ap, 4, cur[4]); interp_col2(trp, nxt, 0);
+        mfma_tap(ap, 5, cur[5]); interp_col2(trp, nxt, 1);
+        mfma_tap(ap, 6, cur[6]); interp_col2(trp, nxt, 2);
+        mfma_tap(ap, 7, cur[7]);
+        mfma_tap(ap, 8, cur[8]);
+      }
       MFN_SCHED_BARRIER();
     };
     for (int k = 0; k < nf;) {
@@ -572,6 +661,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       step(k, DcInt<0>{}, cvn, cv);
       ++k;
     }
+    if (MMA) MFN_REGFENCE_P8(vp);   // the last step's window reads have landed before anybody else gets their registers
     k_done = nf;
   }
 
@@ -663,17 +753,30 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         if (kk == 0 && ch + 1 < nchunks) issue(ch + 1);
         MFN_WAIT_VM(4);  // pair k + 1 landed (see above; a weight chunk requested in this or the last step is waited for too)
         MFN_REGFENCE4(R[SN][0], R[SN][1], R[SN][2], R[SN][3]);
-        const float *ap = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j + (size_t)kk * T * 2 * RL;
+        const float *pw = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + (size_t)kk * G::PAIR_W;
+        const float *ap = pw + half * RL + j;
         // the last step interpolates a repeated pair (results unused): one MFMA stream, no accumulator copies
-        mfma_tap(ap, 0, cur[0]); xrow(R[SN][0], 0);
-        mfma_tap(ap, 1, cur[1]); xrow(R[SN][1], 1);
-        mfma_tap(ap, 2, cur[2]); xrow(R[SN][2], 2);
-        mfma_tap(ap, 3, cur[3]); xrow(R[SN][3], 3);
-        mfma_tap(ap, 4, cur[4]); ycol(nxt, 0);
-        mfma_tap(ap, 5, cur[5]); ycol(nxt, 1);
-        mfma_tap(ap, 6, cur[6]); ycol(nxt, 2);
-        mfma_tap(ap, 7, cur[7]);
-        mfma_tap(ap, 8, cur[8]);
+        if (MMA) {
+          MmaOps o;
+          mma_prepare(pw, cur, o);
+          mma_issue(o, 0); xrow(R[SN][0], 0);
+          mma_issue(o, 1); xrow(R[SN][1], 1);
+          mma_issue(o, 2); xrow(R[SN][2], 2);
+          mma_issue(o, 3); xrow(R[SN][3], 3);
+          mma_issue(o, 4); ycol(nxt, 0);
+          mma_issue(o, 5); ycol(nxt, 1);
+          mma_issue(o, 6); ycol(nxt, 2);
+        } else {
+          mfma_tap(ap, 0, cur[0]); xrow(R[SN][0], 0);
+          mfma_tap(ap, 1, cur[1]); xrow(R[SN][1], 1);
+          mfma_tap(ap, 2, cur[2]); xrow(R[SN][2], 2);
+          mfma_tap(ap, 3, cur[3]); xrow(R[SN][3], 3);
+          mfma_tap(ap, 4, cur[4]); ycol(nxt, 0);
+          mfma_tap(ap, 5, cur[5]); ycol(nxt, 1);
+          mfma_tap(ap, 6, cur[6]); ycol(nxt, 2);
+          mfma_tap(ap, 7, cur[7]);
+          mfma_tap(ap, 8, cur[8]);
+        }
         MFN_REGFENCE9(nxt);  // slot SN is read out: the next step's request may overwrite it
         MFN_SCHED_BARRIER();
       };
@@ -704,17 +807,17 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       if (ch == 0) MFN_STAMP(p.timeline, 1);
       if (ch + 1 < nchunks) issue(ch + 1);
     }
-    const float *abuf = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + half * RL + j;
+    const float *abuf = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F;   // the chunk's weights (uniform; a_of picks the lane's)
     const int cp0 = cp_base + ch * KC;
     int k = resumed ? k_done - ch * KC : 0;
     if (dwgather) {
       const int nrow = max(0, min(KC, full_pairs - cp0));
       MFN_NOUNROLL
-      for (; k < nrow; ++k) dwgather_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);
+      for (; k < nrow; ++k) dwgather_pair(cp0 + k, abuf + (size_t)k * G::PAIR_W);
     }  // otherwise (arbitrary per-tap offsets) every pair of this chunk takes the per-tap path below
     MFN_NOUNROLL
     for (; k < KC; ++k)
-      if (2 * (cp0 + k) < p.Cin) slow_pair(cp0 + k, abuf + (size_t)k * T * 2 * RL);  // padded pairs: zero weights, skip
+      if (2 * (cp0 + k) < p.Cin) slow_pair(cp0 + k, abuf + (size_t)k * G::PAIR_W);  // padded pairs: zero weights, skip
   }
 
   MFN_STAMP(p.timeline, 2);
@@ -846,22 +949,22 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   MFN_STAMP(p.timeline, 3);
 }
 
-template <int MT, int PT, int NW = 4>
+template <int MT, int PT, int NW = 4, int MMA = 0>
 inline size_t dc_lds_bytes() {
   constexpr int KW = NW / PT;
-  constexpr int NI = (KW * DcGeom<MT, KW>::CH4 + NW * 64 - 1) / (NW * 64);
-  const size_t stage = (size_t)2 * NI * NW * 64 * 16;
+  constexpr int NI = (KW * DcGeom<MT, KW, MMA>::CH4 + NW * 64 - 1) / (NW * 64);
+  const size_t stage = MMA ? (size_t)2 * ((KW * DcGeom<MT, KW, MMA>::CH4 + 63) / 64) * 1024 : (size_t)2 * NI * NW * 64 * 16;
   const size_t red = KW > 1 ? (size_t)PT * (KW - 1) * MT * 16 * 64 * 4 : 0;
-  const size_t xwin = (size_t)NW * 3 * (2 * 256) * 4;  // NW waves x 3 buffers x one channel-pair window (XW_F floats)
+  const size_t xwin = (size_t)NW * 3 * (2 * 256) * 4 + (MMA ? 1024 : 0);  // NW waves x 3 buffers x one channel-pair window (XW_F floats) [+ the DMA dump]
   return stage + xwin > red ? stage + xwin : red;
 }
 
-template <int MT, int PT, int NW = 4>
+template <int MT, int PT, int NW = 4, int MMA = 0>
 inline int dc_lds_launch(const DeformParams &p, hipStream_t stream, const char *name) {
   const int tiles = p.tile_w ? p.ntiles : cdiv(p.P, 32);
   const int bx = cdiv(tiles, PT);
   if (bx <= 0) return 0;
-  return launch(name, dc_lds_kernel<MT, PT, NW>, dim3(bx, p.ksb, p.mgroups), dim3(NW * 64), dc_lds_bytes<MT, PT, NW>(),
+  return launch(name, dc_lds_kernel<MT, PT, NW, MMA>, dim3(bx, p.ksb, p.mgroups), dim3(NW * 64), dc_lds_bytes<MT, PT, NW, MMA>(),
                 stream, p);
 }
 
@@ -888,6 +991,11 @@ inline int dc_pack_launch(PackParams pp, hipStream_t stream) {
   const size_t total = (size_t)pp.mgroups * pp.ncp_pad * pp.T * 2 * pp.RL;
   return launch("dc_pack_weights", dc_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                 stream, pp);
+}
+
+inline int dc_pack_bf16_launch(PackBf16Params pp, hipStream_t stream) {
+  const size_t total = (size_t)pp.mgroups * pp.ncp_pad * 2 * 32;
+  return launch("dc_pack_weights_bf16", dc_pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pp);
 }
 
 struct DcCopyParams { const float *src; float *dst; size_t n; };

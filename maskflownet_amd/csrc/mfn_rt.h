@@ -36,6 +36,23 @@ static inline f32x2 mfn_mul2(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b
 #define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(hipemu::dyn_shared())
 #define MFN_MFMA_32x32x2(a, b, c) hipemu_mfma_32x32x2((a), (b), (c))
 #define MFN_MFMA_16x16x4(a, b, c) hipemu_mfma_16x16x4((a), (b), (c))
+// bf16 x 3 operand split (dc.mma = 1): see the device definitions
+typedef bf16x8_emu mfn_bf16x8;
+#define MFN_MFMA_32x32x16_BF16(a, b, c) hipemu_mfma_32x32x16_bf16((a), (b), (c))
+static inline void mfn_split3(float x, unsigned short &h, unsigned short &m, unsigned short &l) {
+  h = hipemu_f32_to_bf16(x);
+  const float r1 = x - hipemu_bf16_to_f32(h);
+  m = hipemu_f32_to_bf16(r1);
+  l = hipemu_f32_to_bf16(r1 - hipemu_bf16_to_f32(m));
+}
+static inline void mfn_split3x8(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &m, mfn_bf16x8 &l) {
+  for (int e = 0; e < 8; ++e) mfn_split3(x[e], h.v[e], m.v[e], l.v[e]);
+}
+static inline mfn_bf16x8 mfn_read_bf16x8(const float *p) { mfn_bf16x8 v; memcpy(&v, p, 16); return v; }
+static inline void mfn_write_bf16x8(float *p, mfn_bf16x8 v) { memcpy(p, &v, 16); }
+static inline float mfn_bf16_at(const float *base, int idx) {   // element idx of a bf16 array, as fp32
+  unsigned short h; memcpy(&h, (const char *)base + 2 * (size_t)idx, 2); return hipemu_bf16_to_f32(h);
+}
 #define MFN_LANE_ID() ((int)hipemu::t_lane)
 #define MFN_UNROLL
 #define MFN_NOUNROLL
@@ -80,6 +97,8 @@ static inline void mfn_gload4_async(f32x4_emu &dst, const float *base_uniform, u
 #define MFN_LANDED4(a, b, c, d, n) ((void)0)
 #define MFN_REGFENCE4(a, b, c, d) ((void)0)
 #define MFN_REGFENCE9(v) ((void)0)
+#define MFN_REGFENCE_P8(vp) ((void)0)
+#define MFN_SCHED_GROUP(mask, n) ((void)0)
 // emulated lanes are independent threads: a wave-private DMA hand-off needs a wave barrier where the
 // hardware needs only the issuing wave's vmcnt wait (lock-step lanes)
 #define MFN_WAIT_VM(n) (hipemu::wave().bar.arrive_and_wait())
@@ -129,11 +148,46 @@ extern __shared__ __attribute__((aligned(16))) unsigned char mfn_lds_raw[];
 #define MFN_DYN_SHARED(T, name) T *name = reinterpret_cast<T *>(mfn_lds_raw)
 #define MFN_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFN_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// ---- bf16 x 3 operand split (dc.mma = 1, measured non-default variant) -------------------------------------------------
+// An fp32 value is written as hi + mid + lo with three bf16 terms (8 significant bits each: 24 together, exact unless the
+// low terms underflow); a product a * b is then the sum of nine bf16 x bf16 products, each EXACT in fp32, of which the six
+// with weight >= 2^-16 (hh, hm, mh, mm, hl, lh) are formed on the matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
+// the omitted terms are below 2^-23 of the product, the size of one fp32 rounding.  Conversions round to nearest even
+// (v_cvt_pk_bf16_f32); x - float(hi) is exact in fp32.
+typedef __bf16 mfn_bf16x8 __attribute__((ext_vector_type(8)));
+#define MFN_MFMA_32x32x16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// two values at a time: one v_cvt_pk_bf16_f32 per term, the terms widened back by a shift / a mask, the residuals by one
+// v_pk_add_f32 -- 38 VALU instructions for eight values
+__device__ __forceinline__ void mfn_split3x8(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &m, mfn_bf16x8 &l) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hw, mw, lw;
+  _Pragma("unroll")
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+    const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+    const f32x2 r1 = v - hf;
+    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf2));
+    const f32x2 mf = {__builtin_bit_cast(float, mp << 16), __builtin_bit_cast(float, mp & 0xffff0000u)};
+    const f32x2 r2 = r1 - mf;
+    hw[q] = hp; mw[q] = mp; lw[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf2));
+  }
+  h = __builtin_bit_cast(mfn_bf16x8, hw); m = __builtin_bit_cast(mfn_bf16x8, mw); l = __builtin_bit_cast(mfn_bf16x8, lw);
+}
+__device__ __forceinline__ mfn_bf16x8 mfn_read_bf16x8(const float *p) { return *reinterpret_cast<const mfn_bf16x8 *>(p); }
+__device__ __forceinline__ void mfn_write_bf16x8(float *p, mfn_bf16x8 v) { *reinterpret_cast<mfn_bf16x8 *>(p) = v; }
+__device__ __forceinline__ float mfn_bf16_at(const float *base, int idx) {   // element idx of a bf16 array, as fp32
+  return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short *>(base)[idx] << 16);
+}
 #define MFN_LANE_ID() ((int)(threadIdx.x & 63))
 #define MFN_UNROLL _Pragma("unroll")
 #define MFN_NOUNROLL _Pragma("nounroll")
 #define MFN_OPAQUE(x) asm volatile("" : "+v"(x))
 #define MFN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// a scheduling group inside the region between two MFN_SCHED_BARRIERs: `n` instructions of the classes in `mask`
+// (0x002 VALU, 0x008 MFMA, 0x100 LDS read) are placed next, in the order the groups are written
+#define MFN_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 #define MFN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // wave-wide integer min / max as a DPP scan (row_shr 1,2,4,8, row_bcast 15/31: six v_min/max_i32_dpp, no LDS
 // round trips as ds_bpermute shuffles would need); the result comes back wave-uniform from lane 63
@@ -223,6 +277,10 @@ __device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_u
 #define MFN_REGFENCE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
 // nine values are COMPUTED here (hipcc otherwise sinks the arithmetic that forms them next to its use, one pipeline step
 // later, and keeps the registers it reads alive across the request that is about to overwrite them)
+// eight register pairs (a [2][4] array of f32x2): what comes out of a conditional group of loads is "defined" on both paths
+// from here on, so the code that consumes it stays outside the branch (no phi copies of its results)
+#define MFN_REGFENCE_P8(vp) asm volatile("" : "+v"((vp)[0][0]), "+v"((vp)[0][1]), "+v"((vp)[0][2]), "+v"((vp)[0][3]), \
+                                              "+v"((vp)[1][0]), "+v"((vp)[1][1]), "+v"((vp)[1][2]), "+v"((vp)[1][3]) : : "memory")
 #define MFN_REGFENCE9(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]), "+v"((v)[4]), "+v"((v)[5]), "+v"((v)[6]), "+v"((v)[7]), "+v"((v)[8]))
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
 // the compiler keeps memory accesses on their side of this point (no instruction): LDS accesses whose ORDER matters to other

@@ -11,6 +11,9 @@
 //   corr.bwdlds   0: corr_bwd_block_kernel at every level; 1 (default): corr_bwd_lds_kernel where W is 8, 16, ... 256
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
+//   dc.mma        1: the deformable convolution's GEMM as a bf16 x 3 operand split on the matrix cores (six products of
+//                 v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate; tap 8 stays on the fp32 MFMA) -- a measured
+//                 variant whose results differ from the exact-fp32 default in the last bits; 0 (default): exact fp32
 //   dc.pt         pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
 //   dc.ksb        K split across blocks (partial sums + reduce kernel); 0 = heuristic
 //   dc.nw         waves per block: 0 auto, 4, 8 (8 only with pt = 1)
@@ -29,10 +32,12 @@ namespace mfn {
 struct Tuning {
   int corr_variant = -1, corr_direct = 0, corr_generic = 0, corr_bwdlds = 1;
   int store_policy = -1;
+  int dc_mma = 0;
   int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_stage = 1, dc_fast = 1, dc_generic = 0, dc_bwdshared = 1, dc_bwdflow = 1;
   int conv_generic = 0, conv_mt = 0, conv_pt = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.variant")) return &corr_variant;
+    if (!strcmp(key, "dc.mma")) return &dc_mma;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
     if (!strcmp(key, "corr.generic")) return &corr_generic;
     if (!strcmp(key, "corr.bwdlds")) return &corr_bwdlds;

@@ -65,6 +65,7 @@ struct Wave {
   std::barrier<> bar{64};
   float f[64];
   float g[64];
+  unsigned short a8[64][8], b8[64][8];  // operands of the 8-element (bf16) MFMA forms
   unsigned long long mask;
   int votes[64];
 };
@@ -217,6 +218,34 @@ static inline f32x16_emu hipemu_mfma_32x32x2(float a, float b, f32x16_emu c) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
     float acc = c[r];
     for (int k = 0; k < 2; ++k) acc = fmaf(w.f[row + 32 * k], w.g[col + 32 * k], acc);
+    c[r] = acc;
+  }
+  w.bar.arrive_and_wait();
+  return c;
+}
+// v_mfma_f32_32x32x16_bf16: lane l holds eight bf16 of A[i=l&31][.] resp. B[.][j=l&31] for k-block l>>5; element e of a
+// k-block of A meets element e of the same k-block of B.  Products of two bf16 are exact in fp32; the hardware's summation
+// order inside the instruction is not documented -- here k-ordered fp32 adds (tests compare with a tolerance).
+struct bf16x8_emu { unsigned short v[8]; };
+static inline float hipemu_bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned short hipemu_f32_to_bf16(float f) {   // round to nearest even, as v_cvt_pk_bf16_f32
+  unsigned u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static inline f32x16_emu hipemu_mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f32x16_emu c) {
+  hipemu::Wave &w = hipemu::wave();
+  const unsigned lane = hipemu::t_lane;
+  for (int e = 0; e < 8; ++e) { w.a8[lane][e] = a.v[e]; w.b8[lane][e] = b.v[e]; }
+  w.bar.arrive_and_wait();
+  const int col = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float acc = c[r];
+    for (int kb = 0; kb < 2; ++kb)
+      for (int e = 0; e < 8; ++e)
+        acc += hipemu_bf16_to_f32(w.a8[row + 32 * kb][e]) * hipemu_bf16_to_f32(w.b8[col + 32 * kb][e]);
     c[r] = acc;
   }
   w.bar.arrive_and_wait();

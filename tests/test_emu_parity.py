@@ -17,7 +17,7 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(corr_variant=-1, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0,
+DEFAULT_TUNING = dict(corr_variant=-1, dc_mma=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0,
                       dc_nw=0, dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0)
 
 
@@ -206,6 +206,33 @@ def test_deform_eight_wave_blocks(ops, oracle):
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 64, 4, 8)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 40, 5, 8, seed=2, fused=False)
     pc.case_deform_pertap(ops, oracle, ident, ident, 1, 36, 33, 4, 8, kernel=(3, 3), pad=(1, 1))
+
+
+@pytest.mark.parametrize("plan", [dict(dc_pt=4), dict(dc_pt=2), dict(dc_pt=1), dict(dc_pt=1, dc_nw=8), dict(dc_pt=2, dc_ksb=2)])
+def test_deform_bf16x3_operand_split(ops, oracle, plan):
+    """dc.mma = 1: fp32 operands as three bf16 terms, six products on v_mfma_f32_32x32x16_bf16 + tap 8 on the fp32 MFMA; every
+    gather tier (LDS window, global row quads under rough offsets, per-tap offsets with the weights rebuilt from their
+    terms, the 32-flattened-pixel form), ragged channels / filters, the matching epilogue.  Same tolerance as the exact kernel."""
+    emu_ops.set_tuning(dc_mma=1, **plan)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8)                       # LDS window tier
+    pc.case_deform_shared(ops, oracle, ident, ident, 2, 40, 5, 12, seed=2, fused=False)  # 20 pairs: chunk tails; drop-in offsets
+    emu_ops.set_tuning(dc_stage=0)
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8, seed=3)               # global-gather tier
+    emu_ops.set_tuning(dc_stage=1)
+    pc.case_deform_pertap(ops, oracle, ident, ident, 1, 36, 33, 4, 8, kernel=(3, 3), pad=(1, 1))   # per-tap offsets, ragged filters
+    pc.case_deform_pertap(ops, oracle, ident, ident, 1, 3, 5, 4, 5, kernel=(3, 3), pad=(1, 1))     # odd Cin, flattened pixels
+    pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 6, 8)
+
+
+def test_deform_bf16x3_pack_is_a_layout_of_its_own(ops, oracle):
+    pk = pc.case_deform_packed(ops, oracle, ident, ident, 1, 32, 32, 6, 8, kernel=(3, 3), pad=(1, 1))
+    emu_ops.set_tuning(dc_mma=1)
+    rng = np.random.default_rng(1)
+    x, off = pc.feat(rng, (1, 32, 6, 8)), np.zeros((1, 18, 6, 8), np.float32)
+    with pytest.raises(RuntimeError, match="re-run mfn_deform_conv_pack_weights"):
+        ops.DeformableConvolution(x, off, np.zeros((32, 32, 3, 3), np.float32), None, kernel=(3, 3), pad=(1, 1), num_filter=32,
+                                  no_bias=True, packed=pk)
+    pc.case_deform_packed(ops, oracle, ident, ident, 1, 32, 32, 6, 8, kernel=(3, 3), pad=(1, 1))   # packs under dc.mma = 1
 
 
 def test_deform_several_filter_groups(ops, oracle):

@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_variant=-1, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0,
+    _lib.set_tuning(corr_variant=-1, dc_mma=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0,
                     dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0)
 
 
@@ -130,6 +130,34 @@ def test_correlation_properties_at_full_size(ops, T):
 @pytest.mark.parametrize("clip", [False, True])
 def test_warp(ops, oracle, dev, shape, clip):
     pc.case_warp(ops, oracle, dev, host, shape, clip)
+
+
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+@pytest.mark.parametrize("flow", ["smooth", "rough"])
+def test_deform_bf16x3_operand_split_at_the_bench_shapes(ops, oracle, dev, level, flow):
+    """dc.mma = 1 (measured variant, not the default): bf16 x 3 operand split on the matrix cores at every level shape of
+    configs[1], smooth (LDS-window tier) and SURVEY 8(d) rough offsets (global-gather tier), drop-in and fused calls.  Its
+    error against the fp64 arbiter must not exceed the exact-fp32 kernel's by more than a rounding."""
+    from maskflownet_amd import _lib, hotpath
+    N, C, H, W = CFG2[level]
+    rng = np.random.default_rng(300 + level)
+    x = pc.feat(rng, (N, C, H, W))
+    w = pc.msra_weight(rng, C, C)
+    b = (rng.standard_normal((C,)) * 0.1).astype(np.float32)
+    stride = float(hotpath.STRIDES[6 - level])
+    fl = pc.flow_field(rng, N, H, W, sigma=2.0) if flow == "smooth" else hotpath.rough_flow(rng, N, H, W)
+    fl = (fl * np.float32(stride / 20.0)).astype(np.float32)
+    off = oracle.offsets_from_flow(fl, 20.0, stride)
+    want64 = oracle.deformable_convolution(x, off, w, b, kernel=(3, 3), pad=(1, 1), dtype=np.float64)
+    res = {}
+    for mma in (0, 1):
+        _lib.set_tuning(dc_mma=mma)
+        got = host(ops.DeformableConvolution(dev(x), dev(off), dev(w), dev(b), kernel=(3, 3), pad=(1, 1), num_filter=C))
+        fused = host(ops.deformable_convolution_shared(dev(x), dev(fl), 20.0, stride, dev(w), dev(b)))
+        np.testing.assert_array_equal(fused, got)
+        res[mma] = float(np.abs(got.astype(np.float64) - want64).max() / np.abs(want64).max())
+    print("level %d %s: max rel err vs fp64  exact fp32 %.3e   bf16x3 %.3e" % (6 - level, flow, res[0], res[1]))
+    assert res[1] <= 1e-5 and res[1] <= 2.0 * res[0] + 2e-7, res
 
 
 def test_warp_matches_grid_sample_and_operator_pair(ops, T):
