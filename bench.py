@@ -674,6 +674,33 @@ def main():
             res["cpu_baseline_multithread"] = cpu_baseline_threads(wl, min(args.cpu_seconds, 8.0), os.cpu_count() or 1)
         except Exception as e:
             res["cpu_baseline_multithread"] = {"error": repr(e)}
+    if gpu and world == 1 and not args.no_side_configs and args.config == "cfg2" and args.mode == "dropin" and args.flow == "smooth" \
+            and not args.no_graph and not args.tuning:
+        # measured variant, NOT the headline: the deformable convolutions' GEMM as a bf16 x 3 operand split on the matrix cores
+        # (dc.mma = 1), same pass, same inputs; its outputs against the same oracle pass
+        try:
+            from maskflownet_amd import _lib as _l
+            _l.set_tuning(dc_mma=1)
+            vw = hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode="dropin").capture()
+            for _ in range(50):
+                vw.step()
+            vw.synchronize()
+            dtv = timed_steps([vw], 400, None, torch)
+            res["bf16x3"] = {"value": round(vw.N * 400 / dtv, 2), "unit": "image-pairs/s", "ms_per_step": round(dtv / 400 * 1e3, 4), "steps": 400,
+                             "what": "dc.mma=1: fp32 operands of the deformable convolutions split into three bf16 terms, six products on "
+                                     "v_mfma_f32_32x32x16_bf16 (fp32 accumulate), tap 8 on the fp32 MFMA; everything else as the headline",
+                             "ops_in_graph_us": {k: v for k, v in per_op_graph_cost(vw, torch, reps=10).items() if k.startswith("deform")},
+                             "note": "not the headline: `value` is the exact-fp32 path; this variant's error against the fp64 oracle is not "
+                                     "above the exact kernel's (tests/test_gpu_parity.py)"}
+            if "parity" in res:
+                vw.replay()
+                vw.synchronize()
+                res["bf16x3"]["parity"] = {k: v for k, v in parity_vs_oracle(vw, want).items() if k in ("max_rel_err", "worst_output", "ok")}
+            del vw
+        except Exception as e:
+            res["bf16x3"] = {"error": repr(e)}
+        finally:
+            _l.set_tuning(dc_mma=0)
     if gpu and world == 1 and not args.no_e2e and wl.kind == "S":
         try:
             res["e2e"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch)

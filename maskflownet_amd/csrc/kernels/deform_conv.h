@@ -26,6 +26,9 @@
 #define MFN_DC_ABLATE 0
 #endif
 
+#ifndef MFN_MMA_GROUPS
+#define MFN_MMA_GROUPS 1   // measurement builds: 0 = no scheduling groups in the bf16 x 3 steps
+#endif
 namespace mfn {
 
 struct DeformParams {
@@ -611,9 +614,10 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       // the loop ends, they land in registers that are dead from the compiler's point of view -- it had handed them to the
       // epilogue without a wait, and one pass in two came back with a wrong 4x8 tile somewhere (tools/r03_det.py; every
       // comparison with the oracle had passed).
-      // MMA: the reads are unconditional (the last step re-reads a stale window, results unused) and MFN_REGFENCE_P8 after
-      // the loop keeps their destination registers alive until they have landed -- no branch, no phi copies of the results
-      if (MMA || k + 1 < nf) gather2(BN, vp);
+      // (MMA: reading the next window unconditionally would save the phi copies of the interpolated values -- measured ~1 us
+      // per launch -- but level 3 then came back with wrong 4x8 tiles in 5-60 of 60 runs, with the reads sunk below the matrix
+      // instructions or pinned ahead of them alike (tools/r03_bf16_det.py): the reads stay conditional.)
+      if (k + 1 < nf) gather2(BN, vp);
       if (MMA) {   // six matrix-core products + tap 8, the next pair's interpolation between them
         MmaOps o;
         mma_prepare(pw, cur, o);
@@ -626,6 +630,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         mma_issue(o, 6);
         // the order the scheduler is asked for: the split (VALU) and the operand reads first, then one matrix instruction per
         // five VALU instructions of the next pair's interpolation
+#if MFN_MMA_GROUPS
         MFN_SCHED_GROUP(0x002, 40); MFN_SCHED_GROUP(0x100, 4);
         MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
         MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
@@ -634,6 +639,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
         MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
         MFN_SCHED_GROUP(0x008, 1);
+#endif
       } else {
         mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
         mfma_tap(ap, 1, cur[1]);
@@ -661,7 +667,6 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       step(k, DcInt<0>{}, cvn, cv);
       ++k;
     }
-    if (MMA) MFN_REGFENCE_P8(vp);   // the last step's window reads have landed before anybody else gets their registers
     k_done = nf;
   }
 

@@ -97,7 +97,6 @@ static inline void mfn_gload4_async(f32x4_emu &dst, const float *base_uniform, u
 #define MFN_LANDED4(a, b, c, d, n) ((void)0)
 #define MFN_REGFENCE4(a, b, c, d) ((void)0)
 #define MFN_REGFENCE9(v) ((void)0)
-#define MFN_REGFENCE_P8(vp) ((void)0)
 #define MFN_SCHED_GROUP(mask, n) ((void)0)
 // emulated lanes are independent threads: a wave-private DMA hand-off needs a wave barrier where the
 // hardware needs only the issuing wave's vmcnt wait (lock-step lanes)
@@ -277,10 +276,6 @@ __device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_u
 #define MFN_REGFENCE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
 // nine values are COMPUTED here (hipcc otherwise sinks the arithmetic that forms them next to its use, one pipeline step
 // later, and keeps the registers it reads alive across the request that is about to overwrite them)
-// eight register pairs (a [2][4] array of f32x2): what comes out of a conditional group of loads is "defined" on both paths
-// from here on, so the code that consumes it stays outside the branch (no phi copies of its results)
-#define MFN_REGFENCE_P8(vp) asm volatile("" : "+v"((vp)[0][0]), "+v"((vp)[0][1]), "+v"((vp)[0][2]), "+v"((vp)[0][3]), \
-                                              "+v"((vp)[1][0]), "+v"((vp)[1][1]), "+v"((vp)[1][2]), "+v"((vp)[1][3]) : : "memory")
 #define MFN_REGFENCE9(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]), "+v"((v)[4]), "+v"((v)[5]), "+v"((v)[6]), "+v"((v)[7]), "+v"((v)[8]))
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
 // the compiler keeps memory accesses on their side of this point (no instruction): LDS accesses whose ORDER matters to other

@@ -1,5 +1,5 @@
 // tuning.h -- kernel-selection knobs behind mfn_set_tuning()/mfn_get_tuning() (include/mfn_hip.h).
-// 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 16 that
+// 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 17 that
 // select between code paths the library ships (tests force every path through them); the measurement knobs of rounds 1 / 2
 // (tilings, ring depths, cache policies per kernel family, staggering, ablation masks) are gone with the variants they chose
 // between -- DESIGN.md records what each of them measured.

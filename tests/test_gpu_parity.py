@@ -160,6 +160,26 @@ def test_deform_bf16x3_operand_split_at_the_bench_shapes(ops, oracle, dev, level
     assert res[1] <= 1e-5 and res[1] <= 2.0 * res[0] + 2e-7, res
 
 
+def test_deform_bf16x3_is_run_to_run_deterministic(ops, T):
+    """40 launches per level on the same inputs, bit-identical (a variant with unconditional window reads was not: hipcc had
+    sunk the LDS reads below the matrix instructions, into one's operand registers)."""
+    from maskflownet_amd import _lib, hotpath
+    _lib.set_tuning(dc_mma=1)
+    wl = hotpath.HotPathWorkload("cfg2")
+    calls = dict(wl.calls())
+    for lvl in (5, 4, 3, 2):
+        wl.packed[lvl] = wl.ops.pack_deform_weights(wl.t["w_%d" % lvl], tuple(wl.t["c2_%d" % lvl].shape), kernel=(3, 3), pad=(1, 1))
+        calls["offsets%d" % lvl]()
+        first = None
+        for _ in range(40):
+            calls["deform%d" % lvl]()
+            wl.stream.synchronize()
+            got = wl.o["deform%d" % lvl].clone()
+            if first is None:
+                first = got
+            assert T.equal(got, first), "level %d" % lvl
+
+
 def test_warp_matches_grid_sample_and_operator_pair(ops, T):
     import torch.nn.functional as F
     g = T.Generator(device="cuda").manual_seed(2)
