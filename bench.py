@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="independent batches in flight per GPU: step i replays on stream i %% S (each stream has its own "
                          "outputs); 1 = every pass strictly after the previous one")
-    ap.add_argument("--tuning", default="", help="library tuning overrides for A/B measurements, e.g. store_policy=0,dc_xcd=0")
+    ap.add_argument("--tuning", default="", help="library tuning overrides for A/B measurements, e.g. store_policy=0,dc_mma=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget of the oracle baseline")
     ap.add_argument("--roofline-iters", type=int, default=200)
@@ -450,7 +450,7 @@ def network_epe_delta(H, W, device):
             "seconds": round(time.perf_counter() - t0, 1)}
 
 
-def end_to_end(N, H, W, device, torch, steps=30, full=False):
+def end_to_end(N, H, W, device, torch, steps=30, full=False, ref_flow=None):
     """Informational: the whole MaskFlownet-S forward (71 convolutions / deconvolutions + the hot path) on libmfn_hip.so
     as one hipGraph -- maskflownet_amd/network.py; seeded MSRAPrelu weights, random images.  full=True: the full
     MaskFlownet (head + cascade, 135 layers, MaskFlownet.py:318-545)."""
@@ -471,6 +471,15 @@ def end_to_end(N, H, W, device, torch, steps=30, full=False):
     net.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ok = bool(torch.isfinite(net.b["gflow_full" if full else "flow_full"]).all().item())
+    if ref_flow is not None:   # a variant run: its final flow against the exact path's on the same weights and images
+        fl = net.b["flow_full"].double()
+        d = (fl - ref_flow.double()).pow(2).sum(1).sqrt().mean().item()
+        m = ref_flow.double().pow(2).sum(1).sqrt().mean().item()
+        return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_forward": round(dt * 1e3, 3), "batch": N, "finite": ok,
+                "epe_vs_exact_px": d, "epe_vs_exact_rel": d / max(m, 1e-30),
+                "what": "the MaskFlownet-S forward with conv.mma=1 and dc.mma=1: every convolution and deformable convolution as a "
+                        "bf16 x 3 operand split on the matrix cores (fp32 accumulate); measured variant, not the default"}
+    net_flow = net.b["flow_full"].clone() if not full else None
     if full:
         return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_forward": round(dt * 1e3, 3), "batch": N,
                 "GFLOP_per_forward": round(net.flops() / 1e9, 1), "achieved_TFLOPs": round(net.flops() / dt / 1e12, 1),
@@ -482,7 +491,7 @@ def end_to_end(N, H, W, device, torch, steps=30, full=False):
             "frac_of_fp32_peak": round(net.flops() / dt / 1e12 / FP32_PEAK_TFLOPS, 3), "finite": ok,
             "what": "MaskFlownet-S forward %dx%d end to end (pyramid + decoder + context convolutions, cost volumes, deformable "
                     "matching, upsampling, warp), every layer a libmfn_hip.so kernel, fp32, one hipGraph replay per forward" % (H, W),
-            "note": "not the headline: `value` above is the matching hot path BASELINE.json's north_star names"}
+            "note": "not the headline: `value` above is the matching hot path BASELINE.json's north_star names", "_flow": net_flow}
 
 
 def make_buffers(spec):
@@ -704,10 +713,19 @@ def main():
     if gpu and world == 1 and not args.no_e2e and wl.kind == "S":
         try:
             res["e2e"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch)
+            exact_flow = res["e2e"].pop("_flow", None)
+            if exact_flow is not None and not args.tuning:
+                from maskflownet_amd import _lib as _l2
+                try:
+                    _l2.set_tuning(conv_mma=1, dc_mma=1)
+                    res["e2e_bf16x3"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch, ref_flow=exact_flow)
+                finally:
+                    _l2.set_tuning(conv_mma=0, dc_mma=0)
         except Exception as e:
             res["e2e"] = {"error": repr(e)}
         try:
             res["e2e_full"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch, full=True)
+            res["e2e_full"].pop("_flow", None)
         except Exception as e:
             res["e2e_full"] = {"error": repr(e)}
     if gpu and world == 1 and not args.no_epe and wl.kind != "train":

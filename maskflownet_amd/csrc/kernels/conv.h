@@ -65,19 +65,28 @@ constexpr int conv_kc(int mt, int pt, int t) {
   return 4 * unit <= 4608 ? 4 : (2 * unit <= 4608 ? 2 : 0);
 }
 
+// MMA = 1 (conv.mma, 3x3 only): the bf16 x 3 operand split of deform_conv.h (DcGeom<.., MMA = 1>) -- a pair's weights are
+// [filter tile][term][channel of the pair][filter][taps 0..7] bf16 + [channel][filter] fp32 for tap 8 (832 words per tile)
+constexpr int conv_kc_mma(int mt, int pt) {
+  const int stage = (4 / pt) * DC_PAIR_W_BF16 * mt;   // words of one pair for all K slices of the block
+  return 4 * stage <= 9216 && mt <= 2 ? 4 : (2 * stage <= 9216 ? 2 : 0);
+}
+
 // ROW3 (3x3, column dilation 1, pad_w <= 1): the three taps of a kernel row are three adjacent floats -- one
 // dword-aligned global_load_dwordx3 per row instead of three dword gathers.  With one or two filter tiles per wave the
 // kernel is bound by what the texture addresser takes per gather instruction, not by the MFMAs (conv4_2: 46 TFLOP/s).
-template <int MT, int PT, int KH, int KWD, bool TRANS, bool ROW3 = false>
+template <int MT, int PT, int KH, int KWD, bool TRANS, bool ROW3 = false, int MMA = 0>
 __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvParams p) {
   static_assert(!ROW3 || (KH == 3 && KWD == 3 && !TRANS), "ROW3 is the 3x3 convolution's row gather");
+  static_assert(MMA == 0 || (KH == 3 && KWD == 3 && !TRANS), "the bf16 x 3 form is built for nine taps");
   constexpr int T = KH * KWD;
   constexpr int NW = 4, NTH = 256;
   constexpr int KS = NW / PT;              // K slices inside the block
   constexpr int RL = 32 * MT;
-  constexpr int KC = conv_kc(MT, PT, T);
+  constexpr int KC = MMA ? conv_kc_mma(MT, PT) : conv_kc(MT, PT, T);
   static_assert(KC >= 2, "weight stage does not fit the LDS budget");
-  constexpr int CHUNK_F = KC * T * 2 * RL;
+  constexpr int PAIR_W = MMA ? MT * DC_PAIR_W_BF16 : T * 2 * RL;   // words of one channel pair's weights
+  constexpr int CHUNK_F = KC * PAIR_W;
   constexpr int CH4 = CHUNK_F / 4;
   constexpr int NI = (KS * CH4 + NTH - 1) / NTH;
   constexpr int STAGE_F = NI * NTH * 4;
@@ -119,14 +128,14 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
   const int ho = min(ho_, Ho - 1), wo = min(wo_, Wo - 1);
 
   // ---- weight staging plan (as dc_lds_kernel) -------------------------------------------------------------
-  const size_t mg_floats = (size_t)p.ncp_pad * T * 2 * RL;
+  const size_t mg_floats = (size_t)p.ncp_pad * PAIR_W;
   const mfn_rsrc_t wrsrc = mfn_make_rsrc(p.wt + (size_t)mg * mg_floats, (unsigned)(mg_floats * 4));
   unsigned voff[NI];
   MFN_UNROLL
   for (int i = 0; i < NI; ++i) {
     const int it = (i * NW + wave) * 64 + lane;
     const int k = it / CH4, idx = it - k * CH4;
-    voff[i] = k < KS ? (unsigned)(((size_t)k * p.cps_per_slice * T * 2 * RL + (size_t)idx * 4) * 4) : 0xFFFFFF00u;
+    voff[i] = k < KS ? (unsigned)(((size_t)k * p.cps_per_slice * PAIR_W + (size_t)idx * 4) * 4) : 0xFFFFFF00u;
   }
   auto issue = [&](int ch) {
     float *buf = lds + (ch & 1) * STAGE_F;
@@ -245,14 +254,52 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
     MFN_RAW_BARRIER();   // ... and for every wave; nobody reads the other buffer any more
     if (ch + 1 < nchunks) issue(ch + 1);
     const float *abuf = lds + (ch & 1) * STAGE_F + ks * CHUNK_F + (half * 32 + j) * MT;
-    load_a(abuf, areg[0]);
+    if (!MMA) load_a(abuf, areg[0]);
     MFN_UNROLL
     for (int kk = 0; kk < KC; ++kk) {
       const int k = ch * KC + kk;
-      if (kk + 1 < KC) load_a(abuf + (size_t)(kk + 1) * T * 2 * RL, areg[(kk + 1) & 1]);
+      if (!MMA && kk + 1 < KC) load_a(abuf + (size_t)(kk + 1) * T * 2 * RL, areg[(kk + 1) & 1]);
       load_pair(min(cp_base + k + PD, cp_last), vb[(kk + PD) % NB]);
       MFN_SCHED_BARRIER();
-      if (k < npairs) {   // uniform
+      if (MMA) {
+        if (k < npairs) {   // uniform
+          const bool lone = 2 * (cp_base + k) + 1 >= p.Cin;   // uniform
+          const float *pw = lds + (ch & 1) * STAGE_F + ks * CHUNK_F + (size_t)kk * PAIR_W;   // this pair's weights (uniform)
+          // operand reads of every filter tile first (their latency runs under the split), then the split, then the products
+          mfn_bf16x8 ah[MT], am[MT], al[MT];
+          float a8[MT];
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) {
+            const float *pm = pw + mt * DC_PAIR_W_BF16;
+            ah[mt] = mfn_read_bf16x8(pm + ((0 * 2 + half) * 32 + j) * 4);
+            am[mt] = mfn_read_bf16x8(pm + ((1 * 2 + half) * 32 + j) * 4);
+            al[mt] = mfn_read_bf16x8(pm + ((2 * 2 + half) * 32 + j) * 4);
+            a8[mt] = pm[768 + half * 32 + j];
+          }
+          float x8[8];
+          MFN_UNROLL
+          for (int t = 0; t < 8; ++t) x8[t] = tap_value(vb[kk % NB], t, lone);
+          const float b8 = tap_value(vb[kk % NB], 8, lone);
+          mfn_bf16x8 bh, bm, bl;
+          mfn_split3x8(x8, bh, bm, bl);
+          // six matrix products + tap 8 in fp32 per filter tile, the tiles interleaved: consecutive instructions are independent
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x16_BF16(al[mt], bh, acc[mt]);
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x16_BF16(ah[mt], bl, acc[mt]);
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x16_BF16(am[mt], bm, acc[mt]);
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x16_BF16(am[mt], bh, acc[mt]);
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x16_BF16(ah[mt], bm, acc[mt]);
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x16_BF16(ah[mt], bh, acc[mt]);
+          MFN_UNROLL
+          for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(a8[mt], b8, acc[mt]);
+          MFN_SCHED_GROUP(0x100, 4 * MT); MFN_SCHED_GROUP(0x002, 60); MFN_SCHED_GROUP(0x008, 7 * MT);
+        }
+      } else if (k < npairs) {   // uniform
         const bool lone = 2 * (cp_base + k) + 1 >= p.Cin;   // uniform
         MFN_UNROLL
         for (int t = 0; t < T; ++t) {
@@ -377,11 +424,11 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
   }
 }
 
-template <int MT, int PT, int KH, int KWD>
+template <int MT, int PT, int KH, int KWD, int MMA = 0>
 inline size_t conv_lds_bytes() {
   constexpr int T = KH * KWD, RL = 32 * MT, KS = 4 / PT;
-  constexpr int KC = conv_kc(MT, PT, T);
-  constexpr int CH4 = KC * T * 2 * RL / 4;
+  constexpr int KC = MMA ? conv_kc_mma(MT, PT) : conv_kc(MT, PT, T);
+  constexpr int CH4 = KC * (MMA ? MT * DC_PAIR_W_BF16 : T * 2 * RL) / 4;
   constexpr int NI = (KS * CH4 + 255) / 256;
   const size_t stage = (size_t)2 * NI * 256 * 16;
   const size_t red = KS > 1 ? (size_t)(KS - 1) * MT * 16 * 64 * 4 : 0;
@@ -390,16 +437,28 @@ inline size_t conv_lds_bytes() {
   return m > tr ? m : tr;
 }
 
-template <int MT, int PT, int KH, int KWD, bool TRANS, bool ROW3 = false>
+template <int MT, int PT, int KH, int KWD, bool TRANS, bool ROW3 = false, int MMA = 0>
 inline int conv_mfma_launch(const ConvParams &p, hipStream_t stream, const char *name) {
   const int bx = cdiv(p.ntiles, PT);
   if (bx <= 0) return 0;
-  return launch(name, conv_mfma_kernel<MT, PT, KH, KWD, TRANS, ROW3>, dim3(bx, 1, p.mgroups), dim3(256),
-                conv_lds_bytes<MT, PT, KH, KWD>(), stream, p);
+  return launch(name, conv_mfma_kernel<MT, PT, KH, KWD, TRANS, ROW3, MMA>, dim3(bx, 1, p.mgroups), dim3(256),
+                conv_lds_bytes<MT, PT, KH, KWD, MMA>(), stream, p);
 }
 
 // weights -> wt[mg][cp][t][half][lane j][mt] (filter mg*RL + mt*32 + j); regular: w (Cout, Cin, T), transposed: w (Cin, Cout, T)
 struct ConvPackParams { const float *w; float *wt; int Cin, Cout, RL, mgroups, ncp_pad, T, transposed; };
+// the weight the kernels multiply channel c's tap t with for (pseudo-)filter o; zero outside the tensors
+__device__ __forceinline__ float conv_weight_at(const ConvPackParams &p, int c, int o, int t) {
+  if (c >= p.Cin || o >= p.Cout) return 0.f;
+  if (p.transposed == 2) {   // 4x4 / stride 2 / pad 1 transposed conv as 3x3 conv with pseudo-filters o = 4*o_real + 2*py + px:
+    // output row 2y+py takes input rows y-1, y, y+1 (3x3 tap r) through kernel rows {3, 1, -} (py = 0) / {-, 2, 0} (py = 1)
+    const int orl = o >> 2, py = (o >> 1) & 1, px = o & 1, r = t / 3, sx = t - 3 * r;
+    const int iy = py ? (r == 1 ? 2 : (r == 2 ? 0 : -1)) : (r == 0 ? 3 : (r == 1 ? 1 : -1));
+    const int ix = px ? (sx == 1 ? 2 : (sx == 2 ? 0 : -1)) : (sx == 0 ? 3 : (sx == 1 ? 1 : -1));
+    return (iy >= 0 && ix >= 0) ? p.w[(((size_t)c * (p.Cout >> 2) + orl) * 4 + iy) * 4 + ix] : 0.f;
+  }
+  return p.transposed ? p.w[((size_t)c * p.Cout + o) * p.T + t] : p.w[((size_t)o * p.Cin + c) * p.T + t];
+}
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(ConvPackParams p) {
   const size_t total = (size_t)p.mgroups * p.ncp_pad * p.T * 2 * p.RL;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -411,19 +470,32 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(ConvPackParams p
   const int mg = (int)(idx / ((size_t)2 * p.RL * p.T * p.ncp_pad));
   const int mtn = p.RL / 32, jl = r / mtn, mt = r - jl * mtn;
   const int c = 2 * cp + half, o = mg * p.RL + mt * 32 + jl;
-  float v = 0.f;
-  if (c < p.Cin && o < p.Cout) {
-    if (p.transposed == 2) {   // 4x4 / stride 2 / pad 1 transposed conv as 3x3 conv with pseudo-filters o = 4*o_real + 2*py + px:
-      // output row 2y+py takes input rows y-1, y, y+1 (3x3 tap r) through kernel rows {3, 1, -} (py = 0) / {-, 2, 0} (py = 1)
-      const int orl = o >> 2, py = (o >> 1) & 1, px = o & 1, r = t / 3, sx = t - 3 * r;
-      const int iy = py ? (r == 1 ? 2 : (r == 2 ? 0 : -1)) : (r == 0 ? 3 : (r == 1 ? 1 : -1));
-      const int ix = px ? (sx == 1 ? 2 : (sx == 2 ? 0 : -1)) : (sx == 0 ? 3 : (sx == 1 ? 1 : -1));
-      if (iy >= 0 && ix >= 0) v = p.w[(((size_t)c * (p.Cout >> 2) + orl) * 4 + iy) * 4 + ix];
-    } else {
-      v = p.transposed ? p.w[((size_t)c * p.Cout + o) * p.T + t] : p.w[((size_t)o * p.Cin + c) * p.T + t];
-    }
-  }
-  p.wt[idx] = v;
+  p.wt[idx] = conv_weight_at(p, c, o, t);
+}
+// the same filters for the bf16 x 3 split (conv_mfma_kernel<.., MMA = 1>): one thread per (filter group, pair, filter tile, channel, filter)
+__global__ __launch_bounds__(256) void conv_pack_weights_bf16_kernel(ConvPackParams p) {
+  const int mtn = p.RL / 32;
+  const size_t total = (size_t)p.mgroups * p.ncp_pad * mtn * 2 * 32;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int m = (int)(idx & 31), kb = (int)((idx >> 5) & 1);
+  const int mt = (int)((idx >> 6) % mtn);
+  const int cp = (int)(((idx >> 6) / mtn) % p.ncp_pad), mg = (int)(((idx >> 6) / mtn) / p.ncp_pad);
+  const int c = 2 * cp + kb, o = mg * p.RL + mt * 32 + m;
+  float x[8];
+  MFN_UNROLL
+  for (int e = 0; e < 8; ++e) x[e] = conv_weight_at(p, c, o, e);
+  mfn_bf16x8 h, mm, l;
+  mfn_split3x8(x, h, mm, l);
+  float *base = p.wt + (((size_t)mg * p.ncp_pad + cp) * mtn + mt) * DC_PAIR_W_BF16;
+  mfn_write_bf16x8(base + ((0 * 2 + kb) * 32 + m) * 4, h);
+  mfn_write_bf16x8(base + ((1 * 2 + kb) * 32 + m) * 4, mm);
+  mfn_write_bf16x8(base + ((2 * 2 + kb) * 32 + m) * 4, l);
+  base[768 + kb * 32 + m] = conv_weight_at(p, c, o, 8);
+}
+inline int conv_pack_bf16_launch(ConvPackParams pp, hipStream_t stream) {
+  const size_t total = (size_t)pp.mgroups * pp.ncp_pad * (pp.RL / 32) * 2 * 32;
+  return launch("conv_pack_weights_bf16", conv_pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pp);
 }
 inline int conv_pack_launch(ConvPackParams pp, hipStream_t stream) {
   const size_t total = (size_t)pp.mgroups * pp.ncp_pad * pp.T * 2 * pp.RL;

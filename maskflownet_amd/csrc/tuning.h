@@ -1,5 +1,5 @@
 // tuning.h -- kernel-selection knobs behind mfn_set_tuning()/mfn_get_tuning() (include/mfn_hip.h).
-// 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 17 that
+// 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 18 that
 // select between code paths the library ships (tests force every path through them); the measurement knobs of rounds 1 / 2
 // (tilings, ring depths, cache policies per kernel family, staggering, ablation masks) are gone with the variants they chose
 // between -- DESIGN.md records what each of them measured.
@@ -14,6 +14,7 @@
 //   dc.mma        1: the deformable convolution's GEMM as a bf16 x 3 operand split on the matrix cores (six products of
 //                 v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate; tap 8 stays on the fp32 MFMA) -- a measured
 //                 variant whose results differ from the exact-fp32 default in the last bits; 0 (default): exact fp32
+//   conv.mma      1: the same bf16 x 3 split for the 3x3 convolutions (and the 4x4 / stride-2 transposed convolution run as one)
 //   dc.pt         pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
 //   dc.ksb        K split across blocks (partial sums + reduce kernel); 0 = heuristic
 //   dc.nw         waves per block: 0 auto, 4, 8 (8 only with pt = 1)
@@ -32,12 +33,13 @@ namespace mfn {
 struct Tuning {
   int corr_variant = -1, corr_direct = 0, corr_generic = 0, corr_bwdlds = 1;
   int store_policy = -1;
-  int dc_mma = 0;
+  int dc_mma = 0, conv_mma = 0;
   int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_stage = 1, dc_fast = 1, dc_generic = 0, dc_bwdshared = 1, dc_bwdflow = 1;
   int conv_generic = 0, conv_mt = 0, conv_pt = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.variant")) return &corr_variant;
     if (!strcmp(key, "dc.mma")) return &dc_mma;
+    if (!strcmp(key, "conv.mma")) return &conv_mma;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
     if (!strcmp(key, "corr.generic")) return &corr_generic;
     if (!strcmp(key, "corr.bwdlds")) return &corr_bwdlds;

@@ -18,7 +18,7 @@ def ops():
 
 
 DEFAULT_TUNING = dict(corr_variant=-1, dc_mma=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0,
-                      dc_nw=0, dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0)
+                      dc_nw=0, dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0, conv_mma=0)
 
 
 @pytest.fixture(autouse=True)
@@ -504,6 +504,17 @@ def test_conv3x3_mfma_tilings(ops, oracle, mt, pt):
         pc.case_conv(ops, oracle, ident, ident, 2, 7, 40, 6, 12, pad=(1, 1), leaky=True)          # odd Cin, ragged filters / tiles
     finally:
         emu_ops.set_tuning(conv_mt=0, conv_pt=0)
+
+
+@pytest.mark.parametrize("mt,pt", [(1, 4), (2, 4), (4, 4), (1, 1), (3, 4), (2, 1)])
+def test_conv3x3_bf16x3_operand_split(ops, oracle, mt, pt):
+    """conv.mma = 1: the 3x3 convolutions (and the 4x4 / stride-2 transposed convolution run as one) with their operands as three
+    bf16 terms on the matrix cores; tilings the variant is not built for ((3,4), (2,1)) fall to the next smaller one."""
+    emu_ops.set_tuning(conv_mma=1, conv_mt=mt, conv_pt=pt)
+    pc.case_conv(ops, oracle, ident, ident, 2, 7, 40, 6, 12, pad=(1, 1), leaky=True)          # odd Cin, ragged filters / tiles
+    pc.case_conv(ops, oracle, ident, ident, 1, 20, 130, 5, 16, pad=(2, 2), dilate=(2, 2), seed=1)   # five filter tiles, dilation
+    pc.case_conv(ops, oracle, ident, ident, 1, 6, 10, 11, 19, pad=(1, 1), stride=(2, 2), seed=2)
+    pc.case_deconv(ops, oracle, ident, ident, 2, 9, 16, 5, 8, leaky=True)                       # upfeat as a 3x3 convolution
 
 
 @pytest.mark.parametrize("kw", [dict(pad=(1, 1), stride=(2, 2)), dict(pad=(2, 2), dilate=(2, 2)), dict(pad=(4, 4), dilate=(4, 4)),

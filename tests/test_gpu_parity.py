@@ -36,7 +36,7 @@ def _reset_tuning():
     from maskflownet_amd import _lib
     yield
     _lib.set_tuning(corr_variant=-1, dc_mma=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0,
-                    dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0)
+                    dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0, conv_mma=0)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -158,6 +158,32 @@ def test_deform_bf16x3_operand_split_at_the_bench_shapes(ops, oracle, dev, level
         res[mma] = float(np.abs(got.astype(np.float64) - want64).max() / np.abs(want64).max())
     print("level %d %s: max rel err vs fp64  exact fp32 %.3e   bf16x3 %.3e" % (6 - level, flow, res[0], res[1]))
     assert res[1] <= 1e-5 and res[1] <= 2.0 * res[0] + 2e-7, res
+
+
+@pytest.mark.parametrize("case", [dict(N=2, Cin=128, Cout=128, H=48, W=64, dilate=(2, 2), pad=(2, 2)),     # four filter tiles per wave
+                                  dict(N=2, Cin=163, Cout=64, H=24, W=32, pad=(1, 1)),                       # odd channels, two tiles
+                                  dict(N=8, Cin=196, Cout=32, H=6, W=8, pad=(1, 1)),                         # coarse level: K slices
+                                  dict(N=2, Cin=32, Cout=64, H=48, W=64, stride=(2, 2), pad=(1, 1))])
+def test_conv_bf16x3_operand_split_error_vs_fp64(ops, T, dev, case):
+    """conv.mma = 1 (measured variant): error against torch's fp64 convolution not above the exact-fp32 kernel's by more than a
+    rounding, at decoder- / pyramid-like shapes with the fused LeakyReLU."""
+    from maskflownet_amd import _lib
+    case = dict(case)
+    N, Cin, Cout, H, W = (case.pop(k) for k in ("N", "Cin", "Cout", "H", "W"))
+    rng = np.random.default_rng(77)
+    x = pc.feat(rng, (N, Cin, H, W))
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (1.01 * Cin * 9))).astype(np.float32)
+    b = (rng.standard_normal(Cout) * 0.1).astype(np.float32)
+    want = T.nn.functional.leaky_relu(T.nn.functional.conv2d(T.from_numpy(x).double(), T.from_numpy(w).double(), T.from_numpy(b).double(),
+                                                            stride=case.get("stride", (1, 1)), padding=case["pad"],
+                                                            dilation=case.get("dilate", (1, 1))), 0.1).numpy()
+    err = {}
+    for mma in (0, 1):
+        _lib.set_tuning(conv_mma=mma)
+        got = host(ops.Convolution(dev(x), dev(w), dev(b), num_filter=Cout, activation="leaky", **case)).astype(np.float64)
+        err[mma] = float(np.abs(got - want).max() / np.abs(want).max())
+    print("conv %s: max rel err vs fp64  exact fp32 %.3e   bf16x3 %.3e" % ((N, Cin, Cout, H, W), err[0], err[1]))
+    assert err[1] <= 1e-5 and err[1] <= 2.0 * err[0] + 2e-7, err
 
 
 def test_deform_bf16x3_is_run_to_run_deterministic(ops, T):

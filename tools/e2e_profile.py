@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT)
 import torch
 from maskflownet_amd import _lib, network
 lib = _lib.lib()
+if os.environ.get("MFN_TUNE"):   # e.g. MFN_TUNE=conv_mma=1,dc_mma=1
+    _lib.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["MFN_TUNE"].split(","))})
 N, H, W = (int(v) for v in (sys.argv[1:4] + ["8", "384", "512"][len(sys.argv) - 1:]))
 net = network.MaskFlownetS(network.random_params(1), N, H, W)
 net.set_input(torch.rand(N, 3, H, W) - 0.5, torch.rand(N, 3, H, W) - 0.5)
