@@ -225,10 +225,12 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
   // wave a pair's MFMAs last 0.25 - 0.5 us, less than a global load under load: three pairs ahead there (PD = 3),
   // one pair ahead with three or four filter tiles.  Every iteration issues exactly one pair's loads (clamped to the
   // slice's last pair), so the counted waits below are exact.
-  constexpr int PD = (MT <= 2 && KC == 4) ? 3 : 1;
+  // MMA: a pair's matrix work is 2-3x shorter, three pairs ahead for every tiling (with two-pair chunks the operand buffer of
+  // pair k is then (two chunks' worth) k % 4: the chunk loop below runs two chunks per trip)
+  constexpr int PD = MMA ? 3 : ((MT <= 2 && KC == 4) ? 3 : 1);
   constexpr int NB = PD + 1;
   constexpr int LOADS = ROW3 ? 3 : T;
-  static_assert(KC % NB == 0, "pair k lives in operand buffer k % NB across chunk boundaries");
+  static_assert(KC % NB == 0 || NB % KC == 0, "pair k lives in operand buffer k % NB across chunk boundaries");
   float vb[NB][T];
   const int cp_last = min(cp_base + max(npairs - 1, 0), max(ncp - 1, 0));
   MFN_UNROLL
@@ -247,7 +249,8 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
       else { MFN_UNROLL for (int mt = 0; mt < MT; ++mt) a[t][mt] = q[mt]; }
     }
   };
-  for (int ch = 0; ch < nchunks; ++ch) {
+  auto run_chunk = [&](int ch, auto base_c) {
+    constexpr int BASE = decltype(base_c)::value;   // operand buffer of the chunk's first pair
     // chunk ch's weights have landed for this wave (they are older than the PD pairs of operand loads in flight) ...
     MFN_WAIT_VM(PD * LOADS);
     MFN_WAIT_LGKM0();
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
     for (int kk = 0; kk < KC; ++kk) {
       const int k = ch * KC + kk;
       if (!MMA && kk + 1 < KC) load_a(abuf + (size_t)(kk + 1) * T * 2 * RL, areg[(kk + 1) & 1]);
-      load_pair(min(cp_base + k + PD, cp_last), vb[(kk + PD) % NB]);
+      load_pair(min(cp_base + k + PD, cp_last), vb[(BASE + kk + PD) % NB]);
       MFN_SCHED_BARRIER();
       if (MMA) {
         if (k < npairs) {   // uniform
@@ -278,8 +281,8 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
           }
           float x8[8];
           MFN_UNROLL
-          for (int t = 0; t < 8; ++t) x8[t] = tap_value(vb[kk % NB], t, lone);
-          const float b8 = tap_value(vb[kk % NB], 8, lone);
+          for (int t = 0; t < 8; ++t) x8[t] = tap_value(vb[(BASE + kk) % NB], t, lone);
+          const float b8 = tap_value(vb[(BASE + kk) % NB], 8, lone);
           mfn_bf16x8 bh, bm, bl;
           mfn_split3x8(x8, bh, bm, bl);
           // six matrix products + tap 8 in fp32 per filter tile, the tiles interleaved: consecutive instructions are independent
@@ -303,12 +306,20 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
         const bool lone = 2 * (cp_base + k) + 1 >= p.Cin;   // uniform
         MFN_UNROLL
         for (int t = 0; t < T; ++t) {
-          const float bv = tap_value(vb[kk % NB], t, lone);
+          const float bv = tap_value(vb[(BASE + kk) % NB], t, lone);
           MFN_UNROLL
           for (int mt = 0; mt < MT; ++mt) acc[mt] = MFN_MFMA_32x32x2(areg[kk & 1][t][mt], bv, acc[mt]);
         }
       }
       MFN_SCHED_BARRIER();
+    }
+  };
+  if (KC % NB == 0) {
+    for (int ch = 0; ch < nchunks; ++ch) run_chunk(ch, DcInt<0>{});
+  } else {   // NB / KC chunks per trip (two): the operand buffer index stays a compile-time constant
+    for (int ch = 0; ch < nchunks; ch += 2) {
+      run_chunk(ch, DcInt<0>{});
+      if (ch + 1 < nchunks) run_chunk(ch + 1, DcInt<KC % NB>{});
     }
   }
 
