@@ -5,14 +5,15 @@
 // used that with lane = CHANNEL: geometry records broadcast through LDS, 18 cross-lane reductions per pixel for the offset
 // gradient, strided 16-byte x loads from 32 channel planes per instruction, ~4.5 atomic instructions per channel and 64
 // pixels -- 114 k cycles per 64 pixels x 32 channels of which 14 k are MFMA (profiles/r01f_bwd_phases.txt).  Here a lane
-// is a PIXEL, as in the forward kernel; a block is an 8x16-pixel region (four waves, one 4x8 tile each) times 32 input
-// channels:
-//   * column gradients D_t[channel][pixel] = sum_o W[o][channel][t] * gout[o][pixel] on v_mfma_f32_32x32x2_f32, nine
-//     accumulator tiles (one per tap); A = the weights in their NATURAL layout, streamed through LDS by DMA (a filter's
-//     32-channel x 9-tap segment is 288 consecutive floats; lane (channel i, half) reads word 288*o + 9*i + t: the two
-//     half-waves' bank sets {9i} and {9i + 32} are disjoint and complementary, no packing pass), B = gout, coalesced;
+// is a PIXEL, as in the forward kernel; a block is an 8x16-pixel region (four waves, one 4x8 tile each) times 16 input
+// channels (32 in round 2: see the note at DCP_LDS_A), two blocks per CU:
+//   * column gradients D_t[channel][pixel] = sum_o W[o][channel][t] * gout[o][pixel] on v_mfma_f32_32x32x2_f32, five
+//     accumulator tiles: the MFMA's 32 rows are (16 channels) x (tap parity), tile tp holds taps 2 tp and 2 tp + 1;
+//     A = the weights in their NATURAL layout, streamed through LDS by DMA (a filter's 16-channel x 9-tap segment is 144
+//     consecutive floats; lane (row i, half) reads word 144*o + 9*channel(i) + 2 tp + (i >> 4), no packing pass),
+//     B = gout, coalesced;
 //   * the tap geometry of a lane's pixel lives in its registers (no LDS records, no broadcasts);
-//   * phase A, offset gradient: lane (pixel j, half) holds 16 of the 32 channels; per channel pair a 16 x 24 source
+//   * phase A, offset gradient: lane (pixel j, half) holds 8 of the 16 channels; per channel pair a 16 x 24 source
 //     window of the tile arrives by LDS-DMA (3-deep ring, as in the forward kernel), 16 ds_read_b32 give the 4x4
 //     neighbourhood, the 18 coordinate-gradient terms are summed over the lane's channels IN THE LANE -- one cross-half
 //     add per tile instead of 18 DPP reductions per pixel;
@@ -24,9 +25,9 @@
 //     pixels of its tile that share its cell (found once per tile through LDS), and the cells are walked once per turn.
 //     The LDS pipe keeps a wave's accesses in order and the two half-waves work on different channels; LDS float
 //     atomics would cost ~170 cycles per wave instruction against ~6 for read + write (tools/ubench/atomic_patterns.hip).
-//     The four waves never meet in a plane: wave w's MFMA rows are the channels rotated by 8w, so at any step the waves
-//     hold different channels (a block barrier every four steps keeps them within the rotation).  Four channels' chains
-//     are interleaved to cover the LDS round trips.  Neighbourhoods that leave the plane (a flow that tears) go to gx
+//     The four waves never meet in a plane: wave w's MFMA rows are the channels permuted (slot ^ {0, 2, 8, 10}[w]), so at
+//     any step the waves hold different channels (a block barrier per step keeps them within the permutation).  Two
+//     channels' chains are interleaved per lane; the CU's other block covers the rest of the LDS round trips.  Neighbourhoods that leave the plane (a flow that tears) go to gx
 //     directly, 16 atomics per pixel and channel;
 //   * the merged planes are flushed to gx once per block with fp32 atomics over the touched box only: global atomics
 //     cost ~0.35 ns per wave INSTRUCTION chip-wide however few lanes are active (same microbenchmark), so what matters is
@@ -39,43 +40,37 @@
 
 namespace mfn {
 
-constexpr int DCP_ROWF = 288;                    // floats of one filter's segment: 32 channels x 9 taps
+constexpr int DCP_CB = 16;                       // input channels of a block
+constexpr int DCP_ROWF = DCP_CB * 9;             // floats of one filter's segment: 16 channels x 9 taps
+constexpr int DCP_KO = 16, DCP_KS = DCP_KO / 2;  // filters per weight chunk; its k-steps (two filters per fp32 MFMA)
+// a chunk is 16 x 36 sixteen-byte items = 9 wave DMA instructions; every wave issues three (uniform wait counts), the
+// three that carry nothing write zeros into a dump
+constexpr int DCP_WNI = 3;
+constexpr int DCP_STAGE_F = 9 * 256, DCP_DUMP_F = 3 * 256;
 constexpr int DCP_ROWS = 16, DCP_COLS = 24;      // source window of a 4x8 tile
 constexpr int DCP_XW_NI = 3;                     // 2 channels x 16 rows x 6 float4 = 192 slots = 3 wave DMA instructions
 constexpr int DCP_XW_F = DCP_XW_NI * 256;        // floats of a channel-pair source window
+constexpr int DCP_RD = 3;                        // source windows in flight (the wave's own ring)
 constexpr int DCP_PR = 22, DCP_PC = 32;          // gx plane of the 8x16 region
 // row stride of a plane in LDS.  ds_read_b32 / ds_write_b32 serve a half-wave (one tile's 4 x 8 pixels on one channel plane) per
 // LDS cycle over 32 banks: with a stride of 32 the tile's four rows sit on the same banks (every access of the walk 4-way
 // conflicted), with 40 they sit 8 banks apart -- a regular tile touches 32 different banks
 constexpr int DCP_PS = 40;
+constexpr int DCP_PLANE = DCP_PR * DCP_PS + 8;
 constexpr int DCP_FS = (DCP_PR * DCP_PC + 63) / 64;  // most 64-cell slices a plane's flush can take
 constexpr int DCP_EXCH = 32;                     // ints of the block's touched-box exchange
-// Three forms of the kernel.  <1, 1, 1> (default): both gradients from one pass over gout, one wave per SIMD (466 registers,
-// 119 KB of LDS).  <0, 1, 2> and <1, 0, 2> (dc.bwdsplit2=1): one gradient each at TWO blocks per CU -- every phase of this kernel
-// waits on its own LDS / memory round trips, and a second wave on the SIMD fills them; the price is the column-gradient GEMM
-// and the setup done twice.  Measured (levels 5..2): 20 + 51 / 33 + 64 / 39 + 77 / 53 + 114 us against 54 / 69 / 106 / 161 for the
-// one-launch form: not a gain -- the input gradient's flush is ~190 atomic instructions per block either way.  What
-// shrinks to make two blocks fit: 8-filter weight chunks, three source windows in flight instead of eight (the other wave
-// covers the rest), 16 of the 32 planes live at a time (the channels whose MFMA row has (row & 3) < 2 first, then the others).
-template <bool WX, bool WO, int OCC> struct DcpCfg {
-  static constexpr bool SPLIT = OCC >= 2;
-  static constexpr int KO = SPLIT ? 8 : 16;                  // filters per weight chunk
-  static constexpr int NI = SPLIT ? 3 : 5;                   // weight DMA instructions per thread and chunk (KO x 72 items)
-  static constexpr int STAGE_F = NI * 256 * 4;               // floats per weight stage buffer (three of them)
-  static constexpr int RD = SPLIT ? 3 : 8;                   // source windows in flight (three are the wave's own ring)
-  static constexpr int NSET = SPLIT ? 2 : 1;                 // plane sets walked one after the other
-  static constexpr int NPL = 32 / NSET;                      // planes live at a time
-  // plane stride: the two half-waves' planes (MFMA rows 4 apart) sit 32 banks apart
-  static constexpr int PLANE = DCP_PR * DCP_PS + (SPLIT ? 16 : 8);
-  static constexpr int STASH = WX ? 21 : 6;                  // words a lane parks in LDS (what only phase B / the end needs)
-  // per wave next to the weight stages: its three source windows (offset gradient), or at least the scratch of the turn
-  // assignment (one int per plane cell)
-  static constexpr int XW_WAVE = WO ? 3 * DCP_XW_F : DCP_PR * DCP_PS;
-  static constexpr int LDS_A = 3 * STAGE_F + 4 * XW_WAVE, LDS_B = WX ? NPL * PLANE : 0;
-  static constexpr int LDS_MAIN = LDS_A > LDS_B ? LDS_A : LDS_B;
-  // K loop and phase A: weight stages + four x-window rings; phase B reuses the same memory for the planes
-  static constexpr size_t lds_bytes() { return ((size_t)LDS_MAIN + DCP_EXCH + 4 * STASH * 64) * sizeof(float); }
-};
+constexpr int DCP_STASH = 21;                    // words a lane parks in LDS (what only phase B / the end needs)
+// K loop and phase A: two weight stages + dump + four x-window rings; phase B reuses the same memory for the 16 planes.
+// 80 000 bytes: TWO blocks per CU (round 3).  Round 2's block was 32 channels -- nine 32 x 32 accumulator tiles, 466
+// registers, 119 KB of LDS, one wave per SIMD, and every phase of this kernel waits on its own LDS / memory round trips
+// with nobody to fill them.  With 16 channels the MFMA's 32 rows are (channel, tap parity): five accumulator tiles
+// (80 registers) hold the nine taps (the tenth slot is dropped), the block fits twice, and the two blocks of a CU are in
+// different phases.
+constexpr int DCP_LDS_A = 2 * DCP_STAGE_F + DCP_DUMP_F + 4 * DCP_RD * DCP_XW_F, DCP_LDS_B = DCP_CB * DCP_PLANE;
+constexpr int DCP_LDS_MAIN = DCP_LDS_A > DCP_LDS_B ? DCP_LDS_A : DCP_LDS_B;
+constexpr size_t dc_bwd_input_pix_lds_bytes() { return ((size_t)DCP_LDS_MAIN + DCP_EXCH + 4 * DCP_STASH * 64) * sizeof(float); }
+static_assert(2 * dc_bwd_input_pix_lds_bytes() <= 160 * 1024, "two blocks per CU");
+static_assert(DCP_PR * DCP_PS <= DCP_RD * DCP_XW_F, "the turn map lives in a wave's window ring");
 
 struct DcBwdPParams {
   const float *gout, *x, *offset, *w;
@@ -95,44 +90,47 @@ struct DcBwdPParams {
   float flow_scale, flow_stride;
 };
 
-template <bool WX, bool WO, int OCC>
-__global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams p) {
-  using Cfg = DcpCfg<WX, WO, OCC>;
-  constexpr int T = 9, KO = Cfg::KO, KS = KO / 2, NI = Cfg::NI, ROWS = DCP_ROWS, COLS = DCP_COLS, XW_NI = DCP_XW_NI;
-  constexpr int PR = DCP_PR, PC = DCP_PC, PS = DCP_PS, PL = Cfg::PLANE, RD = Cfg::RD, NSET = Cfg::NSET, CPG = 4 / NSET;
-  constexpr int DCP_STAGE_F = Cfg::STAGE_F, DCP_STASH = Cfg::STASH;
-  if (!WX) p.req_x = 0;        // the form decides which gradients are formed
-  if (!WO) p.req_offset = 0;
+__global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p) {
+  constexpr int T = 9, TP = 5, KO = DCP_KO, KS = DCP_KS, NI = DCP_WNI, ROWS = DCP_ROWS, COLS = DCP_COLS, XW_NI = DCP_XW_NI;
+  constexpr int PR = DCP_PR, PC = DCP_PC, PS = DCP_PS, PL = DCP_PLANE, RD = DCP_RD, CB = DCP_CB;
+  constexpr int NST = 8;        // channel pairs of a lane: phase A's steps
+  constexpr int CPG = 2;        // channels a lane walks at a time in phase B (four groups)
   MFN_DYN_SHARED(float, lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = MFN_UNIFORM(tid >> 6);
   const int half = lane >> 5, j = lane & 31;
-  int *exch = reinterpret_cast<int *>(lds + Cfg::LDS_MAIN);  // [4 waves][8]
-  float *xwin = lds + 3 * DCP_STAGE_F + wave * Cfg::XW_WAVE;  // this wave's three pair windows (ring)
-  // What only phase B or the final store needs waits in LDS, word k of lane l at [k][l] (the accumulators alone are 144
-  // registers)
+  int *exch = reinterpret_cast<int *>(lds + DCP_LDS_MAIN);  // [4 waves][8]
+  float *wdump = lds + 2 * DCP_STAGE_F;
+  float *xwin = lds + 2 * DCP_STAGE_F + DCP_DUMP_F + wave * (RD * DCP_XW_F);  // this wave's three pair windows (ring)
+  // What only phase B or the final store needs waits in LDS, word k of lane l at [k][l]
   float *stash = reinterpret_cast<float *>(exch) + DCP_EXCH + wave * (DCP_STASH * 64) + lane;
   const unsigned long long tk0 = MFN_CYCLES();
 
   const int H = p.H, W = p.W;
   const size_t plane = (size_t)H * W;
   const int bx = p.xcd ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int cb = blockIdx.y * 32;
-  // the rotation: MFMA row i of wave w is channel cb + ((i + 8w) & 31)
-  const int rot = 8 * wave;
+  const int cb = blockIdx.y * CB;
+  // The MFMA's 32 rows: row i = (channel slot i & 15, tap parity i >> 4).  Slot sigma of wave w is channel
+  // cb + (sigma ^ xw): the waves' slots are the channels permuted so that at any step of phase B the four waves hold
+  // different channels (bits 1 and 3 flipped; bit 2 -- the two half-waves -- stays: a lane pair is channels c and c + 4).
+  const int xw = MFN_UNIFORM(((wave & 1) << 1) | ((wave & 2) << 2));
+  // accumulator register 8 s + q of a lane (tap parity s, q = 0..7): slot (q & 3) + 8 (q >> 2) + 4 half
+  auto slot_of = [&](int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; };
+  auto chan_of = [&](int q, int h) { return slot_of(q, h) ^ xw; };  // channel inside the block
 
-  // ---- weights of this channel block: chunk ch = filters [ch*KO, ch*KO + KO), their 288-float segments as they are
+  // ---- weights of this channel block: chunk ch = filters [ch*KO, ch*KO + KO), their 144-float segments as they are
   const unsigned rowbytes = (unsigned)p.Cin * 36u;
   const mfn_rsrc_t wrsrc = mfn_make_rsrc(p.w + (size_t)cb * T, (unsigned)(((size_t)p.Cout * p.Cin - cb) * T * 4));
   unsigned voff[NI];
   MFN_UNROLL
   for (int i = 0; i < NI; ++i) {
-    const int it = (i * 4 + wave) * 64 + lane;
-    const int row = it / 72, seg = it - row * 72;
-    voff[i] = row < KO ? (unsigned)row * rowbytes + (unsigned)seg * 16u : 0xFFFFFF00u;
+    const int q = i * 4 + wave;                         // wave instruction 0..11; 0..8 carry the chunk
+    const int it = q * 64 + lane;
+    const int row = it / 36, seg = it - row * 36;
+    voff[i] = q < 9 ? (unsigned)row * rowbytes + (unsigned)seg * 16u : 0xFFFFFF00u;
   }
-  // blockIdx.z: a slice of the filters (coarse levels have fewer regions than the chip has CUs; everything after the K
-  // loop is linear in the column gradients, so every slice adds its share of both gradients)
+  // blockIdx.z: a slice of the filters (coarse levels have fewer regions than the chip has block slots; everything after the
+  // K loop is linear in the column gradients, so every slice adds its share of both gradients)
   const int nchunks_all = (p.Cout + KO - 1) / KO;
   const int cpz = (nchunks_all + (int)gridDim.z - 1) / (int)gridDim.z;
   const int ch_lo = (int)blockIdx.z * cpz;
@@ -141,7 +139,10 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
     float *dst = lds + buf * DCP_STAGE_F;
     const unsigned soff = (unsigned)(ch_lo + ch) * (unsigned)KO * rowbytes;
     MFN_UNROLL
-    for (int i = 0; i < NI; ++i) mfn_dma16_so(wrsrc, dst + (i * 4 + wave) * 256, voff[i], soff);
+    for (int i = 0; i < NI; ++i) {
+      const int q = i * 4 + wave;
+      mfn_dma16_so(wrsrc, q < 9 ? dst + q * 256 : wdump + (q - 9) * 256, voff[i], soff);
+    }
   };
 
   // ---- this lane's pixel: region -> (image, region row, region column); wave w = tile (w >> 1, w & 1) of the region
@@ -171,9 +172,9 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
   const size_t pix = (size_t)ho * W + wo;
   const int h_in = ho - p.ph, w_in = wo - p.pw;
 
-  // gout and weights of the first two chunks travel while the geometry is computed
+  // gout and weights of the first chunk travel while the geometry is computed
   const float *gptr = p.gout + (size_t)n * p.Cout * plane + pix;
-  float gb0[KS], gb1[KS], gb2[KS];  // gout values of three chunks in flight (static ring: the chunk loop is unrolled by three)
+  float gb0[KS], gb1[KS];  // gout values of two chunks (static ring: the chunk loop is unrolled by two)
   auto load_g = [&](int ch, float (&g)[KS]) {
     MFN_UNROLL
     for (int kk = 0; kk < KS; ++kk) {
@@ -182,7 +183,6 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
     }
   };
   if (nchunks > 0) { load_g(0, gb0); issue_w(0, 0); }
-  if (nchunks > 1) { load_g(1, gb1); issue_w(1, 1); }
 
   // ---- tap geometry (deform_conv.h: dc_axis; backward.h: dcs_axis) ---------------------------------------------------
   float geo[DCS_GS];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
     const int chs = slot / 96, rem = slot - chs * 96;   // float4 slots: [channel 0/1][16 rows][6 float4]
     const int row = rem / 6, c4 = rem - row * 6;
     const int r = wr0 + row, c = wc0 + 4 * c4;
-    // the pair of step r: the channels of MFMA rows q and q + 4 (the two half-waves)
+    // the pair of a step: the channels of the two half-waves, c and c + 4
     xvoff[i] = (r >= 0 && r <= H - 1 && c >= 0 && c <= W - 4)
                    ? (unsigned)(((size_t)n * p.Cin * plane + (size_t)(4 * chs) * plane + (size_t)r * W + c) * 4)
                    : 0xFFFFFF00u;  // outside the image: never read, the DMA writes zeros
@@ -262,15 +262,15 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
     lrow[m] = half * (ROWS * COLS) + min(max(iy[m] - wr0, 0), ROWS - 1) * COLS;
     lcol[m] = min(max(ix[m] - wc0, 0), COLS - 1);
   }
-  // D row r of the MFMA tile (lane half h): row (r&3) + 8*(r>>2) + 4h = channel cb + ((row + rot) & 31)
-  auto row_q = [](int r) { return (r & 3) + 8 * (r >> 2); };
-  auto issue_x = [&](int r, int buf) {
-    const int c0 = cb + ((row_q(r) + rot) & 31);  // its partner is c0 + 4 (never wraps: row_q + rot is 0..3 mod 8)
-    // channels past Cin (ragged last block) are masked in the sums: whatever lies there (the next image, or zeros past the
-    // end of the buffer) is fetched and dropped
+  auto issue_xb = [&](int r) {
+    // half 0's channel of step r; its partner is + 4 (bit 2 of the slot, which xw leaves alone).  Channels past Cin (ragged
+    // last block) are masked in the sums: whatever lies there (the next image, or zeros past the end of the buffer) is
+    // fetched and dropped
+    const int c0 = cb + chan_of(r, 0);
     const unsigned soff = (unsigned)((size_t)min(c0, p.Cin - 1) * plane * 4);
+    float *dst = xwin + (r % RD) * DCP_XW_F;
     MFN_UNROLL
-    for (int i = 0; i < XW_NI; ++i) mfn_dma16_so(xrsrc, xwin + buf * DCP_XW_F + i * 256, xvoff[i], soff);
+    for (int i = 0; i < XW_NI; ++i) mfn_dma16_so(xrsrc, dst + i * 256, xvoff[i], soff);
   };
 
   // ---- gx plane of the region (phase B): 22 x 32 around the 11 x 19 box the centre pixel's offset predicts ------------
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
     e[0] = 1 << 28; e[1] = -(1 << 28); e[2] = 1 << 28; e[3] = -(1 << 28);
   }
   MFN_WAIT_LGKM0();
-  if (fast && p.req_offset && xfit) { issue_x(0, 0); issue_x(1, 1); issue_x(2, 2); }
+  if (fast && p.req_offset && xfit) { issue_xb(0); issue_xb(1); issue_xb(2); }
   {
     // forward weights with the taps' validity folded in (an invalid tap row / column contributes nothing), the lane's
     // cell of neighbourhood corner (0, 0) in a plane, its turn, and the validity factors of the offset gradient
@@ -337,74 +337,71 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
       const float vy = px_valid ? vyf[i] : 0.f, vx = px_valid ? vxf[i] : 0.f;
       stash[(0 + i) * 64] = vy;
       stash[(3 + i) * 64] = vx;
-      if (WX) {
-        stash[(6 + i) * 64] = vy * geo[DCS_AY + i];
-        stash[(9 + i) * 64] = vy * geo[DCS_BY + i];
-        stash[(12 + i) * 64] = vx * geo[DCS_AX + i];
-        stash[(15 + i) * 64] = vx * geo[DCS_BX + i];
-      }
+      stash[(6 + i) * 64] = vy * geo[DCS_AY + i];
+      stash[(9 + i) * 64] = vy * geo[DCS_BY + i];
+      stash[(12 + i) * 64] = vx * geo[DCS_AX + i];
+      stash[(15 + i) * 64] = vx * geo[DCS_BX + i];
     }
-    if (WX) {
-      int *si = reinterpret_cast<int *>(stash);
-      si[18 * 64] = cry * PS + crx;
-      si[19 * 64] = (px_valid && !inplane) ? -2 : turn;   // -2: the neighbourhood leaves the plane -> straight to gx
-      si[20 * 64] = partner;
-    }
+    int *si = reinterpret_cast<int *>(stash);
+    si[18 * 64] = cry * PS + crx;
+    si[19 * 64] = (px_valid && !inplane) ? -2 : turn;   // -2: the neighbourhood leaves the plane -> straight to gx
+    si[20 * 64] = partner;
   }
 
   const unsigned long long tks = MFN_CYCLES();
-  // ---- column gradients of all nine taps: K = filters, three chunks in flight ----------------------------------------
-  f32x16 acc[T];
+  // ---- column gradients of all nine taps: K = filters.  Tile tp holds taps 2 tp (rows 0..15) and 2 tp + 1 (rows 16..31;
+  // for tp = 4 that is "tap 9", the next channel's tap 0: never read from the accumulators) -----------------------------
+  f32x16 acc[TP];
   MFN_UNROLL
-  for (int t = 0; t < T; ++t)
+  for (int t = 0; t < TP; ++t)
     MFN_UNROLL
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // tap t of the lane's q-th channel
+#define DCP_ACC(t, q) acc[(t) >> 1][(((t) & 1) << 3) | (q)]
+  const int arow = half * DCP_ROWF + ((j & 15) ^ xw) * T + (j >> 4);  // this lane's row of A inside a k-step (two filters)
   auto chunk = [&](int ch, auto buf_c, const float (&cur)[KS], float (&nn)[KS]) {
     constexpr int BUF = decltype(buf_c)::value;
-    // chunk ch and this lane's gout values for it have landed; the 13 operations of chunk ch + 1 may still fly
-    if (ch + 1 < nchunks) MFN_WAIT_VM(KS + NI); else MFN_WAIT_VM(0);
-    MFN_LDS_BARRIER();    // ... for every wave; everyone is past chunk ch - 1, whose buffer takes chunk ch + 2
-    if (ch + 2 < nchunks) {
-      load_g(ch + 2, nn);
-      issue_w(ch + 2, (BUF + 2) % 3);
+    // chunk ch and this lane's gout values for it have landed ...
+    MFN_WAIT_VM(0);
+    MFN_LDS_BARRIER();    // ... for every wave; everyone is past chunk ch - 1, whose buffer takes chunk ch + 1
+    if (ch + 1 < nchunks) {
+      load_g(ch + 1, nn);
+      issue_w(ch + 1, BUF ^ 1);
     }
     if (fast) {
-      const float *ap = lds + BUF * DCP_STAGE_F + half * DCP_ROWF + ((j + rot) & 31) * T;
-      float a[2][T];
+      const float *ap = lds + BUF * DCP_STAGE_F + arow;
+      float a[2][TP];
       MFN_UNROLL
-      for (int t = 0; t < T; ++t) a[0][t] = ap[t];
+      for (int t = 0; t < TP; ++t) a[0][t] = ap[2 * t];
       MFN_UNROLL
       for (int kk = 0; kk < KS; ++kk) {
-        // the next k-step's weights are requested before this k-step's MFMAs issue (one wave per SIMD: nobody else
-        // covers the LDS round trip; left alone hipcc reads them right before their use)
+        // the next k-step's weights are requested before this k-step's MFMAs issue
         if (kk + 1 < KS) {
           MFN_UNROLL
-          for (int t = 0; t < T; ++t) a[(kk + 1) & 1][t] = ap[(kk + 1) * 2 * DCP_ROWF + t];
+          for (int t = 0; t < TP; ++t) a[(kk + 1) & 1][t] = ap[(kk + 1) * 2 * DCP_ROWF + 2 * t];
         }
         const bool o_ok = (ch_lo + ch) * KO + 2 * kk + half < p.Cout;
         const float bv = (o_ok && px_valid) ? cur[kk] : 0.f;
         MFN_SCHED_BARRIER();
         MFN_UNROLL
-        for (int t = 0; t < T; ++t) acc[t] = MFN_MFMA_32x32x2(a[kk & 1][t], bv, acc[t]);
+        for (int t = 0; t < TP; ++t) acc[t] = MFN_MFMA_32x32x2(a[kk & 1][t], bv, acc[t]);
         MFN_SCHED_BARRIER();
       }
     }
   };
-  for (int ch = 0; ch < nchunks; ch += 3) {
-    chunk(ch, DcInt<0>{}, gb0, gb2);
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    chunk(ch, DcInt<0>{}, gb0, gb1);
     if (ch + 1 < nchunks) chunk(ch + 1, DcInt<1>{}, gb1, gb0);
-    if (ch + 2 < nchunks) chunk(ch + 2, DcInt<2>{}, gb2, gb1);
   }
   unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
-  if (p.timeline) { MFN_OPAQUE(acc[0][0]); MFN_OPAQUE(acc[8][15]); tk1 = MFN_CYCLES(); }
+  if (p.timeline) { MFN_OPAQUE(acc[0][0]); MFN_OPAQUE(acc[TP - 1][7]); tk1 = MFN_CYCLES(); }
 
   // ---- phase A: offset gradient ------------------------------------------------------------------------------------------
-  if (p.req_offset) MFN_LDS_BARRIER();  // every wave is done with the weight stages: they become source windows
   if (fast && p.req_offset) {
     float sh[T], sw[T];
     MFN_UNROLL
     for (int t = 0; t < T; ++t) sh[t] = sw[t] = 0.f;
-    const float *xg = p.x + (size_t)n * p.Cin * plane;  // (the rare wave whose window does not hold its neighbourhoods)
+    const unsigned xn0 = (unsigned)n * (unsigned)p.Cin * (unsigned)plane;  // (the rare wave whose window does not hold its neighbourhoods)
     auto gather = [&](auto dma_c, int r, const float *xb, float (&X)[4][4]) {
       if (decltype(dma_c)::value) {
         MFN_UNROLL
@@ -412,98 +409,59 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
           MFN_UNROLL
           for (int q = 0; q < 4; ++q) X[m][q] = xb[lrow[m] + lcol[q]];
       } else {
-        const int c = min(cb + ((row_q(r) + rot) & 31) + 4 * half, p.Cin - 1);
-        const float *xp = xg + (size_t)c * plane;
+        // 32-bit element offsets from the (uniform) tensor base: the host admits N * Cin * H * W < 2^30 here; sixteen
+        // 64-bit lane addresses were this kernel's largest register consumer
+        const int c = min(cb + chan_of(r, half), p.Cin - 1);
+        const unsigned cbase = xn0 + (unsigned)c * (unsigned)plane;
         MFN_UNROLL
         for (int m = 0; m < 4; ++m)
           MFN_UNROLL
-          for (int q = 0; q < 4; ++q) X[m][q] = xp[iy[m] * W + ix[q]];
+          for (int q = 0; q < 4; ++q) X[m][q] = xb[cbase + (unsigned)(iy[m] * W + ix[q])];
       }
     };
     auto sums = [&](auto r_c, const float (&X)[4][4]) {
       constexpr int r = decltype(r_c)::value;
-      const bool c_ok = cb + ((row_q(r) + rot) & 31) + 4 * half < p.Cin;
+      const bool c_ok = cb + chan_of(r, half) < p.Cin;
       MFN_UNROLL
       for (int i = 0; i < 3; ++i)
         MFN_UNROLL
         for (int q = 0; q < 3; ++q) {
           const int t = 3 * i + q;
-          const float cg = c_ok ? acc[t][r] : 0.f;
+          const float cg = c_ok ? DCP_ACC(t, r) : 0.f;
           // d/dh: fw0*(v21-v11) + fw1*(v22-v12);  d/dw: fh0*(v12-v11) + fh1*(v22-v21)   (deformable_col2im_coord)
-          const float th = geo[DCS_FW0 + q] * (X[i + 1][q] - X[i][q]) + geo[DCS_FW1 + q] * (X[i + 1][q + 1] - X[i][q + 1]);
-          const float tw = geo[DCS_FH0 + i] * (X[i][q + 1] - X[i][q]) + geo[DCS_FH1 + i] * (X[i + 1][q + 1] - X[i + 1][q]);
+          float th = geo[DCS_FW0 + q] * (X[i + 1][q] - X[i][q]) + geo[DCS_FW1 + q] * (X[i + 1][q + 1] - X[i][q + 1]);
+          float tw = geo[DCS_FH0 + i] * (X[i][q + 1] - X[i][q]) + geo[DCS_FH1 + i] * (X[i + 1][q + 1] - X[i + 1][q]);
+          // scalar on purpose: paired into v_pk_* by the SLP vectoriser these sums cost a register shuffle per operand and,
+          // at two waves per SIMD, sixty spilled registers
+          MFN_OPAQUE(th);
+          MFN_OPAQUE(tw);
           sh[t] = fmaf(th, cg, sh[t]);
           sw[t] = fmaf(tw, cg, sw[t]);
         }
     };
-    // software pipeline: step r gathers the neighbourhood of pair r + 1, sums pair r from registers, then hands the
-    // buffer it has just read to window r + 1 + RD: RD windows in flight (one wave per SIMD: eight -- nobody else covers the
-    // ~2 us a window takes; two waves per SIMD: three).  Ring buffers 0..2 are the wave's own, 3.. its share of the weight
-    // stages, dead after the K loop.  DMA completion is in issue order: the waits count the newer windows that may still fly.
-    auto xbuf = [&](int b) { return b < 3 ? xwin + b * DCP_XW_F : lds + (wave * (RD - 3) + (b - 3)) * DCP_XW_F; };
-    auto issue_xb = [&](int r) {
-      const int c0 = cb + ((row_q(r) + rot) & 31);
-      const unsigned soff = (unsigned)((size_t)min(c0, p.Cin - 1) * plane * 4);
-      float *dst = xbuf(r % RD);
-      MFN_UNROLL
-      for (int i = 0; i < XW_NI; ++i) mfn_dma16_so(xrsrc, dst + i * 256, xvoff[i], soff);
-    };
-    // two waves per SIMD: no register pair for the look-ahead (a spill would put scratch stores between the counted DMA
-    // waits), and no need -- the other wave runs while this one waits for its gather
-    auto phase_a1 = [&](auto dma_c) {
+    // step r gathers the neighbourhood of pair r, hands the buffer to window r + RD, then sums: no look-ahead in registers
+    // (two waves per SIMD: the other block runs while this wave waits for its gather; a second neighbourhood in registers
+    // made hipcc spill the accumulators around this phase).  DMA completion is in issue order: the waits count the newer
+    // windows that may still fly.
+    auto phase_a = [&](auto dma_c) {
       constexpr bool DMA = decltype(dma_c)::value;
-      auto step_1 = [&](auto r_c) {
+      auto step_a = [&](auto r_c) {
         constexpr int r = decltype(r_c)::value;
-        constexpr int newer = (15 - r) < 2 ? (15 - r) : 2;   // windows r + 1, r + 2
+        constexpr int newer = (NST - 1 - r) < (RD - 1) ? (NST - 1 - r) : (RD - 1);   // windows r + 1 .. min(r + RD - 1, NST - 1)
         float X[4][4];
         if (DMA) MFN_WAIT_VM(newer * XW_NI);
-        gather(dma_c, r, xbuf(r % 3), X);
+        gather(dma_c, r, DMA ? xwin + (r % RD) * DCP_XW_F : p.x, X);
         MFN_WAIT_LGKM0();
-        if (DMA && r + 3 < 16) issue_xb(r + 3);
+        if (DMA && r + RD < NST) issue_xb(r + RD);
         sums(r_c, X);
       };
-      step_1(DcInt<0>{}); step_1(DcInt<1>{}); step_1(DcInt<2>{}); step_1(DcInt<3>{});
-      step_1(DcInt<4>{}); step_1(DcInt<5>{}); step_1(DcInt<6>{}); step_1(DcInt<7>{});
-      step_1(DcInt<8>{}); step_1(DcInt<9>{}); step_1(DcInt<10>{}); step_1(DcInt<11>{});
-      step_1(DcInt<12>{}); step_1(DcInt<13>{}); step_1(DcInt<14>{}); step_1(DcInt<15>{});
-    };
-    auto phase_a = [&](auto dma_c) {
-    constexpr bool DMA = decltype(dma_c)::value;
-    float Xa[4][4], Xb[4][4];
-    if (DMA) {
-      MFN_UNROLL
-      for (int b = 3; b < RD; ++b) issue_xb(b);
-      MFN_WAIT_VM((RD - 1) * XW_NI);
-    }
-    gather(dma_c, 0, xbuf(0), Xa);
-    MFN_WAIT_LGKM0();
-    if (DMA) issue_xb(RD);
-    auto step_a = [&](auto r_c, float (&Xc)[4][4], float (&Xn)[4][4]) {
-      constexpr int r = decltype(r_c)::value;
-      if (r + 1 < 16) {
-        constexpr int newer = (14 - r) < (RD - 1) ? (14 - r) : (RD - 1);   // windows r + 2 .. min(r + RD, 15)
-        if (DMA) MFN_WAIT_VM(newer * XW_NI);
-        gather(dma_c, r + 1, xbuf((r + 1) % RD), Xn);
-      }
-      sums(r_c, Xc);
-      if (r + 1 + RD < 16) {
-        MFN_WAIT_LGKM0();
-        if (DMA) issue_xb(r + 1 + RD);
-      }
-    };
-    step_a(DcInt<0>{}, Xa, Xb); step_a(DcInt<1>{}, Xb, Xa); step_a(DcInt<2>{}, Xa, Xb); step_a(DcInt<3>{}, Xb, Xa);
-    step_a(DcInt<4>{}, Xa, Xb); step_a(DcInt<5>{}, Xb, Xa); step_a(DcInt<6>{}, Xa, Xb); step_a(DcInt<7>{}, Xb, Xa);
-    step_a(DcInt<8>{}, Xa, Xb); step_a(DcInt<9>{}, Xb, Xa); step_a(DcInt<10>{}, Xa, Xb); step_a(DcInt<11>{}, Xb, Xa);
-    step_a(DcInt<12>{}, Xa, Xb); step_a(DcInt<13>{}, Xb, Xa); step_a(DcInt<14>{}, Xa, Xb); step_a(DcInt<15>{}, Xb, Xa);
+      step_a(DcInt<0>{}); step_a(DcInt<1>{}); step_a(DcInt<2>{}); step_a(DcInt<3>{});
+      step_a(DcInt<4>{}); step_a(DcInt<5>{}); step_a(DcInt<6>{}); step_a(DcInt<7>{});
     };
     // two copies on purpose: with the global loads of the rare path in the same code, hipcc waits vmcnt(0) before every
     // gather of the DMA path (a register with a load pending on the OTHER path) and the window ring degenerates
-    if (Cfg::SPLIT) {
-      if (xfit) phase_a1(DcInt<1>{}); else phase_a1(DcInt<0>{});
-    } else {
-      if (xfit) phase_a(DcInt<1>{}); else phase_a(DcInt<0>{});
-    }
-    // the two half-waves hold the other 16 channels of the same pixel; half 0 writes d/dh, half 1 d/dw
+    if (xfit) phase_a(DcInt<1>{}); else phase_a(DcInt<0>{});
+    // the two half-waves hold the other 8 channels of the same pixel; half 0 writes d/dh, half 1 d/dw
     float vt[T], vsum = 0.f;
     {
       // half 0 needs the other half's d/dh sums, half 1 its d/dw sums: ONE exchange per tap (each half sends what the other
@@ -519,9 +477,8 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
         vsum += vt[t];
       }
     }
-    // one writer per value (no channel blocks, no filter slices): plain stores -- the buffer is zero-filled in write mode, so
-    // only "add" reads it, all nine values requested before the first is used (`*dst += v` tap by tap was nine dependent
-    // round trips).  Otherwise atomics.
+    // the channel blocks (and filter slices) of a pixel add up through atomics; the buffer is zero-filled in write mode.
+    // One writer per value (Cin <= 16, no filter slices): plain stores, "add" reads its old values together.
     const bool single = gridDim.y == 1 && gridDim.z == 1;
     if (fm) {  // d/dflow: the nine taps share the offset, so their gradients add up (MaskFlownet.py:230)
       if (px_valid) {
@@ -554,8 +511,7 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
   if (!p.req_x) return;   // uniform
 
   // ---- phase B: input gradient -----------------------------------------------------------------------------------------
-  // NSET plane sets, one after the other (one set of 32 planes, or two of 16: the channels whose MFMA row has (row & 3) < 2,
-  // then the others).  Per set: zero the planes, four groups of CPG channels (chains) per wave, flush.
+  // Zero the 16 planes, four groups of CPG channels (chains) per lane, flush.
   MFN_WAIT_VM(0);
   MFN_LDS_BARRIER();      // the stage buffers and window rings are dead: the planes take their place
   float ay[3], by[3], ax[3], bxw[3];
@@ -569,8 +525,6 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
   const int psrc = mypartner >= 0 ? mypartner + 32 * half : lane;  // the lane whose values are added to this lane's
   const float pmask = mypartner >= 0 ? 1.f : 0.f;
   const bool any_merged = MFN_UNIFORM(merged) != 0;
-  // plane of MFMA row rho in its set: 32 planes: rho; 16 planes: (rho >> 2) * 2 + (rho & 1)
-  auto plane_of = [](int rho) { return NSET == 1 ? rho : ((rho >> 2) * 2 + (rho & 1)); };
   // the flush plan: 64 consecutive cells of the planes' touched box per atomic instruction
   int fy0 = 1 << 28, fy1 = -(1 << 28), fx0 = 1 << 28, fx1 = -(1 << 28);
   MFN_UNROLL
@@ -595,125 +549,112 @@ __global__ __launch_bounds__(256, OCC) void dc_bwd_input_pix_kernel(DcBwdPParams
       fgoff[sl] = (e < ncells && yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
     }
   }
-  unsigned long long td0 = 0, td1 = 0, td2 = 0, td3 = 0, tflush = 0;
+  unsigned long long td0 = 0, td1 = 0, td2 = 0, td3 = 0;
 
-  auto set_b = [&](auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-    for (int e = tid; e < Cfg::NPL * PL / 4; e += 256) reinterpret_cast<float4 *>(lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    MFN_LDS_BARRIER();
-    auto group_b = [&](auto g_c) {
-      constexpr int g = decltype(g_c)::value;   // chains c = 0 .. CPG-1: accumulator register 4g + CS + c, MFMA rows 8g + CS + c + 4 half
-      constexpr int CS = SET * CPG;
-      if (SET == 0 && g == 0 && p.timeline) td0 = MFN_CYCLES();
-      if (fast) {
-        // the nine taps folded onto the 4x4 neighbourhood, along x first, then along y
-        float G[CPG][4][4];
+  for (int e = tid; e < CB * PL / 4; e += 256) reinterpret_cast<float4 *>(lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  MFN_LDS_BARRIER();
+  auto group_b = [&](auto g_c) {
+    constexpr int g = decltype(g_c)::value;   // chains c = 0, 1: the lane's channels q = 2 g + c
+    if (g == 0 && p.timeline) td0 = MFN_CYCLES();
+    if (fast) {
+      // the nine taps folded onto the 4x4 neighbourhood, along x first, then along y
+      float G[CPG][4][4];
+      MFN_UNROLL
+      for (int c = 0; c < CPG; ++c) {
+        float R[3][4];
         MFN_UNROLL
-        for (int c = 0; c < CPG; ++c) {
-          float R[3][4];
-          MFN_UNROLL
-          for (int i = 0; i < 3; ++i) {
-            const float c0 = acc[3 * i][4 * g + CS + c], c1 = acc[3 * i + 1][4 * g + CS + c], c2 = acc[3 * i + 2][4 * g + CS + c];
-            R[i][0] = c0 * ax[0];
-            R[i][1] = fmaf(c0, bxw[0], c1 * ax[1]);
-            R[i][2] = fmaf(c1, bxw[1], c2 * ax[2]);
-            R[i][3] = c2 * bxw[2];
-          }
-          MFN_UNROLL
-          for (int v = 0; v < 4; ++v) {
-            G[c][0][v] = ay[0] * R[0][v];
-            G[c][1][v] = fmaf(by[0], R[0][v], ay[1] * R[1][v]);
-            G[c][2][v] = fmaf(by[1], R[1][v], ay[2] * R[2][v]);
-            G[c][3][v] = by[2] * R[2][v];
-          }
+        for (int i = 0; i < 3; ++i) {
+          const float c0 = DCP_ACC(3 * i, 2 * g + c), c1 = DCP_ACC(3 * i + 1, 2 * g + c), c2 = DCP_ACC(3 * i + 2, 2 * g + c);
+          R[i][0] = c0 * ax[0];
+          R[i][1] = fmaf(c0, bxw[0], c1 * ax[1]);
+          R[i][2] = fmaf(c1, bxw[1], c2 * ax[2]);
+          R[i][3] = c2 * bxw[2];
         }
-        if (any_merged) {  // uniform: every lane takes part in the shuffles
+        MFN_UNROLL
+        for (int v = 0; v < 4; ++v) {
+          G[c][0][v] = ay[0] * R[0][v];
+          G[c][1][v] = fmaf(by[0], R[0][v], ay[1] * R[1][v]);
+          G[c][2][v] = fmaf(by[1], R[1][v], ay[2] * R[2][v]);
+          G[c][3][v] = by[2] * R[2][v];
+        }
+      }
+      if (any_merged) {  // uniform: every lane takes part in the shuffles
+        MFN_UNROLL
+        for (int c = 0; c < CPG; ++c)
           MFN_UNROLL
-          for (int c = 0; c < CPG; ++c)
+          for (int u = 0; u < 4; ++u)
             MFN_UNROLL
-            for (int u = 0; u < 4; ++u)
+            for (int v = 0; v < 4; ++v) G[c][u][v] = fmaf(__shfl(G[c][u][v], psrc), pmask, G[c][u][v]);
+      }
+      if (g == 0 && p.timeline) { MFN_OPAQUE(G[CPG - 1][3][3]); td1 = MFN_CYCLES(); }
+      float *pl[CPG];
+      MFN_UNROLL
+      for (int c = 0; c < CPG; ++c) pl[c] = lds + (size_t)chan_of(2 * g + c, half) * PL + cell0;
+      // (emulation: free-running lanes take a whole walk one lane at a time, mfn_rt.h)
+      for (int t = 0; t < nturns; ++t) {
+        if (myturn == t) {
+          MFN_EMU_LOCK();
+          MFN_UNROLL
+          for (int u = 0; u < 4; ++u)
+            MFN_UNROLL
+            for (int v = 0; v < 4; ++v) {
+              float o[CPG];
               MFN_UNROLL
-              for (int v = 0; v < 4; ++v) G[c][u][v] = fmaf(__shfl(G[c][u][v], psrc), pmask, G[c][u][v]);
+              for (int c = 0; c < CPG; ++c) o[c] = pl[c][u * PS + v];
+              MFN_UNROLL
+              for (int c = 0; c < CPG; ++c) pl[c][u * PS + v] = o[c] + G[c][u][v];
+              // the next cell's reads are ISSUED after this cell's writes: another lane's cell (u, v) is this lane's
+              // cell (u', v'); the in-order LDS pipe then orders them
+              MFN_COMPILER_FENCE();
+            }
+          MFN_EMU_UNLOCK();
         }
-        if (SET == 0 && g == 0 && p.timeline) { MFN_OPAQUE(G[CPG - 1][3][3]); td1 = MFN_CYCLES(); }
-        float *pl[CPG];
-        MFN_UNROLL
-        for (int c = 0; c < CPG; ++c) pl[c] = lds + (size_t)plane_of((8 * g + CS + c + 4 * half + rot) & 31) * PL + cell0;
-        // (emulation: free-running lanes take a whole walk one lane at a time, mfn_rt.h)
-        for (int t = 0; t < nturns; ++t) {
-          if (myturn == t) {
-            MFN_EMU_LOCK();
+      }
+      if (__any(myturn == -2)) {  // neighbourhoods outside the plane: straight to gx
+        if (myturn == -2) {
+          MFN_UNROLL
+          for (int c = 0; c < CPG; ++c) {
+            const int ch = cb + chan_of(2 * g + c, half);
+            float *gim = p.gx + ((size_t)n * p.Cin + min(ch, p.Cin - 1)) * plane;
             MFN_UNROLL
             for (int u = 0; u < 4; ++u)
               MFN_UNROLL
               for (int v = 0; v < 4; ++v) {
-                float o[CPG];
-                MFN_UNROLL
-                for (int c = 0; c < CPG; ++c) o[c] = pl[c][u * PS + v];
-                MFN_UNROLL
-                for (int c = 0; c < CPG; ++c) pl[c][u * PS + v] = o[c] + G[c][u][v];
-                // the next cell's reads are ISSUED after this cell's writes: another lane's cell (u, v) is this lane's
-                // cell (u', v'); the in-order LDS pipe then orders them
-                MFN_COMPILER_FENCE();
+                const int yy = ly0 + u, xx = lx0 + v;
+                if (G[c][u][v] != 0.f && ch < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                  atomicAdd(gim + (size_t)yy * W + xx, G[c][u][v]);
               }
-            MFN_EMU_UNLOCK();
           }
         }
-        if (__any(myturn == -2)) {  // neighbourhoods outside the plane: straight to gx
-          if (myturn == -2) {
-            MFN_UNROLL
-            for (int c = 0; c < CPG; ++c) {
-              const int ch = cb + ((8 * g + CS + c + 4 * half + rot) & 31);
-              float *gim = p.gx + ((size_t)n * p.Cin + min(ch, p.Cin - 1)) * plane;
-              MFN_UNROLL
-              for (int u = 0; u < 4; ++u)
-                MFN_UNROLL
-                for (int v = 0; v < 4; ++v) {
-                  const int yy = ly0 + u, xx = lx0 + v;
-                  if (G[c][u][v] != 0.f && ch < p.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
-                    atomicAdd(gim + (size_t)yy * W + xx, G[c][u][v]);
-                }
-            }
-          }
-        }
-      }
-      if (SET == 0 && g == 0 && p.timeline) { MFN_WAIT_LGKM0(); td2 = MFN_CYCLES(); }
-      MFN_LDS_BARRIER();  // the waves stay within one group of each other: their rotated channel sets never meet
-      if (SET == 0 && g == 0 && p.timeline) td3 = MFN_CYCLES();
-    };
-    group_b(DcInt<0>{}); group_b(DcInt<1>{}); group_b(DcInt<2>{}); group_b(DcInt<3>{});
-    // ---- flush of the set: wave w takes planes w, w + 4, ... ---------------------------------------------------------------
-    const unsigned long long tf0 = p.timeline ? MFN_CYCLES() : 0ull;
-    if (any_cells) {
-      for (int pi = wave; pi < Cfg::NPL; pi += 4) {
-        // plane pi of the set holds MFMA row (32 planes: pi; 16 planes: (pi >> 1) * 4 + (pi & 1) + 2 * SET) = that channel
-        const int rho = NSET == 1 ? pi : ((pi >> 1) * 4 + (pi & 1) + 2 * SET);
-        if (cb + rho >= p.Cin) continue;  // uniform
-        const float *pp = lds + (size_t)pi * PL;
-        float *gim = p.gx + ((size_t)n * p.Cin + cb + rho) * plane;
-        float fv[DCP_FS];
-        MFN_UNROLL
-        for (int sl = 0; sl < DCP_FS; ++sl) fv[sl] = pp[floff[sl]];
-        MFN_UNROLL
-        for (int sl = 0; sl < DCP_FS; ++sl)
-          if (sl * 64 < ncells && fgoff[sl] >= 0 && fv[sl] != 0.f) atomicAdd(gim + fgoff[sl], fv[sl]);
       }
     }
-    if (SET + 1 < NSET) MFN_LDS_BARRIER();  // the planes are free for the next set
-    if (p.timeline) tflush += MFN_CYCLES() - tf0;
+    if (g == 0 && p.timeline) { MFN_WAIT_LGKM0(); td2 = MFN_CYCLES(); }
+    MFN_LDS_BARRIER();  // the waves stay within one group of each other: their permuted channel sets never meet
+    if (g == 0 && p.timeline) td3 = MFN_CYCLES();
   };
-  set_b(DcInt<0>{});
-  if (NSET > 1) set_b(DcInt<NSET - 1>{});
-  if (p.timeline && p.tl_detail && tid == 0) {
-    unsigned long long *b_ = p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
-    b_[1] = td1 - td0; b_[2] = td2 - td1; b_[3] = td3 - td2;
+  group_b(DcInt<0>{}); group_b(DcInt<1>{}); group_b(DcInt<2>{}); group_b(DcInt<3>{});
+#undef DCP_ACC
+  // ---- flush: wave w takes planes w, w + 4, w + 8, w + 12 (plane = channel inside the block) -----------------------------
+  if (p.timeline) tk3 = MFN_CYCLES();
+  if (any_cells) {
+    for (int pi = wave; pi < CB; pi += 4) {
+      if (cb + pi >= p.Cin) continue;  // uniform
+      const float *pp = lds + (size_t)pi * PL;
+      float *gim = p.gx + ((size_t)n * p.Cin + cb + pi) * plane;
+      float fv[DCP_FS];
+      MFN_UNROLL
+      for (int sl = 0; sl < DCP_FS; ++sl) fv[sl] = pp[floff[sl]];
+      MFN_UNROLL
+      for (int sl = 0; sl < DCP_FS; ++sl)
+        if (sl * 64 < ncells && fgoff[sl] >= 0 && fv[sl] != 0.f) atomicAdd(gim + fgoff[sl], fv[sl]);
+    }
   }
-  if (p.timeline) tk3 = MFN_CYCLES() - tflush;
   if (p.timeline && tid == 0) {
     unsigned long long *b_ = p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
     const unsigned long long tk4 = MFN_CYCLES();
     b_[0] = ((tks - tk0) & 0xffffffffull) | ((tk1 - tks) << 32);
-    if (!p.tl_detail) { b_[1] = tk2 - tk1; b_[2] = tk3 - tk2; b_[3] = tk4 - tk3; }
+    if (p.tl_detail) { b_[1] = td1 - td0; b_[2] = td2 - td1; b_[3] = td3 - td2; }
+    else { b_[1] = tk2 - tk1; b_[2] = tk3 - tk2; b_[3] = tk4 - tk3; }
   }
 }
 

@@ -20,7 +20,8 @@ for l in (2, 3, 4, 5):
     n, c, h, w = hotpath.level_shapes(8, 384, 512)[l]
     off = wl.o["offset%d" % l]
     go = torch.randn(n, c, h, w, device="cuda")
-    nblk = n * ((h + 7) // 8) * ((w + 15) // 16) * ((c + 31) // 32)
+    regions, cblocks = n * ((h + 7) // 8) * ((w + 15) // 16), (c + 15) // 16   # api_impl.inc: 16-channel blocks, filter slices on blockIdx.z
+    nblk = regions * cblocks * min(max(512 // (regions * cblocks), 1), (c + 15) // 16)
     for req in (("write", "write"), ("write", "null"), ("null", "write")):
         tl = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
         fn = lambda: ops.DeformableConvolution_backward(go, wl.t["c2_%d" % l], off, wl.t["w_%d" % l], kernel=(3, 3), pad=(1, 1), req=req + ("null", "null"))
