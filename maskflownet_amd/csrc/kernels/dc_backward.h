@@ -82,7 +82,7 @@ struct DcBwdPParams {
   int req_x, req_offset;
   int xcd;
   unsigned long long *timeline;  // measurement only: per block {setup | MFMA << 32, phase A, phase B, flush} shader cycles of wave 0
-  int tl_detail;                 // ... or, instead of the last three, phase B's first group: {fold + shuffles, walk, barrier wait}
+  int tl_detail;                 // ... or, instead of the last three, phase B: {before the groups, first group's fold + walk, its barrier wait}
   // flow mode (mfn_deform_conv_shared_bwd): every tap's offset IS flow[n][dir][pixel] * flow_scale / flow_stride -- no offset
   // tensor is read (offset == NULL), and d/dflow[n][dir][pixel] (req_offset: its request) takes the place of goffset
   const float *flow;
@@ -328,7 +328,9 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
     e[0] = 1 << 28; e[1] = -(1 << 28); e[2] = 1 << 28; e[3] = -(1 << 28);
   }
   MFN_WAIT_LGKM0();
-  if (fast && p.req_offset && xfit) { issue_xb(0); issue_xb(1); issue_xb(2); }
+  // the first three source windows are requested behind the first weight chunk's barrier (K loop): requested here, the
+  // chunk's vmcnt(0) would wait for them before the first MFMA
+  const bool xdma = fast && p.req_offset && xfit;  // uniform
   {
     // forward weights with the taps' validity folded in (an invalid tap row / column contributes nothing), the lane's
     // cell of neighbourhood corner (0, 0) in a plane, its turn, and the validity factors of the offset gradient
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
       load_g(ch + 1, nn);
       issue_w(ch + 1, BUF ^ 1);
     }
+    if (BUF == 0 && ch == 0 && xdma) { issue_xb(0); issue_xb(1); issue_xb(2); }
     if (fast) {
       const float *ap = lds + BUF * DCP_STAGE_F + arow;
       float a[2][TP];
@@ -393,10 +396,14 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
     chunk(ch, DcInt<0>{}, gb0, gb1);
     if (ch + 1 < nchunks) chunk(ch + 1, DcInt<1>{}, gb1, gb0);
   }
+  if (nchunks == 0 && xdma) { issue_xb(0); issue_xb(1); issue_xb(2); }
   unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
   if (p.timeline) { MFN_OPAQUE(acc[0][0]); MFN_OPAQUE(acc[TP - 1][7]); tk1 = MFN_CYCLES(); }
 
   // ---- phase A: offset gradient ------------------------------------------------------------------------------------------
+  float vt[T], vsum = 0.f;   // this lane's offset gradients (half 0: d/dh, half 1: d/dw)
+  MFN_UNROLL
+  for (int t = 0; t < T; ++t) vt[t] = 0.f;
   if (fast && p.req_offset) {
     float sh[T], sw[T];
     MFN_UNROLL
@@ -429,40 +436,42 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
           const int t = 3 * i + q;
           const float cg = c_ok ? DCP_ACC(t, r) : 0.f;
           // d/dh: fw0*(v21-v11) + fw1*(v22-v12);  d/dw: fh0*(v12-v11) + fh1*(v22-v21)   (deformable_col2im_coord)
-          float th = geo[DCS_FW0 + q] * (X[i + 1][q] - X[i][q]) + geo[DCS_FW1 + q] * (X[i + 1][q + 1] - X[i][q + 1]);
-          float tw = geo[DCS_FH0 + i] * (X[i][q + 1] - X[i][q]) + geo[DCS_FH1 + i] * (X[i + 1][q + 1] - X[i + 1][q]);
-          // scalar on purpose: paired into v_pk_* by the SLP vectoriser these sums cost a register shuffle per operand and,
-          // at two waves per SIMD, sixty spilled registers
-          MFN_OPAQUE(th);
-          MFN_OPAQUE(tw);
+          const float th = geo[DCS_FW0 + q] * (X[i + 1][q] - X[i][q]) + geo[DCS_FW1 + q] * (X[i + 1][q + 1] - X[i][q + 1]);
+          const float tw = geo[DCS_FH0 + i] * (X[i][q + 1] - X[i][q]) + geo[DCS_FH1 + i] * (X[i + 1][q + 1] - X[i + 1][q]);
           sh[t] = fmaf(th, cg, sh[t]);
           sw[t] = fmaf(tw, cg, sw[t]);
         }
     };
-    // step r gathers the neighbourhood of pair r, hands the buffer to window r + RD, then sums: no look-ahead in registers
-    // (two waves per SIMD: the other block runs while this wave waits for its gather; a second neighbourhood in registers
-    // made hipcc spill the accumulators around this phase).  DMA completion is in issue order: the waits count the newer
-    // windows that may still fly.
+    // software pipeline: step r gathers the neighbourhood of pair r + 1, sums pair r from registers, then hands the
+    // buffer it has just read to window r + 1 + RD.  DMA completion is in issue order: the waits count the newer windows
+    // that may still fly.  (The K loop ended with every DMA of this wave landed except, without chunks, the three windows.)
     auto phase_a = [&](auto dma_c) {
       constexpr bool DMA = decltype(dma_c)::value;
-      auto step_a = [&](auto r_c) {
+      float Xa[4][4], Xb[4][4];
+      if (DMA) MFN_WAIT_VM((RD - 1) * XW_NI);
+      gather(dma_c, 0, DMA ? xwin : p.x, Xa);
+      MFN_WAIT_LGKM0();
+      if (DMA) issue_xb(RD);
+      auto step_a = [&](auto r_c, float (&Xc)[4][4], float (&Xn)[4][4]) {
         constexpr int r = decltype(r_c)::value;
-        constexpr int newer = (NST - 1 - r) < (RD - 1) ? (NST - 1 - r) : (RD - 1);   // windows r + 1 .. min(r + RD - 1, NST - 1)
-        float X[4][4];
-        if (DMA) MFN_WAIT_VM(newer * XW_NI);
-        gather(dma_c, r, DMA ? xwin + (r % RD) * DCP_XW_F : p.x, X);
-        MFN_WAIT_LGKM0();
-        if (DMA && r + RD < NST) issue_xb(r + RD);
-        sums(r_c, X);
+        if (r + 1 < NST) {
+          constexpr int newer = (NST - 2 - r) < (RD - 1) ? (NST - 2 - r) : (RD - 1);   // windows r + 2 .. min(r + RD, NST - 1)
+          if (DMA) MFN_WAIT_VM(newer * XW_NI);
+          gather(dma_c, r + 1, DMA ? xwin + ((r + 1) % RD) * DCP_XW_F : p.x, Xn);
+        }
+        sums(r_c, Xc);
+        if (r + 1 + RD < NST) {
+          MFN_WAIT_LGKM0();
+          if (DMA) issue_xb(r + 1 + RD);
+        }
       };
-      step_a(DcInt<0>{}); step_a(DcInt<1>{}); step_a(DcInt<2>{}); step_a(DcInt<3>{});
-      step_a(DcInt<4>{}); step_a(DcInt<5>{}); step_a(DcInt<6>{}); step_a(DcInt<7>{});
+      step_a(DcInt<0>{}, Xa, Xb); step_a(DcInt<1>{}, Xb, Xa); step_a(DcInt<2>{}, Xa, Xb); step_a(DcInt<3>{}, Xb, Xa);
+      step_a(DcInt<4>{}, Xa, Xb); step_a(DcInt<5>{}, Xb, Xa); step_a(DcInt<6>{}, Xa, Xb); step_a(DcInt<7>{}, Xb, Xa);
     };
     // two copies on purpose: with the global loads of the rare path in the same code, hipcc waits vmcnt(0) before every
     // gather of the DMA path (a register with a load pending on the OTHER path) and the window ring degenerates
     if (xfit) phase_a(DcInt<1>{}); else phase_a(DcInt<0>{});
     // the two half-waves hold the other 8 channels of the same pixel; half 0 writes d/dh, half 1 d/dw
-    float vt[T], vsum = 0.f;
     {
       // half 0 needs the other half's d/dh sums, half 1 its d/dw sums: ONE exchange per tap (each half sends what the other
       // needs), all nine requested before the first is used
@@ -477,17 +486,20 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
         vsum += vt[t];
       }
     }
-    // the channel blocks (and filter slices) of a pixel add up through atomics; the buffer is zero-filled in write mode.
-    // One writer per value (Cin <= 16, no filter slices): plain stores, "add" reads its old values together.
+  }
+  // With several channel blocks (and filter slices) a pixel's values add up through atomics (the buffer is zero-filled in write
+  // mode) -- nine per lane with an offset tensor, queued here.  Measured on one box, levels 5..2: here 37.8 / 47.1 / 75.0 / 109.3 us;
+  // three taps behind each of phase B's group barriers 36.6 / 47.6 / 77.4 / 113.8; after the flush 36.5 / 47.5 / 82.6 / 116.5
+  // (the wave is 1-5 k cycles late for phase B's first barrier this way, but later the atomics pile up behind the flush's).
+  // One writer per value (Cin <= 16, no filter slices): plain stores, "add" reads its old values together.
+  if (fast && p.req_offset && px_valid) {
     const bool single = gridDim.y == 1 && gridDim.z == 1;
     if (fm) {  // d/dflow: the nine taps share the offset, so their gradients add up (MaskFlownet.py:230)
-      if (px_valid) {
-        const float v = vsum * (p.flow_scale / p.flow_stride);
-        float *dst = p.gflow + ((size_t)n * 2 + half) * plane + pix;
-        if (single) *dst = p.req_offset == 3 ? *dst + v : v;
-        else if (v != 0.f) atomicAdd(dst, v);
-      }
-    } else if (px_valid) {
+      const float v = vsum * (p.flow_scale / p.flow_stride);
+      float *dst = p.gflow + ((size_t)n * 2 + half) * plane + pix;
+      if (single) *dst = p.req_offset == 3 ? *dst + v : v;
+      else if (v != 0.f) atomicAdd(dst, v);
+    } else {
       float *dst = p.goffset + ((size_t)n * 2 * T + half) * plane + pix;
       if (single) {
         if (p.req_offset == 3) {
@@ -512,8 +524,10 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
 
   // ---- phase B: input gradient -----------------------------------------------------------------------------------------
   // Zero the 16 planes, four groups of CPG channels (chains) per lane, flush.
-  MFN_WAIT_VM(0);
-  MFN_LDS_BARRIER();      // the stage buffers and window rings are dead: the planes take their place
+  // Every wave has waited for its own DMAs by now (the K loop's last chunk: vmcnt(0); phase A: its last gather), so the
+  // barrier alone makes the stage buffers and window rings dead: the planes take their place.  No vmcnt(0) here -- it would
+  // wait for the offset gradient's atomics, which may drain under phase B.
+  MFN_LDS_BARRIER();
   float ay[3], by[3], ax[3], bxw[3];
   MFN_UNROLL
   for (int i = 0; i < 3; ++i) {
@@ -540,6 +554,8 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
     const float inv_ncols = 1.f / (float)ncols;
     MFN_UNROLL
     for (int sl = 0; sl < DCP_FS; ++sl) {
+      floff[sl] = 0; fgoff[sl] = -1;
+      if (sl * 64 >= ncells) continue;   // uniform: a regular region's box is 11 x 19 cells, four slices of the eleven
       const int e = sl * 64 + lane;
       int row = (int)((float)e * inv_ncols), col = e - row * ncols;  // cell counts are far below 2^24: off by one at most
       if (col < 0) { --row; col += ncols; }
@@ -636,24 +652,30 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
 #undef DCP_ACC
   // ---- flush: wave w takes planes w, w + 4, w + 8, w + 12 (plane = channel inside the block) -----------------------------
   if (p.timeline) tk3 = MFN_CYCLES();
-  if (any_cells) {
+  // all of a plane's reads are requested before the first atomic (unconditional reads: a branch per slice would wait for each);
+  // a regular region's box (11 x 19 cells) is four slices
+  auto flush = [&](auto nsl_c) {
+    constexpr int NSL = decltype(nsl_c)::value;
     for (int pi = wave; pi < CB; pi += 4) {
       if (cb + pi >= p.Cin) continue;  // uniform
       const float *pp = lds + (size_t)pi * PL;
       float *gim = p.gx + ((size_t)n * p.Cin + cb + pi) * plane;
-      float fv[DCP_FS];
+      float fv[NSL];
       MFN_UNROLL
-      for (int sl = 0; sl < DCP_FS; ++sl) fv[sl] = pp[floff[sl]];
+      for (int sl = 0; sl < NSL; ++sl) fv[sl] = pp[floff[sl]];
       MFN_UNROLL
-      for (int sl = 0; sl < DCP_FS; ++sl)
+      for (int sl = 0; sl < NSL; ++sl)
         if (sl * 64 < ncells && fgoff[sl] >= 0 && fv[sl] != 0.f) atomicAdd(gim + fgoff[sl], fv[sl]);
     }
+  };
+  if (any_cells) {
+    if (ncells <= 256) flush(DcInt<4>{}); else flush(DcInt<DCP_FS>{});
   }
   if (p.timeline && tid == 0) {
     unsigned long long *b_ = p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
     const unsigned long long tk4 = MFN_CYCLES();
     b_[0] = ((tks - tk0) & 0xffffffffull) | ((tk1 - tks) << 32);
-    if (p.tl_detail) { b_[1] = td1 - td0; b_[2] = td2 - td1; b_[3] = td3 - td2; }
+    if (p.tl_detail) { b_[1] = td0 - tk2; b_[2] = td2 - td0; b_[3] = td3 - td2; }  // before the groups | first group: fold + walk | its barrier
     else { b_[1] = tk2 - tk1; b_[2] = tk3 - tk2; b_[3] = tk4 - tk3; }
   }
 }

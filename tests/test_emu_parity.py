@@ -368,7 +368,7 @@ def test_deform_conv_backward_lane_is_pixel(ops, oracle, kind):
 
 
 def test_deform_conv_backward_lane_is_pixel_channel_blocks_and_requests(ops, oracle):
-    # two channel blocks (the second ragged: 36 channels), three filter chunks (the last ragged: 36 filters), two images
+    # three 16-channel blocks (the last ragged: 36 channels), three 16-filter chunks (the last ragged: 36 filters)
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 36, 9, 16, "smooth", req=("write", "write", "null", "null"))
     # one gradient at a time, and accumulation into the caller's buffers
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "outside", req=("write", "null", "null", "null"))

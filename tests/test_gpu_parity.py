@@ -399,7 +399,7 @@ def test_deform_conv_backward_levels(ops, oracle, dev, C, H, W):
 @pytest.mark.parametrize("kind", ["smooth", "integer", "outside", "rough", "mixed"])
 @pytest.mark.parametrize("N,C,H,W", [(2, 128, 12, 16), (2, 96, 24, 32), (1, 64, 48, 64), (1, 32, 96, 128), (2, 40, 11, 21)])
 def test_deform_conv_backward_shared_offsets(ops, oracle, dev, kind, N, C, H, W):
-    """One (dy,dx) per pixel for all nine taps (MaskFlownet.py:230): dc_bwd_input_shared_kernel takes the strips that
+    """One (dy,dx) per pixel for all nine taps (MaskFlownet.py:230): dc_bwd_input_pix_kernel takes the tiles that
     qualify, the tap-by-tap kernel the rest ('mixed'); borders, far-outside and rough flows included."""
     pc.case_deform_bwd_shared(ops, oracle, dev, host, N, C, C if C != 40 else 36, H, W, kind)
 
@@ -411,16 +411,22 @@ def test_deform_conv_backward_lane_is_pixel_requests_and_accumulation(ops, oracl
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "outside", req=("null", "write", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 44, 52, 27, 44, "smooth")
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 8, 96, 96, 24, 32, "smooth", seed=3)
+    # one 16-channel block and no filter slices: the offset gradient has a single writer (plain stores, "add" reads first)
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 16, 24, 24, 32, "smooth", seed=4)
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 12, 20, 13, 20, "rough", seed=5)
+    # 21 regions x 6 channel blocks: four filter slices over six 16-filter chunks -- the last slice holds no chunk
+    pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 96, 96, 24, 112, "smooth", seed=6)
     rng = np.random.default_rng(5)
-    N, C, H, W = 2, 32, 24, 32
-    x, w = pc.feat(rng, (N, C, H, W)), (rng.standard_normal((C, C, 3, 3)) * 0.2).astype(np.float32)
-    off, go = pc.shared_offsets(rng, N, H, W, "smooth"), rng.standard_normal((N, C, H, W)).astype(np.float32)
-    want = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=(3, 3), pad=(1, 1))
-    base = [rng.standard_normal(t.shape).astype(np.float32) for t in want[:2]]
-    got = ops.DeformableConvolution_backward(dev(go), dev(x), dev(off), dev(w), kernel=(3, 3), pad=(1, 1),
-                                             req=("add", "add", "null", "null"), out=(dev(base[0]), dev(base[1]), None, None))
-    pc.check_close(host(got[0]), want[0] + base[0], tol=2e-5, what="lane = pixel gx, req add")
-    pc.check_close(host(got[1]), want[1] + base[1], tol=5e-5, what="lane = pixel goffset, req add")
+    for C in (32, 16):   # two channel blocks (atomics on top of the caller's values) / one (read, add, store)
+        N, H, W = 2, 24, 32
+        x, w = pc.feat(rng, (N, C, H, W)), (rng.standard_normal((C, C, 3, 3)) * 0.2).astype(np.float32)
+        off, go = pc.shared_offsets(rng, N, H, W, "smooth"), rng.standard_normal((N, C, H, W)).astype(np.float32)
+        want = oracle.deformable_convolution_backward(go, x, off, w, with_bias=True, kernel=(3, 3), pad=(1, 1))
+        base = [rng.standard_normal(t.shape).astype(np.float32) for t in want[:2]]
+        got = ops.DeformableConvolution_backward(dev(go), dev(x), dev(off), dev(w), kernel=(3, 3), pad=(1, 1),
+                                                 req=("add", "add", "null", "null"), out=(dev(base[0]), dev(base[1]), None, None))
+        pc.check_close(host(got[0]), want[0] + base[0], tol=2e-5, what="lane = pixel gx, req add, C=%d" % C)
+        pc.check_close(host(got[1]), want[1] + base[1], tol=5e-5, what="lane = pixel goffset, req add, C=%d" % C)
 
 
 def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracle, dev, T):
