@@ -213,11 +213,10 @@ int mfn_deform_conv_matching_fwd(const float *x, const float *flow_yx, float flo
 /* Backward (training).  gx,goffset,gw,gbias as the forward's x,offset,w,bias; req_* per output
  * (MFN_REQ_NULL skips it and the pointer may be NULL).  The column gradient is formed on the fly.
  * Scratch (mfn_deform_conv_bwd_workspace_bytes; 0 for shapes other than 3x3 / stride 1 / dilation 1
- * / one group): one flag per 4x8-pixel tile -- tiles whose nine taps share one offset
- * (MaskFlownet.py:230) take all taps in one pass -- and the per-block partial sums of the weight /
- * bias gradient, which a second kernel adds in a fixed order.  workspace may be NULL or smaller
- * (tap-by-tap input gradient, parameter gradients through atomics: same results up to summation
- * order).  gx and goffset are accumulated with fp32 atomics (as MXNet's GPU kernels do): their
+ * / one group): the per-block partial sums of the weight / bias gradient, which a second kernel
+ * adds in a fixed order.  workspace may be NULL or smaller (parameter gradients through atomics:
+ * same results up to summation order).  Tiles whose nine taps share one offset
+ * (MaskFlownet.py:230) take all taps in one pass, the others tap by tap, in the same launch.  gx and goffset are accumulated with fp32 atomics (as MXNet's GPU kernels do): their
  * bit-level results can differ from run to run by summation order; with the workspace gw and gbias
  * are deterministic. */
 size_t mfn_deform_conv_bwd_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw,

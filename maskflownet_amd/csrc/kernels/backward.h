@@ -971,8 +971,6 @@ struct DcBwdIParams {
   int T, tiles_x, tiles_y;
   int req_x, req_offset;
   unsigned long long *timeline;  // measurement only: per block {geometry, MFMA, scatter, total} shader cycles
-  const int *skip;               // per (tile, strip): non-zero = already done by dc_bwd_input_pix_kernel (dc_backward.h); may be NULL
-  int skip_tiles;                // 1: `skip` holds one flag per 4x8-pixel tile [n][cdiv(H,4)][cdiv(W,8)] (dc_bwd_input_pix_kernel)
   // flow mode (mfn_deform_conv_shared_bwd; dc_backward.h: DcBwdPParams): offsets from flow[n][dir][pixel], d/dflow instead of goffset
   const float *flow;
   float *gflow;
@@ -997,27 +995,6 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   const int n = bx / tpi, rt = bx - n * tpi;
   const int ty0 = (rt / p.tiles_x) * TH, tx0 = (rt % p.tiles_x) * TW;
   const int cb = blockIdx.y * 32;
-  // strips the shared-offset kernel has finished: skipped here (a block whose four strips are all done leaves at once)
-  bool skipw = false;
-  int done_l = 0, done_r = 0;  // 4x8-tile flags of this strip's left / right half (skip_tiles)
-  if (p.skip && p.skip_tiles) {
-    // the 8x16 tile is four 4x8 tiles (a, b); tiles past the image edge count as done
-    const int ty4 = (H + 3) >> 2, tx8 = (W + 7) >> 3;
-    const int ta = 2 * (rt / p.tiles_x), tb = 2 * (rt % p.tiles_x);
-    auto flag = [&](int a, int b) {
-      return (ta + a < ty4 && tb + b < tx8) ? p.skip[((size_t)n * ty4 + ta + a) * tx8 + tb + b] : 1;
-    };
-    const int f00 = flag(0, 0), f01 = flag(0, 1), f10 = flag(1, 0), f11 = flag(1, 1);
-    if (MFN_UNIFORM((int)(f00 && f01 && f10 && f11))) return;
-    done_l = MFN_UNIFORM((wave >> 1) ? f10 : f00);
-    done_r = MFN_UNIFORM((wave >> 1) ? f11 : f01);
-    skipw = done_l && done_r;
-  } else if (p.skip) {
-    const int *sk = p.skip + (size_t)bx * 4;
-    const int s0 = sk[0], s1 = sk[1], s2 = sk[2], s3 = sk[3];
-    if (MFN_UNIFORM((int)(s0 && s1 && s2 && s3))) return;
-    skipw = MFN_UNIFORM(sk[wave]) != 0;
-  }
   // window origin of the block: follows the offset of the tile's centre pixel (centre tap); strip w sits 2w rows lower
   int wy0, wx0;
   {
@@ -1040,8 +1017,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
 
   // this lane as a PIXEL of the strip (geometry build, MFMA A operand) ...
   const int py = ty0 + 2 * wave + (j >> 4), px = tx0 + (j & 15);
-  // pixels of 4x8 tiles that dc_bwd_input_pix_kernel has finished take no part here
-  const bool pix_ok = py < H && px < W && !(((j & 15) >> 3) ? done_r : done_l);
+  const bool pix_ok = py < H && px < W;
   const int pyc = min(py, H - 1), pxc = min(px, W - 1);
   const size_t pix = (size_t)pyc * W + pxc;
   // ... and as a CHANNEL (MFMA B operand, D column, owner of one window plane)
@@ -1054,7 +1030,7 @@ __global__ __launch_bounds__(256) void dc_bwd_input_tile_kernel(DcBwdIParams p) 
   const float *im = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
 
   unsigned long long tk0 = MFN_CYCLES(), tk_geo = 0, tk_mma = 0, tk_sc = 0, tka = tk0;
-  for (int t = 0; t < (skipw ? 0 : T); ++t) {
+  for (int t = 0; t < T; ++t) {
     // ---- geometry of the strip's 32 pixels for tap t (lanes 0..31 write, everyone reads it back as broadcasts)
     MFN_WAIT_LGKM0();  // the previous tap's readers are done (wave-private table: no block barrier)
     if (half == 0) {

@@ -32,8 +32,8 @@
 //   * the merged planes are flushed to gx once per block with fp32 atomics over the touched box only: global atomics
 //     cost ~0.35 ns per wave INSTRUCTION chip-wide however few lanes are active (same microbenchmark), so what matters is
 //     how few instructions there are.
-// Tiles with per-tap offsets or irregular floors (never in the reference network) keep flag 0 and are done pixel by pixel
-// by dc_bwd_input_tile_kernel (backward.h), which skips the pixels of flagged tiles.
+// Tiles with per-tap offsets or irregular floors (never in the reference network) are done tap by tap and pixel by pixel
+// by the same block, straight to memory, from the same column gradients (round 2: a second launch behind a flag buffer).
 #pragma once
 #include "backward.h"
 #include "deform_conv.h"
@@ -75,7 +75,6 @@ static_assert(DCP_PR * DCP_PS <= DCP_RD * DCP_XW_F, "the turn map lives in a wav
 struct DcBwdPParams {
   const float *gout, *x, *offset, *w;
   float *gx, *goffset;
-  int *flags;                    // per 4x8 pixel tile [n][cdiv(H,4)][cdiv(W,8)]: 1 = done here, 0 = left to dc_bwd_input_tile_kernel
   int N, Cin, H, W, Cout, ph, pw;
   int rx, ry;                    // 8x16 regions per row / column of an image
   float inv_rpi, inv_rx;
@@ -227,7 +226,6 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
   }
   const int ly0 = h_in + lo0y, lx0 = w_in + lo0x;  // first line / column of the 4x4 neighbourhood (may lie outside)
   const bool fast = MFN_UNIFORM((int)(tile_ok && (__all(ok || !px_valid) != 0))) != 0;
-  if (tile_ok && lane == 0) p.flags[((size_t)n * ty4 + tyi) * tx8 + txi] = fast ? 1 : 0;  // every channel block: same value
 
   // ---- source window of the tile (phase A): 16 x 24 around the 7 x 11 box the centre pixel's offset predicts -----------
   int iy[4], ix[4];  // clamped lines of the neighbourhood (where x is read; clamped duplicates carry zero weight)
@@ -371,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
       issue_w(ch + 1, BUF ^ 1);
     }
     if (BUF == 0 && ch == 0 && xdma) { issue_xb(0); issue_xb(1); issue_xb(2); }
-    if (fast) {
+    {   // (every tile: the tiles that do not qualify need the same column gradients)
       const float *ap = lds + BUF * DCP_STAGE_F + arow;
       float a[2][TP];
       MFN_UNROLL
@@ -399,6 +397,72 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
   if (nchunks == 0 && xdma) { issue_xb(0); issue_xb(1); issue_xb(2); }
   unsigned long long tk1 = 0, tk2 = 0, tk3 = 0;
   if (p.timeline) { MFN_OPAQUE(acc[0][0]); MFN_OPAQUE(acc[TP - 1][7]); tk1 = MFN_CYCLES(); }
+
+  // ---- tiles that do not qualify (per-tap offsets, irregular floors: never in the reference network) ----------------------
+  // Tap by tap and pixel by pixel, straight to memory (deformable_col2im / deformable_col2im_coord as the tap-by-tap kernel
+  // of backward.h states them): the column gradients are the ones above.  Round 2 left these tiles to a second launch of
+  // dc_bwd_input_tile_kernel behind a flag buffer -- 4 us per call for a kernel whose blocks all found nothing to do.
+  if (tile_ok && !fast) {
+    const float *op = p.offset + (size_t)n * 2 * T * plane + pix;
+    float fsum_h = 0.f, fsum_w = 0.f;  // flow mode: the taps share the offset, their gradients add up
+    auto tap = [&](auto t_c) {
+      constexpr int t = decltype(t_c)::value, ti = t / 3, tj = t % 3;
+      const float oh = fm ? scaled(offn[pix]) : op[(size_t)(2 * t) * plane];
+      const float ow = fm ? scaled(offn[plane + pix]) : op[(size_t)(2 * t + 1) * plane];
+      bool vh, vw;
+      int hl, hh, wl, wh;
+      float lh, lw;
+      dc_axis(oh, h_in, ti, H, vh, hl, hh, lh);
+      dc_axis(ow, w_in, tj, W, vw, wl, wh, lw);
+      const bool valid = vh && vw && px_valid;
+      const int gb = valid ? (h_in + hl) * W + (w_in + wl) : 0, dyg = valid ? (hh - hl) * W : 0, dxg = valid ? wh - wl : 0;
+      const float g0 = (1.f - lh) * (1.f - lw), g1 = (1.f - lh) * lw, g2 = lh * (1.f - lw), g3 = lh * lw;
+      // deformable_col2im_coord: 4 samples with MXNet's clamping, weights of d/dh and d/dw
+      float ah = valid ? (float)(h_in + ti) + oh : 0.f, aw = valid ? (float)(w_in + tj) + ow : 0.f;
+      int chl = (int)ah, cwl = (int)aw, chh, cwh;
+      if (chl >= H - 1) { chh = chl = H - 1; ah = (float)chl; } else chh = chl + 1;
+      if (cwl >= W - 1) { cwh = cwl = W - 1; aw = (float)cwl; } else cwh = cwl + 1;
+      const int i11 = chl * W + cwl, sdh = (chh - chl) * W, sdw = cwh - cwl;
+      const float fw0 = (float)(cwl + 1) - aw, fw1 = aw - (float)cwl, fh0 = (float)(chl + 1) - ah, fh1 = ah - (float)chl;
+      float sh_ = 0.f, sw_ = 0.f;
+      MFN_UNROLL
+      for (int q = 0; q < 8; ++q) {
+        const int ch = cb + chan_of(q, half);
+        const float cg = (ch < p.Cin && valid) ? DCP_ACC(t, q) : 0.f;
+        const size_t cofs = ((size_t)n * p.Cin + min(ch, p.Cin - 1)) * plane;
+        if (p.req_x) {
+          float *gim = p.gx + cofs + gb;
+          const float c1 = g0 * cg, c2 = g1 * cg, c3 = g2 * cg, c4 = g3 * cg;
+          if (c1 != 0.f) atomicAdd(gim, c1);
+          if (c2 != 0.f) atomicAdd(gim + dxg, c2);
+          if (c3 != 0.f) atomicAdd(gim + dyg, c3);
+          if (c4 != 0.f) atomicAdd(gim + dyg + dxg, c4);
+        }
+        if (p.req_offset) {
+          const float *im = p.x + cofs + i11;
+          const float v11 = im[0], v12 = im[sdw], v21 = im[sdh], v22 = im[sdh + sdw];
+          sh_ = fmaf(-fw0 * v11 - fw1 * v12 + fw0 * v21 + fw1 * v22, cg, sh_);
+          sw_ = fmaf(-fh0 * v11 + fh0 * v12 - fh1 * v21 + fh1 * v22, cg, sw_);
+        }
+      }
+      if (p.req_offset && px_valid) {
+        if (fm) { fsum_h += sh_; fsum_w += sw_; }
+        else {
+          float *gof = p.goffset + ((size_t)n * 2 * T + 2 * t) * plane + pix;
+          if (sh_ != 0.f) atomicAdd(gof, sh_);
+          if (sw_ != 0.f) atomicAdd(gof + plane, sw_);
+        }
+      }
+    };
+    tap(DcInt<0>{}); tap(DcInt<1>{}); tap(DcInt<2>{}); tap(DcInt<3>{}); tap(DcInt<4>{});
+    tap(DcInt<5>{}); tap(DcInt<6>{}); tap(DcInt<7>{}); tap(DcInt<8>{});
+    if (fm && p.req_offset && px_valid) {
+      const float ratio = p.flow_scale / p.flow_stride;
+      float *gf = p.gflow + (size_t)n * 2 * plane + pix;
+      if (fsum_h != 0.f) atomicAdd(gf, fsum_h * ratio);
+      if (fsum_w != 0.f) atomicAdd(gf + plane, fsum_w * ratio);
+    }
+  }
 
   // ---- phase A: offset gradient ------------------------------------------------------------------------------------------
   float vt[T], vsum = 0.f;   // this lane's offset gradients (half 0: d/dh, half 1: d/dw)

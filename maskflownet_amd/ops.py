@@ -342,7 +342,7 @@ class OpSet:
         p = lambda a: self.ad.ptr(a) if a is not None else None
         nbytes = self.ns.deform_conv_bwd_workspace_bytes(N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, num_group,
                                                          num_deformable_group)
-        ws = self._workspace(x, nbytes) if nbytes else None   # strip flags of the shared-offset kernel
+        ws = self._workspace(x, nbytes) if nbytes else None   # per-block slabs of the weight / bias gradient
         self.check(self.ns.deform_conv_bwd(self.ad.ptr(go), self.ad.ptr(x), self.ad.ptr(off), self.ad.ptr(w), p(gx),
                                            p(goff), p(gw), p(gb), N, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw,
                                            num_group, num_deformable_group, rq[0], rq[1], rq[2], rq[3],

@@ -82,7 +82,7 @@ if os.path.exists(db5):
         f.write("MI355X (gfx950), ROCm 7.2.  Source: rocprofv3 rocpd database (top_kernels view); durations in microseconds.\n"
                 "Training-step pass (BASELINE configs[4], 8 pairs of 384x512 per GPU): the S forward pass, then corr_bwd -> deform_bwd per "
                 "level.  `dc_bwd_input_pix_kernel` = input + offset gradient of the deformable conv in the forward's orientation "
-                "(kernels/dc_backward.h); `dc_bwd_input_tile_kernel` only sees its skip list here; `dc_bwd_weight_pc_kernel<MTOT>` + "
+                "(kernels/dc_backward.h); `dc_bwd_weight_pc_kernel<MTOT>` + "
                 "`dc_bwd_weight_reduce_kernel` = weight + bias gradient (columns as the forward produces them, per-block slabs, "
                 "fixed-order sum; its blocks also clear gx / goffset on their way in); `corr_bwd_lds_kernel` computes g1 and g2 in separate blocks (the other feature map's rows through LDS); `fill_zero4_kernel` zeroes the "
                 "write-mode gradients of a call where no slab launch does it (level 5).  bench.py also runs the pass on two more streams (`pipelined`) and eager passes for "

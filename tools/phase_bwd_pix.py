@@ -36,10 +36,8 @@ for l in (2, 3, 4, 5):
         raw = tl.cpu().numpy().reshape(nblk, 4)
         mf = (raw[:, 0] >> 32).astype(np.float64); raw[:, 0] &= 0xffffffff
         t = np.concatenate([raw.astype(np.float64), mf[:, None]], axis=1)[:, [0, 4, 1, 2, 3]]
-        nfl = n * ((h + 3) // 4) * ((w + 7) // 8)
-        fl = max((ws.view(torch.int32)[:nfl].cpu().numpy() for ws in ops._ws.values()), key=lambda a: a.mean())
         if DETAIL:
             print("L%d gx=%-5s goffset=%-5s phase B: median cycles before the groups %6.0f  first group fold + walk %6.0f  its barrier wait %6.0f" % (l, req[0], req[1], *np.median(t[:, 2:5], axis=0)), flush=True)
             continue
-        print("L%d gx=%-5s goffset=%-5s blocks %4d tiles taken %.3f | median cycles setup %6.0f  mfma %6.0f  phase A %6.0f  phase B %6.0f  flush %6.0f  sum %6.0f | pix %.1f us, tile %.1f us"
-              % (l, req[0], req[1], nblk, fl.mean(), *np.median(t, axis=0), np.median(t.sum(1)), us.get("dc_bwd_input_pix", 0), us.get("dc_bwd_input_tile", 0)), flush=True)
+        print("L%d gx=%-5s goffset=%-5s blocks %4d | median cycles setup %6.0f  mfma %6.0f  phase A %6.0f  phase B %6.0f  flush %6.0f  sum %6.0f | pix %.1f us"
+              % (l, req[0], req[1], nblk, *np.median(t, axis=0), np.median(t.sum(1)), us.get("dc_bwd_input_pix", 0)), flush=True)
