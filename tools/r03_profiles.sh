@@ -18,6 +18,8 @@ timeout 200 python tools/corr_bwd_levels.py > $G/corr_bwd_levels.txt 2>&1
 # other shapes, which the per-name averages of rocprofv3 would mix with the headline's)
 timeout 600 rocprofv3 --kernel-trace --stats -d $G/prof_bench -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-side-configs --no-e2e > $G/r03p/prof_bench.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $G/prof_cfg5 -o cfg5 -- python bench.py --config cfg5 --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-e2e > $G/r03p/prof_cfg5.log 2>&1
+# SKIP_CORR_PMC=1: the correlation kernels are unchanged since the last counter passes -- keep those (gpurun_out/ is merged, not replaced)
+if [ -n "$SKIP_CORR_PMC" ]; then ls -la $G/prof_bench $G/prof_cfg5 | head; exit 0; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $c --kernel-trace -d $G/pmc_$c -o r -- python tools/prof_one.py corr 2 > $G/r03p/pmc_$c.log 2>&1
 done
