@@ -5,7 +5,8 @@
 // (Reconstruction2DSmooth); semantics as oracle/mfn_ref_body.inc warp_fwd / bilinear_sampler_fwd.
 // Gather-bound (4*N*H*W*(2C+2) bytes): one thread owns a pixel, computes the 4 tap
 // addresses/weights once and reuses them for every channel.  The grid never exists in memory.
-// warp_fwd_fast_kernel is what the pass runs; warp_fwd_kernel<1> is the general form (any size, W = 1).
+// warp_fwd_fast_kernel is what the pass runs (a wave is a 16 x 4 pixel tile where W % 64 == 0 and H % 4 == 0, 64 pixels of
+// a row elsewhere); warp_fwd_kernel<1> is the general form (any size, W = 1).
 #pragma once
 #include "../mfn_rt.h"
 
@@ -148,13 +149,27 @@ __global__ __launch_bounds__(256) void warp_fwd_kernel(WarpParams p) {
 //  * 32-bit index arithmetic;
 //  * the channel loop in groups of G with every tap load of a group issued before the first use, so a pixel costs
 //    two memory round trips (flow, taps) per group instead of one per channel.
-template <int G>
+template <int G, bool T2D>
 __global__ __launch_bounds__(256) void warp_fwd_fast_kernel(WarpParams p, unsigned total) {
-  const unsigned idx = mfn_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
-  if (idx >= total) return;
   const unsigned W = (unsigned)p.W, H = (unsigned)p.H;
-  const unsigned row = idx / W, x = idx - row * W;
-  const unsigned n = row / H, y = row - n * H;
+  unsigned x, y, n;
+  if (T2D) {
+    // a wave is a 16 x 4 pixel tile, a block four of them side by side (W % 64 == 0, H % 4 == 0): full 64-byte lines of flow and
+    // output per tile row, and a footprint of 4 + 2 r rows x (16 + 2 r) / 16 lines under a flow of radius r where 64 pixels
+    // of one row touch 1 + 2 r rows x (64 + 2 r) / 16 lines
+    const unsigned b = mfn_xcd_remap(blockIdx.x, gridDim.x), bw = W >> 6, bh = H >> 2;
+    const unsigned bxi = b % bw, rest = b / bw, byi = rest % bh;
+    n = rest / bh;
+    x = bxi * 64u + (threadIdx.x >> 6) * 16u + (threadIdx.x & 15u);
+    y = byi * 4u + ((threadIdx.x >> 4) & 3u);
+  } else {
+    const unsigned idx = mfn_xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
+    if (idx >= total) return;
+    const unsigned row = idx / W;
+    x = idx - row * W;
+    n = row / H;
+    y = row - n * H;
+  }
   const size_t plane = (size_t)H * W;
   const unsigned pix = y * W + x;
   const float *fl = p.flow + (size_t)n * 2 * plane + pix;
@@ -186,8 +201,15 @@ inline int warp_fwd_launch(WarpParams p, hipStream_t stream) {
   if (total == 0) return 0;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (total < ((size_t)1 << 32) - 256 && p.W >= 2) {   // the fast kernel's 32-bit indices and 8-byte tap pairs apply
-    if (p.C % 4 != 0 && p.C % 3 == 0) return launch("warp_fwd_fast", warp_fwd_fast_kernel<3>, grid, dim3(256), 0, stream, p, (unsigned)total);
-    return launch("warp_fwd_fast", warp_fwd_fast_kernel<4>, grid, dim3(256), 0, stream, p, (unsigned)total);
+#ifndef MFN_WARP_1D
+#define MFN_WARP_1D 0   // measurement hook: 1 = a wave is 64 pixels of one row everywhere
+#endif
+    const bool t2d = !MFN_WARP_1D && p.W % 64 == 0 && p.H % 4 == 0;
+    const bool g3 = p.C % 4 != 0 && p.C % 3 == 0;
+    if (t2d) return g3 ? launch("warp_fwd_fast", warp_fwd_fast_kernel<3, true>, grid, dim3(256), 0, stream, p, (unsigned)total)
+                       : launch("warp_fwd_fast", warp_fwd_fast_kernel<4, true>, grid, dim3(256), 0, stream, p, (unsigned)total);
+    return g3 ? launch("warp_fwd_fast", warp_fwd_fast_kernel<3, false>, grid, dim3(256), 0, stream, p, (unsigned)total)
+              : launch("warp_fwd_fast", warp_fwd_fast_kernel<4, false>, grid, dim3(256), 0, stream, p, (unsigned)total);
   }
   return launch("warp_fwd_v1", warp_fwd_kernel<1>, grid, dim3(256), 0, stream, p);
 }

@@ -158,7 +158,7 @@ def test_correlation_odd_width_uses_generic(ops, oracle):
     pc.case_correlation(ops, oracle, ident, ident, (1, 3, 5, 7), 4)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 8, 12), (1, 2, 5, 7)])
+@pytest.mark.parametrize("shape", [(2, 3, 8, 12), (1, 2, 5, 7), (2, 3, 8, 128), (1, 4, 4, 64)])   # the last two: 16 x 4 pixel tiles per wave
 @pytest.mark.parametrize("clip", [False, True])
 def test_warp(ops, oracle, shape, clip):
     pc.case_warp(ops, oracle, ident, ident, shape, clip)
