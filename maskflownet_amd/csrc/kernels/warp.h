@@ -10,6 +10,10 @@
 #pragma once
 #include "../mfn_rt.h"
 
+#ifndef MFN_WARP_1D
+#define MFN_WARP_1D 0   // measurement hook: 1 = a wave is 64 pixels of one row everywhere
+#endif
+
 namespace mfn {
 
 struct WarpParams {
@@ -201,9 +205,6 @@ inline int warp_fwd_launch(WarpParams p, hipStream_t stream) {
   if (total == 0) return 0;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (total < ((size_t)1 << 32) - 256 && p.W >= 2) {   // the fast kernel's 32-bit indices and 8-byte tap pairs apply
-#ifndef MFN_WARP_1D
-#define MFN_WARP_1D 0   // measurement hook: 1 = a wave is 64 pixels of one row everywhere
-#endif
     const bool t2d = !MFN_WARP_1D && p.W % 64 == 0 && p.H % 4 == 0;
     const bool g3 = p.C % 4 != 0 && p.C % 3 == 0;
     if (t2d) return g3 ? launch("warp_fwd_fast", warp_fwd_fast_kernel<3, true>, grid, dim3(256), 0, stream, p, (unsigned)total)
@@ -243,11 +244,21 @@ __global__ __launch_bounds__(256) void grid_affine_kernel(GridAffineParams p) {
 }
 
 struct SamplerParams { const float *data; const float *grid; float *out; int N, C, iH, iW, oH, oW; };
+template <bool T2D>
 __global__ __launch_bounds__(256) void bilinear_sampler_kernel(SamplerParams p) {
   const size_t oplane = (size_t)p.oH * p.oW, iplane = (size_t)p.iH * p.iW;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)p.N * oplane) return;
-  const size_t n = idx / oplane, pix = idx - n * oplane;
+  size_t n, pix;
+  if (T2D) {  // a wave is a 16 x 4 tile of the output (oW % 64 == 0, oH % 4 == 0), as in warp_fwd_fast_kernel
+    const unsigned bw = (unsigned)p.oW >> 6, bh = (unsigned)p.oH >> 2;
+    const unsigned bxi = blockIdx.x % bw, rest = blockIdx.x / bw, byi = rest % bh;
+    n = rest / bh;
+    pix = (size_t)(byi * 4u + ((threadIdx.x >> 4) & 3u)) * p.oW + bxi * 64u + (threadIdx.x >> 6) * 16u + (threadIdx.x & 15u);
+  } else {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)p.N * oplane) return;
+    n = idx / oplane;
+    pix = idx - n * oplane;
+  }
   const float gx = p.grid[n * 2 * oplane + pix], gy = p.grid[n * 2 * oplane + oplane + pix];
   const Taps t = sampler_taps(gx, gy, p.iH, p.iW);
   for (int c = 0; c < p.C; ++c)
@@ -267,7 +278,10 @@ inline int grid_affine_launch(GridAffineParams p, hipStream_t s) {
 inline int bilinear_sampler_launch(SamplerParams p, hipStream_t s) {
   const size_t total = (size_t)p.N * p.oH * p.oW;
   if (!total) return 0;
-  return launch("bilinear_sampler", bilinear_sampler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (!MFN_WARP_1D && p.oW % 64 == 0 && p.oH % 4 == 0 && total < ((size_t)1 << 32))
+    return launch("bilinear_sampler", bilinear_sampler_kernel<true>, grid, dim3(256), 0, s, p);
+  return launch("bilinear_sampler", bilinear_sampler_kernel<false>, grid, dim3(256), 0, s, p);
 }
 
 }  // namespace mfn

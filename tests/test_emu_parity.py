@@ -180,6 +180,9 @@ def test_grid_generator_and_sampler(ops, oracle):
     ga = ops.GridGenerator(theta, "affine", target_shape=(5, 7))
     np.testing.assert_allclose(ga, oracle.grid_generator_affine(theta, (5, 7)), rtol=0, atol=1e-6)
     pc.check_close(ops.BilinearSampler(x, ga), oracle.bilinear_sampler(x, ga), what="sampler affine")
+    # an output of 8 x 64: a wave is a 16 x 4 pixel tile (bilinear_sampler_kernel<true>), source of another size
+    ga = ops.GridGenerator(theta, "affine", target_shape=(8, 64))
+    pc.check_close(ops.BilinearSampler(x, ga), oracle.bilinear_sampler(x, ga), what="sampler affine, tiled lanes")
 
 
 @pytest.mark.parametrize("pt,ksb", [(1, 1), (4, 1), (2, 1), (2, 2), (1, 2), (1, 0)])
