@@ -1,5 +1,5 @@
 // tuning.h -- kernel-selection knobs behind mfn_set_tuning()/mfn_get_tuning() (include/mfn_hip.h).
-// 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 18 that
+// 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 13 that
 // select between code paths the library ships (tests force every path through them); the measurement knobs of rounds 1 / 2
 // (tilings, ring depths, cache policies per kernel family, staggering, ablation masks) are gone with the variants they chose
 // between -- DESIGN.md records what each of them measured.
@@ -7,8 +7,6 @@
 //                 groups, 26 / 31: the same with a tile's displacement rows spread over 5 / 3 blocks (coarse levels); -1 = the
 //                 plan (api_impl.inc corr_plan)
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
-//   corr.generic  1: force the generic one-thread-per-output kernel
-//   corr.bwdlds   0: corr_bwd_block_kernel at every level; 1 (default): corr_bwd_lds_kernel where W is 8, 16, ... 256
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
 //   dc.mma        1: the deformable convolution's GEMM as a bf16 x 3 operand split on the matrix cores (six products of
@@ -18,41 +16,38 @@
 //   dc.pt         pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
 //   dc.ksb        K split across blocks (partial sums + reduce kernel); 0 = heuristic
 //   dc.nw         waves per block: 0 auto, 4, 8 (8 only with pt = 1)
-//   dc.stage      0: disable the LDS source-window staging of the shared-offset path (every tile on the global-gather tier)
-//   dc.fast       0: disable the shared-offset 4x4-neighbourhood gather (per-tap path)
-//   dc.generic    1: force the generic one-thread-per-output kernel
-//   dc.bwdshared  0: input / offset gradient tap by tap only (no lane = pixel shared-offset kernel)
-//   dc.bwdflow    0: mfn_deform_conv_shared_bwd always composes (offsets into the workspace -> mfn_deform_conv_bwd -> sum of
-//                 the taps' offset gradients); 1 (default): the lane = pixel kernels read the flow field and write d/dflow
-//   conv.generic  1: force the generic one-thread-per-output convolution kernel
+//   dc.off        bits that switch tiers of the shared-offset forward path off: 1 = the LDS source-window staging (every tile on
+//                 the global-gather tier), 2 = the shared-offset 4x4-neighbourhood gather altogether (per-tap path)
+//   path.generic  bits that force the generic one-thread-per-output kernels: 1 = correlation, 2 = deformable convolution
+//                 (forward and backward), 4 = convolution
+//   bwd.off       bits that switch backward kernels off: 1 = the lane = pixel shared-offset input / offset gradient (tap by tap
+//                 only), 2 = flow mode (mfn_deform_conv_shared_bwd then always composes: offsets into the workspace ->
+//                 mfn_deform_conv_bwd -> sum of the taps' offset gradients), 4 = corr_bwd_lds_kernel (corr_bwd_block_kernel at
+//                 every level)
 //   conv.mt / conv.pt  32-filter tiles per wave (1..4) / pixel tiles per block (4, or 1 = four in-block K slices); 0 = plan (the plan
 //                 only picks pt = 4 and mt > 2 for images of >= 1024 pixel tiles: the CPU emulation tests reach those kernels through these)
 #pragma once
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_variant = -1, corr_direct = 0, corr_generic = 0, corr_bwdlds = 1;
+  int corr_variant = -1, corr_direct = 0;
   int store_policy = -1;
   int dc_mma = 0, conv_mma = 0;
-  int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_stage = 1, dc_fast = 1, dc_generic = 0, dc_bwdshared = 1, dc_bwdflow = 1;
-  int conv_generic = 0, conv_mt = 0, conv_pt = 0;
+  int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_off = 0;
+  int path_generic = 0, bwd_off = 0;
+  int conv_mt = 0, conv_pt = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.variant")) return &corr_variant;
     if (!strcmp(key, "dc.mma")) return &dc_mma;
     if (!strcmp(key, "conv.mma")) return &conv_mma;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
-    if (!strcmp(key, "corr.generic")) return &corr_generic;
-    if (!strcmp(key, "corr.bwdlds")) return &corr_bwdlds;
     if (!strcmp(key, "store.policy")) return &store_policy;
     if (!strcmp(key, "dc.pt")) return &dc_pt;
     if (!strcmp(key, "dc.ksb")) return &dc_ksb;
     if (!strcmp(key, "dc.nw")) return &dc_nw;
-    if (!strcmp(key, "dc.stage")) return &dc_stage;
-    if (!strcmp(key, "dc.fast")) return &dc_fast;
-    if (!strcmp(key, "dc.generic")) return &dc_generic;
-    if (!strcmp(key, "dc.bwdshared")) return &dc_bwdshared;
-    if (!strcmp(key, "dc.bwdflow")) return &dc_bwdflow;
-    if (!strcmp(key, "conv.generic")) return &conv_generic;
+    if (!strcmp(key, "dc.off")) return &dc_off;
+    if (!strcmp(key, "path.generic")) return &path_generic;
+    if (!strcmp(key, "bwd.off")) return &bwd_off;
     if (!strcmp(key, "conv.mt")) return &conv_mt;
     if (!strcmp(key, "conv.pt")) return &conv_pt;
     return nullptr;

@@ -107,3 +107,41 @@ def test_library_carries_the_hash_of_its_sources(lib, tmp_path, monkeypatch):
     assert _lib.built_hash() == "0" * 16
     with pytest.raises(ImportError, match="other sources"):
         _lib.lib()
+
+
+def test_every_tuning_key_used_by_tests_tools_and_bench_exists():
+    """mfn_set_tuning refuses unknown keys at run time -- on the GPU box for the `-m gpu` tests.  Checked here, on the CPU build of
+    the same tuning.h: every keyword of every set_tuning(...) call (and of the defaults tables) in tests/, tools/ and bench.py
+    names a key of the library, and the library has no more than 15 of them."""
+    import glob
+    import re
+    from tests.emu import emu_ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "maskflownet_amd", "csrc", "tuning.h")).read()
+    keys = set(re.findall(r'strcmp\(key, "([a-z]+\.[a-z0-9]+)"\)', src))
+    assert 0 < len(keys) <= 15, sorted(keys)
+    ns = emu_ops.emu_ops().ns
+    for k in keys:   # the emulation build answers for each of them
+        v = ctypes.c_int(0)
+        assert ns.get_tuning(k.encode(), ctypes.byref(v)) == 0, k
+    assert ns.get_tuning(b"no.such", ctypes.byref(ctypes.c_int(0))) != 0
+    used = {}
+    files = glob.glob(os.path.join(root, "tests", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")) + \
+        glob.glob(os.path.join(root, "tools", "*.sh")) + [os.path.join(root, "bench.py")]
+    call = re.compile(r"(?:set_tuning|DEFAULT_TUNING = dict)\(((?:[^()]|\([^()]*\))*)\)", re.S)
+    for f in files:
+        text = open(f).read()
+        for m in call.finditer(text):
+            for kw in re.findall(r"(?<![\w.*])([a-z]+_[a-z0-9]+)\s*=(?!=)", m.group(1)):
+                used.setdefault(kw.replace("_", ".", 1), set()).add(os.path.basename(f))
+        for m in re.finditer(r'MFN_TUNE="?([a-z0-9_=,\-]+)"?', text):   # tools/*.sh, tools/prof_one.py: key=value lists
+            for kv in m.group(1).split(","):
+                if "=" in kv:
+                    used.setdefault(kv.split("=")[0].replace("_", ".", 1), set()).add(os.path.basename(f))
+        for m in re.finditer(r'--tuning[ =]"?([a-z0-9_=,\-]+)"?', text):
+            for kv in m.group(1).split(","):
+                if "=" in kv:
+                    used.setdefault(kv.split("=")[0].replace("_", ".", 1), set()).add(os.path.basename(f))
+    unknown = {k: sorted(v) for k, v in used.items() if k not in keys}
+    assert not unknown, unknown
+    assert len(used) >= 8, sorted(used)   # the scan does find the calls

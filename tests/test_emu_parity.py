@@ -17,8 +17,8 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(corr_variant=-1, dc_mma=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0,
-                      dc_nw=0, dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0, conv_mma=0)
+DEFAULT_TUNING = dict(corr_variant=-1, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
+                      bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=0)
 
 
 @pytest.fixture(autouse=True)
@@ -113,7 +113,7 @@ def test_correlation_coarse_levels_run_in_one_launch(ops, oracle):
                                         (dict(corr_variant=16), (1, 8, 6, 36)),                       # LDS-DMA tile kernel
                                         (dict(corr_variant=6, corr_direct=2), (1, 32, 5, 16)),           # reduce kernel
                                         (dict(corr_variant=26), (2, 20, 6, 16)),                      # rows over blocks
-                                        (dict(corr_generic=1), (1, 3, 6, 7))])                        # generic kernel
+                                        (dict(path_generic=1), (1, 3, 6, 7))])                        # generic kernel
 def test_correlation_fused_leaky_relu(ops, oracle, tune, shape):
     emu_ops.set_tuning(**tune)
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, 4)
@@ -126,7 +126,7 @@ def test_correlation_fused_leaky_relu(ops, oracle, tune, shape):
                                            (dict(corr_variant=26), (2, 20, 6, 16), 4),                    # rows over blocks
                                            (dict(corr_direct=1), (2, 30, 6, 8), 4),                       # direct kernel
                                            (dict(), (2, 5, 6, 8), 3),                                     # slice not 16-byte aligned -> generic
-                                           (dict(corr_generic=1), (2, 3, 6, 7), 3)])                      # generic kernel
+                                           (dict(path_generic=1), (2, 3, 6, 7), 3)])                      # generic kernel
 def test_correlation_into_concat_slice(ops, oracle, tune, shape, c0):
     emu_ops.set_tuning(**tune)
     pc.case_correlation_into(ops, oracle, ident, ident, shape, 4, c0=c0)
@@ -199,7 +199,7 @@ def test_deform_matching_epilogue(ops, oracle, opt):
     pc.case_deform_matching(ops, oracle, ident, ident, 1, 8, 5, 7, seed=1, **opt)  # scalar stores (W % 4 != 0)
     emu_ops.set_tuning(dc_ksb=2)
     pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 4, 8, seed=2, **opt)  # split K: epilogue in the reduce kernel
-    emu_ops.set_tuning(dc_ksb=0, dc_generic=1)
+    emu_ops.set_tuning(dc_ksb=0, path_generic=2)
     pc.case_deform_matching(ops, oracle, ident, ident, 1, 8, 4, 6, seed=3, **opt)   # generic kernel
 
 
@@ -219,9 +219,9 @@ def test_deform_bf16x3_operand_split(ops, oracle, plan):
     emu_ops.set_tuning(dc_mma=1, **plan)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8)                       # LDS window tier
     pc.case_deform_shared(ops, oracle, ident, ident, 2, 40, 5, 12, seed=2, fused=False)  # 20 pairs: chunk tails; drop-in offsets
-    emu_ops.set_tuning(dc_stage=0)
+    emu_ops.set_tuning(dc_off=1)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8, seed=3)               # global-gather tier
-    emu_ops.set_tuning(dc_stage=1)
+    emu_ops.set_tuning(dc_off=0)
     pc.case_deform_pertap(ops, oracle, ident, ident, 1, 36, 33, 4, 8, kernel=(3, 3), pad=(1, 1))   # per-tap offsets, ragged filters
     pc.case_deform_pertap(ops, oracle, ident, ident, 1, 3, 5, 4, 5, kernel=(3, 3), pad=(1, 1))     # odd Cin, flattened pixels
     pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 6, 8)
@@ -251,7 +251,7 @@ def test_deform_shared_odd_channels_and_padding_of_filters(ops, oracle):
 
 @pytest.mark.parametrize("stage", [0, 1])
 def test_deform_window_staging_and_per_tap_fallback(ops, oracle, stage):
-    emu_ops.set_tuning(dc_stage=stage)
+    emu_ops.set_tuning(dc_off=1 - stage)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8)      # W % 4 == 0: window staging eligible
     pc.case_deform_shared(ops, oracle, ident, ident, 2, 8, 12, 16, seed=3)
 
@@ -263,7 +263,7 @@ def test_deform_pixel_tile_shapes(ops, oracle, hw):
 
 
 def test_deform_fast_path_off_matches(ops, oracle):
-    emu_ops.set_tuning(dc_fast=0)
+    emu_ops.set_tuning(dc_off=2)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 8, 5, 6, bias=False)
 
 
@@ -318,11 +318,11 @@ def test_correlation_backward_register_blocked(ops, oracle, shape, kw):
 def test_correlation_backward_lds_staged(ops, oracle, shape, kw):
     """corr_bwd_lds_kernel (W = 8 ... 256): the other feature map's rows copied to LDS with their zero border, unaligned gout
     quads for g2 with the edge lanes' selects, ragged channel group and row block, images lower than the search window or than
-    a block's rows; the block kernel (corr.bwdlds=0) gives the same values."""
+    a block's rows; the block kernel (bwd.off=4) gives the same values."""
     emu_ops.launch_log()
     pc.case_correlation_bwd(ops, oracle, ident, ident, shape, **kw)
     assert "corr_bwd_lds;" in emu_ops.launch_log()
-    emu_ops.set_tuning(corr_bwdlds=0)
+    emu_ops.set_tuning(bwd_off=4)
     pc.case_correlation_bwd(ops, oracle, ident, ident, shape, seed=2, **kw)
     assert "corr_bwd_block;" in emu_ops.launch_log()
 
@@ -394,7 +394,7 @@ def test_deform_conv_backward_shared_offsets_partial_requests_and_switch(ops, or
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", req=("null", "write", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 2, 4, 9, 17, "smooth", seed=4, req=("write", "write", "null", "null"))   # W % 4 != 0: tile kernel
-    emu_ops.set_tuning(dc_bwdshared=0)   # the tap-by-tap kernel alone gives the same gradients
+    emu_ops.set_tuning(bwd_off=1)   # the tap-by-tap kernel alone gives the same gradients
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 4, 4, 4, 16, "smooth", seed=3, req=("write", "write", "null", "null"))
 
 
@@ -404,7 +404,7 @@ def test_deform_conv_shared_backward(ops, oracle):
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 5, 16)
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 6, 4, 5, seed=1, pad=(2, 2), dilate=(2, 2), scale=5.0, stride=4.0)
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 4, 8, seed=2, req=("null", "write", "null", "null"))
-    # flow mode of the lane = pixel kernels (dc.bwdflow, the default where they apply): accumulation into the caller's buffers,
+    # flow mode of the lane = pixel kernels (the default where they apply; bwd.off=2 switches it off): accumulation into the caller's buffers,
     # filter slices and two channel blocks adding into d/dflow, offsets too large for a regular floor (per-pixel kernels)
     emu_ops.launch_log()
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 20, 5, 8, seed=3, req=("add", "add", "add", "add"))
@@ -412,7 +412,7 @@ def test_deform_conv_shared_backward(ops, oracle):
     assert "dc_bwd_input_pix" in log and "dc_bwd_weight_pc" in log and "offsets_from_flow" not in log, log
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 36, 4, 4, 8, seed=4, req=("null", "write", "write", "write"))
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 4, 8, seed=5, flow_gain=3.0e6)
-    emu_ops.set_tuning(dc_bwdflow=0)   # the composition gives the same gradients
+    emu_ops.set_tuning(bwd_off=2)   # the composition gives the same gradients
     emu_ops.launch_log()
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 5, 8, seed=6, req=("write", "add", "write", "write"))
     assert "offsets_from_flow;" in emu_ops.launch_log()

@@ -35,8 +35,8 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_variant=-1, dc_mma=0, corr_direct=0, corr_generic=0, corr_bwdlds=1, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0,
-                    dc_stage=1, dc_fast=1, dc_generic=0, dc_bwdshared=1, dc_bwdflow=1, conv_generic=0, conv_mt=0, conv_pt=0, conv_mma=0)
+    _lib.set_tuning(corr_variant=-1, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
+                    bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=0)
 
 
 # MaskFlownet-S pyramid: C = 196,128,96,64,32 at strides 64..4  (MaskFlownet.py:79-96, :71)
@@ -298,10 +298,10 @@ def test_deform_conv_fast_path_equals_per_tap_path(ops, dev, T):
     w = dev(pc.msra_weight(rng, 64, 64))
     fl = dev(pc.flow_field(rng, 2, 48, 64) * np.float32(8.0 / 20.0))
     a = ops.deformable_convolution_shared(x, fl, 20.0, 8.0, w, None)
-    _lib.set_tuning(dc_fast=0)
+    _lib.set_tuning(dc_off=2)
     b = ops.deformable_convolution_shared(x, fl, 20.0, 8.0, w, None)
     assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
-    _lib.set_tuning(dc_generic=1)
+    _lib.set_tuning(dc_off=0, path_generic=2)
     c = ops.deformable_convolution_shared(x, fl, 20.0, 8.0, w, None)
     assert (a - c).abs().max().item() <= 1e-5 * c.abs().max().item()
 
@@ -348,7 +348,7 @@ def test_correlation_backward_levels(ops, oracle, dev, shape):
                                       ((2, 16, 3, 128), dict()), ((1, 16, 40, 128), dict(max_displacement=2, pad_size=2)),
                                       ((8, 196, 6, 8), dict()), ((2, 128, 12, 16), dict()), ((3, 94, 24, 32), dict()), ((1, 7, 70, 32), dict())])
 def test_correlation_backward_lds_staged(ops, oracle, dev, shape, kw):
-    """corr_bwd_lds_kernel against the oracle, request by request, and against the block kernel (corr.bwdlds=0), whose BITS it
+    """corr_bwd_lds_kernel against the oracle, request by request, and against the block kernel (bwd.off=4), whose BITS it
     reproduces: same terms in the same order, zeros outside the image add nothing."""
     from maskflownet_amd import _lib
     pc.case_correlation_bwd(ops, oracle, dev, host, shape, **kw)
@@ -360,7 +360,7 @@ def test_correlation_backward_lds_staged(ops, oracle, dev, shape, kw):
     a1, a2 = ops.Correlation_backward(dev(go), dev(f1), dev(f2), 1, md, 1, 1, md, True)
     c1, _ = ops.Correlation_backward(dev(go), dev(f1), dev(f2), 1, md, 1, 1, md, True, req1="add", req2="null", g1=dev(base))
     _, c2 = ops.Correlation_backward(dev(go), dev(f1), dev(f2), 1, md, 1, 1, md, True, req1="null", req2="write")
-    _lib.set_tuning(corr_bwdlds=0)
+    _lib.set_tuning(bwd_off=4)
     b1, b2 = ops.Correlation_backward(dev(go), dev(f1), dev(f2), 1, md, 1, 1, md, True)
     assert np.array_equal(host(a1), host(b1)) and np.array_equal(host(a2), host(b2))
     assert np.array_equal(host(c2), host(b2))
@@ -436,10 +436,10 @@ def test_deform_conv_backward_shared_kernel_off_and_without_workspace(ops, oracl
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 2, 40, 36, 27, 45, "smooth")   # W % 4 != 0: the tile kernel takes every strip
     pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "mixed")
     try:
-        _lib.set_tuning(dc_bwdshared=0)
+        _lib.set_tuning(bwd_off=1)
         pc.case_deform_bwd_shared(ops, oracle, dev, host, 1, 32, 32, 24, 32, "smooth")
     finally:
-        _lib.set_tuning(dc_bwdshared=1)
+        _lib.set_tuning(bwd_off=0)
     # straight through the C ABI with workspace = NULL: tap-by-tap kernel only, same gradients
     rng = np.random.default_rng(1)
     N, C, H, W = 1, 8, 16, 16
@@ -539,7 +539,7 @@ def test_deform_conv_shared_backward(ops, oracle, dev, N, C, H, W, stride):
 
 
 def test_deform_conv_shared_backward_flow_mode(ops, oracle, dev, T):
-    """dc.bwdflow (default 1): where the lane = pixel kernels apply, mfn_deform_conv_shared_bwd hands them the flow field -- no
+    """Flow mode (the default; bwd.off=2 switches it off): where the lane = pixel kernels apply, mfn_deform_conv_shared_bwd hands them the flow field -- no
     offsets_from_flow launch, no per-tap offset gradient -- and gives the composition's gradients: accumulation into the caller's
     buffers, partial requests, filter slices and channel blocks adding into d/dflow, offsets too large for a regular floor."""
     import ctypes
@@ -562,7 +562,7 @@ def test_deform_conv_shared_backward_flow_mode(ops, oracle, dev, T):
     pc.case_deform_shared_bwd(ops, oracle, dev, host, 1, 16, 16, 10, 20, seed=4, req=("write", "add", "null", "write"))
     pc.case_deform_shared_bwd(ops, oracle, dev, host, 1, 32, 32, 16, 24, seed=5, flow_gain=3.0e6)
     pc.case_deform_shared_bwd(ops, oracle, dev, host, 1, 32, 32, 16, 24, seed=6, flow_gain=6.0)   # windows that do not fit: per-pixel paths
-    _lib.set_tuning(dc_bwdflow=0)
+    _lib.set_tuning(bwd_off=2)
     T.cuda.synchronize(); _lib.lib().profile_reset(); _lib.lib().profile_enable(1)
     try:
         pc.case_deform_shared_bwd(ops, oracle, dev, host, 2, 64, 64, 48, 64, seed=1)

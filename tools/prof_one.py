@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one kernel a few times (for rocprofv3 --pmc / --kernel-trace).  usage: prof_one.py corr|deform|warp [level]
-env: MFN_TUNE="corr_variant=20,dc_stage=0" ITERS=20"""
+env: MFN_TUNE="corr_variant=20,dc_off=1" ITERS=20"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
