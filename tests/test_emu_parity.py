@@ -373,6 +373,9 @@ def test_deform_conv_backward_lane_is_pixel(ops, oracle, kind):
 def test_deform_conv_backward_lane_is_pixel_channel_blocks_and_requests(ops, oracle):
     # three 16-channel blocks (the last ragged: 36 channels), three 16-filter chunks (the last ragged: 36 filters)
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 36, 36, 9, 16, "smooth", req=("write", "write", "null", "null"))
+    # per-tap offsets (the tap-by-tap path inside the same kernel) with three filter slices adding their shares and a ragged
+    # second channel block
+    pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 20, 40, 9, 16, "mixed", seed=2, req=("write", "write", "null", "null"))
     # one gradient at a time, and accumulation into the caller's buffers
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "outside", req=("write", "null", "null", "null"))
     pc.case_deform_bwd_shared(ops, oracle, ident, ident, 1, 8, 8, 9, 16, "rough", seed=1, req=("null", "write", "null", "null"))
