@@ -201,8 +201,13 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
     if (ROW3) {
       MFN_UNROLL
       for (int i = 0; i < 3; ++i) {
+        // the row's three taps are picked from the three loaded floats HERE, on the load's result: picked at use
+        // (`mR ? v[3i+1] : v[3i]`) hipcc turned the selects of array elements into dynamically indexed loads and kept the
+        // operand buffers in scratch (80-160 bytes per lane, profiles/r03_kernel_resources.txt)
         const f3u r = mfn_load3u(base + (off[i] - adj));
-        v[i * 3 + 0] = r.x; v[i * 3 + 1] = r.y; v[i * 3 + 2] = r.z;
+        v[i * 3 + 0] = mR ? r.y : r.x;
+        v[i * 3 + 1] = mL ? r.x : (mR ? r.z : r.y);
+        v[i * 3 + 2] = mL ? r.y : r.z;
       }
     } else {
       MFN_UNROLL
@@ -211,14 +216,7 @@ __global__ __launch_bounds__(256, MT <= 2 ? 3 : 2) void conv_mfma_kernel(ConvPar
   };
   // tap t of the pair in operand buffer v; lone: the pair is an odd Cin's last one (upper half has no channel)
   auto tap_value = [&](const float (&v)[T], int t, bool lone) -> float {
-    float r;
-    if (ROW3) {
-      const int i = t / 3, q = t - 3 * i;
-      r = q == 0 ? (mR ? v[i * 3 + 1] : v[i * 3]) : (q == 1 ? (mL ? v[i * 3] : (mR ? v[i * 3 + 2] : v[i * 3 + 1])) : (mL ? v[i * 3 + 1] : v[i * 3 + 2]));
-    } else {
-      r = v[t];
-    }
-    return (val[t] && !(lone && half)) ? r : 0.f;
+    return (val[t] && !(lone && half)) ? v[t] : 0.f;
   };
 
   // Operand pipeline: the loads of pair k + PD are issued before the MFMAs of pair k.  With one or two filter tiles per
