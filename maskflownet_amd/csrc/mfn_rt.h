@@ -53,6 +53,16 @@ static inline void mfn_write_bf16x8(float *p, mfn_bf16x8 v) { memcpy(p, &v, 16);
 static inline float mfn_bf16_at(const float *base, int idx) {   // element idx of a bf16 array, as fp32
   unsigned short h; memcpy(&h, (const char *)base + 2 * (size_t)idx, 2); return hipemu_bf16_to_f32(h);
 }
+// Gram-band cost volume (correlation_gram.h): bf16 matrix-core tile, DPP row shift, range-checked buffer store, counted wait
+#define MFN_MFMA_16x16x32_BF16(a, b, c) hipemu_mfma_16x16x32_bf16((a), (b), (c))
+template <int N> static inline float mfn_dpp_row_shl(float old, float src) { return hipemu_dpp_row_shl(old, src, N); }
+static inline float mfn_leaky01(float v) { return fmaxf(v, 0.1f * v); }
+static inline void mfn_split2x8(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &l) {
+  for (int e = 0; e < 8; ++e) {
+    h.v[e] = hipemu_f32_to_bf16(x[e]);
+    l.v[e] = hipemu_f32_to_bf16(x[e] - hipemu_bf16_to_f32(h.v[e]));
+  }
+}
 #define MFN_LANE_ID() ((int)hipemu::t_lane)
 #define MFN_UNROLL
 #define MFN_NOUNROLL
@@ -90,6 +100,14 @@ static inline void mfn_dma16(mfn_rsrc_t r, float *lds_wave_base, unsigned voff) 
 static inline void mfn_dma16_so(mfn_rsrc_t r, float *lds_wave_base, unsigned voff, unsigned soff) {
   mfn_dma16(r, lds_wave_base, voff > 0xFFFFFF00u - soff ? 0xFFFFFF00u : voff + soff);
 }
+// 16 bytes per lane through a raw buffer descriptor: lanes whose byte offset is out of the descriptor's range store nothing
+static inline void mfn_bstore4(mfn_rsrc_t r, unsigned voff, f32x4_emu v, int /*policy*/) {
+  if ((unsigned long long)voff + 16 <= r.nrec) memcpy(const_cast<char *>(r.base) + voff, &v, 16);
+}
+// the same with a wave-uniform byte offset that is added to the address but takes no part in the range check (soffset)
+static inline void mfn_bstore4_so(mfn_rsrc_t r, unsigned voff, unsigned soff, f32x4_emu v, int /*policy*/) {
+  if ((unsigned long long)voff + 16 <= r.nrec) memcpy(const_cast<char *>(r.base) + voff + soff, &v, 16);
+}
 // four consecutive floats at dword alignment from a wave-uniform base + a per-lane byte offset; synchronous here
 static inline void mfn_gload4_async(f32x4_emu &dst, const float *base_uniform, unsigned byteoff) {
   memcpy(&dst, (const char *)base_uniform + byteoff, 16);
@@ -102,6 +120,7 @@ static inline void mfn_gload4_async(f32x4_emu &dst, const float *base_uniform, u
 // hardware needs only the issuing wave's vmcnt wait (lock-step lanes)
 #define MFN_WAIT_VM(n) (hipemu::wave().bar.arrive_and_wait())
 #define MFN_WAIT_LGKM0() (hipemu::wave().bar.arrive_and_wait())
+static inline void mfn_wait_vm_dyn(unsigned) { hipemu::wave().bar.arrive_and_wait(); }
 #define MFN_RAW_BARRIER() __syncthreads()
 #define MFN_LDS_BARRIER() __syncthreads()
 #define MFN_COMPILER_FENCE() ((void)0)
@@ -179,6 +198,33 @@ __device__ __forceinline__ void mfn_write_bf16x8(float *p, mfn_bf16x8 v) { *rein
 __device__ __forceinline__ float mfn_bf16_at(const float *base, int idx) {   // element idx of a bf16 array, as fp32
   return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short *>(base)[idx] << 16);
 }
+// ---- Gram-band cost volume on the bf16 matrix cores (correlation_gram.h) ------------------------------------------------
+#define MFN_MFMA_16x16x32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// v_mov_b32_dpp row_shl:N -- lane i of every 16-lane row receives lane i+N of its row; lanes whose source is outside the row keep `old`
+template <int N> __device__ __forceinline__ float mfn_dpp_row_shl(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x100 + N, 0xf, 0xf, false));
+}
+// LeakyReLU(0.1)(v) = max(v, 0.1 v) as v_mul + v_max (fmaxf() puts a canonicalising v_max in front of each operand)
+__device__ __forceinline__ float mfn_leaky01(float v) {
+  const float t = 0.1f * v;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+  return r;
+}
+// two-term split (hi + lo, 16 significant bits): 20 VALU instructions for eight values -- the measured, inexact variant
+__device__ __forceinline__ void mfn_split2x8(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &l) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hw, lw;
+  _Pragma("unroll")
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+    const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+    hw[q] = hp; lw[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf2));
+  }
+  h = __builtin_bit_cast(mfn_bf16x8, hw); l = __builtin_bit_cast(mfn_bf16x8, lw);
+}
 #define MFN_LANE_ID() ((int)(threadIdx.x & 63))
 #define MFN_UNROLL _Pragma("unroll")
 #define MFN_NOUNROLL _Pragma("nounroll")
@@ -253,6 +299,39 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
 }
 #define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// 16 bytes per lane through a raw buffer descriptor (wave-uniform base, per-lane byte offset): lanes whose offset is out of
+// the descriptor's range store nothing -- the band mask of the Gram kernel costs no exec juggling.  Unknown to hipcc like the
+// LDS-DMA loads: it joins the in-order vmcnt queue (gfx9 family: vector memory operations complete in issue order), so the
+// counted waits of a pipeline that stores while it loads have to count it.  s_nop 1: as mfn_store4_stream.
+__device__ __forceinline__ void mfn_bstore4(mfn_rsrc_t rsrc, unsigned voff, f32x4 v, int policy) {
+  if (policy == 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc0 sc1\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+  else if (policy == 1) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+  else if (policy == 3) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc0 sc1 nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+  else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+// the same with a wave-uniform byte offset in the instruction's soffset operand (added to the address, not range-checked)
+__device__ __forceinline__ void mfn_bstore4_so(mfn_rsrc_t rsrc, unsigned voff, unsigned soff, f32x4 v, int policy) {
+  const unsigned so = __builtin_amdgcn_readfirstlane(soff);
+  if (policy == 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+  else if (policy == 1) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+  else if (policy == 3) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1 nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+  else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(so) : "memory");
+}
+// s_waitcnt vmcnt(k) for a wave-uniform RUN-TIME k (the instruction only takes an immediate): a compare tree over the
+// values a pipeline can ask for; larger k wait for 48 (waiting for more than asked is always safe)
+__device__ __forceinline__ void mfn_wait_vm_dyn(unsigned k) {
+#define MFN_WVD_(n) case n: MFN_WAIT_VM(n); break;
+  switch (k) {
+    MFN_WVD_(0) MFN_WVD_(1) MFN_WVD_(2) MFN_WVD_(3) MFN_WVD_(4) MFN_WVD_(5) MFN_WVD_(6) MFN_WVD_(7)
+    MFN_WVD_(8) MFN_WVD_(9) MFN_WVD_(10) MFN_WVD_(11) MFN_WVD_(12) MFN_WVD_(13) MFN_WVD_(14) MFN_WVD_(15)
+    MFN_WVD_(16) MFN_WVD_(17) MFN_WVD_(18) MFN_WVD_(19) MFN_WVD_(20) MFN_WVD_(21) MFN_WVD_(22) MFN_WVD_(23)
+    MFN_WVD_(24) MFN_WVD_(25) MFN_WVD_(26) MFN_WVD_(27) MFN_WVD_(28) MFN_WVD_(29) MFN_WVD_(30) MFN_WVD_(31)
+    MFN_WVD_(32) MFN_WVD_(33) MFN_WVD_(34) MFN_WVD_(35) MFN_WVD_(36) MFN_WVD_(37) MFN_WVD_(38) MFN_WVD_(39)
+    MFN_WVD_(40) MFN_WVD_(41) MFN_WVD_(42) MFN_WVD_(43) MFN_WVD_(44) MFN_WVD_(45) MFN_WVD_(46) MFN_WVD_(47)
+    default: MFN_WAIT_VM(48); break;
+  }
+#undef MFN_WVD_
+}
 // A register load hipcc neither counts nor waits for: four consecutive floats at dword alignment from a wave-uniform
 // base (SGPR pair) + a per-lane 32-bit byte offset.  It joins the same in-order vmcnt queue as the LDS-DMA transfers, so a
 // software pipeline can keep loads of later steps in flight across its counted waits (a load hipcc knows about would make

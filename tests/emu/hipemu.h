@@ -251,6 +251,36 @@ static inline f32x16_emu hipemu_mfma_32x32x16_bf16(bf16x8_emu a, bf16x8_emu b, f
   w.bar.arrive_and_wait();
   return c;
 }
+// v_mfma_f32_16x16x32_bf16: lane l holds eight bf16 of A[i=l&15][.] resp. B[.][j=l&15] for k-block l>>4 (four k-blocks of
+// eight); element e of a k-block of A meets element e of the same k-block of B.  D reg r of lane l = D[row=(l>>4)*4+r][col=l&15].
+static inline f32x4_emu hipemu_mfma_16x16x32_bf16(bf16x8_emu a, bf16x8_emu b, f32x4_emu c) {
+  hipemu::Wave &w = hipemu::wave();
+  const unsigned lane = hipemu::t_lane;
+  for (int e = 0; e < 8; ++e) { w.a8[lane][e] = a.v[e]; w.b8[lane][e] = b.v[e]; }
+  w.bar.arrive_and_wait();
+  const int col = lane & 15, grp = lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const int row = grp * 4 + r;
+    float acc = c[r];
+    for (int kb = 0; kb < 4; ++kb)
+      for (int e = 0; e < 8; ++e)
+        acc += hipemu_bf16_to_f32(w.a8[row + 16 * kb][e]) * hipemu_bf16_to_f32(w.b8[col + 16 * kb][e]);
+    c[r] = acc;
+  }
+  w.bar.arrive_and_wait();
+  return c;
+}
+// DPP row_shl:n -- lane i of every 16-lane row receives the value of lane i+n of the same row; lanes whose source is
+// outside the row keep `old` (bound_ctrl off)
+static inline float hipemu_dpp_row_shl(float old, float src, int n) {
+  hipemu::Wave &w = hipemu::wave();
+  const unsigned lane = hipemu::t_lane;
+  w.f[lane] = src;
+  w.bar.arrive_and_wait();
+  const float r = ((lane & 15) + n <= 15) ? w.f[lane + n] : old;
+  w.bar.arrive_and_wait();
+  return r;
+}
 // v_mfma_f32_16x16x4_f32: A lane l = A[i=l&15][k=l>>4], B lane l = B[k=l>>4][j=l&15],
 // D reg r of lane l = D[row=(l>>4)*4+r][col=l&15].
 static inline f32x4_emu hipemu_mfma_16x16x4(float a, float b, f32x4_emu c) {

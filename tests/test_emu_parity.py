@@ -17,7 +17,7 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(corr_variant=-1, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
+DEFAULT_TUNING = dict(corr_variant=-1, corr_rows=0, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
                       bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=0)
 
 
@@ -42,6 +42,42 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     emu_ops.set_tuning(corr_variant=variant)
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 6, 40), 4)
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 32), 2, seed=2)
+
+
+@pytest.mark.parametrize("shape,md,rows", [((1, 32, 10, 24), 4, 0),     # one item per strip, W % 8 == 0, three strips (one block)
+                                           ((2, 32, 13, 20), 4, 4),     # odd H (half-filled last block), ragged last strip, 4 segments
+                                           ((1, 32, 7, 36), 2, 2),      # md = 2 (25 channels), 5 strips = 2 blocks, ragged, rows = 2
+                                           ((1, 32, 24, 8), 4, 6),      # one strip: the f2 segment hangs over both image borders
+                                           ((1, 32, 6, 16), 2, 0)])     # md = 2: the fewest steps the DMA prologue admits
+def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows):
+    """corr.variant 40: the band of the Gram matrix on the bf16 matrix cores, operands split into three bf16 terms (six
+    products): exact fp32 to the tolerance of every other cost-volume kernel.  Wave-private LDS-DMA rings, counted waits,
+    row-shift de-skew, range-checked band stores; LeakyReLU and the concat-slice form."""
+    emu_ops.set_tuning(corr_variant=40, corr_direct=2, corr_rows=rows)
+    pc.case_correlation(ops, oracle, ident, ident, shape, md)
+    assert "corr_gram_v40" in emu_ops.launch_log()
+    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
+    pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
+
+
+def test_correlation_gram_two_term_variant(ops, oracle):
+    """corr.variant 41: two bf16 terms, three products -- a measured variant, 2^-17 relative per product (never the plan's choice)."""
+    emu_ops.set_tuning(corr_variant=41, corr_direct=2)
+    rng = np.random.default_rng(5)
+    f1, f2 = pc.feat(rng, (1, 32, 10, 24)), pc.feat(rng, (1, 32, 10, 24))
+    got = ops.Correlation(f1, f2, kernel_size=1, max_displacement=4, stride1=1, stride2=1, pad_size=4, is_multiply=True)
+    want = oracle.correlation(f1, f2, max_displacement=4, pad_size=4)
+    err = np.abs(got - want).max() / np.abs(want).max()
+    assert err < 3e-5, err
+    assert "corr_gram_v41" in emu_ops.launch_log()
+
+
+def test_correlation_gram_falls_back_off_its_shapes(ops, oracle):
+    """corr.variant 40 on a level that does not have 32 channels: the plan's kernel runs instead."""
+    emu_ops.set_tuning(corr_variant=40, corr_direct=2)
+    emu_ops.launch_log()
+    pc.case_correlation(ops, oracle, ident, ident, (1, 12, 6, 40), 4)
+    assert "corr_gram" not in emu_ops.launch_log()
 
 
 @pytest.mark.parametrize("shape", [(1, 9, 18, 20), (1, 3, 6, 8), (2, 5, 9, 28)])

@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_variant=-1, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
+    _lib.set_tuning(corr_variant=-1, corr_rows=0, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
                     bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=0)
 
 
@@ -64,6 +64,49 @@ def test_correlation_every_variant(ops, oracle, dev, variant):
     pc.case_correlation(ops, oracle, dev, host, (2, 32, 96, 128), 4)
     pc.case_correlation(ops, oracle, dev, host, (1, 20, 27, 76), 4, seed=1)  # ragged tiles
     pc.case_correlation(ops, oracle, dev, host, (2, 8, 20, 32), 2, seed=2)
+
+
+@pytest.mark.parametrize("shape,md,rows", [((8, 32, 96, 128), 4, 0), ((4, 32, 112, 256), 4, 0),     # level 2 of configs[1] / configs[2]
+                                           ((8, 32, 96, 128), 2, 0), ((4, 32, 112, 256), 2, 12),    # the cascade's md = 2
+                                           ((8, 32, 96, 128), 4, 12), ((8, 32, 96, 128), 4, 96),    # other item heights
+                                           ((2, 32, 37, 76), 4, 6), ((1, 32, 9, 20), 2, 4)])        # ragged strips, odd heights
+def test_correlation_gram_band_on_matrix_cores(ops, oracle, dev, shape, md, rows):
+    """corr.variant 40 (correlation_gram.h): the band of the Gram matrix on the bf16 matrix cores with the operands split
+    into three bf16 terms -- exact fp32 to the tolerance of every other cost-volume kernel; plain, with the fused LeakyReLU
+    and written into a concat slice."""
+    from maskflownet_amd import _lib
+    _lib.set_tuning(corr_variant=40, corr_rows=rows)
+    pc.case_correlation(ops, oracle, dev, host, shape, md)
+    pc.case_correlation_leaky(ops, oracle, dev, host, shape, md)
+    if shape[0] <= 4:
+        pc.case_correlation_into(ops, oracle, dev, host, shape, md, c0=4)
+
+
+def test_correlation_gram_is_deterministic_and_matches_the_fma_kernel(ops, T):
+    """Thirty passes of the matrix-core kernel are bit-identical (counted waits with the stores in the count: a wait that is one
+    short shows up as a stale operand row once in a while), and it agrees with corr_dma_kernel to fp32 rounding."""
+    from maskflownet_amd import _lib
+    g = T.Generator(device="cuda").manual_seed(11)
+    f1 = T.randn(8, 32, 96, 128, device="cuda", generator=g)
+    f2 = T.randn(8, 32, 96, 128, device="cuda", generator=g)
+    _lib.set_tuning(corr_variant=16)
+    ref = ops.Correlation(f1, f2, 1, 4, 1, 1, 4)
+    _lib.set_tuning(corr_variant=40)
+    first = ops.Correlation(f1, f2, 1, 4, 1, 1, 4)
+    for _ in range(30):
+        assert T.equal(ops.Correlation(f1, f2, 1, 4, 1, 1, 4), first)
+    assert (first - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+def test_correlation_gram_two_term_variant(ops, oracle, dev):
+    """corr.variant 41: two bf16 terms, three products (measured variant): 2^-17 relative per product."""
+    from maskflownet_amd import _lib
+    _lib.set_tuning(corr_variant=41)
+    rng = np.random.default_rng(5)
+    f1, f2 = pc.feat(rng, (2, 32, 96, 128)), pc.feat(rng, (2, 32, 96, 128))
+    got = host(ops.Correlation(dev(f1), dev(f2), 1, 4, 1, 1, 4))
+    want = oracle.correlation(f1, f2, max_displacement=4, pad_size=4)
+    assert np.abs(got - want).max() / np.abs(want).max() < 3e-5
 
 
 @pytest.mark.parametrize("shape", [(8, 196, 6, 8), (8, 128, 12, 16), (8, 96, 24, 32), (8, 64, 48, 64), (4, 196, 7, 16),
