@@ -353,8 +353,8 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
 // The one point of (NCH, CK, DYW, PF, WPE) that is still built: one displacement row per wave, one 4-px chunk per lane,
 // 4-channel stages, no register prefetch, >= 4 waves per SIMD -- the kernel of images narrower than 32 columns
 // (corr.variant 6).  Rounds 1 / 2 swept eight points and a half-wave form (corr_hw_kernel); none of them is selected by a plan.
-constexpr int kCorrVariants = 32;  // valid values of corr.variant: 6 (corr_tiled_kernel), 16 / 20 / 22 / 26 / 31 (corr_dma_kernel)
-inline bool corr_variant_known(int v) { return v == 6 || v == 16 || v == 20 || v == 22 || v == 26 || v == 31 || v == 40 || v == 41; }
+constexpr int kCorrVariants = 48;  // valid values of corr.variant: 6 (corr_tiled_kernel), 16 / 20 / 22 / 26 / 31 (corr_dma_kernel), 40 / 41 / 43 (corr_gram_kernel)
+inline bool corr_variant_known(int v) { return v == 6 || v == 16 || v == 20 || v == 22 || v == 26 || v == 31 || v == 40 || v == 41 || v == 43; }
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int /*variant*/, hipStream_t s) {
   return corr_tiled_launch<D, TW, 1, 4, 1, false, 4>(p, s, "corr_tiled_v6");
@@ -691,6 +691,7 @@ template <int D>
 inline int corr_dma_variant(const CorrParams &p, int variant, hipStream_t s) {
   switch (variant) {
     case 20: return corr_dma_launch<D, 8, 2, 2, true, 2>(p, s, "corr_dma_v20");   // two channel groups
+    case 22: return corr_dma_launch<D, 8, 2, 1, true, 3>(p, s, "corr_dma_v22");   // three channel groups (86..127 tiles: one 15-wave block per tile)
     case 26: return corr_dma_launch<D, 4, 2, 2, true, 4, 1>(p, s, "corr_dma_v26");  // one row pair per block (blockIdx.z), 4 channel groups
     case 31: return corr_dma_launch<D, 4, 2, 2, true, 2, 2>(p, s, "corr_dma_v31");  // two row pairs per block, 2 channel groups
     default: return corr_dma_launch<D, 4, 2, 5, false>(p, s, "corr_dma_v16");     // level 2: every block of the launch resident

@@ -33,6 +33,16 @@
 #pragma once
 #include "../mfn_rt.h"
 
+// measurement builds only (tools/gram_ablate_build.py): bit 1 no matrix instructions / de-skew / stores (DMA, LDS reads and
+// conversions remain), 2 no stores, 4 no conversions (operands are the raw bits), 8 no DMA (the ring is never filled)
+#ifndef MFN_GRAM_ABLATE
+#define MFN_GRAM_ABLATE 0
+#endif
+// 1: the conversions of the next step's operands are pinned between this step's matrix instructions; 0: hipcc's own order
+#ifndef MFN_GRAM_SCHED
+#define MFN_GRAM_SCHED 1
+#endif
+
 namespace mfn {
 
 struct CorrGramParams {
@@ -48,52 +58,95 @@ struct CorrGramParams {
   int leaky;              // fused LeakyReLU(0.1)
   int xcd_swizzle;
   float inv_c;            // 1/32, folded into the f1 operand before the split (a power of two: exact)
+  unsigned long long *timeline;  // measurement builds only (-DMFN_TIMELINE=1): 4 stamps per block, or NULL
 };
 
 struct GramOp { mfn_bf16x8 h, m, l; };
 
-// D = 2*md+1; AU = units (f1 block + two f2 rows) the LDS-DMA runs ahead = ring slots per wave; NWV waves per block;
-// TERMS = 3 exact, 2 measured variant.
-//
-// Iteration q of a wave (q = 0 .. T+MD-1, T = f1 blocks of the item): "unit" q = f2 rows 2q, 2q+1 of the item's window (image
-// rows ys-MD+2q, +1) and f1 block q-MD.  The f2 rows live CONVERTED in a register window of 2*(MD+1) rows; block t = q-MD meets
-// the rows 2t .. 2t+2MD+1 = window slots (2t+e) mod 2(MD+1), e = 0 .. 2MD+1: 2(MD+1) chains, every one of them active in
-// every iteration (rows outside the image are zeros and produce the zeros MXNet's padding produces), so the body is ONE basic
-// block -- hipcc interleaves the chains, the de-skew moves, the stores and the conversion of unit q+1.  The first MD
-// iterations only fill the window.
-// POL (store policy, mfn_bstore4) and LEAKY (fused LeakyReLU(0.1)) are compile-time: a uniform branch per chain would cut the
-// body into basic blocks again.
-template <int D, int AU, int NWV, int TERMS, int POL, bool LEAKY>
-__global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p) {
-  constexpr int MD = (D - 1) / 2;
-  constexpr int NP = MD + 1;         // f2 row pairs under one f1 block
-  constexpr int NROW = 2 * NP;       // rows of the register window = chains per block
+// One PAIR of fp32 values -> word q of the three bf16 terms (mfn_split3x8 / mfn_split2x8 of mfn_rt.h, a quarter at a time, so that
+// the kernel can place the nine VALU instructions of a pair behind one matrix instruction).
+struct GramWords { unsigned h[4], m[4], l[4]; };
+template <int TERMS>
+__device__ __forceinline__ void gram_split_pair(float x0, float x1, GramWords &w, int q) {
+#if defined(MFN_EMU)
+  unsigned short h0, m0, l0, h1, m1, l1;
+  if (TERMS == 3) { mfn_split3(x0, h0, m0, l0); mfn_split3(x1, h1, m1, l1); }
+  else {
+    h0 = hipemu_f32_to_bf16(x0); l0 = hipemu_f32_to_bf16(x0 - hipemu_bf16_to_f32(h0)); m0 = l0;
+    h1 = hipemu_f32_to_bf16(x1); l1 = hipemu_f32_to_bf16(x1 - hipemu_bf16_to_f32(h1)); m1 = l1;
+  }
+  w.h[q] = (unsigned)h0 | ((unsigned)h1 << 16); w.m[q] = (unsigned)m0 | ((unsigned)m1 << 16); w.l[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+#else
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {x0, x1};
+  const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+  const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+  const f32x2 r1 = v - hf;
+  const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf2));
+  w.h[q] = hp;
+  if (TERMS == 3) {
+    const f32x2 mf = {__builtin_bit_cast(float, mp << 16), __builtin_bit_cast(float, mp & 0xffff0000u)};
+    w.m[q] = mp; w.l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1 - mf, bf2));
+  } else { w.m[q] = mp; w.l[q] = mp; }
+#endif
+}
+__device__ __forceinline__ void gram_words_to_op(const GramWords &w, GramOp &o) {
+#if defined(MFN_EMU)
+  memcpy(&o.h, w.h, 16); memcpy(&o.m, w.m, 16); memcpy(&o.l, w.l, 16);
+#else
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ h = {w.h[0], w.h[1], w.h[2], w.h[3]}, m = {w.m[0], w.m[1], w.m[2], w.m[3]}, l = {w.l[0], w.l[1], w.l[2], w.l[3]};
+  o.h = __builtin_bit_cast(mfn_bf16x8, h); o.m = __builtin_bit_cast(mfn_bf16x8, m); o.l = __builtin_bit_cast(mfn_bf16x8, l);
+#endif
+}
+
+// The static schedule of a wave.  D = 2*md+1; T = f1 blocks (8 x 2 px) per work item: the item's rows are 2T.  Step
+// s = 0 .. 2T+2MD-1 brings f2 row s of the item's window (image row ys-MD+s); block t (rows ys+2t, +1) meets it when
+// e = s - 2t is in [0, 2MD+1]: block row 0 then has displacement row e, block row 1 has e-1.  SP waves share an item: wave
+// PAR < SP takes the steps s = SP*j + PAR (its own steps j = 0 .. J-1) -- every wave converts all T blocks, but each f2 row
+// is converted by one wave only, so SP = 2 doubles the waves in flight at 18 % more conversions (6-row items).
+// Tile sequence of a wave in consumption order: per own step j [block t if this is the first own step with s >= 2t], f2 row s(j).
+template <int D, int T, int SP, int PAR>
+struct GramSched {
+  static constexpr int MD = (D - 1) / 2;
+  static constexpr int S = 2 * T + 2 * MD;
+  static constexpr int J = (S - PAR + SP - 1) / SP;           // own steps
+  static constexpr int TT = J + T;                            // tiles
+  static constexpr int step(int j) { return SP * j + PAR; }
+  static constexpr int blocks_by(int j) { return (step(j) / 2 + 1) < T ? (step(j) / 2 + 1) : T; }   // blocks due at or before own step j
+  static constexpr int block_at(int j) { return (j == 0 ? blocks_by(0) : blocks_by(j) - blocks_by(j - 1)) > 0 ? blocks_by(j) - 1 : -1; }
+  static constexpr int seqN(int j) { return j + blocks_by(j); }                                     // position of own step j's f2 row
+  static constexpr int kind(int k) {   // tile k: block t (>= 0) or -(j+1) for the f2 row of own step j
+    int pos = 0;
+    for (int j = 0; j < J; ++j) {
+      if (block_at(j) >= 0) { if (pos == k) return block_at(j); ++pos; }
+      if (pos == k) return -(j + 1);
+      ++pos;
+    }
+    return -1;
+  }
+  // at most one block becomes due per own step (2 steps per block, SP <= 2)
+  static_assert(SP == 1 || SP == 2, "one or two waves per item");
+};
+
+// The body of a wave: straight-line code (mfn_static_for), every counted wait an immediate.  NSLOT = 2 KB ring slots (= tiles
+// in flight).  Stores start in the first step: loads, matrix work and stores overlap over the whole life of an item (the first form
+// of this kernel kept the f2 rows in a register window and walked the blocks; its first MD iterations only filled the window and
+// the launch was load phase, then store phase -- profiles/r04_corr_gram_experiments.md).
+template <int D, int T, int NSLOT, int TERMS, int POL, bool LEAKY, int SP, int PAR>
+__device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *ring, int lane, int n, int ys, int x0) {
+  using SC = GramSched<D, T, SP, PAR>;
+  constexpr int MD = SC::MD;
+  constexpr int J = SC::J;
+  constexpr int TT = SC::TT;
   constexpr int SLOT_F = 512;        // floats per raw tile: 32 channels x 16 px
-  constexpr int UNIT_F = 3 * SLOT_F; // f1 block, f2 row 2q, f2 row 2q+1
   constexpr int XOFF = 4;            // the f2 segment starts XOFF columns left of the strip (16-byte aligned, >= MD)
   constexpr unsigned INVALID = 0xFFFFFF00u;
-  static_assert(MD >= 1 && MD <= 4 && AU >= 2 && AU <= 8, "band wider than the 16-px segment / stamp FIFO is 8 bytes");
+  static_assert(MD >= 1 && MD <= 4 && T >= 1 && NSLOT >= 3 && NSLOT <= TT, "band wider than the 16-px segment / ring deeper than the item");
 
-  MFN_DYN_SHARED(float, lds_all);
-  const int lane = threadIdx.x & 63;
-  const int wave = MFN_UNIFORM(threadIdx.x >> 6);
-  float *ring = lds_all + (size_t)wave * AU * UNIT_F;
-
-  // ---- work item: (image, row segment, strip) ---------------------------------------------------------------------------
-  int bid = blockIdx.x;
-  if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, gridDim.x);
-  const int bxs = bid % p.bx_per_row;
-  const int rest = bid / p.bx_per_row;
-  const int seg = rest % p.segs;
-  const int n = rest / p.segs;
-  const int sx = bxs * NWV + wave;
-  if (sx >= p.strips) return;   // no block-wide synchronisation in this kernel
   const int H = p.H, W = p.W;
   const int plane = H * W;
-  const int x0 = sx * 8, ys = seg * p.rows;
-  const int R = min(p.rows, H - ys);     // output rows of this item
-  const int T = (R + 1) >> 1;            // 8 x 2 blocks of f1
-  const int Q = T + MD;                  // iterations
+  const int R = min(2 * T, H - ys);      // output rows of this item (the last segment may be short)
   const float *f1n = p.f1 + (size_t)n * 32 * plane;
   const float *f2n = p.f2 + (size_t)n * 32 * plane;
   float *outn = p.out + (size_t)n * p.out_nstride;
@@ -118,8 +171,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p
   // operand gather: lane (g = lane/16, idx = lane%16) reads channels 4j + g, j < 8, of pixel idx
   const int rdoff = (lane >> 4) * 16 + (lane & 15);
   // store: after the row shifts lane (g, n0) owns displacement dx = n0 - XOFF - 4h for the pixels x0+4h .. +3 of block row yy
-  // (h = g&1, yy = g>>1).  Byte offset relative to the chain's base, which points at plane (e-1)*D of output row ys+2t:
-  // block row yy = 0 is displacement row e (exists while e < D), row yy = 1 is e-1 (exists from e = 1).
+  // (h = g&1, yy = g>>1).  Byte offset relative to the block's base, which points at plane -D (displacement row -1) of output
+  // row ys+2t; the chain adds e*D*plane*4 as soffset: block row 0 lands in displacement row e, block row 1 in e-1.
   unsigned voffS, voffS_up, voffS_lo;   // both block rows / row 0 only (e = 0) / row 1 only (e = D)
   {
     const int g = lane >> 4, n0 = lane & 15, h = g & 1, yy = g >> 1;
@@ -129,186 +182,232 @@ __global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p
     voffS_up = yy == 0 ? voffS : INVALID;
     voffS_lo = yy == 1 ? voffS : INVALID;
   }
+  const unsigned dplane4 = (unsigned)(D * plane) * 4u;   // bytes between displacement rows of the output
 
-  // ---- the DMA pipeline ------------------------------------------------------------------------------------------------
-  // Every unit is six DMA instructions, also the ones that bring nothing (f1 blocks of the fill iterations, units past
-  // the item's end: num_records 0 -> zeros, no memory traffic): the body has no branch around them.
-  unsigned n_issued = 0;            // vector memory instructions issued by this wave so far (uniform)
-  unsigned long long fifo = 0;      // n_issued right after each in-flight unit's DMA, oldest in the low byte
-  auto issue_unit = [&](int u) {
-    float *slot = ring + (u % AU) * UNIT_F;
-    {   // f1 block u-MD: rows ys+2(u-MD), +1.  The row is folded into the descriptor's base and its range shrunk by as much:
-        // the range check is exact for the image (a second row that is row H reads zeros, not the next image).
-      const int t = u - MD;
-      const bool in = t >= 0 && t < T;
-      const int rw = in ? (ys + 2 * t) * W : 0;
-      const mfn_rsrc_t r = mfn_make_rsrc(f1n + rw, in ? img_bytes - (unsigned)rw * 4u : 0u);
-      mfn_dma16(r, slot, voffM[0]);
-      mfn_dma16(r, slot + 256, voffM[1]);
+  // ---- the DMA pipeline: everything below is unrolled, so n_issued, the stamps and every wait count fold to constants ------
+  unsigned n_issued = 0;            // vector memory instructions issued by this wave so far
+  unsigned stamp[TT];               // n_issued right after tile k's DMA
+  auto issue_tile = [&](auto k_c) __attribute__((always_inline)) {    // tile k of the sequence -> ring slot k % NSLOT
+    constexpr int k = decltype(k_c)::value;
+    constexpr int kd = SC::kind(k);
+    float *slot = ring + (k % NSLOT) * SLOT_F;
+    if (MFN_GRAM_ABLATE & 8) { stamp[k] = n_issued; return; }
+    if (kd >= 0) {   // f1 block t: rows ys+2t, +1 (a second row that is row H reads zeros: the range check is exact for the image)
+      const bool in = ys + 2 * kd < H;
+      const unsigned soff = (unsigned)((ys + 2 * kd) * W) * 4u;
+      mfn_dma16_row(f1n, img_bytes, soff, in, slot, voffM[0]);
+      mfn_dma16_row(f1n, img_bytes, soff, in, slot + 256, voffM[1]);
+    } else {         // f2 row ys-MD+s; rows outside the image (MXNet's pad_size border) read zeros
+      const int row = ys - MD + SC::step(-kd - 1);
+      const bool in = row >= 0 && row < H;
+      const unsigned soff = (unsigned)(row * W) * 4u;
+      mfn_dma16_row(f2n, img_bytes, soff, in, slot, voffN[0]);
+      mfn_dma16_row(f2n, img_bytes, soff, in, slot + 256, voffN[1]);
     }
-    MFN_UNROLL
-    for (int k = 0; k < 2; ++k) {   // f2 rows ys-MD+2u+k; rows outside the image (MXNet's pad_size border) read zeros
-      const int row = ys - MD + 2 * u + k;
-      const bool in = row >= 0 && row < H && u < Q;
-      const int rw = in ? row * W : 0;
-      const mfn_rsrc_t r = mfn_make_rsrc(f2n + rw, in ? img_bytes - (unsigned)rw * 4u : 0u);
-      mfn_dma16(r, slot + (1 + k) * SLOT_F, voffN[0]);
-      mfn_dma16(r, slot + (1 + k) * SLOT_F + 256, voffN[1]);
-    }
-    n_issued += 6;
+    n_issued += 2;
+    stamp[k] = n_issued;
   };
-  MFN_UNROLL
-  for (int u = 0; u < AU; ++u) {
-    issue_unit(u);
-    fifo |= (unsigned long long)(n_issued & 0xffu) << (8 * u);
-  }
-
-  // Program order of an iteration (fenced with MFN_SCHED_BARRIER so that hipcc keeps ONE raw tile -- eight registers -- alive
-  // at a time; left alone it hoists all 24 LDS reads and the three conversions to the top and spills):
-  //   wait(unit q+1) | chain 0, read f2 row a | chain 1 || chain 2 + convert a -> window slot of e=0 | chain 3, read f2 row b ||
-  //   chain 4 + convert b -> slot of e=1 | chain 5, read f1 block || chain 6, refill the ring slot | chain 7 + convert -> Mnext |
-  //   chains 8, 9 (NROW = 10; for md = 2 the same stations at chains 0..5)
+  auto wait_tile = [&](int k) { mfn_wait_vm_dyn(n_issued - stamp[k]); };
   float raw[8];
-  int cslot = 0;                          // ring slot of the unit being consumed = (q+1) % AU
-  auto wait_unit = [&]() {                // the unit in ring slot `cslot` has landed
-    const unsigned stamp = (unsigned)(fifo & 0xffu);
-    fifo >>= 8;
-    mfn_wait_vm_dyn((n_issued - stamp) & 0xffu);
-  };
-  auto read_raw = [&](int part) {         // part 0: f1 block, 1 / 2: f2 rows
-    const float *su = ring + cslot * UNIT_F + part * SLOT_F + rdoff;
+  auto read_raw = [&](int k) {
+    const float *su = ring + (k % NSLOT) * SLOT_F + rdoff;
     MFN_UNROLL
     for (int j = 0; j < 8; ++j) raw[j] = su[64 * j];
   };
-  auto refill = [&](int u) {              // the slot just read is free: unit u + AU goes there
-    MFN_WAIT_LGKM0();
-    issue_unit(u + AU);
-    fifo |= (unsigned long long)(n_issued & 0xffu) << (8 * (AU - 1));
-  };
-
-  GramOp Mcur, Mnext;
-  GramOp Nwin[NROW];
+  GramOp Mreg[T];
+  GramOp Ncur;
   auto convert = [&](GramOp &o, float scale) {
-    float v[8];
+    GramWords w;
     MFN_UNROLL
-    for (int j = 0; j < 8; ++j) v[j] = raw[j] * scale;
-    if (TERMS == 3) mfn_split3x8(v, o.h, o.m, o.l);
-    else { mfn_split2x8(v, o.h, o.l); o.m = o.l; }
+    for (int q = 0; q < 4; ++q) gram_split_pair<TERMS>(raw[2 * q] * scale, raw[2 * q + 1] * scale, w, q);
+    gram_words_to_op(w, o);
   };
+  // per block: descriptor of its output rows and the store offsets with the rows a short last segment does not have masked
+  mfn_rsrc_t rs[T];
+  unsigned vo_mid[T], vo_first[T], vo_last[T];
+  MFN_UNROLL
+  for (int t = 0; t < T; ++t) {
+    rs[t] = mfn_make_rsrc(outn + ((long long)(ys + 2 * t) * W - (long long)D * plane), 0x80000000u);
+    const bool r0 = 2 * t < R, r1 = 2 * t + 1 < R;
+    vo_first[t] = r0 ? voffS_up : INVALID;
+    vo_mid[t] = r1 ? voffS : vo_first[t];
+    vo_last[t] = r1 ? voffS_lo : INVALID;
+  }
 
-  wait_unit();
-  read_raw(1); convert(Nwin[0], 1.0f);
-  read_raw(2); convert(Nwin[1], 1.0f);
-  read_raw(0); convert(Mcur, p.inv_c);     // block -MD: zeros (fill iteration), unused
-  refill(0);
-  cslot = 1 % AU;
+  // prologue: the first NSLOT tiles; tiles 0 (block 0) and 1 (the f2 row of own step 0) -> operands; two more tiles
+  mfn_static_for<NSLOT>([&](auto k_c) __attribute__((always_inline)) { issue_tile(k_c); });
+  wait_tile(1);
+  MFN_STAMP(p.timeline, 1);
+  read_raw(0); convert(Mreg[0], p.inv_c);
+  read_raw(1); convert(Ncur, 1.0f);
+  MFN_WAIT_LGKM0();
+  mfn_static_for<2>([&](auto i_c) __attribute__((always_inline)) {
+    constexpr int k = NSLOT + decltype(i_c)::value;
+    if constexpr (k < TT) issue_tile(std::integral_constant<int, k>{});
+  });
 
-  const unsigned dplane4 = (unsigned)(D * plane) * 4u;   // bytes between displacement rows of the output
-  for (int qb = 0; qb < Q; qb += NP) {
+  mfn_static_for<J>([&](auto j_c) __attribute__((always_inline)) {
+    constexpr int j = decltype(j_c)::value;
+    constexpr int s = SC::step(j);
+    // the tiles of own step j+1: its f2 row and, if one becomes due, a block (which precedes the row in the sequence)
+    constexpr bool more = j + 1 < J;
+    constexpr int tM = more ? SC::block_at(j + 1) : -1;
+    constexpr bool moreM = tM >= 0;
+    constexpr int kN = more ? SC::seqN(j + 1) : 0;
+    if (more) wait_tile(kN);
+    GramOp Nnext;
+    // raw tiles of the next step out of LDS first: their conversion (VALU) hides behind this step's matrix instructions
+    float rawM[8], rawN[8];
+    if (moreM) { read_raw(kN - 1); MFN_UNROLL for (int i = 0; i < 8; ++i) rawM[i] = raw[i] * p.inv_c; }
+    if (more) { read_raw(kN); MFN_UNROLL for (int i = 0; i < 8; ++i) rawN[i] = raw[i]; }
+    GramWords wM, wN;
+    // The chains of a step have independent accumulators: their matrix instructions are written interleaved (product k of
+    // every active block, then product k+1 ...), so that a block's dependent accumulate never waits for its own predecessor,
+    // and the conversion of the next step's operands is spread between them pair by pair (MFN_GRAM_SCHED pins that order with
+    // scheduling fences; measured: 13.85 us with, 13.75 us without -- the wave is bound by its VALU / VMEM issue, not by
+    // the order, profiles/r04_corr_gram_experiments.md).
+    constexpr int NPROD = TERMS == 3 ? 6 : 3;
+    constexpr int npairs = (moreM ? 4 : 0) + (more ? 4 : 0);
+    int done_pairs = 0, unit = 0, nunits = 0;
     MFN_UNROLL
-    for (int qq = 0; qq < NP; ++qq) {
-      const int q = qb + qq;
-      if (q < Q) {
-        wait_unit();                       // unit q+1; past the item's end: a unit of zeros
-        const int t = q - MD;
-        const int s0 = (2 * (qq + 1)) % NROW, s1 = (2 * (qq + 1) + 1) % NROW;   // window slots of rows 2(q+1), +1 = this block's e = 0, 1
-        if (t >= 0) {
-          const bool odd_end = 2 * t + 1 >= R;                 // last block of an item with an odd row count
-          const unsigned vo_mid = odd_end ? voffS_up : voffS;
-          const unsigned vo_last = odd_end ? INVALID : voffS_lo;
-          // one descriptor per block: base = plane -D (displacement row -1) of output row ys+2t; chain e adds e*D*plane*4 as soffset
-          const mfn_rsrc_t rs = mfn_make_rsrc(outn + ((long long)(ys + 2 * t) * W - (long long)D * plane), 0x80000000u);
-          auto chain = [&](int e, int ws) {
-            const GramOp &No = Nwin[ws];
-            f32x4 acc;
-            acc[0] = 0.f; acc[1] = 0.f; acc[2] = 0.f; acc[3] = 0.f;
-            if (TERMS == 3) {   // smallest terms first
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.l, No.h, acc);
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.h, No.l, acc);
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.m, No.m, acc);
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.m, No.h, acc);
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.h, No.m, acc);
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.h, No.h, acc);
-            } else {
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.l, No.h, acc);
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.h, No.l, acc);
-              acc = MFN_MFMA_16x16x32_BF16(Mcur.h, No.h, acc);
+    for (int t = 0; t < T; ++t) if (s - 2 * t >= 0 && s - 2 * t <= 2 * MD + 1) nunits += NPROD;
+    auto convert_next_pair = [&]() {
+      if (done_pairs < npairs) {
+        const int q = done_pairs & 3;
+        if (moreM && done_pairs < 4) gram_split_pair<TERMS>(rawM[2 * q], rawM[2 * q + 1], wM, q);
+        else gram_split_pair<TERMS>(rawN[2 * q], rawN[2 * q + 1], wN, q);
+        ++done_pairs;
+      }
+    };
+    f32x4 acc[T];
+    MFN_UNROLL
+    for (int t = 0; t < T; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+    if (!(MFN_GRAM_ABLATE & 1)) {
+      MFN_UNROLL
+      for (int k = 0; k < NPROD; ++k) {
+        MFN_UNROLL
+        for (int t = 0; t < T; ++t) {
+          const int e = s - 2 * t;
+          if (e >= 0 && e <= 2 * MD + 1) {
+            const GramOp &Mo = Mreg[t];
+            // smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h (two terms: l*h, h*l, h*h)
+            const mfn_bf16x8 &a = TERMS == 3 ? (k == 0 ? Mo.l : (k == 2 || k == 3 ? Mo.m : Mo.h)) : (k == 0 ? Mo.l : Mo.h);
+            const mfn_bf16x8 &b = TERMS == 3 ? (k == 1 ? Ncur.l : (k == 2 || k == 4 ? Ncur.m : Ncur.h)) : (k == 1 ? Ncur.l : Ncur.h);
+            acc[t] = MFN_MFMA_16x16x32_BF16(a, b, acc[t]);
+            if (MFN_GRAM_SCHED) {   // pair i behind unit floor(i * nunits / npairs)
+              while (done_pairs < npairs && done_pairs * nunits <= unit * npairs) convert_next_pair();
+              MFN_SCHED_BARRIER();
             }
-            // de-skew: register i of lane n holds (x = 4h+i, dx = n-XOFF-4h-i); lane n0 collects dx0 = n0-XOFF-4h from lanes n0+i
-            f32x4 v;
-            v[0] = acc[0];
-            v[1] = mfn_dpp_row_shl<1>(acc[1], acc[1]);
-            v[2] = mfn_dpp_row_shl<2>(acc[2], acc[2]);
-            v[3] = mfn_dpp_row_shl<3>(acc[3], acc[3]);
-            if (LEAKY) {
-              MFN_UNROLL
-              for (int i = 0; i < 4; ++i) v[i] = mfn_leaky01(v[i]);
-            }
-            const unsigned vo = e == 0 ? voffS_up : (e == NROW - 1 ? vo_last : vo_mid);
-            mfn_bstore4_so(rs, vo, (unsigned)e * dplane4, v, POL);
-          };
-          MFN_UNROLL
-          for (int e = 0; e < NROW; ++e) {
-            const int ws = (((2 * (qq - MD) + e) % NROW) + NROW) % NROW;   // window slot of row 2t+e: compile-time (qb % NP == 0)
-            // stations (see above); NROW >= 6
-            if (e == 2) convert(Nwin[s0], 1.0f);
-            if (e == 4) convert(Nwin[s1], 1.0f);
-            if (e == (NROW >= 8 ? 6 : 5)) refill(q + 1);
-            if (e == (NROW >= 8 ? 7 : 5)) convert(Mnext, p.inv_c);
-            chain(e, ws);
-            if (e == 0) read_raw(1);
-            if (e == 3) read_raw(2);
-            if (e == (NROW >= 8 ? 5 : 4)) read_raw(0);
-            if (e == 1 || e == 3 || e == 5) MFN_SCHED_BARRIER();
+            ++unit;
           }
-          n_issued += NROW;
-          Mcur = Mnext;
-        } else {   // fill iteration: the window is not complete yet
-          read_raw(1); convert(Nwin[s0], 1.0f);
-          read_raw(2); convert(Nwin[s1], 1.0f);
-          read_raw(0); convert(Mcur, p.inv_c);
-          refill(q + 1);
         }
-        cslot = cslot + 1 == AU ? 0 : cslot + 1;
       }
     }
+    while (done_pairs < npairs) convert_next_pair();
+    if (moreM) gram_words_to_op(wM, Mreg[moreM ? tM : 0]);
+    if (more) gram_words_to_op(wN, Nnext);
+    MFN_WAIT_LGKM0();                      // the ring slots of the tiles just read are free: the next tiles of the sequence go there
+    {
+      constexpr int consumed = more ? kN + 1 : TT;       // tiles read so far
+      constexpr int issued_before = moreM ? consumed - 2 + NSLOT : consumed - 1 + NSLOT;   // issued = NSLOT + tiles read before this step's reads
+      mfn_static_for<2>([&](auto i_c) __attribute__((always_inline)) {
+        constexpr int k = issued_before + decltype(i_c)::value;
+        if constexpr (more && decltype(i_c)::value < (moreM ? 2 : 1) && k < TT) issue_tile(std::integral_constant<int, k>{});
+      });
+    }
+    if (!(MFN_GRAM_ABLATE & 1)) {
+      MFN_UNROLL
+      for (int t = 0; t < T; ++t) {
+        const int e = s - 2 * t;
+        if (e >= 0 && e <= 2 * MD + 1) {
+          // de-skew: register i of lane n holds (x = 4h+i, dx = n-XOFF-4h-i); lane n0 collects dx0 = n0-XOFF-4h from lanes n0+i
+          f32x4 v;
+          v[0] = acc[t][0];
+          v[1] = mfn_dpp_row_shl<1>(acc[t][1], acc[t][1]);
+          v[2] = mfn_dpp_row_shl<2>(acc[t][2], acc[t][2]);
+          v[3] = mfn_dpp_row_shl<3>(acc[t][3], acc[t][3]);
+          if (LEAKY) {
+            MFN_UNROLL
+            for (int i = 0; i < 4; ++i) v[i] = mfn_leaky01(v[i]);
+          }
+          const unsigned vo = e == 0 ? vo_first[t] : (e == 2 * MD + 1 ? vo_last[t] : vo_mid[t]);
+          if (MFN_GRAM_ABLATE & 2) { if (v[0] == 1.2345e30f) mfn_bstore4_so(rs[t], vo, (unsigned)e * dplane4, v, POL); }   // keeps the chain live
+          else { mfn_bstore4_so(rs[t], vo, (unsigned)e * dplane4, v, POL); n_issued += 1; }
+        }
+      }
+    }
+    if (more) Ncur = Nnext;
+    if (j == J / 2 - 1) MFN_STAMP(p.timeline, 2);
+    MFN_SCHED_BARRIER();
+  });
+  if (MFN_GRAM_ABLATE & 1) {   // keep the conversions live
+    float sink = mfn_bf16_at(reinterpret_cast<const float *>(&Ncur), 0) + mfn_bf16_at(reinterpret_cast<const float *>(&Mreg[T - 1]), 1);
+    if (sink == 1.2345e30f) outn[lane] = sink;
   }
+  MFN_STAMP(p.timeline, 3);
 }
 
-template <int D, int AU, int NWV, int TERMS, int POL, bool LEAKY>
+// One wave per (image, row segment, strip, step parity); NWV adjacent strips per block, no block-wide synchronisation.
+template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP>
+__global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p) {
+  MFN_DYN_SHARED(float, lds_all);
+  const int lane = threadIdx.x & 63;
+  const int wave = MFN_UNIFORM(threadIdx.x >> 6);
+  float *ring = lds_all + (size_t)wave * NSLOT * 512;
+  MFN_STAMP(p.timeline, 0);
+  int bid = blockIdx.x;
+  if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, gridDim.x);
+  const int bxs = bid % p.bx_per_row;
+  int rest = bid / p.bx_per_row;
+  const int par = rest % SP;
+  rest /= SP;
+  const int seg = rest % p.segs;
+  const int n = rest / p.segs;
+  const int sx = bxs * NWV + wave;
+  if (sx >= p.strips) return;
+  const int x0 = sx * 8, ys = seg * (2 * T);
+  if (SP == 1 || par == 0) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, 0>(p, ring, lane, n, ys, x0);
+  else corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, SP - 1>(p, ring, lane, n, ys, x0);
+}
+
+template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP = 1>
 inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *name) {
+  p.rows = 2 * T;
   p.strips = cdiv(p.W, 8);
   p.segs = cdiv(p.H, p.rows);
   p.bx_per_row = cdiv(p.strips, NWV);
-  const long nblk = (long)p.N * p.segs * p.bx_per_row;
+  const long nblk = (long)p.N * p.segs * SP * p.bx_per_row;
   if (nblk <= 0) return 0;
-  const size_t lds = (size_t)NWV * AU * 3 * 512 * sizeof(float);
-  return launch(name, corr_gram_kernel<D, AU, NWV, TERMS, POL, LEAKY>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
+  const size_t lds = (size_t)NWV * NSLOT * 512 * sizeof(float);
+  return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
-inline bool corr_variant_gram(int v) { return v == 40 || v == 41; }
-// Output rows per work item (even).  One wave per item and eight resident waves per CU (two blocks of four, 72 KB of LDS each):
-// the whole launch is one residency round when the items number 2048; fewer rows per item mean more halo (an item converts
-// rows + 2*md f2 rows).  corr.rows overrides.
-inline int corr_gram_rows(int N, int H, int W, int override_rows) {
-  if (override_rows >= 2) return override_rows & ~1;
-  const long strip_rows = (long)N * cdiv(W, 8) * H;
-  int rows = (int)((strip_rows + 2047) / 2048);
-  rows = (rows + 1) & ~1;
-  if (rows < 4) rows = 4;
-  if (rows > H) rows = (H + 1) & ~1;
-  return rows;
+inline bool corr_variant_gram(int v) { return v == 40 || v == 41 || v == 43; }
+// Output rows per work item: 6 or 8 (T = 3 / 4 blocks; the schedule is compile-time).  One wave per item, eight resident waves
+// per CU (two blocks of four): the level-2 launch of 384x512 at batch 8 is 2048 items of 6 rows = one residency round.  Fewer
+// rows per item mean more halo (an item converts rows + 2*md f2 rows); 8 where 6 does not divide H and 8 does (448x1024:
+// 112 rows).  corr.rows overrides.
+inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
+  if (override_rows == 6 || override_rows == 8) return override_rows;
+  return (H % 6 != 0 && H % 8 == 0) ? 8 : 6;
 }
 // corr.variant 40: exact (three terms, six products); 41: two terms, three products (measured variant, ~1e-5 relative; md = 4,
-// no fused activation).  The store policy is write-through (sc0 sc1) when the caller's policy has that bit, plain otherwise.
+// six-row items, no fused activation); 43: 40 with TWO waves per item (md = 4, six rows; measured: slower -- kept as the one
+// instantiation that exercises GramSched<SP = 2>).  Ring of 4 tiles (13.2 us; 5: 13.7, 9: 14.6 -- a deep ring only delays the
+// first tiles of 2048 waves that all start together).  Stores: plain unless the caller's policy asks for write-through (the band
+// pattern is 36 x 16 bytes in 32-byte runs per instruction: written through, 14.2 us for the 31.85 MB of level 2 against 8.4 us
+// plain -- profiles/r04_store_pattern_ubench.txt).
 template <int D>
 inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s) {
   const bool wt = (p.store_policy & 2) != 0;
-  if (variant == 41 && D == 9 && !p.leaky)
-    return wt ? corr_gram_launch<9, 3, 4, 2, 2, false>(p, s, "corr_gram_v41") : corr_gram_launch<9, 3, 4, 2, 0, false>(p, s, "corr_gram_v41");
-  if (p.leaky)
-    return wt ? corr_gram_launch<D, 3, 4, 3, 2, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, 3, 4, 3, 0, true>(p, s, "corr_gram_v40");
-  return wt ? corr_gram_launch<D, 3, 4, 3, 2, false>(p, s, "corr_gram_v40") : corr_gram_launch<D, 3, 4, 3, 0, false>(p, s, "corr_gram_v40");
+  if (variant == 43 && D == 9 && !p.leaky && !wt && p.rows == 6) return corr_gram_launch<9, 3, 4, 4, 3, 0, false, 2>(p, s, "corr_gram_v43");
+  if (variant == 41 && D == 9 && !p.leaky && p.rows == 6)
+    return wt ? corr_gram_launch<9, 3, 4, 4, 2, 2, false>(p, s, "corr_gram_v41") : corr_gram_launch<9, 3, 4, 4, 2, 0, false>(p, s, "corr_gram_v41");
+#define MFN_GRAM_(TT_) \
+  (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, true>(p, s, "corr_gram_v40")) \
+           : (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, false>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, false>(p, s, "corr_gram_v40")))
+  return p.rows == 8 ? MFN_GRAM_(4) : MFN_GRAM_(3);
+#undef MFN_GRAM_
 }
 
 }  // namespace mfn

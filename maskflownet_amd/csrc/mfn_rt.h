@@ -104,9 +104,16 @@ static inline void mfn_dma16_so(mfn_rsrc_t r, float *lds_wave_base, unsigned vof
 static inline void mfn_bstore4(mfn_rsrc_t r, unsigned voff, f32x4_emu v, int /*policy*/) {
   if ((unsigned long long)voff + 16 <= r.nrec) memcpy(const_cast<char *>(r.base) + voff, &v, 16);
 }
-// the same with a wave-uniform byte offset that is added to the address but takes no part in the range check (soffset)
+// the same with a wave-uniform byte offset (soffset): added to the address AND to the offset the range check sees
 static inline void mfn_bstore4_so(mfn_rsrc_t r, unsigned voff, unsigned soff, f32x4_emu v, int /*policy*/) {
-  if ((unsigned long long)voff + 16 <= r.nrec) memcpy(const_cast<char *>(r.base) + voff + soff, &v, 16);
+  if ((unsigned long long)voff + soff + 16 <= r.nrec) memcpy(const_cast<char *>(r.base) + voff + soff, &v, 16);
+}
+// DMA of one row of a tensor: a fixed base, the row's byte offset as a wave-uniform soffset, and a range check that is exact for
+// base .. base+full_bytes (lanes whose voff+soff+16 exceeds it, or every lane when !valid, write zeros)
+static inline void mfn_dma16_row(const void *base, unsigned full_bytes, unsigned soff, bool valid, float *lds_wave_base, unsigned voff) {
+  char *dst = (char *)lds_wave_base + hipemu::t_lane * 16;
+  if (valid && (unsigned long long)voff + soff + 16 <= full_bytes) memcpy(dst, (const char *)base + voff + soff, 16);
+  else memset(dst, 0, 16);
 }
 // four consecutive floats at dword alignment from a wave-uniform base + a per-lane byte offset; synchronous here
 static inline void mfn_gload4_async(f32x4_emu &dst, const float *base_uniform, unsigned byteoff) {
@@ -297,6 +304,22 @@ __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_ba
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(so)
                : "memory", "m0");
 }
+// DMA of one row of a tensor: ONE descriptor per tensor, the row's byte offset in soffset.  The hardware's range check of a raw
+// buffer is offset >= num_records - soffset, i.e. voff + soff against the descriptor's range: exact for the tensor (measured:
+// shrinking num_records by soff as well zero-fills the lower half of the image).  !valid: num_records 0, every lane reads zeros.
+__device__ __forceinline__ void mfn_dma16_row(const void *base, unsigned full_bytes, unsigned soff, bool valid, float *lds_wave_base,
+                                              unsigned voff) {
+  const unsigned long long a = (unsigned long long)base;
+  mfn_rsrc_t r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));
+  r.z = __builtin_amdgcn_readfirstlane((int)(valid ? full_bytes : 0u));
+  r.w = 0x00020000;
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
+  const unsigned so = __builtin_amdgcn_readfirstlane(valid ? soff : 0u);
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(so)
+               : "memory", "m0");
+}
 #define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // 16 bytes per lane through a raw buffer descriptor (wave-uniform base, per-lane byte offset): lanes whose offset is out of
@@ -309,7 +332,7 @@ __device__ __forceinline__ void mfn_bstore4(mfn_rsrc_t rsrc, unsigned voff, f32x
   else if (policy == 3) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc0 sc1 nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
   else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
-// the same with a wave-uniform byte offset in the instruction's soffset operand (added to the address, not range-checked)
+// the same with a wave-uniform byte offset in the instruction's soffset operand (added to the address and to the range-checked offset)
 __device__ __forceinline__ void mfn_bstore4_so(mfn_rsrc_t rsrc, unsigned voff, unsigned soff, f32x4 v, int policy) {
   const unsigned so = __builtin_amdgcn_readfirstlane(soff);
   if (policy == 2) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(so) : "memory");
@@ -402,6 +425,15 @@ __device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_u
 #include <stddef.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) in order: an unrolled loop by construction (a `#pragma unroll`
+// loop is a request that hipcc drops above its size threshold -- and a kernel whose counted waits fold only when unrolled
+// cannot live with that)
+template <int... I, class F>
+__host__ __device__ __forceinline__ void mfn_static_for_(std::integer_sequence<int, I...>, F &&f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__host__ __device__ __forceinline__ void mfn_static_for(F &&f) { mfn_static_for_(std::make_integer_sequence<int, N>{}, f); }
 
 namespace mfn {
 

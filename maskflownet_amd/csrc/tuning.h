@@ -7,8 +7,10 @@
 //                 groups, 26 / 31: the same with a tile's displacement rows spread over 5 / 3 blocks (coarse levels); -1 = the
 //                 plan (api_impl.inc corr_plan)
 //                 40 / 41: corr_gram_kernel (32-channel levels: the band of the Gram matrix on the bf16 matrix cores with the
-//                 operands split into three / two bf16 terms -- 40 is exact fp32, 41 a measured variant)
-//   corr.rows     output rows per work item of corr_gram_kernel (even; 0 = the plan)
+//                 operands split into three / two bf16 terms -- 40 is exact fp32, 41 a measured variant, 43 = 40 with two waves per item)
+//   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 0 = the plan)
+//   corr.gram     the plan's use of corr_gram_kernel (variant 40) for 32-channel levels of >= 400 tiles: -1 the library's default
+//                 (api_impl.inc corr_plan), 0 never, 1 always
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
@@ -33,7 +35,7 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_variant = -1, corr_direct = 0, corr_rows = 0;
+  int corr_variant = -1, corr_direct = 0, corr_rows = 0, corr_gram = -1;
   int store_policy = -1;
   int dc_mma = 0, conv_mma = 0;
   int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_off = 0;
@@ -45,6 +47,7 @@ struct Tuning {
     if (!strcmp(key, "conv.mma")) return &conv_mma;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
     if (!strcmp(key, "corr.rows")) return &corr_rows;
+    if (!strcmp(key, "corr.gram")) return &corr_gram;
     if (!strcmp(key, "store.policy")) return &store_policy;
     if (!strcmp(key, "dc.pt")) return &dc_pt;
     if (!strcmp(key, "dc.ksb")) return &dc_ksb;

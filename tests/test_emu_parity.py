@@ -17,7 +17,7 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(corr_variant=-1, corr_rows=0, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
+DEFAULT_TUNING = dict(corr_variant=-1, corr_rows=0, corr_gram=-1, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
                       bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=0)
 
 
@@ -44,11 +44,11 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 32), 2, seed=2)
 
 
-@pytest.mark.parametrize("shape,md,rows", [((1, 32, 10, 24), 4, 0),     # one item per strip, W % 8 == 0, three strips (one block)
-                                           ((2, 32, 13, 20), 4, 4),     # odd H (half-filled last block), ragged last strip, 4 segments
-                                           ((1, 32, 7, 36), 2, 2),      # md = 2 (25 channels), 5 strips = 2 blocks, ragged, rows = 2
-                                           ((1, 32, 24, 8), 4, 6),      # one strip: the f2 segment hangs over both image borders
-                                           ((1, 32, 6, 16), 2, 0)])     # md = 2: the fewest steps the DMA prologue admits
+@pytest.mark.parametrize("shape,md,rows", [((1, 32, 10, 24), 4, 0),     # 6-row items: a full and a 4-row item per strip, three strips (one block)
+                                           ((2, 32, 13, 20), 4, 8),     # 8-row items, odd H (a 5-row last item: half-filled last block), ragged last strip
+                                           ((1, 32, 7, 36), 2, 6),      # md = 2 (25 channels), 5 strips = 2 blocks, a 1-row last item
+                                           ((1, 32, 24, 8), 4, 0),      # 24 % 6 == 0 -> 6 rows; one strip: the f2 segment hangs over both image borders
+                                           ((1, 32, 16, 16), 2, 0)])    # 16 % 6 != 0, 16 % 8 == 0 -> the plan picks 8-row items
 def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows):
     """corr.variant 40: the band of the Gram matrix on the bf16 matrix cores, operands split into three bf16 terms (six
     products): exact fp32 to the tolerance of every other cost-volume kernel.  Wave-private LDS-DMA rings, counted waits,
@@ -58,6 +58,24 @@ def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows):
     assert "corr_gram_v40" in emu_ops.launch_log()
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
     pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
+
+
+def test_correlation_gram_two_waves_per_item(ops, oracle):
+    """corr.variant 43: two waves per item, each takes every other f2 row -- the same schedule generator (GramSched<SP = 2>), exact."""
+    emu_ops.set_tuning(corr_variant=43, corr_direct=2)
+    pc.case_correlation(ops, oracle, ident, ident, (2, 32, 13, 20), 4)
+    assert "corr_gram_v43" in emu_ops.launch_log()
+    pc.case_correlation(ops, oracle, ident, ident, (1, 32, 24, 72), 4, seed=3)
+
+
+def test_correlation_gram_by_plan(ops, oracle):
+    """corr.gram = 1: the plan hands 32-channel levels of >= 400 tiles to the matrix-core kernel (and nothing else)."""
+    emu_ops.set_tuning(corr_gram=1)
+    emu_ops.launch_log()
+    pc.case_correlation(ops, oracle, ident, ident, (4, 32, 1, 3200), 4)        # 4 x 100 x 1 = 400 tiles of 32 x 4
+    assert "corr_gram_v40" in emu_ops.launch_log()
+    pc.case_correlation(ops, oracle, ident, ident, (1, 32, 16, 64), 4, seed=2)  # 8 tiles: the usual plan
+    assert "corr_gram" not in emu_ops.launch_log()
 
 
 def test_correlation_gram_two_term_variant(ops, oracle):

@@ -35,7 +35,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_variant=-1, corr_rows=0, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
+    _lib.set_tuning(corr_variant=-1, corr_rows=0, corr_gram=-1, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
                     bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=0)
 
 
@@ -66,10 +66,10 @@ def test_correlation_every_variant(ops, oracle, dev, variant):
     pc.case_correlation(ops, oracle, dev, host, (2, 8, 20, 32), 2, seed=2)
 
 
-@pytest.mark.parametrize("shape,md,rows", [((8, 32, 96, 128), 4, 0), ((4, 32, 112, 256), 4, 0),     # level 2 of configs[1] / configs[2]
-                                           ((8, 32, 96, 128), 2, 0), ((4, 32, 112, 256), 2, 12),    # the cascade's md = 2
-                                           ((8, 32, 96, 128), 4, 12), ((8, 32, 96, 128), 4, 96),    # other item heights
-                                           ((2, 32, 37, 76), 4, 6), ((1, 32, 9, 20), 2, 4)])        # ragged strips, odd heights
+@pytest.mark.parametrize("shape,md,rows", [((8, 32, 96, 128), 4, 0), ((4, 32, 112, 256), 4, 0),     # level 2 of configs[1] / configs[2] (6- / 8-row items)
+                                           ((8, 32, 96, 128), 2, 0), ((4, 32, 112, 256), 2, 6),     # the cascade's md = 2; a short last item
+                                           ((8, 32, 96, 128), 4, 8),                                # the other item height
+                                           ((2, 32, 37, 76), 4, 6), ((1, 32, 9, 20), 2, 8)])        # ragged strips, odd heights
 def test_correlation_gram_band_on_matrix_cores(ops, oracle, dev, shape, md, rows):
     """corr.variant 40 (correlation_gram.h): the band of the Gram matrix on the bf16 matrix cores with the operands split
     into three bf16 terms -- exact fp32 to the tolerance of every other cost-volume kernel; plain, with the fused LeakyReLU

@@ -1,18 +1,17 @@
 #!/bin/bash
-# r04 session 1: the Gram-band correlation (corr.variant 40 / 41) -- parity on the GPU, store-pattern ubench, A/B against the
-# shipped level-2 kernel (variant 16) inside a hipGraph, then the bench line with the variant forced.
+# r04 correlation session: the Gram-band kernel (corr.variant 40 / 41) -- parity on the GPU, A/B against the shipped level-2
+# kernel (variant 16) inside a hipGraph, then the bench line with the variant forced.  usage: r04_corr_session.sh <outdir> [quick]
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r04_corr}
 mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "gram" > $O/pytest_gram.log 2>&1
-tail -6 $O/pytest_gram.log
-timeout 120 tools/ubench/store_pattern > $O/store_pattern.txt 2>&1
-cat $O/store_pattern.txt
-timeout 400 python tools/corr_ab.py "corr_variant=16;corr_variant=40;corr_variant=40,corr_rows=4;corr_variant=40,corr_rows=8;corr_variant=40,corr_rows=12;corr_variant=40,corr_rows=24;corr_variant=41;corr_variant=40,store_policy=0" 2 cfg2 7 > $O/corr_ab_l2.txt 2>&1
-cat $O/corr_ab_l2.txt | tail -12
-timeout 400 python tools/corr_ab.py "corr_variant=16;corr_variant=40;corr_variant=40,corr_rows=4;corr_variant=40,corr_rows=14;corr_variant=40,corr_rows=28;corr_variant=41" 2 cfg3 7 > $O/corr_ab_l2_cfg3.txt 2>&1
-cat $O/corr_ab_l2_cfg3.txt | tail -8
+tail -4 $O/pytest_gram.log
+timeout 400 python tools/corr_ab.py "corr_variant=16;corr_variant=40;corr_variant=40,corr_rows=8;corr_variant=41;corr_variant=40,store_policy=2" 2 cfg2 7 > $O/corr_ab_l2.txt 2>&1
+grep "corr L" $O/corr_ab_l2.txt
+timeout 400 python tools/corr_ab.py "corr_variant=16;corr_variant=40;corr_variant=40,corr_rows=6;corr_variant=40,store_policy=2" 2 cfg3 7 > $O/corr_ab_l2_cfg3.txt 2>&1
+grep "corr L" $O/corr_ab_l2_cfg3.txt
+[ "$2" = "quick" ] && exit 0
 timeout 600 python bench.py --no-side-configs --no-e2e --no-epe --tuning corr_variant=40 > $O/bench_v40.log 2> $O/bench_v40.err
 python - "$O" <<'PY'
 import json, sys
