@@ -296,9 +296,20 @@ def correlation(im1, im2, md, stride1=1, stride2=1, leaky=False, out=None):
                            stride2=stride2, is_multiply=1, activation="leaky" if leaky else None, out=out)
 
 
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, factor):
+        ctx.factor = factor
+        return ops.Upsample(img, factor)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ops.default_ops().Upsample_backward(gout.contiguous(), ctx.factor), None
+
+
 class Upsample(nn.Module):
-    """Upsample(factor) of flow / mask between pyramid levels (MaskFlownet.py:35-62); forward only -- the network
-    back-propagates through it in training, which is not on the a7 rows and raises here."""
+    """Upsample(factor) of flow / mask between pyramid levels (MaskFlownet.py:35-62).  Under autograd the adjoint is
+    mfn_upsample_bwd (the network back-propagates through it in training, pipeline.py:112-113)."""
 
     def __init__(self, factor, **kwargs):
         super().__init__()
@@ -308,5 +319,5 @@ class Upsample(nn.Module):
         if self.factor == 1:
             return img
         if _any_grad(img):
-            raise NotImplementedError("Upsample: backward is not implemented (forward / inference only)")
+            return _UpsampleFn.apply(img, self.factor)
         return ops.Upsample(img, self.factor)

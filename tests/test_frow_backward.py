@@ -106,6 +106,32 @@ def test_leaky_correlation_backward_gpu(gpu_ops):
     pc.case_leaky_corr_backward(gpu_ops, oracle, _dev, _host, (2, 64, 12, 16), md=2, seed=3)
 
 
+@pytest.mark.gpu
+def test_layer_upsample_under_autograd_gpu():
+    """layer.Upsample inside a torch graph (MaskFlownet.py:35-62, trained through by pipeline.py:112-113): the adjoint is
+    mfn_upsample_bwd -- checked as the adjoint of the (linear, bit-exact) forward map."""
+    import torch
+    from maskflownet_amd import layer
+    for factor, shape in ((2, (2, 2, 12, 16)), (4, (1, 1, 6, 8))):
+        x = torch.randn(*shape, device="cuda", requires_grad=True)
+        y = layer.Upsample(factor)(x)
+        go = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, x, go)
+        yd = torch.from_numpy(oracle.upsample(x.detach().cpu().numpy(), factor)).cuda()
+        assert torch.equal(y.detach(), yd)
+        # the map is linear: its adjoint applied to go equals d/dx <Upsample(x), go>; finite differences are exact for a linear map
+        basis = torch.zeros_like(x)
+        flat = basis.view(-1)
+        want = torch.empty_like(flat)
+        idx = torch.randperm(flat.numel(), device="cuda")[:64]
+        for i in idx.tolist():
+            flat.zero_()
+            flat[i] = 1.0
+            want[i] = (layer.Upsample(factor)(basis) * go).sum()
+        got = gx.reshape(-1)
+        assert (got[idx] - want[idx]).abs().max().item() <= 1e-5 * go.abs().max().item() * 16
+
+
 def test_superseded_workspaces_are_parked_until_released(emu):
     """OpSet keeps a workspace that a larger one replaced (a hipGraph captured earlier still points at it) until its owner
     calls release_retired(); gradient destinations are never silently copied."""

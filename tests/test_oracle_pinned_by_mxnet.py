@@ -64,3 +64,16 @@ def test_deformable_convolution_forward_and_backward_match_mxnet(pinned):
         assert res[k][0] <= 2e-6, (k, res[k], ans["Q5_dc_context"])
     for k in ("dc_gx", "dc_goffset", "dc_gw", "dc_gb"):   # MXNet's GPU backward accumulates with atomics: order differs
         assert res[k][0] <= (2e-5 if "gpu" in ans["Q5_dc_context"] else 5e-6), (k, res[k], ans["Q5_dc_context"])
+
+
+def test_restated_network_matches_the_reference_under_mxnet(pinned):
+    """The harness itself: oracle/network_ref.Net (what bench.py's EPE delta and tests/test_network_epe.py are measured
+    against) vs the reference's own MaskFlownet_S run by MXNet with the same seeded weights (tools/pin_oracle_with_mxnet.py
+    run_network; absent from fixtures written with --no-network)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pin_oracle_with_mxnet as pin
+    res = pin.compare_network(np.load(FIX), verbose=False)
+    if not res:
+        pytest.skip("the fixture holds no network-level probe")
+    for k, e in res.items():
+        assert e <= 1e-4, (k, e)   # north_star's tolerance for the whole network

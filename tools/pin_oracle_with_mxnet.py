@@ -17,6 +17,8 @@ outputs, and runs a probe per open question of SURVEY.md Appendix A.5:
                                                                                                -> dc_out, both oracle modes
   Q5  DeformableConvolution has a CPU kernel in this MXNet build                                -> meta_dc_context
   Q6  Correlation / BilinearSampler loop order (fp32 summation order): bit-exact or 1 ulp class  -> reported as max ulps
+  NET the reference's own MaskFlownet_S (network/MaskFlownet.py, from MFN_REFERENCE) under MXNet with the seeded weights of
+      oracle/network_ref.Params(seed=3) against the restatement oracle/network_ref.Net                -> net_pred*, net_occlusion
 
 Call sites restated here (test infrastructure; the product never imports this):
   /root/reference/network/MaskFlownet.py:193-195, :440-441   F.Correlation(..., pad_size=md, kernel_size=1, max_displacement=md,
@@ -116,6 +118,84 @@ def run_mxnet():
     return out
 
 
+def run_network(out):
+    """Network-level probe: the reference's OWN MaskFlownet_S (network/MaskFlownet.py:66-315, imported
+    from MFN_REFERENCE, default /root/reference) on mx.cpu() with the seeded weights of oracle/network_ref.Params(seed=3) on the
+    synthetic pair of the EPE tests -> its predictions, occlusion mask and warped image.  One MXNet run then pins the harness
+    (oracle/network_ref.py, which bench.py's EPE delta and tests/test_network_epe.py are measured against) as well as the
+    operators.  Parameter names: Gluon's are '<model prefix><block prefix>...weight'; the restatement's keys are
+    '<block prefix>.weight' -- matched by the longest block prefix contained in the name, and the match must be a bijection."""
+    import importlib
+    import types
+    import mxnet as mx
+    from oracle import network_ref as nr
+    ref_root = os.environ.get("MFN_REFERENCE", "/root/reference")
+    pkg = types.ModuleType("mfn_refnet_pin")
+    pkg.__path__ = [os.path.join(ref_root, "network")]   # a bare namespace: network/__init__.py (pipeline, trainer) is not executed
+    sys.modules["mfn_refnet_pin"] = pkg
+    net_mod = importlib.import_module("mfn_refnet_pin.MaskFlownet")
+
+    class _Knob:
+        def get(self, default=None):
+            return default
+
+    class _Section:
+        def __getattr__(self, name):
+            return _Knob()
+
+    class _Config:   # network/config.py's Reader with an empty file: every knob at its default
+        network = _Section()
+        optimizer = _Section()
+
+    im1, im2 = nr.synthetic_pair(1, 64, 64, seed=5)
+    P = nr.Params(seed=3)
+    want = nr.Net(P, nr.OracleMatching(), "cpu").forward(im1, im2)    # creates every key of P.store
+    net = net_mod.MaskFlownet_S(_Config())
+    net.initialize(mx.initializer.Zero(), ctx=mx.cpu())
+    a, b = mx.nd.array(im1), mx.nd.array(im2)
+    net(a, b)                                                          # shapes the deferred parameters
+    layers = sorted({k.rsplit(".", 1)[0] for k in P.store}, key=len, reverse=True)
+    used = set()
+    for name, par in net.collect_params().items():
+        kind = "weight" if name.endswith("weight") else ("bias" if name.endswith("bias") else None)
+        hit = next((l for l in layers if l in name), None)
+        if kind is None or hit is None:
+            raise RuntimeError("cannot map Gluon parameter %r to a layer of the restatement (layers: %s ...)" % (name, layers[:6]))
+        key = hit + "." + kind
+        if key in used:
+            raise RuntimeError("two Gluon parameters map to %r (second: %r)" % (key, name))
+        used.add(key)
+        par.set_data(mx.nd.array(P.get(key, tuple(par.shape))))
+    if used != set(P.store):
+        raise RuntimeError("parameters of the restatement without a Gluon counterpart: %s" % sorted(set(P.store) - used)[:8])
+    preds, occ, srcs = net(a, b)
+    for i, pr in enumerate(preds):
+        out["net_pred%d" % i] = pr.asnumpy()
+    out["net_occlusion"] = occ[0].asnumpy()
+    out["net_warped"] = srcs[4].asnumpy()[:, :3]
+    out["net_npreds"] = np.array(len(preds))
+    return want
+
+
+def compare_network(M, verbose=True):
+    """oracle/network_ref.Net against the stored outputs of the reference's MaskFlownet_S under MXNet ({name: rel err})."""
+    from oracle import network_ref as nr
+    if "net_npreds" not in M:
+        return {}
+    im1, im2 = nr.synthetic_pair(1, 64, 64, seed=5)
+    want = nr.Net(nr.Params(seed=3), nr.OracleMatching(), "cpu").forward(im1, im2)
+    res = {}
+    rel = lambda got, ref: float(np.abs(np.asarray(got, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+    for i in range(int(M["net_npreds"])):
+        res["net_pred%d" % i] = rel(want["predictions"][i], M["net_pred%d" % i])
+    res["net_occlusion"] = rel(want["occlusion"], M["net_occlusion"])
+    res["net_warped"] = rel(want["warped"], M["net_warped"])
+    if verbose:
+        for k in sorted(res):
+            print("  %-16s rel err %.3e   (restated MaskFlownet_S vs the reference's own under MXNet)" % (k, res[k]))
+    return res
+
+
 def ulps(a, b):
     """Largest difference in units of the last place of the larger magnitude (0 = bit-exact)."""
     a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
@@ -182,6 +262,11 @@ def compare(M, verbose=True):
 
 if __name__ == "__main__":
     if "--compare-only" not in sys.argv:
-        np.savez_compressed(OUT, **run_mxnet())
+        out = run_mxnet()
+        if "--no-network" not in sys.argv:
+            run_network(out)
+        np.savez_compressed(OUT, **out)
         print("wrote", OUT)
-    compare(np.load(OUT))
+    M = np.load(OUT)
+    compare(M)
+    compare_network(M)
