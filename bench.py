@@ -109,22 +109,32 @@ def timed_steps(wls, steps, dist, torch, gpu=True):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    timed_steps.last_rank_seconds = [dt]
     if dist is not None:
         t = torch.tensor([dt], device="cuda" if gpu else "cpu", dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)                       # every rank's own clock, for the line's self-check
+        timed_steps.last_rank_seconds = [float(e.item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
 
 
-def roofline_of_dominant_kernel(wl, iters, torch):
-    """Level-2 correlation (N,32,H/4,W/4) -> (N,81,H/4,W/4): the largest byte mover of the pass."""
+timed_steps.last_rank_seconds = []
+
+
+def roofline_of_dominant_kernel(wl, iters, torch, md=4):
+    """Level-2 correlation (N,32,H/4,W/4) -> (N,81,H/4,W/4): the largest byte mover of the pass.  md = 2: the cascade's
+    25-channel cost volume of the full model at the same level (corr_u2, MaskFlownet.py:440-441)."""
     import ctypes
     from maskflownet_amd import _lib, hotpath
     lib = _lib.lib()
     t, o = wl.t, wl.o
     n, c, h, w = hotpath.level_shapes(wl.N, wl.H, wl.W)[2]
-    nbytes = 4 * n * h * w * (2 * c + 81)
-    nflops = 2 * n * h * w * c * 81
+    D2 = (2 * md + 1) ** 2
+    op_name, in2, outk = ("corr2", "deform2", "corr2") if md == 4 else ("corr_u2", "deform_u2", "corr_u2")
+    nbytes = 4 * n * h * w * (2 * c + D2)
+    nflops = 2 * n * h * w * c * D2
     def query(tag=b""):
         c_, m_ = ctypes.c_int(0), ctypes.c_double(0.0)
         buf = ctypes.create_string_buffer(32768)
@@ -136,7 +146,7 @@ def roofline_of_dominant_kernel(wl, iters, torch):
                 return nm.split("@")[0], c_.value, m_.value
         return None, 0, 0.0
 
-    corr2 = lambda: wl.ops.Correlation(t["c1_2"], o["deform2"], 1, 4, 1, 1, 4, True, out=o["corr2"])
+    corr2 = lambda: wl.ops.Correlation(t["c1_2"], o[in2], 1, md, 1, 1, md, True, out=o[outk])
     with torch.cuda.stream(wl.stream):
         # (a) back to back on hot caches: the kernel alone
         for _ in range(10):
@@ -176,17 +186,17 @@ def roofline_of_dominant_kernel(wl, iters, torch):
             per_set = nbytes
             nsets = int(need // per_set) + 1
             f1s = [torch.empty_like(t["c1_2"]).copy_(t["c1_2"]) for _ in range(nsets)]
-            f2s = [torch.empty_like(o["deform2"]).copy_(o["deform2"]) for _ in range(nsets)]
-            outs = [torch.empty_like(o["corr2"]) for _ in range(nsets)]
+            f2s = [torch.empty_like(o[in2]).copy_(o[in2]) for _ in range(nsets)]
+            outs = [torch.empty_like(o[outk]) for _ in range(nsets)]
             for i in range(nsets):
-                wl.ops.Correlation(f1s[i], f2s[i], 1, 4, 1, 1, 4, True, out=outs[i])
+                wl.ops.Correlation(f1s[i], f2s[i], 1, md, 1, 1, md, True, out=outs[i])
             wl.stream.synchronize()
             lib.profile_reset()
             lib.profile_enable(1)
             for it in range(3 * nsets):   # three rounds over the sets: enough for a mean, few enough not to skew the
                                           # rocprofv3 average of this kernel (profiles/*_bench_kernel_stats.md)
                 i = it % nsets
-                wl.ops.Correlation(f1s[i], f2s[i], 1, 4, 1, 1, 4, True, out=outs[i])
+                wl.ops.Correlation(f1s[i], f2s[i], 1, md, 1, 1, md, True, out=outs[i])
             lib.profile_enable(0)
             wl.stream.synchronize()
             _, rc, rms = query()
@@ -206,7 +216,7 @@ def roofline_of_dominant_kernel(wl, iters, torch):
             if kern.startswith("corr_") and "reduce" not in kern:
                 best = (kern, c_, ms_)
         return best or (None, 0, 0.0)
-    kname, cnt_v, ms_v = pick("corr2")
+    kname, cnt_v, ms_v = pick(op_name)
     lib.profile_reset()
     wl._per_op_profile = per_op   # the same profiled pass also prices the warp (roofline_warp) and the other calls
     if cnt_v == 0:
@@ -216,13 +226,13 @@ def roofline_of_dominant_kernel(wl, iters, torch):
     traffic, traffic_src = None, None
     import glob
     tfs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_corr_l2_hbm_traffic.json")))
-    if tfs and (wl.N, wl.H, wl.W) == (8, 384, 512):
+    if tfs and (wl.N, wl.H, wl.W) == (8, 384, 512) and md == 4:
         rec = json.load(open(tfs[-1]))  # newest rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this very launch shape
         traffic = rec["traffic_bytes_per_launch"]
         traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; %s)" % (
             os.path.basename(tfs[-1]), rec.get("kernel", ""))
     achieved = nbytes / avg_s / 1e9
-    return {"bound": "hbm", "kernel": "%s (level 2: N=%d C=%d %dx%d -> 81 ch)" % (kname, n, c, h, w),
+    return {"bound": "hbm", "kernel": "%s (level 2: N=%d C=%d %dx%d -> %d ch)" % (kname, n, c, h, w, D2),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg_s * 1e6, 3),
@@ -276,7 +286,7 @@ def warp_roofline(wl, hotpath):
             "timed_where": "inside the operator sequence of the pass (eager, HIP events)"}
 
 
-def side_config(cfg, mode, steps, torch, hotpath, want_roofline=False, want_dominant=False):
+def side_config(cfg, mode, steps, torch, hotpath, want_roofline=False, want_dominant=False, roofline_md=4):
     """Another BASELINE configuration timed the same way as the headline (hipGraph replay, one stream, `steps` steps after
     a warm-up) -- sub-objects of the default line so that the driver's run carries them."""
     wl = hotpath.HotPathWorkload(cfg, device="cuda:%d" % torch.cuda.current_device(), mode=mode).capture()
@@ -289,7 +299,7 @@ def side_config(cfg, mode, steps, torch, hotpath, want_roofline=False, want_domi
            "mode": mode, "value": round(wl.N * steps / dt, 2), "unit": "image-pairs/s", "ms_per_step": round(dt / steps * 1e3, 4),
            "steps": steps}
     if want_roofline:
-        r, rc = roofline_of_dominant_kernel(wl, 60, torch)
+        r, rc = roofline_of_dominant_kernel(wl, 60, torch, md=roofline_md)
         if r:
             out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us",
                                                  "algorithmic_bytes_per_launch") if k in r}
@@ -309,6 +319,76 @@ def side_config(cfg, mode, steps, torch, hotpath, want_roofline=False, want_domi
         out["dominant_kernel"] = dom
     del wl
     return out
+
+
+def customop_leg(wl, steps, torch, hotpath):
+    """The pass as the REFERENCE would run it (SURVEY.md 8b "Threading"): every operator through
+    maskflownet_amd.mxnet_ops -- mx.nd.Correlation / contrib.DeformableConvolution / GridGenerator + BilinearSampler routed by
+    install() to mx.nd.Custom(op_type='mfn_*'), each CustomOp.forward doing hipSetDevice, a launch on the NULL stream and
+    hipDeviceSynchronize -- over the MXNet stub of tests/fake_mxnet (MXNet has no ROCm build; the stub implements the CustomOp
+    protocol over torch tensors, its Python overhead is inside the number).  11 Custom calls per pass (5 + 4 + 2); the offset
+    tensors are built as network/MaskFlownet.py:230 builds them (repeat / expand_dims / reshape: MXNet's own operators, torch in
+    the stub).  Reports pairs/s and what one call costs on top of its kernels."""
+    import importlib
+    import time
+    fake = os.path.join(ROOT, "tests", "fake_mxnet")
+    saved = {k: sys.modules.pop(k) for k in [k for k in sys.modules if k == "mxnet" or k.startswith("mxnet.")]}
+    sys.path.insert(0, fake)
+    try:
+        import mxnet as mx
+        import maskflownet_amd.mxnet_ops as m
+        if m.mx is not mx:
+            m = importlib.reload(m)
+        m._ns, m._rt = None, None
+        m.install()
+        t = wl.t
+        A = {k: mx.nd.NDArray(v) for k, v in t.items() if hasattr(v, "is_cuda") and v.is_cuda}
+        F = mx.nd
+        kw = lambda c: {"kernel": (3, 3), "stride": (1, 1), "dilate": (1, 1), "pad": (1, 1), "num_filter": c, "num_group": 1,
+                        "no_bias": False, "layout": "NCHW", "num_deformable_group": 1}      # network/layer.py:91-95
+        ck = dict(pad_size=hotpath.MD, kernel_size=1, max_displacement=hotpath.MD, stride1=1, stride2=1, is_multiply=1)
+
+        def one_pass():
+            outs = [F.Correlation(A["c1_6"], A["c2_6"], **ck)]
+            for l in (5, 4, 3, 2):
+                off = F.repeat(F.expand_dims(A["flow_%d" % l] * hotpath.SCALE / hotpath.STRIDES[l], axis=1), 9, axis=1).reshape((0, -3, -2))
+                warp = F.contrib.DeformableConvolution(A["c2_%d" % l], off, A["w_%d" % l], A["b_%d" % l], name="fwd",
+                                                       **kw(hotpath.CHANNELS[l]))
+                outs.append(F.Correlation(A["c1_%d" % l], warp, **ck))
+            grid = F.GridGenerator(data=A["flow_full"].flip(axis=1), transform_type="warp")
+            outs.append(F.BilinearSampler(A["img2"], grid))
+            return outs
+
+        for _ in range(5):
+            outs = one_pass()
+        torch.cuda.synchronize()
+        worst = 0.0   # the adapter's outputs against the pass the headline timed (same inputs, same library)
+        for got, name in zip(outs, ["corr6", "corr5", "corr4", "corr3", "corr2", "warp"]):
+            ref = wl.o[name]
+            worst = max(worst, float((got._tensor - ref).abs().max() / ref.abs().max().clamp_min(1e-30)))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_pass()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        m.uninstall()
+    finally:
+        sys.path.remove(fake)
+        for k in [k for k in sys.modules if k == "mxnet" or k.startswith("mxnet.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    ncalls = 11
+    us_pass = dt / steps * 1e6
+    kern = per_kernel_breakdown(wl, 10, torch)
+    us_kernels = sum(v["us_per_pass"] for v in kern.values())
+    return {"value": round(wl.N * steps / dt, 2), "unit": "image-pairs/s", "ms_per_step": round(us_pass / 1e3, 4), "steps": steps,
+            "custom_calls_per_pass": ncalls, "kernel_us_per_pass": round(us_kernels, 1),
+            "overhead_us_per_call": round((us_pass - us_kernels) / ncalls, 1),
+            "max_rel_diff_vs_headline_outputs": worst,
+            "what": "the cfg2 pass through maskflownet_amd.mxnet_ops CustomOps (install()) over tests/fake_mxnet: per call hipSetDevice "
+                    "+ NULL-stream launch + hipDeviceSynchronize + the stub's Python; offsets built with the framework's own "
+                    "repeat/expand_dims/reshape as MaskFlownet.py:230 does",
+            "note": "not the headline: `value` above is the same kernels behind the C ABI as one hipGraph replay"}
 
 
 def per_kernel_breakdown(wl, iters, torch):
@@ -536,9 +616,9 @@ def main():
 
     def workload(flow_model=None):
         fm = flow_model or args.flow
-        if gpu:
+        if gpu:   # every rank its own shard of the global batch: rank r draws from seed + 1000 r (rank 0 = the single-GPU batch)
             return hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode=args.mode,
-                                           prepack=not args.repack, flow_model=fm)
+                                           prepack=not args.repack, flow_model=fm, seed=20260925 + 1000 * rank)
         return hotpath.HotPathWorkload(args.config, mode=args.mode, prepack=not args.repack, seed=20260925 + rank,
                                        buffers=make_buffers(args.buffers), flow_model=fm)
 
@@ -563,6 +643,7 @@ def main():
     for w in wls:
         w.synchronize()
     dt = timed_steps(wls, args.steps, dist, torch, gpu)
+    rank_seconds = list(timed_steps.last_rank_seconds)
 
     # 2-float record all-reduced over RCCL (the only collective: SURVEY.md 8e)
     local_ck = wl.checksum()
@@ -620,6 +701,21 @@ def main():
         "aggregate_GBps_per_gpu": round(sum(ab.values()) / (dt / args.steps) / 1e9, 1),
         "checksum_allreduce_ok": ck_ok,
     }
+    # self-verification of an N > 1 line (no 8-GPU node has run this yet): what the process group says it is, and every
+    # rank's own rate over the same K steps (the headline uses the slowest rank's clock)
+    rates = [wl.N * args.steps / t_ for t_ in rank_seconds if t_ > 0]
+    coll = {"world_size_env": world, "process_group": None}
+    if dist is not None:
+        coll["process_group"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rank0": dist.get_rank()}
+        try:
+            if gpu and args.backend == "nccl":
+                v = torch.cuda.nccl.version()
+                coll["process_group"]["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as e:
+            coll["process_group"]["rccl_version"] = "unavailable: %r" % (e,)
+    coll["per_rank_pairs_per_s"] = {"min": round(min(rates), 2), "max": round(max(rates), 2), "n": len(rates)} if rates else None
+    coll["shard_seeds"] = "rank r draws its per-GPU batch from seed 20260925 + 1000 r" if gpu else "seed 20260925 + r"
+    res["distributed"] = coll
     if gpu and len(wls) == 1 and world == 1 and not args.no_graph:
         try:  # informational: the same pass with 3 independent batches in flight (3 streams, own outputs each)
             extra = [workload().capture() for _ in range(2)]
@@ -667,12 +763,21 @@ def main():
         # the other configurations north_star names, in the driver's own run: 448x1024 (configs[2]), the fused operator
         # forms on the headline batch, and the training step (configs[4]) -- 200 steps each
         for key, (cfg_, mode_, kw_) in (("cfg3", ("cfg3", "dropin", dict(want_roofline=True))),
+                                        ("cfg4", ("cfg4", "dropin", dict(want_roofline=True, roofline_md=2))),
                                         ("fused", ("cfg2", "fused", {})),
                                         ("train", ("cfg5", "dropin", dict(want_dominant=True)))):
             try:
                 res[key] = side_config(cfg_, mode_, 200, torch, hotpath, **kw_)
             except Exception as e:
                 res[key] = {"error": repr(e)}
+    if gpu and world == 1 and not args.no_side_configs and args.config == "cfg2" and args.mode == "dropin" and args.flow == "smooth" \
+            and len(wls) == 1:
+        try:
+            wl.replay()
+            wl.synchronize()
+            res["customop"] = customop_leg(wl, 200, torch, hotpath)
+        except Exception as e:
+            res["customop"] = {"error": repr(e)}
     if not args.no_cpu_baseline and world == 1 and gpu:  # rank 0 at N=1 only: other ranks would idle in the barrier meanwhile
         res["cpu_baseline"], want = cpu_baseline(wl, args.cpu_seconds)
         res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)

@@ -66,7 +66,7 @@ def test_rccl_path_runs_on_the_gpu_with_one_rank():
     """The box has one GPU, so N > 1 cannot run here; what can: the very same code path with a real RCCL process group
     of one rank under torch.distributed.run (init, barrier, MAX all-reduce of the step time, checksum all-reduce, and
     for the training pass the all-reduce of the flat gradient bucket)."""
-    for config in ("tiny", "tiny_train"):
+    for config in ("tiny", "tiny_train", "cfg5"):   # cfg5: BASELINE configs[4] at its full per-GPU size -- the 1.1 MB gradient bucket through RCCL
         env = dict(os.environ)
         env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -78,6 +78,11 @@ def test_rccl_path_runs_on_the_gpu_with_one_rank():
         rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert rec["n_gpus"] == 1 and rec["config"]["backend"] == "nccl" and rec["checksum_allreduce_ok"] is True
         assert rec["value"] > 0 and rec["data"] == "synthetic"
+        # the line's self-check for the day N > 1 runs: what the process group says it is, every rank's own rate
+        pg = rec["distributed"]["process_group"]
+        assert pg["world_size"] == 1 and pg["backend"] == "nccl" and rec["distributed"]["world_size_env"] == 1
+        assert "rccl_version" in pg and rec["distributed"]["per_rank_pairs_per_s"]["n"] == 1
+        assert abs(rec["distributed"]["per_rank_pairs_per_s"]["max"] - rec["value"]) <= 1e-6 * rec["value"] + 0.01
 
 
 @pytest.mark.gpu
