@@ -133,8 +133,14 @@ struct GramSched {
 // in flight).  Stores start in the first step: loads, matrix work and stores overlap over the whole life of an item (the first form
 // of this kernel kept the f2 rows in a register window and walked the blocks; its first MD iterations only filled the window and
 // the launch was load phase, then store phase -- profiles/r04_corr_gram_experiments.md).
-template <int D, int T, int NSLOT, int TERMS, int POL, bool LEAKY, int SP, int PAR>
-__device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *ring, int lane, int n, int ys, int x0) {
+// COOP: the NWV = 4 waves of a block (adjacent strips, 32 px = one 128-byte line per output row) hand their de-skewed results
+// to each other through LDS and store FULL lines, written through: a wave alone owns 32-byte runs -- one L2 write request per
+// run (995 k per level-2 launch against 498 k for the FMA kernel), 36 of 64 lanes per store instruction, and written through
+// they are partial-line writes (14.2 us for the volume alone), so the non-cooperative form stores plain and leaves the lines
+// to the L2 and to the flush at the end of the kernel.  One block barrier per step; `stg` = the block's two staging buffers.
+template <int D, int T, int NSLOT, int TERMS, int POL, bool LEAKY, int SP, int PAR, bool COOP = false>
+__device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *ring, int lane, int n, int ys, int x0,
+                                               float *stg = nullptr, int wave = 0, int xb0 = 0) {
   using SC = GramSched<D, T, SP, PAR>;
   constexpr int MD = SC::MD;
   constexpr int J = SC::J;
@@ -234,6 +240,46 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     vo_last[t] = r1 ? voffS_lo : INVALID;
   }
 
+  // ---- cooperative stores: staging geometry (all per-lane values are step-invariant) --------------------------------------
+  // A step's results are `nch` chains (f1 blocks, highest block first: ci = 0 ... ) x 2 block rows x D displacements = lines of
+  // 128 bytes (32 px); line = (ci*2 + yy)*D + dxi.  Consecutive chains of a step are blocks t, t-1 with e, e+2: their output
+  // addresses differ by the CONSTANT (2*D*plane - 2*W) floats, so a lane's global offset is a per-step uniform base (the
+  // first chain's, in soffset) + a lane constant.  Staging is XOR-swizzled per line so that the 8 lanes of a ds_write_b128
+  // group (8 displacements = 8 lines, same 16-byte column) hit 8 different bank groups; a store instruction reads 1 KB = 8
+  // lines back, lane -> (line 8k + lane/8, 16-byte chunk lane%8).
+  constexpr int MAXCH = T < MD + 1 ? T : MD + 1;          // chains per step at most
+  constexpr int LINES = MAXCH * 2 * D;
+  constexpr int STG_F = LINES * 32;                       // floats per staging buffer
+  constexpr int NSJ_MAX = ((LINES + 7) / 8 + 3) / 4;      // store instructions per wave and step at most
+  int stw[MAXCH];                                         // staging write: float offset of this lane's 16 bytes of chain ci (or -1)
+  unsigned cvoff[NSJ_MAX > 0 ? NSJ_MAX : 1];              // store: lane constant of slot j (or INVALID)
+  int cbit[NSJ_MAX > 0 ? NSJ_MAX : 1];                    // store: bit (ci*2 + yy) of the line slot j reads
+  int strd_off = 0;                                       // staging read: float offset inside a 1 KB group
+  mfn_rsrc_t rs_item = rs[0];
+  unsigned rowok_bits = 0;                                // bit (t*2 + yy): output row ys + 2t + yy exists in this item
+  if (COOP) {
+    const int g = lane >> 4, n0 = lane & 15, h = g & 1, yy = g >> 1;
+    const int dxi = n0 - XOFF - 4 * h + MD;
+    MFN_UNROLL
+    for (int ci = 0; ci < MAXCH; ++ci) {
+      const int line = (ci * 2 + yy) * D + dxi;
+      stw[ci] = (dxi >= 0 && dxi < D) ? line * 32 + (((wave * 2 + h) ^ (line & 7)) * 4) : -1;
+    }
+    strd_off = (lane >> 3) * 32 + (((lane & 7) ^ ((lane >> 3) & 7)) * 4);
+    MFN_UNROLL
+    for (int j = 0; j < NSJ_MAX; ++j) {
+      const int line = 8 * (wave + 4 * j) + (lane >> 3);
+      const int ci = line / (2 * D), yl = (line / D) & 1, dl = line % D;
+      const int x = xb0 + 4 * (lane & 7);
+      const bool ok = line < LINES && x < W;
+      cbit[j] = 1 << (ci * 2 + yl);
+      cvoff[j] = ok ? (unsigned)(ci * (2 * D * plane - 2 * W) + ((1 - yl) * D + dl) * plane + yl * W + 4 * (lane & 7)) * 4u : INVALID;
+    }
+    rs_item = mfn_make_rsrc(outn + ((long long)ys * W + xb0 - (long long)D * plane), 0x80000000u);
+    MFN_UNROLL
+    for (int t = 0; t < T; ++t) rowok_bits |= (2 * t < R ? 1u : 0u) << (2 * t) | (2 * t + 1 < R ? 1u : 0u) << (2 * t + 1);
+  }
+
   // prologue: the first NSLOT tiles; tiles 0 (block 0) and 1 (the f2 row of own step 0) -> operands; two more tiles
   mfn_static_for<NSLOT>([&](auto k_c) __attribute__((always_inline)) { issue_tile(k_c); });
   wait_tile(1);
@@ -316,23 +362,50 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
       });
     }
     if (!(MFN_GRAM_ABLATE & 1)) {
+      // active chains of this step, highest block first (ci = 0, 1, ...): t_hi = min(T-1, s/2) downwards while e = s - 2t <= 2MD+1
+      constexpr int t_hi = (s / 2) < (T - 1) ? (s / 2) : (T - 1);
+      constexpr int t_lo = (s - (2 * MD + 1) + 1) / 2 > 0 ? (s - (2 * MD + 1) + 1) / 2 : 0;
+      constexpr int nch = t_hi - t_lo + 1;
+      float *sbuf = stg + (j & 1) * STG_F;
+      unsigned valid_bits = 0;                               // bit (ci*2 + yy): that line group is written this step and its row exists
       MFN_UNROLL
-      for (int t = 0; t < T; ++t) {
+      for (int ci = 0; ci < nch; ++ci) {
+        const int t = t_hi - ci;
         const int e = s - 2 * t;
-        if (e >= 0 && e <= 2 * MD + 1) {
-          // de-skew: register i of lane n holds (x = 4h+i, dx = n-XOFF-4h-i); lane n0 collects dx0 = n0-XOFF-4h from lanes n0+i
-          f32x4 v;
-          v[0] = acc[t][0];
-          v[1] = mfn_dpp_row_shl<1>(acc[t][1], acc[t][1]);
-          v[2] = mfn_dpp_row_shl<2>(acc[t][2], acc[t][2]);
-          v[3] = mfn_dpp_row_shl<3>(acc[t][3], acc[t][3]);
-          if (LEAKY) {
-            MFN_UNROLL
-            for (int i = 0; i < 4; ++i) v[i] = mfn_leaky01(v[i]);
-          }
+        // de-skew: register i of lane n holds (x = 4h+i, dx = n-XOFF-4h-i); lane n0 collects dx0 = n0-XOFF-4h from lanes n0+i
+        f32x4 v;
+        v[0] = acc[t][0];
+        v[1] = mfn_dpp_row_shl<1>(acc[t][1], acc[t][1]);
+        v[2] = mfn_dpp_row_shl<2>(acc[t][2], acc[t][2]);
+        v[3] = mfn_dpp_row_shl<3>(acc[t][3], acc[t][3]);
+        if (LEAKY) {
+          MFN_UNROLL
+          for (int i = 0; i < 4; ++i) v[i] = mfn_leaky01(v[i]);
+        }
+        if (COOP) {
+          // block row 0 is displacement row e (exists while e < D), block row 1 is e-1 (exists from e = 1)
+          if (e < D) valid_bits |= ((rowok_bits >> (2 * t)) & 1u) << (ci * 2);
+          if (e >= 1) valid_bits |= ((rowok_bits >> (2 * t + 1)) & 1u) << (ci * 2 + 1);
+          if (stw[ci] >= 0) *reinterpret_cast<f32x4 *>(sbuf + stw[ci]) = v;
+        } else {
           const unsigned vo = e == 0 ? vo_first[t] : (e == 2 * MD + 1 ? vo_last[t] : vo_mid[t]);
           if (MFN_GRAM_ABLATE & 2) { if (v[0] == 1.2345e30f) mfn_bstore4_so(rs[t], vo, (unsigned)e * dplane4, v, POL); }   // keeps the chain live
           else { mfn_bstore4_so(rs[t], vo, (unsigned)e * dplane4, v, POL); n_issued += 1; }
+        }
+      }
+      if (COOP) {
+        MFN_LDS_BARRIER();                                   // every wave's 32 bytes of every line are in the staging buffer
+        constexpr int ninstr = (nch * 2 * D + 7) / 8;        // 1 KB groups holding this step's lines
+        constexpr int nsj = (ninstr + 3) / 4;                // per wave (the same for every wave: the counted waits are static)
+        // first chain: block t_hi, e0 = s - 2 t_hi; its base = plane (e0-1)*D of row ys + 2 t_hi (relative to rs_item: plane -D of row ys)
+        const unsigned soff = (unsigned)((s - 2 * t_hi) * D * plane + 2 * t_hi * W) * 4u;
+        MFN_UNROLL
+        for (int jj = 0; jj < nsj; ++jj) {
+          const float *src = sbuf + (wave + 4 * jj) * 256 + strd_off;
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+          const unsigned vo = (valid_bits & (unsigned)cbit[jj]) ? cvoff[jj] : INVALID;
+          if (MFN_GRAM_ABLATE & 2) { if (v[0] == 1.2345e30f) mfn_bstore4_so(rs_item, vo, soff, v, POL); }
+          else { mfn_bstore4_so(rs_item, vo, soff, v, POL); n_issued += 1; }
         }
       }
     }
@@ -347,9 +420,11 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   MFN_STAMP(p.timeline, 3);
 }
 
-// One wave per (image, row segment, strip, step parity); NWV adjacent strips per block, no block-wide synchronisation.
-template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP>
+// One wave per (image, row segment, strip, step parity); NWV adjacent strips per block.  COOP (NWV = 4, SP = 1): the block's
+// waves exchange their results through LDS (one barrier per step) and store full 128-byte lines.
+template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP, bool COOP>
 __global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p) {
+  static_assert(!COOP || (NWV == 4 && SP == 1), "cooperative stores: four strips = one 128-byte line, one wave per item");
   MFN_DYN_SHARED(float, lds_all);
   const int lane = threadIdx.x & 63;
   const int wave = MFN_UNIFORM(threadIdx.x >> 6);
@@ -364,25 +439,28 @@ __global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p
   const int seg = rest % p.segs;
   const int n = rest / p.segs;
   const int sx = bxs * NWV + wave;
-  if (sx >= p.strips) return;
+  if (!COOP && sx >= p.strips) return;   // COOP: a wave past the last strip keeps the block's barriers company (its lanes are all masked)
   const int x0 = sx * 8, ys = seg * (2 * T);
-  if (SP == 1 || par == 0) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, 0>(p, ring, lane, n, ys, x0);
+  if (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * 512, wave, bxs * NWV * 8);
+  else if (SP == 1 || par == 0) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, 0>(p, ring, lane, n, ys, x0);
   else corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, SP - 1>(p, ring, lane, n, ys, x0);
 }
 
-template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP = 1>
+template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP = 1, bool COOP = false>
 inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *name) {
+  constexpr int MD = (D - 1) / 2;
+  constexpr int MAXCH = T < MD + 1 ? T : MD + 1;
   p.rows = 2 * T;
   p.strips = cdiv(p.W, 8);
   p.segs = cdiv(p.H, p.rows);
   p.bx_per_row = cdiv(p.strips, NWV);
   const long nblk = (long)p.N * p.segs * SP * p.bx_per_row;
   if (nblk <= 0) return 0;
-  const size_t lds = (size_t)NWV * NSLOT * 512 * sizeof(float);
-  return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
+  const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? 2 * MAXCH * 2 * D * 32 : 0)) * sizeof(float);
+  return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
-inline bool corr_variant_gram(int v) { return v == 40 || v == 41 || v == 43; }
+inline bool corr_variant_gram(int v) { return v >= 40 && v <= 43; }
 // Output rows per work item: 6 or 8 (T = 3 / 4 blocks; the schedule is compile-time).  One wave per item, eight resident waves
 // per CU (two blocks of four): the level-2 launch of 384x512 at batch 8 is 2048 items of 6 rows = one residency round.  Fewer
 // rows per item mean more halo (an item converts rows + 2*md f2 rows); 8 where 6 does not divide H and 8 does (448x1024:
@@ -391,21 +469,25 @@ inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
   if (override_rows == 6 || override_rows == 8) return override_rows;
   return (H % 6 != 0 && H % 8 == 0) ? 8 : 6;
 }
-// corr.variant 40: exact (three terms, six products); 41: two terms, three products (measured variant, ~1e-5 relative; md = 4,
-// six-row items, no fused activation); 43: 40 with TWO waves per item (md = 4, six rows; measured: slower -- kept as the one
-// instantiation that exercises GramSched<SP = 2>).  Ring of 4 tiles (13.2 us; 5: 13.7, 9: 14.6 -- a deep ring only delays the
-// first tiles of 2048 waves that all start together).  Stores: plain unless the caller's policy asks for write-through (the band
-// pattern is 36 x 16 bytes in 32-byte runs per instruction: written through, 14.2 us for the 31.85 MB of level 2 against 8.4 us
-// plain -- profiles/r04_store_pattern_ubench.txt).
+// corr.variant 40: exact (three terms, six products), cooperative stores (full lines through LDS, written through unless the
+// caller's policy says plain); 42: the same with every wave storing its own 32-byte runs (plain stores -- written through that
+// pattern costs 14.2 us for the 31.85 MB of level 2 against 8.4 us, profiles/r04_store_pattern_ubench.txt); 41: two terms,
+// three products on the form of 42 (measured variant, ~1e-5 relative; md = 4, six-row items, no fused activation); 43: 42 with
+// TWO waves per item (md = 4, six rows; measured slower -- the one instantiation that exercises GramSched<SP = 2>).  Ring of 4
+// tiles (13.2 us; 5: 13.7, 9: 14.6 -- a deep ring only delays the first tiles of 2048 waves that all start together).
 template <int D>
 inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s) {
   const bool wt = (p.store_policy & 2) != 0;
-  if (variant == 43 && D == 9 && !p.leaky && !wt && p.rows == 6) return corr_gram_launch<9, 3, 4, 4, 3, 0, false, 2>(p, s, "corr_gram_v43");
-  if (variant == 41 && D == 9 && !p.leaky && p.rows == 6)
-    return wt ? corr_gram_launch<9, 3, 4, 4, 2, 2, false>(p, s, "corr_gram_v41") : corr_gram_launch<9, 3, 4, 4, 2, 0, false>(p, s, "corr_gram_v41");
+  if (variant == 43 && D == 9 && !p.leaky && p.rows == 6) return corr_gram_launch<9, 3, 4, 4, 3, 0, false, 2>(p, s, "corr_gram_v43");
+  if (variant == 41 && D == 9 && !p.leaky && p.rows == 6) return corr_gram_launch<9, 3, 4, 4, 2, 0, false>(p, s, "corr_gram_v41");
+  if (variant == 42) {
+#define MFN_GRAM_(TT_) (p.leaky ? corr_gram_launch<D, TT_, 4, 4, 3, 0, true>(p, s, "corr_gram_v42") : corr_gram_launch<D, TT_, 4, 4, 3, 0, false>(p, s, "corr_gram_v42"))
+    return p.rows == 8 ? MFN_GRAM_(4) : MFN_GRAM_(3);
+#undef MFN_GRAM_
+  }
 #define MFN_GRAM_(TT_) \
-  (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, true>(p, s, "corr_gram_v40")) \
-           : (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, false>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, false>(p, s, "corr_gram_v40")))
+  (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, true, 1, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, true, 1, true>(p, s, "corr_gram_v40")) \
+           : (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, false, 1, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, false, 1, true>(p, s, "corr_gram_v40")))
   return p.rows == 8 ? MFN_GRAM_(4) : MFN_GRAM_(3);
 #undef MFN_GRAM_
 }

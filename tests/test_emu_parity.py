@@ -60,12 +60,16 @@ def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows):
     pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
 
 
-def test_correlation_gram_two_waves_per_item(ops, oracle):
-    """corr.variant 43: two waves per item, each takes every other f2 row -- the same schedule generator (GramSched<SP = 2>), exact."""
-    emu_ops.set_tuning(corr_variant=43, corr_direct=2)
+@pytest.mark.parametrize("variant", [42, 43])
+def test_correlation_gram_wave_private_stores(ops, oracle, variant):
+    """corr.variant 42: every wave stores its own 32-byte runs (no block barrier, plain stores); 43: the same with two waves per
+    item, each taking every other f2 row (GramSched<SP = 2>).  Exact like 40."""
+    emu_ops.set_tuning(corr_variant=variant, corr_direct=2)
     pc.case_correlation(ops, oracle, ident, ident, (2, 32, 13, 20), 4)
-    assert "corr_gram_v43" in emu_ops.launch_log()
+    assert "corr_gram_v%d" % variant in emu_ops.launch_log()
     pc.case_correlation(ops, oracle, ident, ident, (1, 32, 24, 72), 4, seed=3)
+    if variant == 42:
+        pc.case_correlation_leaky(ops, oracle, ident, ident, (1, 32, 7, 36), 2)
 
 
 def test_correlation_gram_by_plan(ops, oracle):

@@ -98,6 +98,15 @@ def test_correlation_gram_is_deterministic_and_matches_the_fma_kernel(ops, T):
     assert (first - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("variant", [42, 43])
+def test_correlation_gram_wave_private_stores(ops, oracle, dev, variant):
+    """corr.variant 42 / 43: the matrix-core kernel without the cooperative stores (every wave its own 32-byte runs, plain)."""
+    from maskflownet_amd import _lib
+    _lib.set_tuning(corr_variant=variant)
+    pc.case_correlation(ops, oracle, dev, host, (8, 32, 96, 128), 4)
+    pc.case_correlation(ops, oracle, dev, host, (2, 32, 37, 76), 4, seed=1)
+
+
 def test_correlation_gram_two_term_variant(ops, oracle, dev):
     """corr.variant 41: two bf16 terms, three products (measured variant): 2^-17 relative per product."""
     from maskflownet_amd import _lib

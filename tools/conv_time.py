@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Measurement: the convolution layers of MaskFlownet-S (MaskFlownet.py:79-163) at the bench batch, inside a hipGraph --
-us per layer and fp32 TFLOP/s, next to torch's (MIOpen) convolution of the same shape.  usage: conv_time.py [N] [tuning]"""
+us per layer and fp32 TFLOP/s, next to torch's (MIOpen) convolution of the same shape.  usage: conv_time.py [N] [tuning] [dc]"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,6 +18,8 @@ LAYERS = [("conv1a", 3, 16, 384, 512, 2, 1), ("conv1b", 16, 16, 192, 256, 1, 1),
           ("conv2_0", 131, 128, 96, 128, 1, 1), ("conv2_1", 259, 128, 96, 128, 1, 1), ("conv2_2", 387, 96, 96, 128, 1, 1),
           ("conv2_3", 483, 64, 96, 128, 1, 1), ("conv2_4", 547, 32, 96, 128, 1, 1), ("pred_flow2", 579, 2, 96, 128, 1, 1),
           ("dc_conv1", 579, 128, 96, 128, 1, 1), ("dc_conv3", 128, 128, 96, 128, 1, 4), ("dc_conv5", 96, 64, 96, 128, 1, 16)]
+if len(sys.argv) > 3 and sys.argv[3] == "dc":   # the 3x3 convolutions that sit inside the four DeformableConvolutions of the pass
+    LAYERS = [("deform5", 128, 128, 12, 16, 1, 1), ("deform4", 96, 96, 24, 32, 1, 1), ("deform3", 64, 64, 48, 64, 1, 1), ("deform2", 32, 32, 96, 128, 1, 1)]
 st = torch.cuda.Stream()
 tot = [0.0, 0.0, 0.0]
 for name, cin, cout, h, w, s, d in LAYERS:
