@@ -42,6 +42,8 @@
 #ifndef MFN_GRAM_SCHED
 #define MFN_GRAM_SCHED 1
 #endif
+// (measured and removed: the residuals of the operand split by v_dot2c_f32_bf16 d, {-1, 0}, packed -- 7 instead of 9 VALU per pair,
+// exact in isolation (tools/ubench/dot2c_check.hip), no faster in the kernel (11.5 against 11.4 us) and it needs hand-placed wait states)
 
 namespace mfn {
 
@@ -86,7 +88,8 @@ __device__ __forceinline__ void gram_split_pair(float x0, float x1, GramWords &w
   w.h[q] = hp;
   if (TERMS == 3) {
     const f32x2 mf = {__builtin_bit_cast(float, mp << 16), __builtin_bit_cast(float, mp & 0xffff0000u)};
-    w.m[q] = mp; w.l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1 - mf, bf2));
+    const f32x2 r2 = r1 - mf;
+    w.m[q] = mp; w.l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf2));
   } else { w.m[q] = mp; w.l[q] = mp; }
 #endif
 }
@@ -292,6 +295,32 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     if constexpr (k < TT) issue_tile(std::integral_constant<int, k>{});
   });
 
+  // chains of step s: blocks t_hi .. t_lo (e = s - 2t within [0, 2MD+1]); 1 KB groups of their lines, per wave
+  struct Ch {
+    static constexpr int hi(int s) { return (s / 2) < (T - 1) ? (s / 2) : (T - 1); }
+    static constexpr int lo(int s) { return (s - (2 * MD + 1) + 1) / 2 > 0 ? (s - (2 * MD + 1) + 1) / 2 : 0; }
+    static constexpr int per_wave(int s) { return (((hi(s) - lo(s) + 1) * 2 * D + 7) / 8 + 3) / 4; }
+  };
+  auto chains_hi = [](int s) constexpr { return Ch::hi(s); };
+  auto chains_lo = [](int s) constexpr { return Ch::lo(s); };
+  auto stores_per_wave = [](int s) constexpr { return Ch::per_wave(s); };
+  unsigned valid_pending = 0;       // valid_bits of the step whose lines wait in the staging buffer
+  // the staged lines of own step jp (already read back into v[]) -> global memory: the same number of store instructions in
+  // every wave (the counted waits are static); first chain = block t_hi, e0 = s - 2 t_hi: its base is plane (e0-1)*D of row
+  // ys + 2 t_hi, i.e. soffset (e0*D*plane + 2 t_hi W)*4 from rs_item (plane -D of row ys)
+  auto store_lines = [&](auto jp_c, const f32x4 *v, unsigned valid) __attribute__((always_inline)) {
+    constexpr int sp = SC::step(decltype(jp_c)::value);
+    constexpr int th = Ch::hi(sp);
+    constexpr int nsj = Ch::per_wave(sp);
+    const unsigned soff = (unsigned)((sp - 2 * th) * D * plane + 2 * th * W) * 4u;
+    MFN_UNROLL
+    for (int jj = 0; jj < nsj; ++jj) {
+      const unsigned vo = (valid & (unsigned)cbit[jj]) ? cvoff[jj] : INVALID;
+      if (MFN_GRAM_ABLATE & 2) { if (v[jj][0] == 1.2345e30f) mfn_bstore4_so(rs_item, vo, soff, v[jj], POL); }
+      else { mfn_bstore4_so(rs_item, vo, soff, v[jj], POL); n_issued += 1; }
+    }
+  };
+
   mfn_static_for<J>([&](auto j_c) __attribute__((always_inline)) {
     constexpr int j = decltype(j_c)::value;
     constexpr int s = SC::step(j);
@@ -363,10 +392,20 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     }
     if (!(MFN_GRAM_ABLATE & 1)) {
       // active chains of this step, highest block first (ci = 0, 1, ...): t_hi = min(T-1, s/2) downwards while e = s - 2t <= 2MD+1
-      constexpr int t_hi = (s / 2) < (T - 1) ? (s / 2) : (T - 1);
-      constexpr int t_lo = (s - (2 * MD + 1) + 1) / 2 > 0 ? (s - (2 * MD + 1) + 1) / 2 : 0;
-      constexpr int nch = t_hi - t_lo + 1;
+      constexpr int t_hi = chains_hi(s);
+      constexpr int nch = t_hi - chains_lo(s) + 1;
       float *sbuf = stg + (j & 1) * STG_F;
+      // Cooperative stores are one step late: the lines of step j-1 (staged before the barrier below) are read back here,
+      // behind this step's matrix instructions, and stored after this step's own results went into the other staging buffer --
+      // the barrier wait and the LDS round trip hide behind work instead of ending every step.
+      constexpr int nsj_prev = COOP && j > 0 ? stores_per_wave(SC::step(j > 0 ? j - 1 : 0)) : 0;
+      f32x4 vprev[nsj_prev > 0 ? nsj_prev : 1];
+      if (COOP && j > 0) {
+        MFN_LDS_BARRIER();                                   // every wave's 32 bytes of every line of step j-1 are staged
+        const float *pbuf = stg + ((j - 1) & 1) * STG_F;
+        MFN_UNROLL
+        for (int jj = 0; jj < nsj_prev; ++jj) vprev[jj] = *reinterpret_cast<const f32x4 *>(pbuf + (wave + 4 * jj) * 256 + strd_off);
+      }
       unsigned valid_bits = 0;                               // bit (ci*2 + yy): that line group is written this step and its row exists
       MFN_UNROLL
       for (int ci = 0; ci < nch; ++ci) {
@@ -386,33 +425,29 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
           // block row 0 is displacement row e (exists while e < D), block row 1 is e-1 (exists from e = 1)
           if (e < D) valid_bits |= ((rowok_bits >> (2 * t)) & 1u) << (ci * 2);
           if (e >= 1) valid_bits |= ((rowok_bits >> (2 * t + 1)) & 1u) << (ci * 2 + 1);
-          if (stw[ci] >= 0) *reinterpret_cast<f32x4 *>(sbuf + stw[ci]) = v;
+          if (stw[ci] >= 0) *reinterpret_cast<f32x4 *>(sbuf + stw[ci]) = v;   // (an unconditional write into a dummy slot instead of the exec mask: measured, no gain)
         } else {
           const unsigned vo = e == 0 ? vo_first[t] : (e == 2 * MD + 1 ? vo_last[t] : vo_mid[t]);
           if (MFN_GRAM_ABLATE & 2) { if (v[0] == 1.2345e30f) mfn_bstore4_so(rs[t], vo, (unsigned)e * dplane4, v, POL); }   // keeps the chain live
           else { mfn_bstore4_so(rs[t], vo, (unsigned)e * dplane4, v, POL); n_issued += 1; }
         }
       }
-      if (COOP) {
-        MFN_LDS_BARRIER();                                   // every wave's 32 bytes of every line are in the staging buffer
-        constexpr int ninstr = (nch * 2 * D + 7) / 8;        // 1 KB groups holding this step's lines
-        constexpr int nsj = (ninstr + 3) / 4;                // per wave (the same for every wave: the counted waits are static)
-        // first chain: block t_hi, e0 = s - 2 t_hi; its base = plane (e0-1)*D of row ys + 2 t_hi (relative to rs_item: plane -D of row ys)
-        const unsigned soff = (unsigned)((s - 2 * t_hi) * D * plane + 2 * t_hi * W) * 4u;
-        MFN_UNROLL
-        for (int jj = 0; jj < nsj; ++jj) {
-          const float *src = sbuf + (wave + 4 * jj) * 256 + strd_off;
-          const f32x4 v = *reinterpret_cast<const f32x4 *>(src);
-          const unsigned vo = (valid_bits & (unsigned)cbit[jj]) ? cvoff[jj] : INVALID;
-          if (MFN_GRAM_ABLATE & 2) { if (v[0] == 1.2345e30f) mfn_bstore4_so(rs_item, vo, soff, v, POL); }
-          else { mfn_bstore4_so(rs_item, vo, soff, v, POL); n_issued += 1; }
-        }
-      }
+      if (COOP && j > 0) store_lines(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{}, vprev, valid_pending);
+      valid_pending = valid_bits;
     }
     if (more) Ncur = Nnext;
     if (j == J / 2 - 1) MFN_STAMP(p.timeline, 2);
     MFN_SCHED_BARRIER();
   });
+  if (COOP && !(MFN_GRAM_ABLATE & 1)) {   // the last step's lines
+    constexpr int nsj = Ch::per_wave(SC::step(J - 1));
+    f32x4 vlast[nsj];
+    MFN_LDS_BARRIER();
+    const float *pbuf = stg + ((J - 1) & 1) * STG_F;
+    MFN_UNROLL
+    for (int jj = 0; jj < nsj; ++jj) vlast[jj] = *reinterpret_cast<const f32x4 *>(pbuf + (wave + 4 * jj) * 256 + strd_off);
+    store_lines(std::integral_constant<int, J - 1>{}, vlast, valid_pending);
+  }
   if (MFN_GRAM_ABLATE & 1) {   // keep the conversions live
     float sink = mfn_bf16_at(reinterpret_cast<const float *>(&Ncur), 0) + mfn_bf16_at(reinterpret_cast<const float *>(&Mreg[T - 1]), 1);
     if (sink == 1.2345e30f) outn[lane] = sink;
@@ -474,7 +509,8 @@ inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
 // pattern costs 14.2 us for the 31.85 MB of level 2 against 8.4 us, profiles/r04_store_pattern_ubench.txt); 41: two terms,
 // three products on the form of 42 (measured variant, ~1e-5 relative; md = 4, six-row items, no fused activation); 43: 42 with
 // TWO waves per item (md = 4, six rows; measured slower -- the one instantiation that exercises GramSched<SP = 2>).  Ring of 4
-// tiles (13.2 us; 5: 13.7, 9: 14.6 -- a deep ring only delays the first tiles of 2048 waves that all start together).
+// tiles (wave-private stores: 13.2 us; 5: 13.7, 9: 14.6; cooperative: 10.45 us, 6: 10.8 and no better on cold buffers -- a deep
+// ring only delays the first tiles of 2048 waves that all start together).
 template <int D>
 inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s) {
   const bool wt = (p.store_policy & 2) != 0;
