@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # MFN_HIP_SO: measurement builds of the same HIP library (tools/ablate.py); never a different backend
 SO_PATH = os.environ.get("MFN_HIP_SO") or os.path.join(CSRC, "libmfn_hip.so")
+RES_PATH = os.path.join(CSRC, "libmfn_hip.resources.txt")   # hipcc's kernel-resource-usage remarks of the shipped build
 # -fno-slp-vectorize: the SLP vectoriser rewrites the correlation inner product into v_pk_fma_f32 fed by
 # dozens of re-issued ds_read2_b32 (unaligned operand pairs re-read from LDS), which made the kernel
 # LDS-bound with 64% bank-conflict cycles (profiles/r01_corr_pmc.md)
@@ -72,23 +73,54 @@ def build(force=False, verbose=False):
     hash of its sources; it is reused only when that hash equals the sources' present one (mtimes play no role)."""
     global last_build, _lib
     want = source_hash()
-    if not force and built_hash() == want:
+    res_ok = os.path.exists(RES_PATH) and open(RES_PATH).readline().strip() == "# src=%s" % want
+    if not force and built_hash() == want and res_ok:
         last_build = "reused"
         if verbose:
             print("libmfn_hip.so reused (src=%s)" % want)
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "hipcc")
     tmp = SO_PATH + ".tmp%d" % os.getpid()   # never dlopen()ed under this name: a fresh inode replaces the old library
-    cmd = [hipcc] + HIPCC_FLAGS + ['-DMFN_SOURCE_HASH="%s"' % want, "-o", tmp, os.path.join(CSRC, "api.hip")]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage", '-DMFN_SOURCE_HASH="%s"' % want, "-o", tmp,
+           os.path.join(CSRC, "api.hip")]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # the compiler's per-kernel resource remarks (registers, scratch, LDS, occupancy) go next to the library: kernels whose waits
+    # are counted by hand (correlation_gram.h, the asynchronous gathers of deform_conv.h) are only correct without compiler-made
+    # scratch traffic, and tests/test_abi.py checks exactly that on the build that ships
+    proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    remarks = [l for l in proc.stderr.splitlines() if "remark:" in l]
+    other = [l for l in proc.stderr.splitlines() if "remark:" not in l and "-Rpass-analysis" not in l]
+    if proc.returncode != 0:
+        raise subprocess.CalledProcessError(proc.returncode, cmd, stderr="\n".join(other[-60:]))
+    with open(RES_PATH + ".tmp%d" % os.getpid(), "w") as f:
+        f.write("# src=%s\n" % want)
+        f.write("\n".join(remarks) + "\n")
+    os.replace(RES_PATH + ".tmp%d" % os.getpid(), RES_PATH)
     os.replace(tmp, SO_PATH)
     _lib = None
     last_build = "rebuilt"
     if verbose:
         print("libmfn_hip.so rebuilt (src=%s)" % want)
     return SO_PATH
+
+
+def kernel_resources():
+    """{demangled kernel name: {"VGPRs": n, "ScratchSize [bytes/lane]": n, ...}} of the shipped build (written by build())."""
+    import re
+    out, cur = {}, None
+    if not os.path.exists(RES_PATH):
+        return out
+    with open(RES_PATH) as f:
+        for line in f:
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = out.setdefault(m.group(1), {})
+                continue
+            m = re.search(r"remark:\s+([A-Za-z \[\]/]+?):\s+(\S+)", line)
+            if m and cur is not None:
+                cur[m.group(1).strip()] = m.group(2)
+    return out
 
 
 def lib():

@@ -145,3 +145,32 @@ def test_every_tuning_key_used_by_tests_tools_and_bench_exists():
     unknown = {k: sorted(v) for k, v in used.items() if k not in keys}
     assert not unknown, unknown
     assert len(used) >= 8, sorted(used)   # the scan does find the calls
+
+
+def test_kernels_with_hand_counted_waits_have_no_compiler_scratch():
+    """correlation_gram.h counts its own vmcnt waits (LDS-DMA loads AND stores, all inline asm) and the deformable convolution's
+    default gather tier keeps asynchronous global loads in flight (mfn_gload4_async): a compiler-made scratch load or store in
+    those kernels would join the same in-order queue uncounted.  _lib.build() keeps hipcc's kernel-resource-usage remarks of the
+    build that ships; the kernels concerned must show no scratch and no spills (a build-time check instead of
+    trusting the register allocator).  dc.mma = 1 (a measured, non-default variant) may use scratch in one instantiation --
+    reported, not asserted."""
+    import subprocess
+    from maskflownet_amd import _lib
+    _lib.build()
+    res = _lib.kernel_resources()
+    assert len(res) > 50, "no kernel-resource remarks next to libmfn_hip.so: %s" % _lib.RES_PATH
+    seen = {"gram": 0, "dc": 0}
+    for mangled, r in res.items():
+        name = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout.strip()
+        clean = r.get("ScratchSize [bytes/lane]") == "0" and r.get("VGPRs Spill") == "0"
+        if "corr_gram_kernel" in name:
+            seen["gram"] += 1
+            assert clean, (name, r)
+        elif "dc_lds_kernel<" in name:
+            mma = name.split("<")[1].split(">")[0].split(",")[3].strip() == "1"
+            seen["dc"] += 1
+            if not mma:
+                assert clean, (name, r)
+            elif not clean:
+                print("note: %s uses %s bytes of scratch per lane" % (name, r.get("ScratchSize [bytes/lane]")))
+    assert seen["gram"] >= 8 and seen["dc"] >= 4, seen
