@@ -72,6 +72,9 @@ def test_correlation_gram_wave_private_stores(ops, oracle, variant):
         pc.case_correlation_leaky(ops, oracle, ident, ident, (1, 32, 7, 36), 2)
 
 
+@pytest.mark.skipif(__import__("os").environ.get("MFN_SLOW_TESTS") != "1",
+                    reason="95 s on the emulation (400 tiles of 32 x 4 is the plan's threshold): MFN_SLOW_TESTS=1 runs it; the GPU "
+                           "suite runs the plan's choice at every BASELINE level shape")
 def test_correlation_gram_by_plan(ops, oracle):
     """corr.gram = 1: the plan hands 32-channel levels of >= 400 tiles to the matrix-core kernel (and nothing else)."""
     emu_ops.set_tuning(corr_gram=1)
