@@ -511,6 +511,205 @@ inline int conv_pack_launch(ConvPackParams pp, hipStream_t stream) {
   return launch("conv_pack_weights", conv_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pp);
 }
 
+// ---- few-filter 3x3 convolution: the prediction heads (MaskFlownet.py:131-163: pred_flow / pred_mask, 2 + 1 filters over up to
+// 579 channels) --------------------------------------------------------------------------------------------------------------
+// On the 32-filter MFMA tile a 2-filter head runs at 6 TFLOP/s (pred_flow2: 322 us for 228 MB of input); the layer is a
+// channel reduction that is bound by reading x once.  Here a lane owns a 4 x 2 block of output pixels and ALL CO <= 4 filters:
+// per channel four rows, ONE 16-byte load each -- the left / right neighbour columns come from the adjacent lanes by a DPP
+// wave shift (lanes are consecutive 4-pixel groups of a row and 64 is a multiple of the groups per row or the other way
+// round, so lane 0 always starts a row) -- feed 72 * CO FMAs; the filter taps are scalar loads.  The block's NW waves split
+// the channels (c = wave, wave + NW, ...) and add their partial sums through LDS in wave order (deterministic).
+// Levels with few lane tiles (heads3 .. heads6: 48 .. 1 tiles of 64 lanes) also split the channels over blockIdx.y; those
+// blocks write raw partial sums and conv_few_reduce_kernel adds them in block order (+ bias, activation).
+// stride 1, pad 1, dilation 1, W % 4 == 0, 16-byte aligned rows (the plan checks).
+struct ConvFewParams {
+  const float *x, *w, *bias;
+  float *out;
+  int N, Cin, H, W, Cout;
+  size_t x_nstride, out_nstride;
+  int leaky;
+  int gw, gh, G;   // 4-pixel groups per row, row pairs per image, lanes in total
+  int kb, cpk;     // channel blocks over blockIdx.y (coarse levels: a level's few lane tiles leave CUs idle) and channels per block;
+  float *partial;  // kb > 1: raw partial sums [kb][N][CO][H][W], summed in block order by conv_few_reduce_kernel
+};
+template <int CO, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_few_kernel(ConvFewParams p) {
+  MFN_DYN_SHARED(float, red);   // [NW-1][CO*8][64]
+  const int lane = threadIdx.x & 63;
+  const int wave = MFN_UNIFORM(threadIdx.x >> 6);
+  const int gid = blockIdx.x * 64 + lane;
+  const bool valid = gid < p.G;
+  const int gc = valid ? gid : 0;
+  const int H = p.H, W = p.W;
+  const int rowi = gc / p.gw, xq = gc - rowi * p.gw;
+  const int n = rowi / p.gh, y0 = 2 * (rowi - n * p.gh);
+  const int x0 = 4 * xq;
+  const size_t plane = (size_t)H * W;
+  // the four source rows y0-1 .. y0+2: clamped index + a 0 / 1 factor (the zero padding of the convolution)
+  int ro[4];
+  float rk[4];
+  MFN_UNROLL
+  for (int r = 0; r < 4; ++r) {
+    const int yy = y0 - 1 + r;
+    rk[r] = (yy >= 0 && yy < H && valid) ? 1.f : 0.f;
+    ro[r] = min(max(yy, 0), H - 1) * W + x0;
+  }
+  const float lk = xq > 0 ? 1.f : 0.f, rrk = xq + 1 < p.gw ? 1.f : 0.f;   // the row's first / last group: padding columns
+  float acc[CO][2][4];
+  MFN_UNROLL
+  for (int o = 0; o < CO; ++o)
+    MFN_UNROLL
+    for (int i = 0; i < 8; ++i) acc[o][i >> 2][i & 3] = 0.f;
+  const float *xn = p.x + (size_t)n * p.x_nstride;
+  // two channels per iteration, the loads (rows and filter taps) of both requested before either is used: on the coarse levels
+  // a block is alone on its CU and every iteration is one memory round trip (one channel per iteration: 59 us for 33 channels
+  // per wave at level 6)
+  auto rows_of = [&](int c, float4 (&m)[4]) {
+    const float *pc = xn + (size_t)(c < p.Cin ? c : 0) * plane;
+    MFN_UNROLL
+    for (int r = 0; r < 4; ++r) m[r] = *reinterpret_cast<const float4 *>(pc + ro[r]);
+  };
+  auto accumulate = [&](int c, int c_hi, const float4 (&m)[4]) {
+    const float live = c < c_hi ? 1.f : 0.f;    // the odd channel out of a pair contributes nothing
+    const float *wc = p.w + (size_t)(c < p.Cin ? c : 0) * 9;   // filter o: + o * Cin * 9 (uniform: scalar loads)
+    float v[4][6];
+    MFN_UNROLL
+    for (int r = 0; r < 4; ++r) {
+      const float k = rk[r] * live;
+      v[r][1] = m[r].x * k; v[r][2] = m[r].y * k; v[r][3] = m[r].z * k; v[r][4] = m[r].w * k;
+      v[r][0] = mfn_dpp_wave_shr1(0.f, v[r][4]) * lk;    // the previous lane's last column
+      v[r][5] = mfn_dpp_wave_shl1(0.f, v[r][1]) * rrk;   // the next lane's first column
+    }
+    MFN_UNROLL
+    for (int o = 0; o < CO; ++o)
+      MFN_UNROLL
+      for (int r = 0; r < 3; ++r) {
+        const float w0 = wc[(size_t)o * p.Cin * 9 + r * 3], w1 = wc[(size_t)o * p.Cin * 9 + r * 3 + 1], w2 = wc[(size_t)o * p.Cin * 9 + r * 3 + 2];
+        MFN_UNROLL
+        for (int yy = 0; yy < 2; ++yy)
+          MFN_UNROLL
+          for (int i = 0; i < 4; ++i)
+            acc[o][yy][i] = fmaf(w2, v[r + yy][i + 2], fmaf(w1, v[r + yy][i + 1], fmaf(w0, v[r + yy][i], acc[o][yy][i])));
+      }
+  };
+  const int c_end = min(p.Cin, ((int)blockIdx.y + 1) * p.cpk);
+  MFN_NOUNROLL
+  for (int c = (int)blockIdx.y * p.cpk + wave; c < c_end; c += 2 * NW) {
+    float4 ma[4], mb[4];
+    rows_of(c, ma);
+    rows_of(c + NW, mb);
+    accumulate(c, c_end, ma);
+    accumulate(c + NW, c_end, mb);
+  }
+  // K slices -> wave 0, in wave order
+  if (NW > 1) {
+    if (wave > 0) {
+      float *dst = red + ((size_t)(wave - 1) * CO * 8) * 64 + lane;
+      MFN_UNROLL
+      for (int o = 0; o < CO; ++o)
+        MFN_UNROLL
+        for (int i = 0; i < 8; ++i) dst[(o * 8 + i) * 64] = acc[o][i >> 2][i & 3];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    MFN_NOUNROLL
+    for (int k = 1; k < NW; ++k) {
+      const float *src = red + ((size_t)(k - 1) * CO * 8) * 64 + lane;
+      MFN_UNROLL
+      for (int o = 0; o < CO; ++o)
+        MFN_UNROLL
+        for (int i = 0; i < 8; ++i) acc[o][i >> 2][i & 3] += src[(o * 8 + i) * 64];
+    }
+  }
+  if (!valid) return;
+  if (p.kb > 1) {   // raw partial sums of this channel block
+    float *pn = p.partial + (((size_t)blockIdx.y * p.N + n) * CO) * plane + (size_t)y0 * W + x0;
+    MFN_UNROLL
+    for (int o = 0; o < CO; ++o)
+      MFN_UNROLL
+      for (int yy = 0; yy < 2; ++yy)
+        if (y0 + yy < H)
+          *reinterpret_cast<float4 *>(pn + (size_t)o * plane + (size_t)yy * W) = make_float4(acc[o][yy][0], acc[o][yy][1], acc[o][yy][2], acc[o][yy][3]);
+    return;
+  }
+  float *on = p.out + (size_t)n * p.out_nstride + (size_t)y0 * W + x0;
+  MFN_UNROLL
+  for (int o = 0; o < CO; ++o) {
+    const float b = p.bias ? p.bias[o] : 0.f;
+    MFN_UNROLL
+    for (int yy = 0; yy < 2; ++yy) {
+      if (y0 + yy >= H) continue;
+      float v[4];
+      MFN_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        const float s = acc[o][yy][i] + b;
+        v[i] = p.leaky ? fmaxf(s, 0.1f * s) : s;
+      }
+      *reinterpret_cast<float4 *>(on + (size_t)o * plane + (size_t)yy * W) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+inline bool conv_few_shape_ok(int W) {   // lane 0 of every wave must start a row: 64 % (W/4) == 0 or (W/4) % 64 == 0
+  const int gw = W / 4;
+  return W % 4 == 0 && gw >= 1 && (64 % gw == 0 || gw % 64 == 0);
+}
+// channel blocks of a level: until the launch has ~256 blocks, at most 8, at least 32 channels each
+inline int conv_few_kb(int N, int Cin, int H, int W) {
+  const int nblk = cdiv(N * ((H + 1) / 2) * (W / 4), 64);
+  int kb = 1;
+  while (kb < 8 && nblk * kb < 192 && Cin / (kb * 2) >= 32) kb *= 2;
+  return kb;
+}
+struct ConvFewReduceParams { const float *partial; const float *bias; float *out; int N, CO, kb, leaky; size_t plane4, out_nstride4; };
+__global__ __launch_bounds__(256) void conv_few_reduce_kernel(ConvFewReduceParams p) {
+  const size_t n4 = (size_t)p.N * p.CO * p.plane4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 *src = reinterpret_cast<const float4 *>(p.partial);
+  float4 sum = src[i];
+  for (int k = 1; k < p.kb; ++k) {
+    const float4 v = src[(size_t)k * n4 + i];
+    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  }
+  const size_t img = i / ((size_t)p.CO * p.plane4), rem = i - img * (size_t)p.CO * p.plane4;
+  const int o = (int)(rem / p.plane4);
+  const float b = p.bias ? p.bias[o] : 0.f;
+  float r[4] = {sum.x + b, sum.y + b, sum.z + b, sum.w + b};
+  if (p.leaky) { MFN_UNROLL for (int q = 0; q < 4; ++q) r[q] = fmaxf(r[q], 0.1f * r[q]); }
+  reinterpret_cast<float4 *>(p.out)[img * p.out_nstride4 + rem] = make_float4(r[0], r[1], r[2], r[3]);
+}
+template <int CO>
+inline int conv_few_launch_co(ConvFewParams p, hipStream_t s) {
+  const int nblk = cdiv(p.G, 64);
+  // channels over 8 waves where the level has >= 128 wave tiles (level 2: 192 blocks = 1536 waves), over 16 below
+  int rc;
+  if (nblk >= 128) rc = launch("conv3x3_few", conv_few_kernel<CO, 8>, dim3(nblk, p.kb), dim3(512), (size_t)7 * CO * 8 * 64 * sizeof(float), s, p);
+  else rc = launch("conv3x3_few", conv_few_kernel<CO, 16>, dim3(nblk, p.kb), dim3(1024), (size_t)15 * CO * 8 * 64 * sizeof(float), s, p);
+  if (rc || p.kb <= 1) return rc;
+  const size_t plane4 = (size_t)p.H * p.W / 4;
+  ConvFewReduceParams rp{p.partial, p.bias, p.out, p.N, CO, p.kb, p.leaky, plane4, p.out_nstride / 4};
+  const size_t n4 = (size_t)p.N * CO * plane4;
+  return launch("conv3x3_few_reduce", conv_few_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, rp);
+}
+// workspace: the channel blocks' partial sums (0 when the level needs one block)
+inline size_t conv_few_workspace_bytes(int N, int Cin, int H, int W, int Cout) {
+  const int kb = conv_few_kb(N, Cin, H, W);
+  return kb > 1 ? (size_t)kb * N * Cout * H * W * sizeof(float) : 0;
+}
+inline int conv_few_launch(const ConvParams &c, void *workspace, size_t ws_bytes, hipStream_t s) {
+  int kb = conv_few_kb(c.N, c.Cin, c.H, c.W);
+  if (kb > 1 && (!workspace || ws_bytes < conv_few_workspace_bytes(c.N, c.Cin, c.H, c.W, c.Cout) || ((uintptr_t)workspace & 15))) kb = 1;   // still correct
+  const int cpk = kb > 1 ? ((cdiv(c.Cin, kb) + 1) & ~1) : c.Cin;
+  ConvFewParams p{c.x, c.w, c.bias, c.out, c.N, c.Cin, c.H, c.W, c.Cout, c.x_nstride, c.out_nstride, c.leaky, c.W / 4, (c.H + 1) / 2,
+                  c.N * ((c.H + 1) / 2) * (c.W / 4), kb, cpk, (float *)workspace};
+  switch (c.Cout) {
+    case 1: return conv_few_launch_co<1>(p, s);
+    case 2: return conv_few_launch_co<2>(p, s);
+    case 3: return conv_few_launch_co<3>(p, s);
+    default: return conv_few_launch_co<4>(p, s);
+  }
+}
+
 // ---- generic fallback: one thread per output element ------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_generic_kernel(ConvParams p) {
   const size_t oplane = (size_t)p.Ho * p.Wo;

@@ -56,6 +56,8 @@ static inline float mfn_bf16_at(const float *base, int idx) {   // element idx o
 // Gram-band cost volume (correlation_gram.h): bf16 matrix-core tile, DPP row shift, range-checked buffer store, counted wait
 #define MFN_MFMA_16x16x32_BF16(a, b, c) hipemu_mfma_16x16x32_bf16((a), (b), (c))
 template <int N> static inline float mfn_dpp_row_shl(float old, float src) { return hipemu_dpp_row_shl(old, src, N); }
+static inline float mfn_dpp_wave_shr1(float old, float src) { return hipemu_dpp_wave_shift(old, src, -1); }   // lane i <- lane i-1
+static inline float mfn_dpp_wave_shl1(float old, float src) { return hipemu_dpp_wave_shift(old, src, +1); }   // lane i <- lane i+1
 static inline float mfn_leaky01(float v) { return fmaxf(v, 0.1f * v); }
 static inline void mfn_split2x8(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &l) {
   for (int e = 0; e < 8; ++e) {
@@ -210,6 +212,13 @@ __device__ __forceinline__ float mfn_bf16_at(const float *base, int idx) {   // 
 // v_mov_b32_dpp row_shl:N -- lane i of every 16-lane row receives lane i+N of its row; lanes whose source is outside the row keep `old`
 template <int N> __device__ __forceinline__ float mfn_dpp_row_shl(float old, float src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x100 + N, 0xf, 0xf, false));
+}
+// v_mov_b32_dpp wave_shr:1 / wave_shl:1 (gfx9 family): lane i receives lane i-1 / i+1 of the whole wave; lane 0 / 63 keeps `old`
+__device__ __forceinline__ float mfn_dpp_wave_shr1(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float mfn_dpp_wave_shl1(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x130, 0xf, 0xf, false));
 }
 // LeakyReLU(0.1)(v) = max(v, 0.1 v) as v_mul + v_max (fmaxf() puts a canonicalising v_max in front of each operand)
 __device__ __forceinline__ float mfn_leaky01(float v) {

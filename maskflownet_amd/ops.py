@@ -634,9 +634,13 @@ class OpSet:
         p = lambda a: self.ad.ptr(a) if a is not None else None
         if packed is not None:
             packed.require(dims)
+            # plain-layout weights = the generic or the few-filter kernel; the latter wants scratch for the partial sums of its
+            # channel blocks on the coarse levels (0 bytes otherwise; the MFMA plans' figure is the re-layout they do not need)
+            nbytes = self.ns.conv2d_workspace_bytes(*dims) if packed.tag == 0x4d43ffff00000000 else 0
+            ws = self._workspace(x, nbytes) if nbytes else None
             self.check(self.ns.conv2d_fwd(p(x), x_nstride, None, self.ad.ptr(packed.buf), packed.nbytes, packed.tag, p(b),
-                                          self.ad.ptr(out), nstride, *dims, ah, aw, 1 if activation == "leaky" else 0, None, 0,
-                                          self.ad.stream(x)))
+                                          self.ad.ptr(out), nstride, *dims, ah, aw, 1 if activation == "leaky" else 0, p(ws),
+                                          self.ad.nbytes(ws) if ws is not None else 0, self.ad.stream(x)))
             return out
         nbytes = self.ns.conv2d_workspace_bytes(*dims)
         ws = self._workspace(x, nbytes) if nbytes else None

@@ -281,6 +281,17 @@ static inline float hipemu_dpp_row_shl(float old, float src, int n) {
   w.bar.arrive_and_wait();
   return r;
 }
+// DPP wave_shr:1 (dir = -1: lane i receives lane i-1) / wave_shl:1 (dir = +1: lane i+1); the lane without a source keeps `old`
+static inline float hipemu_dpp_wave_shift(float old, float src, int dir) {
+  hipemu::Wave &w = hipemu::wave();
+  const int lane = (int)hipemu::t_lane;
+  w.f[lane] = src;
+  w.bar.arrive_and_wait();
+  const int from = lane + dir;
+  const float r = (from >= 0 && from < 64) ? w.f[from] : old;
+  w.bar.arrive_and_wait();
+  return r;
+}
 // v_mfma_f32_16x16x4_f32: A lane l = A[i=l&15][k=l>>4], B lane l = B[k=l>>4][j=l&15],
 // D reg r of lane l = D[row=(l>>4)*4+r][col=l&15].
 static inline f32x4_emu hipemu_mfma_16x16x4(float a, float b, f32x4_emu c) {

@@ -592,6 +592,38 @@ def test_conv3x3_strides_and_dilations(ops, oracle, kw):
     pc.case_conv(ops, oracle, ident, ident, 1, 6, 10, 11, 19, bias=bias, **kw)
 
 
+@pytest.mark.parametrize("Cout", [1, 2, 3, 4])
+def test_conv3x3_few_filters(ops, oracle, Cout):
+    """The prediction heads (pred_flow / pred_mask: 2 + 1 filters over hundreds of channels, MaskFlownet.py:131-163):
+    conv_few_kernel -- a lane owns four pixels and every filter, the block's waves split the channels and add through LDS."""
+    emu_ops.launch_log()
+    pc.case_conv(ops, oracle, ident, ident, 2, 37, Cout, 6, 16, pad=(1, 1), seed=Cout)               # 16 K slices (few groups), ragged channel split
+    assert "conv3x3_few" in emu_ops.launch_log()
+    pc.case_conv(ops, oracle, ident, ident, 1, 5, Cout, 3, 8, pad=(1, 1), leaky=True, bias=False, seed=9)   # fewer channels than waves
+    # packed-weight form (what network.py passes) and a concat-buffer suffix as input
+    rng = np.random.default_rng(3)
+    buf = pc.feat(rng, (2, 9, 5, 8))
+    w = (rng.standard_normal((Cout, 6, 3, 3)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    pk = ops.pack_conv_weights(w, (2, 6, 5, 8), kernel=(3, 3), pad=(1, 1))
+    got = ops.Convolution(buf[:, 3:], w, b, pad=(1, 1), num_filter=Cout, packed=pk)
+    pc.check_close(got, oracle.convolution(np.ascontiguousarray(buf[:, 3:]), w, b, pad=(1, 1)))
+    # a coarse level: the channels also split over blocks (partial sums in the workspace + conv3x3_few_reduce), plain and packed
+    emu_ops.launch_log()
+    pc.case_conv(ops, oracle, ident, ident, 1, 150, Cout, 4, 8, pad=(1, 1), leaky=True, seed=6)
+    assert "conv3x3_few_reduce" in emu_ops.launch_log()
+    x2 = pc.feat(rng, (1, 150, 4, 8))
+    w2 = (rng.standard_normal((Cout, 150, 3, 3)) * 0.05).astype(np.float32)
+    pk2 = ops.pack_conv_weights(w2, (1, 150, 4, 8), kernel=(3, 3), pad=(1, 1))
+    emu_ops.launch_log()
+    pc.check_close(ops.Convolution(x2, w2, None, pad=(1, 1), num_filter=Cout, no_bias=True, packed=pk2), oracle.convolution(x2, w2, None, pad=(1, 1)))
+    assert "conv3x3_few_reduce" in emu_ops.launch_log()
+    # a width whose 4-pixel groups per row do not divide 64 (lane 0 of a wave would not start a row): the matrix-core kernel
+    emu_ops.launch_log()
+    pc.case_conv(ops, oracle, ident, ident, 1, 9, Cout, 6, 12, pad=(1, 1), seed=4)
+    assert "conv3x3_few" not in emu_ops.launch_log()
+
+
 @pytest.mark.parametrize("kw", [dict(kernel=(1, 1)), dict(kernel=(5, 3), pad=(2, 1)), dict(kernel=(3, 3), pad=(1, 1), num_group=2)])
 def test_conv_generic_parameter_space(ops, oracle, kw):
     pc.case_conv(ops, oracle, ident, ident, 2, 6, 8, 7, 9, **kw)

@@ -12,7 +12,7 @@ lib, ops = _lib.lib(), default_ops()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 if len(sys.argv) > 2:
     _lib.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in sys.argv[2].split(","))})
-LAYERS = [("conv1a", 3, 16, 384, 512, 2, 1), ("conv1b", 16, 16, 192, 256, 1, 1), ("conv2a", 16, 32, 192, 256, 2, 1),
+LAYERS = [("heads6", 529, 3, 6, 8, 1, 1), ("heads4", 643, 3, 24, 32, 1, 1), ("heads3", 611, 3, 48, 64, 1, 1), ("conv1a", 3, 16, 384, 512, 2, 1), ("conv1b", 16, 16, 192, 256, 1, 1), ("conv2a", 16, 32, 192, 256, 2, 1),
           ("conv3b", 64, 64, 48, 64, 1, 1), ("conv6b", 196, 196, 6, 8, 1, 1), ("conv6_0", 81, 128, 6, 8, 1, 1),
           ("conv5_1", 403, 128, 12, 16, 1, 1), ("conv4_2", 499, 96, 24, 32, 1, 1), ("conv3_0", 163, 128, 48, 64, 1, 1),
           ("conv2_0", 131, 128, 96, 128, 1, 1), ("conv2_1", 259, 128, 96, 128, 1, 1), ("conv2_2", 387, 96, 96, 128, 1, 1),
