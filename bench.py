@@ -694,6 +694,10 @@ def main():
                    "flow_fields": ("smooth: the reference's Upsample(2) applied recursively to a coarse field, as flow_l is inside "
                                    "the network" if args.flow == "smooth" else
                                    "rough: SURVEY.md 8(d), i.i.d. N(0, 2 px) per pixel + 2% outliers in [-h, h]"),
+                   "arithmetic": "fp32 in, fp32 out, fp32 accumulate everywhere; the level-2 cost volume (32 channels) contracts on "
+                                 "v_mfma_f32_16x16x32_bf16 with each fp32 operand split into three bf16 terms and the six products of "
+                                 "weight >= 2^-16 kept (error against fp64 as the fp32-FMA kernel's; corr.gram=0 selects that kernel: "
+                                 "`fma_correlation`)",
                    "backend": (args.backend if dist is not None else None),
                    **({"tuning_overrides": args.tuning} if args.tuning else {}), "parallelism": "batch shard x%d" % world},
         "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
@@ -778,6 +782,19 @@ def main():
             res["customop"] = customop_leg(wl, 200, torch, hotpath)
         except Exception as e:
             res["customop"] = {"error": repr(e)}
+    if gpu and world == 1 and not args.no_side_configs and args.config == "cfg2" and args.mode == "dropin" and args.flow == "smooth" \
+            and not args.no_graph and not args.tuning:
+        # transparency: the same pass with the level-2 cost volume on the fp32-FMA kernel (corr.gram = 0) instead of the Gram band
+        # on the bf16 matrix cores (operands split into three bf16 terms: exact to fp32 rounding, not bit-identical to an FMA chain)
+        try:
+            from maskflownet_amd import _lib as _lg
+            _lg.set_tuning(corr_gram=0)
+            res["fma_correlation"] = side_config("cfg2", "dropin", 200, torch, hotpath, want_roofline=True)
+            res["fma_correlation"]["what"] = "corr.gram=0: every kernel of the pass on fp32 FMA / fp32 MFMA arithmetic (round 3's level-2 kernel)"
+        except Exception as e:
+            res["fma_correlation"] = {"error": repr(e)}
+        finally:
+            _lg.set_tuning(corr_gram=-1)
     if not args.no_cpu_baseline and world == 1 and gpu:  # rank 0 at N=1 only: other ranks would idle in the barrier meanwhile
         res["cpu_baseline"], want = cpu_baseline(wl, args.cpu_seconds)
         res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)

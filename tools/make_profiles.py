@@ -60,7 +60,7 @@ if fe and wr:
                         "rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python tools/prof_one.py corr 2"]}
     json.dump(rec, open(os.path.join(P, "%s_corr_l2_hbm_traffic.json" % tag), "w"), indent=1)
     print("wrote", "%s_corr_l2_hbm_traffic.json" % tag, "traffic %.2f MB" % (traffic / 1e6))
-for name in ("bench", "bench_fused", "bench_cfg3", "bench_repack", "bench_streams3"):
+for name in ("bench", "bench_fused", "bench_cfg3", "bench_cfg4", "bench_repack", "bench_streams3"):
     src = os.path.join(G, name + ".log")
     if os.path.exists(src):
         line = open(src).read().strip().splitlines()[-1]
