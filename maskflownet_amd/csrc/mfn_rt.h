@@ -110,6 +110,12 @@ static inline void mfn_bstore4(mfn_rsrc_t r, unsigned voff, f32x4_emu v, int /*p
 static inline void mfn_bstore4_so(mfn_rsrc_t r, unsigned voff, unsigned soff, f32x4_emu v, int /*policy*/) {
   if ((unsigned long long)voff + soff + 16 <= r.nrec) memcpy(const_cast<char *>(r.base) + voff + soff, &v, 16);
 }
+// one float per lane through a raw buffer descriptor + wave-uniform soffset: out of range (or !valid) reads 0
+static inline float mfn_bload1_row(const void *base, unsigned full_bytes, unsigned soff, bool valid, unsigned voff) {
+  float v = 0.f;
+  if (valid && (unsigned long long)voff + soff + 4 <= full_bytes) memcpy(&v, (const char *)base + voff + soff, 4);
+  return v;
+}
 // DMA of one row of a tensor: a fixed base, the row's byte offset as a wave-uniform soffset, and a range check that is exact for
 // base .. base+full_bytes (lanes whose voff+soff+16 exceeds it, or every lane when !valid, write zeros)
 static inline void mfn_dma16_row(const void *base, unsigned full_bytes, unsigned soff, bool valid, float *lds_wave_base, unsigned voff) {
@@ -328,6 +334,13 @@ __device__ __forceinline__ void mfn_dma16_row(const void *base, unsigned full_by
   const unsigned so = __builtin_amdgcn_readfirstlane(valid ? soff : 0u);
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(so)
                : "memory", "m0");
+}
+// one float per lane into a REGISTER through the same kind of descriptor (the compiler sees this load and places its wait):
+// lanes whose voff + soff is out of the tensor, or every lane when !valid, read 0
+__device__ __forceinline__ float mfn_bload1_row(const void *base, unsigned full_bytes, unsigned soff, bool valid, unsigned voff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(valid ? full_bytes : 0u), 0x00020000);
+  const unsigned so = __builtin_amdgcn_readfirstlane(valid ? soff : 0u);
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)so, 0));
 }
 #define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")

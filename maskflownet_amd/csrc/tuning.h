@@ -8,9 +8,12 @@
 //                 plan (api_impl.inc corr_plan)
 //                 40 / 41: corr_gram_kernel (32-channel levels: the band of the Gram matrix on the bf16 matrix cores with the
 //                 operands split into three / two bf16 terms -- 40 is exact fp32, 41 a measured variant, 43 = 40 with two waves per item)
+//                 44 / 45: corr_gramk_kernel (coarse levels: the same band, a block = an 8 x 2 pixel block of f1 and two / half of the
+//                 f2 rows it meets, one wave per 32 channels)
 //   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 0 = the plan)
-//   corr.gram     the plan's use of corr_gram_kernel (variant 40) for 32-channel levels of >= 400 tiles: -1 the library's default
-//                 (api_impl.inc corr_plan), 0 never, 1 always
+//   corr.gram     the plan's use of the matrix-core kernels (variant 40 for 32-channel levels of >= 400 tiles, 44 / 45 for the
+//                 coarse levels): -1 the library's default (api_impl.inc corr_plan, corr_gramk_plan), 0 never (fp32-FMA kernels
+//                 everywhere), 1 always where the shape allows
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt

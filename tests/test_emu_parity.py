@@ -97,6 +97,35 @@ def test_correlation_gram_two_term_variant(ops, oracle):
     assert "corr_gram_v41" in emu_ops.launch_log()
 
 
+@pytest.mark.parametrize("variant", [44, 45])
+@pytest.mark.parametrize("shape,md", [((2, 196, 6, 8), 4),      # level 6: 7 waves, the last with 4 of its 32 channels; one strip hanging over both borders
+                                      ((1, 96, 5, 16), 4),      # odd H: the last block row has one pixel row; 3 waves
+                                      ((1, 64, 4, 24), 2),      # md = 2 (25 channels), 2 waves, 3 strips
+                                      ((1, 20, 6, 8), 4)])      # one wave with 20 channels: no meeting in LDS
+def test_correlation_gram_coarse_levels(ops, oracle, variant, shape, md):
+    """corr.variant 44 / 45: the Gram band of the coarse levels, a block = (8 x 2 pixel block of f1, two / half of
+    the 2 md + 2 rows of f2 it meets), one wave per 32 channels, partial tiles added in LDS in wave order."""
+    emu_ops.set_tuning(corr_variant=variant, corr_direct=2)
+    pc.case_correlation(ops, oracle, ident, ident, shape, md)
+    assert "corr_gramk" in emu_ops.launch_log()
+    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
+    pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
+
+
+@pytest.mark.parametrize("variant", [46, 47, 48, 49, 50])
+@pytest.mark.parametrize("shape,md", [((1, 196, 6, 8), 4),      # 7 waves, the last with 4 of its 32 channels; one strip hanging over both borders
+                                      ((1, 96, 5, 16), 4),      # odd H: a block row with one pixel row, items with blocks past the image
+                                      ((1, 64, 9, 24), 2)])     # md = 2, 2 waves, 3 strips, odd H
+def test_correlation_gram_register_operands(ops, oracle, variant, shape, md):
+    """corr.variant 46 .. 50 (corr_gramr_kernel): the Gram band with the operands loaded straight into registers, an item = T
+    stacked 8 x 2 blocks x one of G groups of the f2 rows they meet."""
+    emu_ops.set_tuning(corr_variant=variant, corr_direct=2)
+    pc.case_correlation(ops, oracle, ident, ident, shape, md)
+    assert "corr_gramr" in emu_ops.launch_log()
+    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
+    pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
+
+
 def test_correlation_gram_falls_back_off_its_shapes(ops, oracle):
     """corr.variant 40 on a level that does not have 32 channels: the plan's kernel runs instead."""
     emu_ops.set_tuning(corr_variant=40, corr_direct=2)
@@ -479,7 +508,7 @@ def test_deform_conv_shared_backward(ops, oracle):
     emu_ops.set_tuning(bwd_off=2)   # the composition gives the same gradients
     emu_ops.launch_log()
     pc.case_deform_shared_bwd(ops, oracle, ident, ident, 1, 4, 4, 5, 8, seed=6, req=("write", "add", "write", "write"))
-    assert "offsets_from_flow;" in emu_ops.launch_log()
+    assert "offsets_from_flow" in emu_ops.launch_log()
     rng = np.random.default_rng(4)
     goff = rng.standard_normal((2, 18, 5, 6)).astype(np.float32)
     base = rng.standard_normal((2, 2, 5, 6)).astype(np.float32)

@@ -33,7 +33,8 @@ for s in settings:
     kv.update({a.split("=")[0]: int(a.split("=")[1]) for a in s.split(",") if a})
     if kv:
         _lib.set_tuning(**kv)
-    fn = (lambda: ops.Correlation(t["c1_%d" % lvl], o["deform%d" % lvl], 1, 4, 1, 1, 4, True, out=o["corr%d" % lvl])) if op == "corr" \
+    f2 = t["c2_6"] if lvl == 6 else o["deform%d" % lvl]   # level 6 correlates the features themselves (MaskFlownet.py:217)
+    fn = (lambda: ops.Correlation(t["c1_%d" % lvl], f2, 1, 4, 1, 1, 4, True, out=o["corr%d" % lvl])) if op == "corr" \
         else calls["warp" if op == "warp" else "%s%d" % (op, lvl)]
     if op == "deform":   # the packed weights' layout follows the plan: pack again under this setting
         wl.packed[lvl] = ops.pack_deform_weights(t["w_%d" % lvl], tuple(t["c2_%d" % lvl].shape), kernel=(3, 3), pad=(1, 1))

@@ -38,7 +38,7 @@ for line in buf.value.decode().splitlines():
         other += us
         rows.append((us, "-", nm))
 tot = sum(r[0] for r in rows)
-for us, layer, kern in sorted(rows, reverse=True)[:40]:
+for us, layer, kern in sorted(rows, reverse=True)[:(None if os.environ.get("MFN_ALL") else 40)]:
     fl = net._flops.get(layer, 0.0)
     print("%-12s %-18s %8.1f us  %5.1f%%  %6.1f TF" % (layer, kern, us, 100 * us / tot, fl / us / 1e6 if fl else 0.0))
 print("kernels total %.1f us (torch element-wise ops not included)" % tot)
