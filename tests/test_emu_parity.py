@@ -104,24 +104,11 @@ def test_correlation_gram_two_term_variant(ops, oracle):
                                       ((1, 20, 6, 8), 4)])      # one wave with 20 channels: no meeting in LDS
 def test_correlation_gram_coarse_levels(ops, oracle, variant, shape, md):
     """corr.variant 44 / 45: the Gram band of the coarse levels, a block = (8 x 2 pixel block of f1, two / half of
-    the 2 md + 2 rows of f2 it meets), one wave per 32 channels, partial tiles added in LDS in wave order."""
+    the 2 md + 2 rows of f2 it meets), one wave per 32 channels, operands loaded straight into registers through range-checked
+    buffer loads, partial tiles added in LDS in wave order."""
     emu_ops.set_tuning(corr_variant=variant, corr_direct=2)
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
     assert "corr_gramk" in emu_ops.launch_log()
-    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
-    pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
-
-
-@pytest.mark.parametrize("variant", [46, 47, 48, 49, 50])
-@pytest.mark.parametrize("shape,md", [((1, 196, 6, 8), 4),      # 7 waves, the last with 4 of its 32 channels; one strip hanging over both borders
-                                      ((1, 96, 5, 16), 4),      # odd H: a block row with one pixel row, items with blocks past the image
-                                      ((1, 64, 9, 24), 2)])     # md = 2, 2 waves, 3 strips, odd H
-def test_correlation_gram_register_operands(ops, oracle, variant, shape, md):
-    """corr.variant 46 .. 50 (corr_gramr_kernel): the Gram band with the operands loaded straight into registers, an item = T
-    stacked 8 x 2 blocks x one of G groups of the f2 rows they meet."""
-    emu_ops.set_tuning(corr_variant=variant, corr_direct=2)
-    pc.case_correlation(ops, oracle, ident, ident, shape, md)
-    assert "corr_gramr" in emu_ops.launch_log()
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
     pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
 

@@ -121,10 +121,10 @@ def test_correlation_gram_two_term_variant(ops, oracle, dev):
 @pytest.mark.parametrize("variant", [44, 45])
 @pytest.mark.parametrize("shape,md", [((8, 196, 6, 8), 4), ((8, 128, 12, 16), 4), ((8, 96, 24, 32), 4), ((8, 64, 48, 64), 4),   # levels 6..3 of configs[1]
                                       ((4, 196, 7, 16), 4), ((4, 128, 14, 32), 4),                                          # configs[2]: odd heights
-                                      ((8, 196, 6, 8), 2), ((8, 96, 24, 32), 2), ((2, 33, 9, 24), 2)])                      # the cascade's md = 2
+                                      ((8, 196, 6, 8), 2), ((8, 96, 24, 32), 2), ((2, 64, 9, 24), 2)])                      # the cascade's md = 2
 def test_correlation_gram_coarse_levels(ops, oracle, dev, variant, shape, md):
-    """corr.variant 44 / 45 (correlation_gramk.h): the Gram band of the coarse levels, one wave per 32 channels, partial tiles
-    added in LDS in wave order; plain, with the fused LeakyReLU, into a concat slice; twenty passes bit-identical."""
+    """corr.variant 44 / 45 (corr_gramk_kernel, correlation_gramk.h): the Gram band of the coarse levels, one wave per 32 channels,
+    operands loaded straight into registers, partial tiles added in LDS in wave order; plain, with the fused LeakyReLU, into a concat slice; twenty passes bit-identical."""
     from maskflownet_amd import _lib
     _lib.set_tuning(corr_variant=variant)
     pc.case_correlation(ops, oracle, dev, host, shape, md)

@@ -10,7 +10,7 @@ tail -3 $O/parity.txt
 : > $O/ab.txt
 for cfg in cfg2 cfg3; do
 for lvl in 6 5 4 3; do
-timeout 300 python tools/corr_ab.py ";corr_variant=44;corr_variant=45;corr_variant=46" $lvl $cfg 5 >> $O/ab.txt 2>&1
+timeout 300 python tools/corr_ab.py ";corr_variant=44;corr_variant=45" $lvl $cfg 5 >> $O/ab.txt 2>&1
 done
 done
 grep "^L\|us" $O/ab.txt | head -60
