@@ -18,9 +18,9 @@ if os.path.exists(db):
     with open(os.path.join(P, "%s_bench_kernel_stats.md" % tag), "w") as f:
         f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-side-configs --no-e2e`\n\n" % tag)
         f.write("MI355X (gfx950), ROCm 7.2.  Source: gpurun_out/prof_bench/bench_results.db (top_kernels view); durations in "
-                "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (level 6: direct "
-                "kernel; levels 5/4: LDS-DMA tile kernel, displacement rows over 5 blocks x 4 channel groups; level 3: two channel groups; level 2: "
-                "LDS-DMA tile kernel), 4 x (offsets + deformable conv `dc_lds_kernel`), 1 warp.  bench.py also runs the pass on two more "
+                "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (levels 6 / 5 / 4: "
+                "`corr_gramk_kernel`, the Gram band on the bf16 matrix cores with a wave per 32 channels; level 3: `corr_dma_kernel`, two channel "
+                "groups; level 2: `corr_gram_kernel`, the Gram band with cooperative full-line stores), 4 x (offsets + deformable conv `dc_lds_kernel`), 1 warp.  bench.py also runs the pass on two more "
                 "streams for its informational `pipelined` figure, the level-2 correlation 200 more times back to back, 200 eager "
                 "passes with every kernel timed (`roofline`, `kernels`), 18 launches on rotated buffers, and the rough-flow batch.\n"
                 "Only `mfn::` kernels belong to the pass; the `at::native` rows are bench.py's checksum.\n\n")
