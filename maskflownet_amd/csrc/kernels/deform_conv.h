@@ -618,28 +618,43 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       // per launch -- but level 3 then came back with wrong 4x8 tiles in 5-60 of 60 runs, with the reads sunk below the matrix
       // instructions or pinned ahead of them alike (tools/r03_bf16_det.py): the reads stay conditional.)
       if (k + 1 < nf) gather2(BN, vp);
-      if (MMA) {   // six matrix-core products + tap 8, the next pair's interpolation between them
+      if (MMA) {   // six matrix-core products + tap 8 with this wave's own VALU work between them
+        // The seven instructions accumulate into the same tile: back to back each waits for its predecessor (8 passes) and nothing
+        // else of the wave issues meanwhile.  So the split is staged -- hi terms (4 VALU), mid (16), lo (16) -- and the products
+        // are ordered by which term they need, still smallest first by class (2^-16: l*h, m*m, h*l; 2^-8: m*h, h*m; then h*h);
+        // the next pair's interpolation fills the rest.  Scheduling fences pin the order; the register fence at the end keeps
+        // the interpolation in THIS basic block (hipcc sinks it past the branches of the next step's DMA section otherwise --
+        // found in the ISA: MMMMMMM back to back, then 30 VALU a block later).
         MmaOps o;
-        mma_prepare(pw, cur, o);
-        mma_issue(o, 0); interp_rows2(vp, trp, 0);
-        mma_issue(o, 1); interp_rows2(vp, trp, 1);
-        mma_issue(o, 2); interp_col2(trp, nxt, 0);
-        mma_issue(o, 3); interp_col2(trp, nxt, 1);
-        mma_issue(o, 4); interp_col2(trp, nxt, 2);
-        mma_issue(o, 5);
-        mma_issue(o, 6);
-        // the order the scheduler is asked for: the split (VALU) and the operand reads first, then one matrix instruction per
-        // five VALU instructions of the next pair's interpolation
-#if MFN_MMA_GROUPS
-        MFN_SCHED_GROUP(0x002, 40); MFN_SCHED_GROUP(0x100, 4);
-        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
-        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
-        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
-        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
-        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
-        MFN_SCHED_GROUP(0x008, 1); MFN_SCHED_GROUP(0x002, 6);
-        MFN_SCHED_GROUP(0x008, 1);
-#endif
+        o.ah = mfn_read_bf16x8(pw + ((0 * 2 + half) * 32 + j) * 4);
+        o.am = mfn_read_bf16x8(pw + ((1 * 2 + half) * 32 + j) * 4);
+        o.al = mfn_read_bf16x8(pw + ((2 * 2 + half) * 32 + j) * 4);
+        o.a8 = pw[768 + half * 32 + j];
+        o.b8 = cur[8];
+        const float x8[8] = {cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]};
+        mfn_split_state sp;
+        MFN_REGFENCE8(vp[0][0], vp[0][1], vp[0][2], vp[0][3], vp[1][0], vp[1][1], vp[1][2], vp[1][3]);   // ... and from rising into the gather's block
+        interp_rows2(vp, trp, 0); interp_rows2(vp, trp, 1);
+        mfn_split_stage_h(x8, o.bh, sp);
+        MFN_SCHED_BARRIER();
+        acc[0] = MFN_MFMA_32x32x16_BF16(o.al, o.bh, acc[0]);
+        mfn_split_stage_m(sp, o.bm);
+        MFN_SCHED_BARRIER();
+        acc[0] = MFN_MFMA_32x32x16_BF16(o.am, o.bm, acc[0]);
+        mfn_split_stage_l(sp, o.bl);
+        MFN_SCHED_BARRIER();
+        acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bl, acc[0]);
+        interp_col2(trp, nxt, 0);
+        MFN_SCHED_BARRIER();
+        acc[0] = MFN_MFMA_32x32x16_BF16(o.am, o.bh, acc[0]);
+        interp_col2(trp, nxt, 1);
+        MFN_SCHED_BARRIER();
+        acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bm, acc[0]);
+        interp_col2(trp, nxt, 2);
+        MFN_SCHED_BARRIER();
+        acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bh, acc[0]);
+        acc[0] = MFN_MFMA_32x32x2(o.a8, o.b8, acc[0]);
+        MFN_REGFENCE9(nxt);
       } else {
         mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
         mfma_tap(ap, 1, cur[1]);

@@ -48,6 +48,17 @@ static inline void mfn_split3(float x, unsigned short &h, unsigned short &m, uns
 static inline void mfn_split3x8(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &m, mfn_bf16x8 &l) {
   for (int e = 0; e < 8; ++e) mfn_split3(x[e], h.v[e], m.v[e], l.v[e]);
 }
+// the same split one term at a time (the kernel places a matrix instruction between the stages)
+struct mfn_split_state { float r[8]; };
+static inline void mfn_split_stage_h(const float (&x)[8], mfn_bf16x8 &h, mfn_split_state &st) {
+  for (int e = 0; e < 8; ++e) { h.v[e] = hipemu_f32_to_bf16(x[e]); st.r[e] = x[e] - hipemu_bf16_to_f32(h.v[e]); }
+}
+static inline void mfn_split_stage_m(mfn_split_state &st, mfn_bf16x8 &m) {
+  for (int e = 0; e < 8; ++e) { m.v[e] = hipemu_f32_to_bf16(st.r[e]); st.r[e] = st.r[e] - hipemu_bf16_to_f32(m.v[e]); }
+}
+static inline void mfn_split_stage_l(const mfn_split_state &st, mfn_bf16x8 &l) {
+  for (int e = 0; e < 8; ++e) l.v[e] = hipemu_f32_to_bf16(st.r[e]);
+}
 static inline mfn_bf16x8 mfn_read_bf16x8(const float *p) { mfn_bf16x8 v; memcpy(&v, p, 16); return v; }
 static inline void mfn_write_bf16x8(float *p, mfn_bf16x8 v) { memcpy(p, &v, 16); }
 static inline float mfn_bf16_at(const float *base, int idx) {   // element idx of a bf16 array, as fp32
@@ -130,6 +141,7 @@ static inline void mfn_gload4_async(f32x4_emu &dst, const float *base_uniform, u
 #define MFN_LANDED4(a, b, c, d, n) ((void)0)
 #define MFN_REGFENCE4(a, b, c, d) ((void)0)
 #define MFN_REGFENCE9(v) ((void)0)
+#define MFN_REGFENCE8(a, b, c, d, e, f, g, h) ((void)0)
 #define MFN_SCHED_GROUP(mask, n) ((void)0)
 // emulated lanes are independent threads: a wave-private DMA hand-off needs a wave barrier where the
 // hardware needs only the issuing wave's vmcnt wait (lock-step lanes)
@@ -207,6 +219,46 @@ __device__ __forceinline__ void mfn_split3x8(const float (&x)[8], mfn_bf16x8 &h,
     hw[q] = hp; mw[q] = mp; lw[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf2));
   }
   h = __builtin_bit_cast(mfn_bf16x8, hw); m = __builtin_bit_cast(mfn_bf16x8, mw); l = __builtin_bit_cast(mfn_bf16x8, lw);
+}
+// the same split one term at a time (4 + 16 + 16 VALU instructions; the kernel places a matrix instruction between the stages):
+// h: the hi terms, the state keeps the values; m: widen hi, first residual, mid terms; l: widen mid, second residual, lo terms
+struct mfn_split_state { f32x2 v[4]; unsigned hp[4], mp[4]; };
+__device__ __forceinline__ void mfn_split_stage_h(const float (&x)[8], mfn_bf16x8 &h, mfn_split_state &st) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hw;
+  _Pragma("unroll")
+  for (int q = 0; q < 4; ++q) {
+    st.v[q] = f32x2{x[2 * q], x[2 * q + 1]};
+    st.hp[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(st.v[q], bf2));
+    hw[q] = st.hp[q];
+  }
+  h = __builtin_bit_cast(mfn_bf16x8, hw);
+}
+__device__ __forceinline__ void mfn_split_stage_m(mfn_split_state &st, mfn_bf16x8 &m) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 mw;
+  _Pragma("unroll")
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 hf = {__builtin_bit_cast(float, st.hp[q] << 16), __builtin_bit_cast(float, st.hp[q] & 0xffff0000u)};
+    st.v[q] = st.v[q] - hf;
+    st.mp[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(st.v[q], bf2));
+    mw[q] = st.mp[q];
+  }
+  m = __builtin_bit_cast(mfn_bf16x8, mw);
+}
+__device__ __forceinline__ void mfn_split_stage_l(const mfn_split_state &st, mfn_bf16x8 &l) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 lw;
+  _Pragma("unroll")
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 mf = {__builtin_bit_cast(float, st.mp[q] << 16), __builtin_bit_cast(float, st.mp[q] & 0xffff0000u)};
+    const f32x2 r2 = st.v[q] - mf;
+    lw[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf2));
+  }
+  l = __builtin_bit_cast(mfn_bf16x8, lw);
 }
 __device__ __forceinline__ mfn_bf16x8 mfn_read_bf16x8(const float *p) { return *reinterpret_cast<const mfn_bf16x8 *>(p); }
 __device__ __forceinline__ void mfn_write_bf16x8(float *p, mfn_bf16x8 v) { *reinterpret_cast<mfn_bf16x8 *>(p) = v; }
@@ -401,6 +453,8 @@ __device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_u
 // nine values are COMPUTED here (hipcc otherwise sinks the arithmetic that forms them next to its use, one pipeline step
 // later, and keeps the registers it reads alive across the request that is about to overwrite them)
 #define MFN_REGFENCE9(v) asm volatile("" : "+v"((v)[0]), "+v"((v)[1]), "+v"((v)[2]), "+v"((v)[3]), "+v"((v)[4]), "+v"((v)[5]), "+v"((v)[6]), "+v"((v)[7]), "+v"((v)[8]))
+// eight values (any register class width) are opaque from here on: what is computed from them cannot move above this point
+#define MFN_REGFENCE8(a, b, c, d, e, f, g, h) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
 #define MFN_RAW_BARRIER() __builtin_amdgcn_s_barrier()
 // the compiler keeps memory accesses on their side of this point (no instruction): LDS accesses whose ORDER matters to other
 // lanes of the wave -- the in-order LDS pipe does the rest
