@@ -626,10 +626,16 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         // the interpolation in THIS basic block (hipcc sinks it past the branches of the next step's DMA section otherwise --
         // found in the ISA: MMMMMMM back to back, then 30 VALU a block later).
         MmaOps o;
-        o.ah = mfn_read_bf16x8(pw + ((0 * 2 + half) * 32 + j) * 4);
-        o.am = mfn_read_bf16x8(pw + ((1 * 2 + half) * 32 + j) * 4);
-        o.al = mfn_read_bf16x8(pw + ((2 * 2 + half) * 32 + j) * 4);
-        o.a8 = pw[768 + half * 32 + j];
+        if (MFN_DC_ABLATE & 16) {   // measurement builds: no weight reads
+          const float fk[4] = {(float)k, 1.f, 2.f, 3.f};
+          o.ah = o.am = o.al = mfn_read_bf16x8(fk);
+          o.a8 = (float)k;
+        } else {
+          o.ah = mfn_read_bf16x8(pw + ((0 * 2 + half) * 32 + j) * 4);
+          o.am = mfn_read_bf16x8(pw + ((1 * 2 + half) * 32 + j) * 4);
+          o.al = mfn_read_bf16x8(pw + ((2 * 2 + half) * 32 + j) * 4);
+          o.a8 = pw[768 + half * 32 + j];
+        }
         o.b8 = cur[8];
         const float x8[8] = {cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]};
         mfn_split_state sp;
@@ -637,23 +643,28 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         interp_rows2(vp, trp, 0); interp_rows2(vp, trp, 1);
         mfn_split_stage_h(x8, o.bh, sp);
         MFN_SCHED_BARRIER();
-        acc[0] = MFN_MFMA_32x32x16_BF16(o.al, o.bh, acc[0]);
+#if MFN_DC_ABLATE & 1
+#define MFN_DC_MMA_(a, b) acc[0][0] += mfn_bf16_at(reinterpret_cast<const float *>(&(a)), 0) * mfn_bf16_at(reinterpret_cast<const float *>(&(b)), 1)
+#else
+#define MFN_DC_MMA_(a, b) acc[0] = MFN_MFMA_32x32x16_BF16((a), (b), acc[0])
+#endif
+        MFN_DC_MMA_(o.al, o.bh);
         mfn_split_stage_m(sp, o.bm);
         MFN_SCHED_BARRIER();
-        acc[0] = MFN_MFMA_32x32x16_BF16(o.am, o.bm, acc[0]);
+        MFN_DC_MMA_(o.am, o.bm);
         mfn_split_stage_l(sp, o.bl);
         MFN_SCHED_BARRIER();
-        acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bl, acc[0]);
+        MFN_DC_MMA_(o.ah, o.bl);
         interp_col2(trp, nxt, 0);
         MFN_SCHED_BARRIER();
-        acc[0] = MFN_MFMA_32x32x16_BF16(o.am, o.bh, acc[0]);
+        MFN_DC_MMA_(o.am, o.bh);
         interp_col2(trp, nxt, 1);
         MFN_SCHED_BARRIER();
-        acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bm, acc[0]);
+        MFN_DC_MMA_(o.ah, o.bm);
         interp_col2(trp, nxt, 2);
         MFN_SCHED_BARRIER();
-        acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bh, acc[0]);
-        acc[0] = MFN_MFMA_32x32x2(o.a8, o.b8, acc[0]);
+        MFN_DC_MMA_(o.ah, o.bh);
+        if (MFN_DC_ABLATE & 1) acc[0][1] += o.a8 * o.b8; else acc[0] = MFN_MFMA_32x32x2(o.a8, o.b8, acc[0]);
         MFN_REGFENCE9(nxt);
       } else {
         mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
