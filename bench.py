@@ -530,6 +530,36 @@ def network_epe_delta(H, W, device):
             "seconds": round(time.perf_counter() - t0, 1)}
 
 
+def end_to_end_train(N, H, W, device, torch, steps=5):
+    """Informational: one training step of the whole MaskFlownet-S (pipeline.py:89-114) -- forward, MultiscaleEpe loss, backward,
+    Adam step -- with every layer's forward AND backward a libmfn_hip.so kernel (maskflownet_amd/training.py); eager, driven by
+    torch's autograd tape as the reference's is by MXNet's."""
+    from maskflownet_amd import network, training
+    torch.cuda.set_device(torch.device(device))
+    net = training.MaskFlownetSTrainable(network.random_params(seed=1)).to(device)
+    loss_fn = training.MultiscaleEpe()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    im1 = (torch.rand(N, 3, H, W, generator=g) - 0.5).to(device)
+    im2 = (torch.rand(N, 3, H, W, generator=g) - 0.5).to(device)
+    label = (torch.randn(N, 2, H, W, generator=g) * 3.0).to(device)
+    mask = torch.ones(N, 1, H, W, device=device)
+    for _ in range(2):
+        loss = training.train_step(net, loss_fn, opt, im1, im2, label, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = training.train_step(net, loss_fn, opt, im1, im2, label, mask)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_step": round(dt * 1e3, 2), "batch": N, "steps": steps,
+            "finite": bool(torch.isfinite(loss).all().item()),
+            "what": "MaskFlownet-S training step 384x512 end to end (forward, multiscale EPE loss, backward, Adam): every layer's forward "
+                    "and backward a libmfn_hip.so kernel (142 parameter tensors), eager under torch's autograd tape; concat / gating / "
+                    "loss arithmetic and the optimizer are torch element-wise kernels",
+            "note": "not the headline; the hot path's own training pass (graph replay, flat gradient bucket) is `train`"}
+
+
 def end_to_end(N, H, W, device, torch, steps=30, full=False, ref_flow=None):
     """Informational: the whole MaskFlownet-S forward (71 convolutions / deconvolutions + the hot path) on libmfn_hip.so
     as one hipGraph -- maskflownet_amd/network.py; seeded MSRAPrelu weights, random images.  full=True: the full
@@ -850,6 +880,10 @@ def main():
             res["e2e_full"].pop("_flow", None)
         except Exception as e:
             res["e2e_full"] = {"error": repr(e)}
+        try:
+            res["e2e_train"] = end_to_end_train(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch)
+        except Exception as e:
+            res["e2e_train"] = {"error": repr(e)}
     if gpu and world == 1 and not args.no_epe and wl.kind != "train":
         try:
             res["epe"] = network_epe_delta(wl.H, wl.W, "cuda:%d" % torch.cuda.current_device())

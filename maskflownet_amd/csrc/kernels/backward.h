@@ -121,6 +121,44 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(ChanSumParams p) {
   }
   if (threadIdx.x == 0) p.out[o] = (p.add ? p.out[o] : 0.f) + red[0];
 }
+// The same sum with the (n, pixel) range of a channel cut into `S` slices over blockIdx.y (a block per channel leaves most CUs idle:
+// 107 us for the 50 MB of a level-2 layer): partial[c][s] here, the slices added in index order by channel_sum_final_kernel --
+// deterministic, no atomics.  plane % 4 == 0 and 16-byte aligned `g`: float4 loads (a quad never straddles two images).
+struct ChanSumPartParams { const float *g; float *partial; int N, C, S; size_t plane, chunk; int vec; };
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(ChanSumPartParams p) {
+  MFN_DYN_SHARED(float, red);
+  const int o = blockIdx.x, sl = blockIdx.y;
+  const size_t total = (size_t)p.N * p.plane;
+  const size_t q0 = (size_t)sl * p.chunk, q1 = q0 + p.chunk < total ? q0 + p.chunk : total;
+  float s = 0.f;
+  if (p.vec) {
+    for (size_t q = q0 + 4 * (size_t)threadIdx.x; q < q1; q += 1024) {
+      const size_t n = q / p.plane, pix = q - n * p.plane;
+      const float4 v = *reinterpret_cast<const float4 *>(p.g + (n * p.C + o) * p.plane + pix);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (size_t q = q0 + threadIdx.x; q < q1; q += 256) {
+      const size_t n = q / p.plane, pix = q - n * p.plane;
+      s += p.g[(n * p.C + o) * p.plane + pix];
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.partial[(size_t)o * p.S + sl] = red[0];
+}
+struct ChanSumFinalParams { const float *partial; float *out; int C, S, add; };
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(ChanSumFinalParams p) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= p.C) return;
+  float s = 0.f;
+  for (int k = 0; k < p.S; ++k) s += p.partial[(size_t)o * p.S + k];
+  p.out[o] = (p.add ? p.out[o] : 0.f) + s;
+}
 // Upsample(factor) backward (MaskFlownet.py:35-62 is linear: its adjoint).  One thread per INPUT pixel gathers the at most
 // (2f-1)^2 outputs it fed, with the forward's weights (upsample.h): row i receives weight ka0(r) from output rows i*f + r and
 // ka1(r) from rows whose lower neighbour min(iy0 + 1, H - 1) is i (the edge pad makes the last row its own neighbour).
@@ -152,6 +190,41 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(UpsampleBwdParams p) 
     for (int ox = ox_lo; ox <= ox_hi; ++ox) s += g[(size_t)oy * Wout + ox] * (wy * wline(ox, ix, p.W));
   }
   p.gx[idx] = p.add ? p.gx[idx] + s : s;
+}
+// Large factors (the multiscale loss upsamples the coarse predictions by 8 .. 64: an input pixel feeds up to 127 x 127 outputs):
+// one BLOCK per input pixel, its threads stride over the footprint, partial sums meet in LDS in a fixed tree -- the
+// thread-per-pixel form above runs 768 threads of 16 k serial terms each at factor 64 (345 us per call in the training step).
+__global__ __launch_bounds__(256) void upsample_bwd_block_kernel(UpsampleBwdParams p) {
+  MFN_DYN_SHARED(float, red);
+  const size_t idx = blockIdx.x;
+  const int f = p.f, cc = f - 1;
+  const int ix = (int)(idx % p.W), iy = (int)((idx / p.W) % p.H);
+  const size_t nc = idx / ((size_t)p.W * p.H);
+  const int Hout = p.H * f, Wout = p.W * f;
+  const float *g = p.gout + nc * (size_t)Hout * Wout;
+  auto tri = [&](int a) { return 1.f - fabsf((float)(cc - a)) / (float)(cc + 1); };
+  auto wline = [&](int o, int i, int n) {
+    const int i0 = o / f, r = o - i0 * f;
+    float w = 0.f;
+    if (i0 == i) w += tri(r + f - 1);
+    if (r && min(i0 + 1, n - 1) == i) w += tri(r - 1);
+    return w;
+  };
+  const int oy_lo = max((iy - 1) * f + 1, 0), oy_hi = min((iy + 1) * f - 1, Hout - 1);
+  const int ox_lo = max((ix - 1) * f + 1, 0), ox_hi = min((ix + 1) * f - 1, Wout - 1);
+  const int nx = ox_hi - ox_lo + 1, ny = oy_hi - oy_lo + 1;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < nx * ny; e += 256) {
+    const int ry = e / nx, oy = oy_lo + ry, ox = ox_lo + (e - ry * nx);
+    s += g[(size_t)oy * Wout + ox] * (wline(oy, iy, p.H) * wline(ox, ix, p.W));
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p.gx[idx] = p.add ? p.gx[idx] + red[0] : red[0];
 }
 
 // ---- correlation -----------------------------------------------------------------------------------

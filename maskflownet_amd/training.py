@@ -1,0 +1,171 @@
+"""The training step of MaskFlownet-S with EVERY layer's forward and backward on libmfn_hip.so.
+
+Caller of the hot path on the training side: /root/reference/network/pipeline.py:89-114 (`train_batch`: forward under
+autograd, `MultiscaleEpe` loss, `loss.backward()`, `trainer.step`) over /root/reference/network/MaskFlownet.py:197-315
+(`MaskFlownet_S.hybrid_forward`).  MXNet's autograd is torch's here (device memory, tape and the optimizer are plumbing);
+what the tape calls is the library:
+
+* convolutions / transposed convolutions with their fused LeakyReLU: `mfn_conv2d_fwd` / `mfn_conv2d_bwd` (`_ConvFn`),
+* cost volumes, the deformable matching step, `Upsample`: the autograd functions of `layer.py`
+  (`mfn_correlation_fwd/_bwd`, `mfn_deform_conv_shared_fwd/_bwd`, `mfn_upsample_fwd/_bwd`),
+* concatenation, the gating `warp * sigmoid(mask) + tradeoff`, the loss arithmetic: torch element-wise glue, as the
+  reference's are MXNet's.
+
+`network.MaskFlownetS` is the inference form of the same graph (pre-allocated concat buffers, packed weights, one
+hipGraph); the parameter names are shared (`network.random_params`, the reference checkpoint's keys).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import layer, ops
+from .network import CONTEXT, DECODER, MD, PYRAMID, SCALE, STRIDES, UPFEAT
+
+
+class _ConvFn(torch.autograd.Function):
+    """Convolution / Deconvolution + bias [+ LeakyReLU(0.1)] in one launch; backward through mfn_conv2d_bwd (which undoes the
+    fused activation from the saved output)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, dilation, act, transposed):
+        o = ops.default_ops()
+        x = x.contiguous()
+        if transposed:
+            y = o.Deconvolution(x, w, b, kernel=(4, 4), stride=(2, 2), pad=(1, 1), activation="leaky" if act else None)
+        else:
+            y = o.Convolution(x, w, b, kernel=(3, 3), stride=(stride, stride), dilate=(dilation, dilation),
+                              pad=(dilation, dilation), activation="leaky" if act else None)
+        ctx.save_for_backward(x, w, y)
+        ctx.cfg = (stride, dilation, act, transposed)
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, w, y = ctx.saved_tensors
+        stride, dilation, act, transposed = ctx.cfg
+        o = ops.default_ops()
+        need = ctx.needs_input_grad
+        req = tuple("write" if need[i] else "null" for i in range(3))
+        gout = gout.contiguous()
+        if transposed:
+            gx, gw, gb = o.Deconvolution_backward(gout, x, w, output=y, kernel=(4, 4), stride=(2, 2), pad=(1, 1),
+                                                  activation="leaky" if act else None, req=req)
+        else:
+            gx, gw, gb = o.Convolution_backward(gout, x, w, output=y, kernel=(3, 3), stride=(stride, stride),
+                                                dilate=(dilation, dilation), pad=(dilation, dilation),
+                                                activation="leaky" if act else None, req=req)
+        return gx, gw, gb, None, None, None, None
+
+
+class LibraryBackend:
+    """The differentiable layer set of the network, every member's forward AND backward a libmfn_hip.so call.  (The tests pass
+    a pure-torch implementation of the same four members to check the gradients of the composition.)"""
+
+    def __init__(self):
+        self._up = {}
+
+    def conv(self, x, w, b, stride=1, dilation=1, act=True, transposed=False):
+        return _ConvFn.apply(x, w, b, stride, dilation, act, transposed)
+
+    def correlation(self, a, b, md):     # MaskFlownet.py:193-195 + the LeakyReLU around every call (:217)
+        return layer.correlation(a.contiguous(), b.contiguous(), md, leaky=True)
+
+    def deform(self, x, flow, w, b, scale, stride):   # MaskFlownet.py:230: deform(x, repeat9(flow * scale / stride))
+        return layer._SharedDeformConvFn.apply(x.contiguous(), flow.contiguous(), w, b, scale, stride,
+                                               {"kernel": (3, 3), "dilate": (1, 1), "pad": (1, 1), "num_group": 1}, None)
+
+    def upsample(self, x, factor):
+        if factor not in self._up:
+            self._up[factor] = layer.Upsample(factor)
+        return self._up[factor](x.contiguous())
+
+
+def _key(name):
+    return name.replace(".", "__")
+
+
+class MaskFlownetSTrainable(nn.Module):
+    """MaskFlownet_S.hybrid_forward (MaskFlownet.py:197-315) as a differentiable module on the library.
+    forward(im1, im2) -> ([flow6 .. flow2] x scale, [sigmoid(mask2)]) = the reference's (predictions, occlusion_masks)."""
+
+    def __init__(self, params, backend=None, dtype=torch.float32):
+        super().__init__()
+        self.P = nn.ParameterDict({_key(k): nn.Parameter(torch.as_tensor(np.ascontiguousarray(v)).to(dtype))
+                                   for k, v in params.items()})
+        self.B = backend if backend is not None else LibraryBackend()
+
+    def _p(self, name):
+        return self.P[_key(name + ".weight")], self.P[_key(name + ".bias")]
+
+    def conv(self, name, x, stride=1, dilation=1, act=True, transposed=False):
+        w, b = self._p(name)
+        return self.B.conv(x, w, b, stride, dilation, act, transposed)
+
+    def forward(self, im1, im2):
+        N = im1.shape[0]
+        x = torch.cat([im1, im2], 0)
+        c = {}
+        for l in range(1, 7):                        # both images as one batch through the shared pyramid
+            for k, s in (("a", 2), ("b", 1), ("c", 1)):
+                x = self.conv("conv%d%s" % (l, k), x, stride=s)
+            c[l] = x
+        preds = []
+        flow = mask = feat = None
+        for l in (6, 5, 4, 3, 2):
+            c1, c2 = c[l][:N], c[l][N:]
+            if l == 6:
+                x = self.B.correlation(c1, c2, MD)
+            else:
+                flow_up, mask_up = self.B.upsample(flow, 2), self.B.upsample(mask, 2)
+                trade = self.conv("conv%df" % l, feat, act=False)
+                w, b = self._p("deform%d" % l)
+                # MaskFlownet.py:230-233: deform(c2, repeat9(flow * scale / stride)) * sigmoid(mask) + tradeoff, LeakyReLU
+                warp = self.B.deform(c2, flow_up, w, b, SCALE, float(STRIDES[l]))
+                warp = torch.nn.functional.leaky_relu(warp * torch.sigmoid(mask_up) + trade, 0.1)
+                corr = self.B.correlation(c1, warp, MD)
+                x = torch.cat([corr, c1, feat, flow_up], 1)
+            for k in range(len(DECODER)):            # x = concat(conv(x), x)
+                x = torch.cat([self.conv("conv%d_%d" % (l, k), x), x], 1)
+            if l > 2:
+                d = torch.cat([self.conv("pred_flow%d" % l, x, act=False), self.conv("pred_mask%d" % l, x, act=False)], 1)
+            else:
+                d = self.conv("pred_flow2", x, act=False)
+            flow = d[:, :2] if l == 6 else flow_up + d[:, :2]
+            if l > 2:
+                mask = d[:, 2:3]
+                feat = self.conv("upfeat%d" % (l - 1), x, transposed=True)
+                preds.append(flow)
+        y = x
+        for i, (_, dil) in enumerate(CONTEXT):
+            y = self.conv("dc_conv%d" % (i + 1), y, dilation=dil)
+        flow = flow + self.conv("dc_conv7", y, act=False)
+        preds.append(flow)
+        return [f * SCALE for f in preds], [torch.sigmoid(mask_up)]      # MaskFlownet.py:303-305
+
+
+class MultiscaleEpe(nn.Module):
+    """MaskFlownet.py:585-611 with match='upsampling' (pipeline.py:42-44): sum_s w_s * EpeLossWithMask(Upsample(s)(pred_s) ,
+    label, mask); EpeLossWithMask (:563-583) = sum(sqrt(sum_c (p - l)^2 + eps) * mask) / sum(mask) per sample.
+    `label` in pixels, as the predictions (flow x scale)."""
+
+    def __init__(self, scales=(64, 32, 16, 8, 4), weights=(.005, .01, .02, .08, .32), eps=1e-8, backend=None):
+        super().__init__()
+        self.scales, self.weights, self.eps = tuple(scales), tuple(weights), float(eps)
+        self.B = backend if backend is not None else LibraryBackend()
+
+    def forward(self, label, mask, *preds):
+        total = 0.
+        for p, w, s in zip(preds, self.weights, self.scales):
+            e = torch.sqrt(((self.B.upsample(p, s) - label) ** 2).sum(1) + self.eps) * mask[:, 0]
+            total = total + w * e.flatten(1).sum(1) / mask.flatten(1).sum(1)
+        return total
+
+
+def train_step(net, loss_fn, opt, im1, im2, label, mask):
+    """pipeline.py:95-114 for one device: forward, loss, backward, optimizer step.  Returns the per-sample loss."""
+    opt.zero_grad(set_to_none=True)
+    preds, _ = net(im1, im2)
+    loss = loss_fn(label, mask, *preds)
+    loss.sum().backward()
+    opt.step()
+    return loss.detach()

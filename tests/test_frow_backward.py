@@ -19,6 +19,8 @@ CONV_CASES = [
     dict(N=1, Cin=8, Cout=4, H=4, W=8, transposed=True, kernel=(4, 4), stride=(2, 2), pad=(1, 1), leaky=True),   # upfeat
     dict(N=2, Cin=4, Cout=8, H=8, W=8, req=("add", "add", "add")),
     dict(N=1, Cin=4, Cout=4, H=8, W=8, req=("null", "write", "null")),
+    dict(N=2, Cin=4, Cout=6, H=40, W=52, leaky=True),            # 4160 (n, pixel) terms per channel: the bias gradient in two slices
+    dict(N=1, Cin=4, Cout=5, H=65, W=65, req=("null", "null", "add")),   # odd plane: scalar loads in the slices; accumulate
 ]
 
 
@@ -33,7 +35,8 @@ def test_conv_backward_emulated(emu, case):
     pc.case_conv_backward(emu, ident, ident, **case)
 
 
-@pytest.mark.parametrize("shape,factor", [((1, 2, 3, 4), 2), ((2, 1, 4, 5), 4), ((1, 1, 1, 1), 2), ((1, 2, 5, 3), 1)])
+@pytest.mark.parametrize("shape,factor", [((1, 2, 3, 4), 2), ((2, 1, 4, 5), 4), ((1, 1, 1, 1), 2), ((1, 2, 5, 3), 1),
+                                          ((1, 2, 2, 3), 8), ((1, 1, 1, 2), 16)])     # factor >= 8: a block per input pixel (the loss's Upsample(8 .. 64))
 def test_upsample_backward_emulated(emu, shape, factor):
     pc.case_upsample_backward(emu, oracle, ident, ident, shape, factor)
     pc.case_upsample_backward(emu, oracle, ident, ident, shape, factor, req="add", seed=1)
@@ -94,7 +97,8 @@ def test_conv_backward_gpu(gpu_ops, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,factor", [((8, 2, 12, 16), 2), ((8, 1, 48, 64), 2), ((2, 2, 24, 32), 4), ((1, 2, 7, 5), 2)])
+@pytest.mark.parametrize("shape,factor", [((8, 2, 12, 16), 2), ((8, 1, 48, 64), 2), ((2, 2, 24, 32), 4), ((1, 2, 7, 5), 2),
+                                          ((2, 2, 6, 8), 64), ((2, 2, 12, 16), 32), ((1, 2, 24, 32), 16), ((1, 2, 48, 64), 8)])   # MultiscaleEpe's
 def test_upsample_backward_gpu(gpu_ops, shape, factor):
     pc.case_upsample_backward(gpu_ops, oracle, _dev, _host, shape, factor)
     pc.case_upsample_backward(gpu_ops, oracle, _dev, _host, shape, factor, req="add", seed=2)

@@ -1,0 +1,138 @@
+"""The whole-network training step on the library (maskflownet_amd/training.py) -- pipeline.py:89-114 over
+MaskFlownet_S.hybrid_forward (MaskFlownet.py:197-315).  GPU tests: the trainable module's forward equals the inference
+network's; its parameter gradients (every layer's backward a library kernel) equal those of the same graph with every
+layer stated in differentiable torch (fp64 on the CPU); one optimizer step moves the loss."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+F = torch.nn.functional
+GRAD_TOL = 5e-3   # fp32 kernels against fp64 autograd through ~70 layers, relative to each tensor's largest gradient
+
+
+class _OracleDeform(torch.autograd.Function):
+    """DeformableConvolution with one (dy, dx) = flow * scale / stride for all nine taps: the fp64 oracle's forward and backward
+    (MXNet's deformable_im2col / col2im / col2im_coord, whose coordinate gradient at the clamped last row / column is NOT the
+    derivative of its forward -- which is why this layer is not stated in torch like the others)."""
+
+    @staticmethod
+    def forward(ctx, x, flow, w, b, scale, stride):
+        from oracle import ref
+        ref.build()
+        f64 = np.float64
+        off = ref.offsets_from_flow(flow.detach().numpy(), scale, stride, dtype=f64)
+        ctx.save_for_backward(x, flow, w)
+        ctx.cfg = (scale, stride)
+        return torch.from_numpy(ref.deformable_convolution(x.detach().numpy(), off, w.detach().numpy(), b.detach().numpy(), dtype=f64))
+
+    @staticmethod
+    def backward(ctx, gout):
+        from oracle import ref
+        x, flow, w = ctx.saved_tensors
+        scale, stride = ctx.cfg
+        f64 = np.float64
+        off = ref.offsets_from_flow(flow.detach().numpy(), scale, stride, dtype=f64)
+        gx, goff, gw, gb = ref.deformable_convolution_backward(gout.contiguous().numpy(), x.detach().numpy(), off, w.detach().numpy(), dtype=f64)
+        gflow = goff.reshape(goff.shape[0], 9, 2, *goff.shape[2:]).sum(1) * (scale / stride)
+        return torch.from_numpy(gx), torch.from_numpy(gflow), torch.from_numpy(gw), torch.from_numpy(gb), None, None
+
+
+class TorchBackend:
+    """The layer kinds of training.LibraryBackend as plain differentiable torch, fp64 on the CPU (test infrastructure); the
+    deformable convolution through the fp64 oracle."""
+
+    def conv(self, x, w, b, stride=1, dilation=1, act=True, transposed=False):
+        y = F.conv_transpose2d(x, w, b, stride=2, padding=1) if transposed else \
+            F.conv2d(x, w, b, stride=stride, padding=dilation, dilation=dilation)
+        return F.leaky_relu(y, 0.1) if act else y
+
+    def correlation(self, a, b, md):   # MXNet Correlation(kernel 1, stride 1, pad md, multiply) / C, LeakyReLU(0.1)
+        H, W = a.shape[2:]
+        bp = F.pad(b, (md, md, md, md))
+        D = 2 * md + 1
+        out = torch.stack([(a * bp[:, :, dy:dy + H, dx:dx + W]).mean(1) for dy in range(D) for dx in range(D)], 1)
+        return F.leaky_relu(out, 0.1)
+
+    def deform(self, x, flow, w, b, scale, stride):
+        return _OracleDeform.apply(x, flow, w, b, float(scale), float(stride))
+
+    def upsample(self, x, f):   # MaskFlownet.py:35-62
+        if f == 1:
+            return x
+        N, C, H, W = x.shape
+        xi = F.pad(x.reshape(N * C, 1, H, W), (0, 1, 0, 1), mode="replicate")
+        wk = 2 * f - 1
+        c = wk // 2
+        k1 = 1 - (c - torch.arange(wk, dtype=x.dtype)).abs() / (c + 1)
+        y = F.conv_transpose2d(xi, (k1[:, None] * k1[None, :])[None, None], stride=f, padding=f - 1)[:, :, :-1, :-1]
+        return y.reshape(N, C, H * f, W * f)
+
+
+def _batch(N, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    im1 = torch.rand(N, 3, H, W, generator=g) - 0.5
+    im2 = torch.roll(im1, shifts=(2, -3), dims=(2, 3)) + 0.02 * torch.randn(N, 3, H, W, generator=g)
+    label = torch.randn(N, 2, H, W, generator=g) * 3.0
+    mask = (torch.rand(N, 1, H, W, generator=g) > 0.1).float()
+    return im1, im2, label, mask
+
+
+def test_trainable_forward_equals_the_inference_network():
+    from maskflownet_amd import network, training
+    N, H, W = 1, 128, 192
+    params = network.random_params(5)
+    im1, im2, _, _ = _batch(N, H, W, 1)
+    ref = network.MaskFlownetS(params, N, H, W)(im1, im2)
+    net = training.MaskFlownetSTrainable(params).cuda()
+    with torch.no_grad():
+        preds, occ = net(im1.cuda(), im2.cuda())
+    for a, b in zip(preds, ref["predictions"]):
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3)
+    assert (occ[0] - ref["occlusion"]).abs().max().item() <= 1e-5
+
+
+def test_parameter_gradients_match_a_torch_statement_of_the_graph():
+    """Every parameter's gradient of the multiscale loss: library backward kernels (GPU, fp32) against autograd over plain
+    torch layers (CPU, fp64).  The biases are moved off zero so that no LeakyReLU sits on its kink."""
+    from maskflownet_amd import network, training
+    N, H, W = 1, 128, 128
+    params = network.random_params(7)
+    rng = np.random.default_rng(3)
+    for k in params:
+        if k.endswith(".bias"):
+            params[k] = (rng.standard_normal(params[k].shape) * 0.05).astype(np.float32)
+    im1, im2, label, mask = _batch(N, H, W, 2)
+    lib_net = training.MaskFlownetSTrainable(params).cuda()
+    lib_loss = training.MultiscaleEpe()
+    preds, _ = lib_net(im1.cuda(), im2.cuda())
+    loss = lib_loss(label.cuda(), mask.cuda(), *preds).sum()
+    loss.backward()
+    tb = TorchBackend()
+    ref_net = training.MaskFlownetSTrainable(params, backend=tb, dtype=torch.float64)
+    ref_loss = training.MultiscaleEpe(backend=tb)
+    rpreds, _ = ref_net(im1.double(), im2.double())
+    rl = ref_loss(label.double(), mask.double(), *rpreds).sum()
+    rl.backward()
+    assert abs(loss.item() - rl.item()) <= 1e-4 * abs(rl.item())
+    errs = []
+    for k, p in lib_net.P.items():
+        g, r = p.grad.detach().cpu().double(), ref_net.P[k].grad
+        assert g.shape == r.shape and torch.isfinite(g).all(), k
+        errs.append(((g - r).abs().max().item() / max(r.abs().max().item(), 1e-12), k))
+    errs.sort(reverse=True)
+    print("relative gradient errors, worst first:", ["%s %.1e" % (k, e) for e, k in errs[:8]], "median %.1e" % errs[len(errs) // 2][0])
+    assert errs[0][0] <= GRAD_TOL, errs[:5]
+
+
+def test_one_optimizer_step_lowers_the_loss():
+    from maskflownet_amd import network, training
+    N, H, W = 2, 64, 128
+    net = training.MaskFlownetSTrainable(network.random_params(9)).cuda()
+    loss_fn = training.MultiscaleEpe()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    im1, im2, label, mask = (t.cuda() for t in _batch(N, H, W, 4))
+    first = training.train_step(net, loss_fn, opt, im1, im2, label, mask)
+    for _ in range(3):
+        last = training.train_step(net, loss_fn, opt, im1, im2, label, mask)
+    assert torch.isfinite(last).all() and last.sum().item() < first.sum().item()
