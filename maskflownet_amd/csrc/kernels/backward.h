@@ -103,6 +103,33 @@ inline int conv_flip_weights_launch(FlipParams p, hipStream_t s) {
   if (!total) return 0;
   return launch("conv_flip_weights", conv_flip_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
 }
+// Data gradient of the network's 4x4 / stride 2 / pad 1 Deconvolution = a 4x4 / stride 2 / pad 1 CONVOLUTION of the output gradient;
+// on the pixel-unshuffled gradient t[(py,px,co)][Y][X] = g[co][2Y+py][2X+px] that is a 3x3 / stride 1 / pad 1 convolution (the MFMA
+// kernels' shape): kernel row ky reads input row 2y-1+ky = 2(y+r-1)+p with (p, r) = (1,0) (0,1) (1,1) (0,2) for ky = 0..3 -- four of
+// the nine taps of a parity are used, the others are zero weights.  The generic kernel took 1.6 ms per such layer.
+struct S2dParams { const float *g; float *t; int N, C, H, W; };   // g: (N, C, 2H, 2W) -> t: (N, 4C, H, W)
+__global__ __launch_bounds__(256) void conv_s2d_kernel(S2dParams p) {
+  const size_t total = (size_t)p.N * 4 * p.C * p.H * p.W;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int X = (int)(idx % p.W), Y = (int)((idx / p.W) % p.H);
+  const size_t rest = idx / ((size_t)p.W * p.H);
+  const int cc = (int)(rest % (4 * p.C)), n = (int)(rest / (4 * p.C));
+  const int par = cc / p.C, co = cc - par * p.C, py = par >> 1, px = par & 1;
+  p.t[idx] = p.g[(((size_t)n * p.C + co) * (2 * p.H) + 2 * Y + py) * (2 * p.W) + 2 * X + px];
+}
+struct S2dWeightParams { const float *w; float *w3; int Cin, Cout; };   // w: (Cin, Cout, 4, 4) -> w3: (Cin, 4 Cout, 3, 3)
+__global__ __launch_bounds__(256) void conv_s2d_weights_kernel(S2dWeightParams p) {
+  const size_t total = (size_t)p.Cin * 4 * p.Cout * 9;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int sx = (int)(idx % 3), r = (int)((idx / 3) % 3);
+  const int cc = (int)((idx / 9) % (4 * p.Cout)), ci = (int)(idx / ((size_t)9 * 4 * p.Cout));
+  const int par = cc / p.Cout, co = cc - par * p.Cout, py = par >> 1, px = par & 1;
+  auto tap = [](int par1, int r1) { return par1 ? (r1 == 0 ? 0 : (r1 == 1 ? 2 : -1)) : (r1 == 1 ? 1 : (r1 == 2 ? 3 : -1)); };
+  const int ky = tap(py, r), kx = tap(px, sx);
+  p.w3[idx] = (ky >= 0 && kx >= 0) ? p.w[(((size_t)ci * p.Cout + co) * 4 + ky) * 4 + kx] : 0.f;
+}
 // per-channel sum over (n, pixel) of a (N, C, plane) tensor (bias gradient)
 struct ChanSumParams { const float *g; float *out; int N, C; size_t plane; int add; };
 __global__ __launch_bounds__(256) void channel_sum_kernel(ChanSumParams p) {

@@ -466,6 +466,13 @@ __device__ __forceinline__ float conv_weight_at(const ConvPackParams &p, int c, 
     const int ix = px ? (sx == 1 ? 2 : (sx == 2 ? 0 : -1)) : (sx == 0 ? 3 : (sx == 1 ? 1 : -1));
     return (iy >= 0 && ix >= 0) ? p.w[(((size_t)c * (p.Cout >> 2) + orl) * 4 + iy) * 4 + ix] : 0.f;
   }
+  if (p.transposed == 3) {   // 3x3 / stride 2 / pad 1 / adj 1 transposed conv, same pseudo-filters: output row 2y+py takes input row y
+    // through kernel row 1 (py = 0) or 2 (py = 1) and input row y+1 through kernel row 0 (py = 1)
+    const int orl = o >> 2, py = (o >> 1) & 1, px = o & 1, r = t / 3, sx = t - 3 * r;
+    const int iy = py ? (r == 1 ? 2 : (r == 2 ? 0 : -1)) : (r == 1 ? 1 : -1);
+    const int ix = px ? (sx == 1 ? 2 : (sx == 2 ? 0 : -1)) : (sx == 1 ? 1 : -1);
+    return (iy >= 0 && ix >= 0) ? p.w[(((size_t)c * (p.Cout >> 2) + orl) * 3 + iy) * 3 + ix] : 0.f;
+  }
   return p.transposed ? p.w[((size_t)c * p.Cout + o) * p.T + t] : p.w[((size_t)o * p.Cin + c) * p.T + t];
 }
 __global__ __launch_bounds__(256) void conv_pack_weights_kernel(ConvPackParams p) {
