@@ -15,6 +15,10 @@ CONV_CASES = [
     dict(N=2, Cin=6, Cout=5, H=9, W=12, leaky=True),                                   # ragged channels + fused LeakyReLU
     dict(N=1, Cin=8, Cout=16, H=12, W=16, stride=(2, 2)),                              # the pyramid's stride-2 layers
     dict(N=1, Cin=4, Cout=8, H=12, W=16, dilate=(2, 2), pad=(2, 2), leaky=True),       # the context network's dilations
+    dict(N=1, Cin=4, Cout=8, H=12, W=16, dilate=(4, 4), pad=(4, 4)),                   # dilation % 4 == 0: shifted quads are aligned loads
+    dict(N=2, Cin=40, Cout=33, H=9, W=24, leaky=True, req=("write", "add", "write")),  # two channel tiles (32 + 8), two filter tiles (32 + 1), odd H, accumulate
+    dict(N=1, Cin=6, Cout=8, H=5, W=32),                                               # W % 32 == 0: four quads per lane and run
+    dict(N=1, Cin=4, Cout=8, H=6, W=64, dilate=(2, 2), pad=(2, 2)),                    # the same at dilation 2, two runs per row
     dict(N=1, Cin=8, Cout=2, H=8, W=8, bias=False),                                    # a flow head
     dict(N=1, Cin=8, Cout=4, H=4, W=8, transposed=True, kernel=(4, 4), stride=(2, 2), pad=(1, 1), leaky=True),   # upfeat
     dict(N=2, Cin=4, Cout=8, H=8, W=8, req=("add", "add", "add")),
