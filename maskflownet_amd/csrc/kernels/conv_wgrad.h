@@ -93,28 +93,33 @@ __global__ __launch_bounds__(64) void conv_wgrad_kernel(ConvWgradParams p) {
     // s (left alone hipcc requested each quad right before its use -- a dozen exposed round trips per run, 60 TFLOP/s).  Two
     // register sets, the loop unrolled over two runs so that every index is static; a run past the slice loads zeros.
     f32x4 A[2][QPL], C[2][QPL + 2];
+    // masks are out-of-range offsets of range-checked buffer loads (zeros from the hardware): a select on the loaded value would
+    // need the value -- hipcc then waits for the quads of step s+1 before the matrix instructions of step s
+    constexpr unsigned OOR = 0xFFFFFF00u;
+    const unsigned gbytes = (unsigned)(p.Cout * plane) * 4u, xbytes = (unsigned)(p.Cin * plane) * 4u;
     auto issue = [&](int run, int ky, f32x4 (&Cb)[QPL + 2], f32x4 (&Ab)[QPL]) {
-#ifdef MFN_WGRAD_ABLATE   // measurement builds: operands loaded for the first two runs only (1) / never (2)
-      if (MFN_WGRAD_ABLATE == 2 || run >= r0 + 2) return;
+#ifdef MFN_WGRAD_ABLATE   // measurement builds: operands loaded for the first two runs only
+      if (run >= r0 + 2) return;
 #endif
       const bool live = run < r1;
       const int rr = live ? run : r0;
       const int xr = rr % wr, row = rr / wr;
-      const int y = row % H, n = row / H;
+      const int y = row % H, n = MFN_UNIFORM(row / H);
       const int xq = xr * (8 * QPL) + 4 * QPL * half;
       if (ky == 0) {
-        const float *gp = p.g + ((size_t)n * p.Cout + (o_ok ? o : 0)) * plane;
+        const float *gimg = p.g + (size_t)n * p.Cout * plane;
+        const unsigned go = (unsigned)(o * plane + y * W + xq) * 4u;
         MFN_UNROLL
-        for (int q = 0; q < QPL; ++q) Ab[q] = ld4(gp, y * W + xq + 4 * q, o_ok && live);
+        for (int q = 0; q < QPL; ++q) Ab[q] = mfn_bload4(gimg, gbytes, (o_ok && live) ? go + 16u * q : OOR);
       }
-      const float *xp = p.x + ((size_t)n * p.Cin + (c_ok ? c : 0)) * plane;
+      const float *ximg = p.x + (size_t)n * p.Cin * plane;
       const int yy = y + (ky - 1) * d;
       const bool rok = live && c_ok && yy >= 0 && yy < H;
-      const int ro = (rok ? yy : 0) * W;
-      Cb[0] = ld4(xp, ro + xq - 4, rok && xq >= 4);              // the quad left of the lane's, its own, the one right of them
+      const unsigned xo = (unsigned)(c * plane + yy * W + xq) * 4u;
+      Cb[0] = mfn_bload4(ximg, xbytes, (rok && xq >= 4) ? xo - 16u : OOR);     // the quad left of the lane's, its own, the one right of them
       MFN_UNROLL
-      for (int q = 0; q < QPL; ++q) Cb[q + 1] = ld4(xp, ro + xq + 4 * q, rok);
-      Cb[QPL + 1] = ld4(xp, ro + xq + 4 * QPL, rok && xq + 4 * QPL < W);
+      for (int q = 0; q < QPL; ++q) Cb[q + 1] = mfn_bload4(ximg, xbytes, rok ? xo + 16u * q : OOR);
+      Cb[QPL + 1] = mfn_bload4(ximg, xbytes, (rok && xq + 4 * QPL < W) ? xo + 16u * QPL : OOR);
     };
     auto mma = [&](int ky, const f32x4 (&Cb)[QPL + 2], const f32x4 (&Ab)[QPL]) {
       MFN_UNROLL

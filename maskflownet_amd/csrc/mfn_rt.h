@@ -127,6 +127,12 @@ static inline float mfn_bload1_row(const void *base, unsigned full_bytes, unsign
   if (valid && (unsigned long long)voff + soff + 4 <= full_bytes) memcpy(&v, (const char *)base + voff + soff, 4);
   return v;
 }
+// sixteen bytes per lane through a raw buffer descriptor: a lane whose byte offset is out of the range reads zeros
+static inline f32x4_emu mfn_bload4(const void *base, unsigned range_bytes, unsigned voff) {
+  f32x4_emu v = {{0.f, 0.f, 0.f, 0.f}};
+  if ((unsigned long long)voff + 16 <= range_bytes) memcpy(&v, (const char *)base + voff, 16);
+  return v;
+}
 // DMA of one row of a tensor: a fixed base, the row's byte offset as a wave-uniform soffset, and a range check that is exact for
 // base .. base+full_bytes (lanes whose voff+soff+16 exceeds it, or every lane when !valid, write zeros)
 static inline void mfn_dma16_row(const void *base, unsigned full_bytes, unsigned soff, bool valid, float *lds_wave_base, unsigned voff) {
@@ -393,6 +399,13 @@ __device__ __forceinline__ float mfn_bload1_row(const void *base, unsigned full_
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(valid ? full_bytes : 0u), 0x00020000);
   const unsigned so = __builtin_amdgcn_readfirstlane(valid ? soff : 0u);
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)so, 0));
+}
+// sixteen bytes per lane through a raw buffer descriptor (wave-uniform base, per-lane byte offset): out-of-range lanes read
+// zeros -- a mask that costs no VALU instruction and, unlike a select on the loaded value, does not pull the wait up to the load
+__device__ __forceinline__ f32x4 mfn_bload4(const void *base, unsigned range_bytes, unsigned voff) {
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)range_bytes, 0x00020000);
+  return __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
 }
 #define MFN_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define MFN_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
