@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(ConvWgradReduceP
 
 inline bool conv_wgrad_shape_ok(int Cin, int Cout, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw) {
   return kh == 3 && kw == 3 && sh == 1 && sw == 1 && dh == dw && ph == dh && pw == dw && (dh == 1 || dh == 2 || dh % 4 == 0) &&
-         W % 8 == 0 && Cout > 4 && (size_t)Cin * H * W < ((size_t)1 << 30) && (size_t)Cout * H * W < ((size_t)1 << 30);
+         W % 8 == 0 && (size_t)Cin * H * W < ((size_t)1 << 30) && (size_t)Cout * H * W < ((size_t)1 << 30);
 }
 struct ConvWgradPlan { int qpl, tiles_o, tiles_c, slices, runs, runs_per_slice; size_t slab_bytes; };
 inline ConvWgradPlan conv_wgrad_plan(int N, int Cin, int Cout, int H, int W) {
