@@ -252,8 +252,9 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   // lines back, lane -> (line 8k + lane/8, 16-byte chunk lane%8).
   constexpr int MAXCH = T < MD + 1 ? T : MD + 1;          // chains per step at most
   constexpr int LINES = MAXCH * 2 * D;
-  constexpr int STG_F = LINES * 32;                       // floats per staging buffer
   constexpr int NSJ_MAX = ((LINES + 7) / 8 + 3) / 4;      // store instructions per wave and step at most
+  constexpr int STG_F = NSJ_MAX * 4 * 8 * 32;             // floats per staging buffer: whole 1 KB groups for every (wave, slot) -- the
+                                                          // read-back of a group past LINES (its lanes' stores are masked) stays inside
   int stw[MAXCH];                                         // staging write: float offset of this lane's 16 bytes of chain ci (or -1)
   unsigned cvoff[NSJ_MAX > 0 ? NSJ_MAX : 1];              // store: lane constant of slot j (or INVALID)
   int cbit[NSJ_MAX > 0 ? NSJ_MAX : 1];                    // store: bit (ci*2 + yy) of the line slot j reads
@@ -491,7 +492,8 @@ inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *na
   p.bx_per_row = cdiv(p.strips, NWV);
   const long nblk = (long)p.N * p.segs * SP * p.bx_per_row;
   if (nblk <= 0) return 0;
-  const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? 2 * MAXCH * 2 * D * 32 : 0)) * sizeof(float);
+  constexpr int NSJ_MAX = ((MAXCH * 2 * D + 7) / 8 + 3) / 4;
+  const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? 2 * NSJ_MAX * 4 * 8 * 32 : 0)) * sizeof(float);
   return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
