@@ -79,6 +79,9 @@ class LibraryBackend:
             self._up[factor] = layer.Upsample(factor)
         return self._up[factor](x.contiguous())
 
+    def warp(self, x, flow):             # layer.py:14-18 (Reconstruction2D); only ever called on the frozen head's outputs
+        return ops.warp(x.contiguous(), flow.contiguous(), clip_grid=False)
+
 
 def _key(name):
     return name.replace(".", "__")
@@ -102,6 +105,12 @@ class MaskFlownetSTrainable(nn.Module):
         return self.B.conv(x, w, b, stride, dilation, act, transposed)
 
     def forward(self, im1, im2):
+        r = self.run(im1, im2)
+        return r["predictions"], [r["occlusion"]]
+
+    def run(self, im1, im2):
+        """forward() with what MaskFlownet_S hands to the cascade (`srcs`, MaskFlownet.py:305-314) kept: the pyramid c[l] (both
+        images as one batch), the flows per level (network units) and mask2."""
         N = im1.shape[0]
         x = torch.cat([im1, im2], 0)
         c = {}
@@ -109,7 +118,7 @@ class MaskFlownetSTrainable(nn.Module):
             for k, s in (("a", 2), ("b", 1), ("c", 1)):
                 x = self.conv("conv%d%s" % (l, k), x, stride=s)
             c[l] = x
-        preds = []
+        preds, flows = [], {}
         flow = mask = feat = None
         for l in (6, 5, 4, 3, 2):
             c1, c2 = c[l][:N], c[l][N:]
@@ -130,9 +139,71 @@ class MaskFlownetSTrainable(nn.Module):
                 d = torch.cat([self.conv("pred_flow%d" % l, x, act=False), self.conv("pred_mask%d" % l, x, act=False)], 1)
             else:
                 d = self.conv("pred_flow2", x, act=False)
-            flow = d[:, :2] if l == 6 else flow_up + d[:, :2]
+            flow = d[:, :2].contiguous() if l == 6 else flow_up + d[:, :2]
             if l > 2:
-                mask = d[:, 2:3]
+                mask = d[:, 2:3].contiguous()
+                feat = self.conv("upfeat%d" % (l - 1), x, transposed=True)
+                preds.append(flow)
+                flows[l] = flow
+        y = x
+        for i, (_, dil) in enumerate(CONTEXT):
+            y = self.conv("dc_conv%d" % (i + 1), y, dilation=dil)
+        flow = flow + self.conv("dc_conv7", y, act=False)
+        preds.append(flow)
+        flows[2] = flow
+        return {"predictions": [f * SCALE for f in preds], "occlusion": torch.sigmoid(mask_up),      # MaskFlownet.py:303-305
+                "c": c, "flows": flows, "mask2": mask_up}
+
+
+class MaskFlownetTrainable(nn.Module):
+    """The full MaskFlownet (MaskFlownet.hybrid_forward, MaskFlownet.py:436-545) for its training stage: the S head frozen
+    (`fix_head`, :413-415, main.py:139) and run without a tape, the cascade -- second pyramid over (image 1 | 0) and (warped image 2 |
+    occlusion mask - 0.5), per level a deformable warp by the cascade's own flow, two md = 2 cost volumes, decoder, flow head, the
+    context network -- differentiable on the library.  `params`: the head under 'MaskFlownet_S.<block>', the cascade under '<block>'.
+    forward -> ([gflow6 .. gflow2] x scale, [the head's occlusion mask])."""
+
+    def __init__(self, params, backend=None, dtype=torch.float32):
+        super().__init__()
+        from .network import HEAD
+        self.B = backend if backend is not None else LibraryBackend()
+        self.head = MaskFlownetSTrainable({k[len(HEAD):]: v for k, v in params.items() if k.startswith(HEAD)}, self.B, dtype)
+        for q in self.head.parameters():
+            q.requires_grad_(False)
+        self.P = nn.ParameterDict({_key(k): nn.Parameter(torch.as_tensor(np.ascontiguousarray(v)).to(dtype))
+                                   for k, v in params.items() if not k.startswith(HEAD)})
+
+    def conv(self, name, x, stride=1, dilation=1, act=True, transposed=False):
+        return self.B.conv(x, self.P[_key(name + ".weight")], self.P[_key(name + ".bias")], stride, dilation, act, transposed)
+
+    def forward(self, im1, im2):
+        from .network import MD_CASCADE
+        N = im1.shape[0]
+        with torch.no_grad():
+            h = self.head.run(im1, im2)
+            warped = self.B.warp(im2, self.B.upsample(h["flows"][2], 4) * SCALE)                       # :311
+            mask0 = torch.sigmoid(self.B.upsample(h["mask2"], 4)) - 0.5                                 # :309-310
+            x = torch.cat([torch.cat([im1, torch.zeros_like(mask0)], 1), torch.cat([warped, mask0], 1)], 0)   # c30, c40 (:312-313)
+        d = {}
+        for l in range(1, 7):                        # the second pyramid, both 4-channel inputs as one batch
+            for k, s in (("x", 2), ("y", 1), ("z", 1)):
+                x = self.conv("conv%d%s" % (l, k), x, stride=s)
+            d[l] = x
+        preds = []
+        flow = feat = None
+        for l in (6, 5, 4, 3, 2):
+            c1 = h["c"][l][:N]
+            c2 = c1 if l in (2, 3) else h["c"][l][N:]          # c2s = [c21, c12, c13, c24, c25, c26] (:307)
+            c3, c4 = d[l][:N], d[l][N:]
+            flow_in = h["flows"][6] if l == 6 else self.B.upsample(flow, 2)                              # :457
+            w, b = self.P[_key("deform%d.weight" % l)], self.P[_key("deform%d.bias" % l)]
+            warp = torch.nn.functional.leaky_relu(self.B.deform(c2, flow_in, w, b, SCALE, float(STRIDES[l])), 0.1)   # :460-461
+            cu = self.B.correlation(c1, warp, MD_CASCADE)
+            cv = self.B.correlation(c3, c4, MD_CASCADE)
+            x = torch.cat([cu, cv, flow_in], 1) if l == 6 else torch.cat([c1, feat, cu, cv, flow_in, h["flows"][l]], 1)   # :466, :480
+            for k in range(len(DECODER)):
+                x = torch.cat([self.conv("conv%d_%d" % (l, k), x), x], 1)
+            flow = flow_in + self.conv("pred_flow%d" % l, x, act=False)
+            if l > 2:
                 feat = self.conv("upfeat%d" % (l - 1), x, transposed=True)
                 preds.append(flow)
         y = x
@@ -140,7 +211,7 @@ class MaskFlownetSTrainable(nn.Module):
             y = self.conv("dc_conv%d" % (i + 1), y, dilation=dil)
         flow = flow + self.conv("dc_conv7", y, act=False)
         preds.append(flow)
-        return [f * SCALE for f in preds], [torch.sigmoid(mask_up)]      # MaskFlownet.py:303-305
+        return [f * SCALE for f in preds], [h["occlusion"]]
 
 
 class MultiscaleEpe(nn.Module):

@@ -57,6 +57,13 @@ class TorchBackend:
     def deform(self, x, flow, w, b, scale, stride):
         return _OracleDeform.apply(x, flow, w, b, float(scale), float(stride))
 
+    def warp(self, x, flow):    # GridGenerator('warp') on the flipped flow + BilinearSampler (layer.py:14-18); flow = (dy, dx)
+        N, C, H, W = x.shape
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=x.dtype), torch.arange(W, dtype=x.dtype), indexing="ij")
+        gx = (xs + flow[:, 1]) / ((W - 1) / 2.0) - 1
+        gy = (ys + flow[:, 0]) / ((H - 1) / 2.0) - 1
+        return F.grid_sample(x, torch.stack([gx, gy], -1), mode="bilinear", padding_mode="zeros", align_corners=True)
+
     def upsample(self, x, f):   # MaskFlownet.py:35-62
         if f == 1:
             return x
@@ -136,3 +143,38 @@ def test_one_optimizer_step_lowers_the_loss():
     for _ in range(3):
         last = training.train_step(net, loss_fn, opt, im1, im2, label, mask)
     assert torch.isfinite(last).all() and last.sum().item() < first.sum().item()
+
+
+def test_full_model_cascade_forward_and_gradients():
+    """training.MaskFlownetTrainable (the full model's training stage: head frozen, cascade differentiable): its forward equals
+    network.MaskFlownet's, the cascade's parameter gradients equal the torch / oracle statement's, the head receives none."""
+    from maskflownet_amd import network, training
+    N, H, W = 1, 128, 128
+    params = network.random_params(11, full=True)
+    rng = np.random.default_rng(5)
+    for k in params:
+        if k.endswith(".bias"):
+            params[k] = (rng.standard_normal(params[k].shape) * 0.05).astype(np.float32)
+    im1, im2, label, mask = _batch(N, H, W, 6)
+    ref = network.MaskFlownet(params, N, H, W)(im1, im2)
+    lib_net = training.MaskFlownetTrainable(params).cuda()
+    preds, _ = lib_net(im1.cuda(), im2.cuda())
+    for a, b in zip(preds, ref["predictions"]):
+        assert (a.detach() - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3)
+    loss = training.MultiscaleEpe()(label.cuda(), mask.cuda(), *preds).sum()
+    loss.backward()
+    assert all(q.grad is None for q in lib_net.head.parameters())
+    tb = TorchBackend()
+    ref_net = training.MaskFlownetTrainable(params, backend=tb, dtype=torch.float64)
+    rpreds, _ = ref_net(im1.double(), im2.double())
+    rl = training.MultiscaleEpe(backend=tb)(label.double(), mask.double(), *rpreds).sum()
+    rl.backward()
+    assert abs(loss.item() - rl.item()) <= 1e-4 * abs(rl.item())
+    errs = []
+    for k, q in lib_net.P.items():
+        g, r = q.grad.detach().cpu().double(), ref_net.P[k].grad
+        assert torch.isfinite(g).all(), k
+        errs.append(((g - r).abs().max().item() / max(r.abs().max().item(), 1e-12), k))
+    errs.sort(reverse=True)
+    print("full model, relative gradient errors, worst first:", ["%s %.1e" % (k, e) for e, k in errs[:6]], "median %.1e" % errs[len(errs) // 2][0])
+    assert errs[0][0] <= GRAD_TOL, errs[:5]
