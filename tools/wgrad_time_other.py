@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Measurement: weight gradients of the layers that are NOT on conv_wgrad_kernel's shapes or were not at first (stride-2 pyramid
+layers, the few-filter heads, the transposed upfeat layers): mfn_conv2d_bwd with only the weight gradient requested, us per call."""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from maskflownet_amd.ops import default_ops
 ops = default_ops()
