@@ -24,7 +24,7 @@ CONV_CASES = [
     dict(N=2, Cin=4, Cout=8, H=8, W=8, req=("add", "add", "add")),
     dict(N=1, Cin=4, Cout=4, H=8, W=8, req=("null", "write", "null")),
     dict(N=2, Cin=4, Cout=6, H=40, W=52, leaky=True),            # 4160 (n, pixel) terms per channel: the bias gradient in two slices
-    dict(N=1, Cin=4, Cout=5, H=65, W=65, req=("null", "null", "add")),   # odd plane: scalar loads in the slices; accumulate
+    dict(N=1, Cin=1, Cout=3, H=65, W=65, req=("null", "null", "add")),   # odd plane: scalar loads in the slices; accumulate
 ]
 
 
