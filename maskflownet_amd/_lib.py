@@ -15,7 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # MFN_HIP_SO: measurement builds of the same HIP library (tools/ablate.py); never a different backend
 SO_PATH = os.environ.get("MFN_HIP_SO") or os.path.join(CSRC, "libmfn_hip.so")
-RES_PATH = os.path.join(CSRC, "libmfn_hip.resources.txt")   # hipcc's kernel-resource-usage remarks of the shipped build
+# hipcc's kernel-resource-usage remarks of the build at SO_PATH (next to it: a measurement build under MFN_HIP_SO keeps its own
+# table and never overwrites the shipped build's, which tests/test_abi.py asserts on)
+RES_PATH = os.path.splitext(SO_PATH)[0] + ".resources.txt"
 # -fno-slp-vectorize: the SLP vectoriser rewrites the correlation inner product into v_pk_fma_f32 fed by
 # dozens of re-issued ds_read2_b32 (unaligned operand pairs re-read from LDS), which made the kernel
 # LDS-bound with 64% bank-conflict cycles (profiles/r01_corr_pmc.md)
@@ -92,7 +94,13 @@ def build(force=False, verbose=False):
     remarks = [l for l in proc.stderr.splitlines() if "remark:" in l]
     other = [l for l in proc.stderr.splitlines() if "remark:" not in l and "-Rpass-analysis" not in l]
     if proc.returncode != 0:
-        raise subprocess.CalledProcessError(proc.returncode, cmd, stderr="\n".join(other[-60:]))
+        # CalledProcessError's str() does not show its stderr: print the compiler's diagnostics before raising
+        import sys
+        sys.stderr.write("\n".join(other[-200:]) + "\n")
+        raise subprocess.CalledProcessError(proc.returncode, cmd, stderr="\n".join(other[-200:]))
+    warnings = [l for l in other if "warning:" in l]
+    if warnings and verbose:
+        print("hipcc: %d warning(s), first: %s" % (len(warnings), warnings[0]))
     with open(RES_PATH + ".tmp%d" % os.getpid(), "w") as f:
         f.write("# src=%s\n" % want)
         f.write("\n".join(remarks) + "\n")

@@ -656,9 +656,12 @@ __global__ __launch_bounds__(NW * 64) void conv_few_kernel(ConvFewParams p) {
     }
   }
 }
-inline bool conv_few_shape_ok(int W) {   // lane 0 of every wave must start a row: 64 % (W/4) == 0 or (W/4) % 64 == 0
+// A row's 4-pixel groups must lie inside ONE wave (64 % (W/4) == 0, i.e. W <= 256): the halo columns travel by DPP wave shifts, and
+// lane 0 / 63 of a wave has no neighbour to receive from -- a row that spans several waves (W = 512, 768, ...) would lose the
+// column at every wave seam (wider images take conv_mfma_kernel)
+inline bool conv_few_shape_ok(int W) {
   const int gw = W / 4;
-  return W % 4 == 0 && gw >= 1 && (64 % gw == 0 || gw % 64 == 0);
+  return W % 4 == 0 && gw >= 1 && gw <= 64 && 64 % gw == 0;
 }
 // channel blocks of a level: until the launch has ~256 blocks, at most 8, at least 32 channels each
 inline int conv_few_kb(int N, int Cin, int H, int W) {

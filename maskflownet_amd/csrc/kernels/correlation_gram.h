@@ -11,9 +11,14 @@
 //     G[(y,x)][(y',x')] = sum_c f1[c,y,x] f2[c,y',x'].  A 16 x 16 tile of G with M = an 8 x 2 pixel block of f1 and
 //     N = a 16 x 1 row segment of f2 starting 4 columns left of the block is 50.6 % useful for md = 4 (10 tiles per 16 pixels x 81
 //     displacements) -- the densest (M, N) shape pair for the 16 x 16 tile.
-//   * exact fp32: every operand is split hi + mid + lo into three bf16 terms (24 significant bits) and the six products with
-//     weight >= 2^-16 are accumulated in fp32 by the matrix core (the dropped ones are below one fp32 rounding): mfn_rt.h
-//     mfn_split3x8.  TERMS = 2 is the measured two-term / three-product variant (2^-17 relative per product; not the default).
+//   * fp32-EQUIVALENT arithmetic (not the bit pattern of an fp32 FMA chain): every operand is split hi + mid + lo into three
+//     bf16 terms (24 significant bits, the split itself is exact) and SIX of the nine partial products -- those of weight
+//     >= 2^-16: hh, hm, mh, mm, hl, lh -- are accumulated in fp32 by the matrix core; the three dropped ones (ml, lm, ll) are
+//     <= 2^-24 of the product each, i.e. together up to ~1 ulp PER PRODUCT (not per sum), which is what an fp32 FMA chain loses per
+//     accumulation step anyway.  Held to it by tests/test_gpu_parity.py::test_correlation_gram_error_vs_fp64 (error against the
+//     fp64 oracle <= 1.5 x the FMA kernel's on the same input, plus a per-element relative check).  Non-finite inputs differ:
+//     an inf feature splits into inf + NaN (inf - bf16(inf)), so the affected outputs are NaN where the FMA chain gives inf
+//     (include/mfn_hip.h, "Arithmetic").  mfn_rt.h mfn_split3x8.
 //   * one WAVE = one work item: an 8-pixel wide column strip x `rows` output rows of one image.  The wave walks down the f2 rows
 //     ys-md .. ys+rows-1+md ("steps"); each f2 row segment (16 px x 32 ch) is converted ONCE into a B operand (12 VGPRs) and
 //     multiplied with the up to md+1 resident A operands (8 x 2 pixel blocks of f1, converted once, 12 VGPRs each) whose rows
@@ -201,7 +206,10 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     constexpr int kd = SC::kind(k);
     float *slot = ring + (k % NSLOT) * SLOT_F;
     if (MFN_GRAM_ABLATE & 8) { stamp[k] = n_issued; return; }
-    if (kd >= 0) {   // f1 block t: rows ys+2t, +1 (a second row that is row H reads zeros: the range check is exact for the image)
+    if (kd >= 0) {   // f1 block t: rows ys+2t, +1.  A second row that is row H (odd H) is NOT zero-filled except for channel 31: for
+      // c < 31 the transfer reads row 0 of channel c + 1 (voff + soff is still inside the image's 32 planes).  Those lanes' results
+      // are never stored -- the row masks vo_mid / vo_last (r1 false) and, in the cooperative store, rowok_bits drop them; the
+      // odd-H cases of tests/test_emu_parity.py::test_correlation_gram_band_on_matrix_cores ((2,32,13,20), (1,32,7,36)) pin that
       const bool in = ys + 2 * kd < H;
       const unsigned soff = (unsigned)((ys + 2 * kd) * W) * 4u;
       mfn_dma16_row(f1n, img_bytes, soff, in, slot, voffM[0]);

@@ -638,6 +638,14 @@ def test_conv3x3_few_filters(ops, oracle, Cout):
     emu_ops.launch_log()
     pc.case_conv(ops, oracle, ident, ident, 1, 9, Cout, 6, 12, pad=(1, 1), seed=4)
     assert "conv3x3_few" not in emu_ops.launch_log()
+    # a row wider than one wave's 64 groups (W = 512: ADVICE r04 -- the DPP halo has no neighbour across a wave seam, columns
+    # 255 / 256 came back without their neighbour): the matrix-core kernel, and every column right
+    if Cout == 2:
+        emu_ops.launch_log()
+        pc.case_conv(ops, oracle, ident, ident, 1, 3, Cout, 2, 512, pad=(1, 1), seed=5)
+        assert "conv3x3_few" not in emu_ops.launch_log()
+        pc.case_conv(ops, oracle, ident, ident, 1, 3, Cout, 2, 256, pad=(1, 1), seed=5)   # W = 256: one row = one wave, still the few-filter kernel
+        assert "conv3x3_few" in emu_ops.launch_log()
 
 
 @pytest.mark.parametrize("kw", [dict(kernel=(1, 1)), dict(kernel=(5, 3), pad=(2, 1)), dict(kernel=(3, 3), pad=(1, 1), num_group=2)])

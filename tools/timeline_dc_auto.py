@@ -9,7 +9,9 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from maskflownet_amd import _lib, hotpath
 lib = _lib.lib()
-wl = hotpath.HotPathWorkload(sys.argv[1] if len(sys.argv) > 1 else "cfg2")
+if len(sys.argv) > 2 and sys.argv[2]:   # tuning overrides "k=v,k=v" (set before the workload packs its weights)
+    _lib.set_tuning(**{a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[2].split(",") if a})
+wl = hotpath.HotPathWorkload(sys.argv[1] if len(sys.argv) > 1 else "cfg2", mode=sys.argv[3] if len(sys.argv) > 3 else "dropin")
 calls = dict(wl.calls())
 wl.run_eager()
 MAXB = 16384
