@@ -58,6 +58,7 @@ struct DeformParams {
   int tile_w, tiles_x, tiles_y, ntiles;      // 32-pixel tiles: (32/tile_w) x tile_w output pixels (tile_w 16 or 8), or
                                              // tile_w == 0: 32 consecutive pixels of the flattened (n,ho,wo) index
   float *partial;                             // ksb > 1: raw partial sums [ksb][N][Cout][Ho][Wo]
+  int dcm_groups, dcm_gps;                    // dc_mma_kernel (deform_conv_mma.h): 16-channel groups of the call / per K slice
 };
 
 constexpr int DC_PAIR_W_BF16 = 3 * 2 * 32 * 8 / 2 + 2 * 32;   // words of a channel pair's weights in the bf16 x 3 form (832; 576 in fp32)
@@ -314,9 +315,12 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       dc_axis(offh[0], h_in, i, H, v, lo, hi, l);
       v = v && px_valid;
       const int ulo = (int)fminf(fmaxf(floorf((float)i + offh[0]), -1.0e6f), 1.0e6f);  // unclamped floor
-      if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i);
-      ay.a[i] = v ? 1.f - l : 0.f;
-      ay.b[i] = v ? l : 0.f;
+      // (i + off can round UP to an integer in fp32 -- off a hair below one: the oracle then reads line i + 1 with weight 1, which
+      // is the same pair of lines with weights (0, 1): still the shared path, see deform_conv_mma.h)
+      const bool up = i > 0 && ulo == lo0 + i + 1 && l == 0.f;
+      if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i || up);
+      ay.a[i] = v ? (up ? 0.f : 1.f - l) : 0.f;
+      ay.b[i] = v ? (up ? 1.f : l) : 0.f;
     }
     MFN_UNROLL
     for (int m = 0; m < 4; ++m) ay.idx[m] = min(max(h_in + lo0 + m, 0), H - 1);
@@ -326,9 +330,10 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       dc_axis(offw[0], w_in, i, W, v, lo, hi, l);
       v = v && px_valid;
       const int ulo = (int)fminf(fmaxf(floorf((float)i + offw[0]), -1.0e6f), 1.0e6f);
-      if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i);
-      ax.a[i] = v ? 1.f - l : 0.f;
-      ax.b[i] = v ? l : 0.f;
+      const bool up = i > 0 && ulo == lo0 + i + 1 && l == 0.f;
+      if (i == 0) lo0 = ulo; else regular = regular && (ulo == lo0 + i || up);
+      ax.a[i] = v ? (up ? 0.f : 1.f - l) : 0.f;
+      ax.b[i] = v ? (up ? 1.f : l) : 0.f;
     }
     MFN_UNROLL
     for (int m = 0; m < 4; ++m) ax.idx[m] = min(max(w_in + lo0 + m, 0), W - 1);

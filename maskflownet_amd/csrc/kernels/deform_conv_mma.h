@@ -1,0 +1,746 @@
+// deform_conv_mma.h -- DeformableConvolution forward on the bf16 matrix cores of gfx950 (round 5).
+//
+// Replaces MXNet contrib.DeformableConvolution at /root/reference/network/layer.py:117-124 for the shapes the network
+// uses it with (3x3, stride 1, pad 1, dilation 1, one group: MaskFlownet.py:155-158); semantics as
+// oracle/mfn_ref_body.inc deform_conv_fwd.  Everything else stays on deform_conv.h (dc_lds_kernel / dc_generic_kernel).
+//
+//   out[o, p] = bias[o] + sum_{c, tap} W[o, c, tap] * col[c, tap, p],   col = bilinear gather of x at p + tap + offset(p)
+//
+// fp32-EQUIVALENT arithmetic on v_mfma_f32_32x32x16_bf16 (16x the rate of the fp32 MFMA, and beside the VALU instead of on
+// its ALUs): both operands are written as three bf16 terms (hi + mid + lo = 24 significant bits, the split is exact) and SIX
+// of the nine partial products -- those of weight >= 2^-16 -- are accumulated in fp32; the dropped ones are <= 2^-24 of a
+// product each (~1 ulp per product, what an fp32 FMA chain loses per step anyway).  The acceptance rule is the one of the
+// Gram cost volume: error against the fp64 oracle not above the exact-fp32 kernel's (tests/test_gpu_parity.py
+// test_deform_mma_error_vs_fp64).  Non-finite inputs differ: an inf column value splits into inf + NaN.
+//
+// What changed against dc_lds_kernel<.., MMA = 1> (round 3/4, removed), from its timelines (profiles/r05_dc_probe_before.txt:
+// level 2 = 0.7 us start + 4.4 set-up + 12.0 loop + 1.5 epilogue + 4 us of late blocks; 16.2 us with every matrix
+// instruction, gather and DMA compiled out):
+//   * the weights are split ONCE, at pack time (dcm_pack_weights_kernel); a column value is split once per (pixel, channel)
+//     and its B operand is reused by ALL MT filter tiles of the wave and all six products (before: one 32-filter tile per
+//     wave, the gather / interpolation / split repeated per filter group);
+//   * no fp32 MFMA: K is ordered in GROUPS of 16 channels = 8 pair steps (lane (pixel j, half kb) owns channel 2 s + kb:
+//     its taps 0..7 are the eight K elements of its k-block) + 1 left-over step whose K elements are tap 8 of the lane's
+//     eight channels of the group -- 9 K = 16 steps for 144 (channel, tap) pairs, nothing padded (before: tap 8 on
+//     v_mfma_f32_32x32x2_f32, 64 cycles per step on the VALU's ALUs);
+//   * a wave's MFMAs never wait for each other: MT >= 2 interleaves the filter tiles, MT = 1 alternates two accumulators;
+//   * B(t + 1) is formed completely (gather, interpolation, split) under the MFMAs of step t (double-buffered operands);
+//   * set-up for the shared-offset case only (the reference feeds one offset to all nine taps, MaskFlownet.py:230): one
+//     floor per axis, the 4x4 neighbourhood at UNCLAMPED consecutive rows / columns of a zero-filled window (clamped taps
+//     carry weight 0 on the row / column behind the image, so the clamp never has to move an address): ONE LDS address
+//     register and 16 immediates instead of 16 address registers;
+//   * every DMA is issued unconditionally (prefetches past the end of a K slice read zeros or the next slice and are never
+//     used): the issue sequence is periodic, every s_waitcnt count is a compile-time constant (dcm_wait_count);
+//   * lanes whose neighbourhood falls outside the wave's 12 x 20 window (2 % of the tiles of the bench flows; before: the
+//     whole tile fell to the slower global-gather tier and its block finished ~4 us after the others) fetch their 16 values
+//     from global memory under an exec mask, everybody else keeps the window;
+//   * the K-slice reduction and the epilogue run on the waves in parallel (tile mt is summed and stored by slice mt % KW).
+// Per-tap offsets (MXNet's general semantics, never hot in the reference) take a lean per-tap column path inside the same kernel.
+#pragma once
+#include "deform_conv.h"
+
+namespace mfn {
+
+// The wave's source window of one channel pair: [channel 0/1][ROWS][COLS] floats, transferred as NI 1 KB wave instructions into a
+// slot of the wave's ring (RING * 512 floats).  Two shapes: 12 x 20 (three slots: the window of pair k + 3 is requested in step k) for
+// the tiles whose neighbourhoods fit it (>= 98 % under the bench's flows); 16 x 24 (two slots of 768 floats in the same ring: one
+// step of cover instead of two) for the rest -- before, such a tile fell to per-lane global loads and its block finished ~6 us
+// after the others, which is what the whole launch then takes.
+constexpr int DCM_XW_F = 512;      // floats of a ring slot of the small window
+template <bool BIG, int RING> struct DcmWin {
+  static constexpr int ROWS = BIG ? 16 : 12, COLS = BIG ? 24 : 20, C4 = COLS / 4, CH = ROWS * COLS;
+  static constexpr int NI = BIG ? 3 : 2, SLOT_F = BIG ? 768 : 512;
+  static constexpr int DEPTH = BIG ? (RING * DCM_XW_F) / 768 : RING;   // slots = how many pairs ahead a window is requested
+  static_assert(2 * CH <= SLOT_F && 2 * ROWS * C4 <= NI * 64 && DEPTH >= 2, "the pair's window fits its slot and its transfers");
+};
+
+// K steps per weight chunk (= block barrier period).  One M-group's step is 3 * MT KB per K slice.
+constexpr int dcm_kc(int mt, int kw) { return mt * kw == 1 ? 3 : 1; }
+// stage buffers of the weight ring: chunk c + NSTAGE - 1 is requested when chunk c opens (KC = 1: two steps of latency cover,
+// where three stages + the window rings + the tap-8 slots still fit the CU's 160 KB)
+constexpr int dcm_nstage(int mt, int pt, int kw, int ring) {
+  if (dcm_kc(mt, kw) != 1) return 2;
+  const int words3 = 3 * kw * 3 * mt * 256 + pt * kw * (ring * DCM_XW_F + 512) + 256;
+  return words3 * 4 <= 160 * 1024 ? 3 : 2;
+}
+// waves per SIMD the register allocator is held to: what one block needs to fit a CU at all (nw / 4), and three / two / one for
+// one / two / more filter tiles per wave (level 2: three 4-wave blocks per CU = the whole launch in one residency round)
+constexpr int dcm_min_waves(int mt, int nw) {
+  const int fit = (nw + 3) / 4, want = mt == 1 ? 3 : (mt == 2 ? 2 : 1);
+  return fit > want ? fit : want;
+}
+
+// measurement builds only (tools/dcm_ablate_build.py): 1 no matrix instructions, 2 no LDS gather reads, 4 no window transfers,
+// 8 no operand split, 16 no interpolation, 32 no weight transfers, 64 no weight reads, 128 no block barrier in the loop
+#ifndef MFN_DCM_ABLATE
+#define MFN_DCM_ABLATE 0
+#endif
+#ifndef MFN_DCM_MINW   // measurement builds override the register budget
+#define MFN_DCM_MINW(mt, nw) dcm_min_waves(mt, nw)
+#endif
+
+template <int MT, int PT, int KW, int RING> struct DcmGeom {
+  static constexpr int NW = PT * KW, NTH = NW * 64;
+  static constexpr int KC = dcm_kc(MT, KW);
+  static constexpr int NSTAGE = dcm_nstage(MT, PT, KW, RING);
+  static constexpr int STEP_W = 3 * MT * 256;          // words of one K step's A operands (one M-group): [term][ft][kb][m][8 bf16]
+  static constexpr int WI_TOTAL = KW * KC * 3 * MT;    // 1 KB wave transfers per weight chunk (all K slices of the block)
+  static constexpr int NI = (WI_TOTAL + NW - 1) / NW;  // ... per wave at most; a wave whose last one would be past WI_TOTAL issues one fewer
+  static constexpr int NI_MIN = WI_TOTAL / NW;         // ... at least: the waits count with this (a wave that issued one more waits for it too)
+  static constexpr int STAGE_W = WI_TOTAL * 256;       // words per stage buffer
+  static constexpr int RED_W = KW > 1 ? PT * (KW - 1) * 1024 : 0;   // K-slice reduction: one 32 x 32 tile per non-owner slice
+  static constexpr int XW_OFF = NSTAGE * STAGE_W > RED_W ? NSTAGE * STAGE_W : RED_W;
+  static constexpr int T8_OFF = XW_OFF + NW * RING * DCM_XW_F;      // tap 8 of a group's eight pairs: [wave][pair][lane]
+  static constexpr int DUMP_OFF = T8_OFF + NW * 512;
+  static constexpr int LDS_W = DUMP_OFF + 256;
+  static_assert(LDS_W * 4 <= 160 * 1024, "a block's LDS must fit the CU");
+};
+
+// s_waitcnt vmcnt count at the head of step s (0..8) of a group, from a simulation of the periodic issue sequence: a step
+// issues, after its wait, [NI weight transfers of chunk c + NSTAGE - 1 if it opens chunk c (s % KC == 0)] then [XW_NI window
+// transfers of pair k + RING if s < 8].  Needed at the wait: the window of the next pair step (gathered in this step; none in
+// step 7) and, at a chunk boundary, this step's weight chunk.  Transfers complete in issue order, so the count is the number
+// issued after the youngest needed one.  1000 = nothing needed.
+template <int KC, int NSTAGE, int RING, int NI, int XW_NI> constexpr int dcm_wait_count(int s) {
+  int issued = 0, result = 1000;
+  int stampW[64] = {}, stampX[80] = {};
+  for (int u = 0; u < 45; ++u) {
+    const int ss = u % 9, grp = u / 9;
+    if (u == 36 + s) {
+      int need = -1;
+      if (ss % KC == 0 && stampW[u / KC] > need) need = stampW[u / KC];
+      if (ss != 7) {
+        const int np = ss == 8 ? 8 * (grp + 1) : 8 * grp + ss + 1;
+        if (stampX[np] > need) need = stampX[np];
+      }
+      result = need < 0 ? 1000 : issued - need;
+    }
+    if (ss % KC == 0) { issued += NI; stampW[u / KC + NSTAGE - 1] = issued; }
+    if (ss < 8) { issued += XW_NI; stampX[8 * grp + ss + RING] = issued; }
+  }
+  return result;
+}
+
+// the steps that wait with the same count as step s, as a bit mask -- for the first such step only (0 for the others)
+template <int KC, int NSTAGE, int RING, int NI, int XW_NI> constexpr unsigned dcm_wait_mask(int s) {
+  const int v = dcm_wait_count<KC, NSTAGE, RING, NI, XW_NI>(s);
+  unsigned m = 0;
+  for (int q = 0; q < 9; ++q) {
+    if (dcm_wait_count<KC, NSTAGE, RING, NI, XW_NI>(q) != v) continue;
+    if (q < s) return 0;
+    m |= 1u << q;
+  }
+  return m;
+}
+
+// transfers the prologue issues after window 0: what may still be outstanding when pair 0 is gathered
+template <int KC, int NSTAGE, int RING, int NI, int XW_NI> constexpr int dcm_prologue_after_x0() {
+  int issued = 0, at_x0 = -1;
+  for (int u = -36; u < 0; ++u) {
+    const int ss = ((u % 9) + 9) % 9;
+    const int kl = (u - ss) / 9 * 8 + ss;
+    if (ss % KC == 0 && u / KC + NSTAGE - 1 >= 0) issued += NI;
+    if (ss < 8 && kl + RING >= 0) { issued += XW_NI; if (kl + RING == 0) at_x0 = issued; }
+  }
+  return issued - at_x0;
+}
+
+// weights (Cout, Cin, 9) -> packed[mg][grp][s 0..8][term h|m|l][ft][kb][m 0..31][e 0..7] bf16; filter o = (mg * MT + ft) * 32 + m;
+// s < 8: channel 16 grp + 2 s + kb, tap e; s == 8: channel 16 grp + 2 e + kb, tap 8.  Zero padded in o and c.  One thread per
+// (mg, grp, s, ft, kb, m); one M-group is one linear array (+ one chunk of padding: the prefetch past the last step).
+struct DcmPackParams { const float *w; float *wt; int Cin, Cout, MT, mgroups, ngroups; size_t mg_words; };
+__global__ __launch_bounds__(256) void dcm_pack_weights_kernel(DcmPackParams p) {
+  const size_t total = (size_t)p.mgroups * p.ngroups * 9 * p.MT * 64;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int m = (int)(idx & 31), kb = (int)((idx >> 5) & 1);
+  size_t r = idx >> 6;
+  const int ft = (int)(r % p.MT); r /= p.MT;
+  const int s = (int)(r % 9); r /= 9;
+  const int grp = (int)(r % p.ngroups);
+  const int mg = (int)(r / p.ngroups);
+  const int o = (mg * p.MT + ft) * 32 + m;
+  float x[8];
+  MFN_UNROLL
+  for (int e = 0; e < 8; ++e) {
+    const int c = s < 8 ? 16 * grp + 2 * s + kb : 16 * grp + 2 * e + kb;
+    const int tap = s < 8 ? e : 8;
+    x[e] = (o < p.Cout && c < p.Cin) ? p.w[((size_t)o * p.Cin + c) * 9 + tap] : 0.f;
+  }
+  mfn_bf16x8 h, mm, l;
+  mfn_split3x8(x, h, mm, l);
+  float *base = p.wt + (size_t)mg * p.mg_words + ((size_t)grp * 9 + s) * (3 * p.MT * 256) + (size_t)(kb * 32 + m) * 4;
+  mfn_write_bf16x8(base + (0 * p.MT + ft) * 256, h);
+  mfn_write_bf16x8(base + (1 * p.MT + ft) * 256, mm);
+  mfn_write_bf16x8(base + (2 * p.MT + ft) * 256, l);
+}
+inline int dcm_pack_launch(DcmPackParams pp, hipStream_t stream) {
+  const size_t total = (size_t)pp.mgroups * pp.ngroups * 9 * pp.MT * 64;
+  return launch("dcm_pack_weights", dcm_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pp);
+}
+
+struct DcmB { mfn_bf16x8 h, m, l; };
+
+template <int MT, int PT, int KW, int RING>
+__global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mma_kernel(DeformParams p) {
+  using G = DcmGeom<MT, PT, KW, RING>;
+  constexpr int NW = G::NW, KC = G::KC, NI = G::NI, NIW = G::NI_MIN;
+  constexpr int NACC = MT == 1 ? 2 : 1;   // MT = 1: two accumulators take the products alternately (no dependent MFMA pair)
+  static_assert(9 % KC == 0, "chunk boundaries at fixed steps of a group");
+  static_assert(RING >= 3 && RING * DCM_XW_F >= 32 * 40, "the epilogue transposes a tile through the wave's window ring");
+  MFN_DYN_SHARED(float, lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = MFN_UNIFORM(tid >> 6);
+  const int kb = lane >> 5, j = lane & 31;
+  const int pt = wave / KW, kw = wave % KW;
+  MFN_STAMP(p.timeline, 0);
+  const int bx = p.xcd ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tile = bx * PT + pt;
+  const int mg = blockIdx.z;
+  const int m0 = mg * MT * 32;
+  const int H = p.H, W = p.W;
+  const size_t plane = (size_t)H * W;
+
+  // ---- weight staging plan ------------------------------------------------------------------------------------------
+  const int gps = p.dcm_gps;   // groups per K slice
+  const size_t mg_words = (size_t)(p.dcm_groups * 9 + KC) * G::STEP_W;
+  const mfn_rsrc_t wrsrc = mfn_make_rsrc(p.wt + (size_t)mg * mg_words, (unsigned)(mg_words * 4));
+  unsigned voffW[NI];
+  MFN_UNROLL
+  for (int i = 0; i < NI; ++i) {
+    const int ii = i * NW + wave;
+    const int k = ii / (KC * 3 * MT), rem = ii - k * (KC * 3 * MT);
+    voffW[i] = ii < G::WI_TOTAL ? (unsigned)((((size_t)k * gps * 9) * G::STEP_W + (size_t)rem * 256) * 4) + (unsigned)lane * 16u : 0xFFFFFF00u;
+  }
+  auto issue_w = [&](int ch) {   // chunk ch of every K slice of the block -> stage ch % NSTAGE
+    float *buf = lds + (ch % G::NSTAGE) * G::STAGE_W;
+    const unsigned soff = (unsigned)((size_t)ch * KC * G::STEP_W * 4);
+    if (MFN_DCM_ABLATE & 32) return;
+    MFN_UNROLL
+    for (int i = 0; i < NI; ++i) {
+      const int ii = i * NW + wave;
+      if (ii < G::WI_TOTAL) mfn_dma16_so(wrsrc, buf + ii * 256, voffW[i], soff);   // wave-uniform
+    }
+  };
+
+  // ---- the wave's pixel tile: 4 rows x 8 columns of one image ---------------------------------------------------------
+  int n, ty, tx;
+  {
+    auto divmod = [](int a, int b, float inv_b, int &q, int &r) {   // a / b for a, b < 2^24 without an integer division
+      q = (int)((float)a * inv_b);
+      r = a - q * b;
+      if (r < 0) { --q; r += b; }
+      if (r >= b) { ++q; r -= b; }
+    };
+    const int tl = min(tile, p.ntiles - 1);
+    int rt;
+    divmod(tl, p.tiles_y * p.tiles_x, p.inv_tpi, n, rt);
+    divmod(rt, p.tiles_x, p.inv_tiles_x, ty, tx);
+  }
+  const int tile_ho0 = ty * 4, tile_wo0 = tx * 8;
+  int ho = tile_ho0 + (j >> 3), wo = tile_wo0 + (j & 7);
+  const bool px_valid = tile < p.ntiles && ho < H && wo < W;
+  ho = min(ho, H - 1);
+  wo = min(wo, W - 1);
+  const int h_in = ho - 1, w_in = wo - 1;   // stride 1, pad 1
+
+  // ---- offsets: one (dy, dx) per pixel (flow mode), or the eighteen of the operator's tensor, which qualify when equal --------
+  float off_h, off_w;
+  bool shared = true;
+  if (p.offset) {
+    const float *op = p.offset + (size_t)n * 18 * plane + (size_t)ho * W + wo;
+    float oh[9], ow[9];
+    MFN_UNROLL
+    for (int t = 0; t < 9; ++t) {
+      oh[t] = op[(size_t)(2 * t) * plane];
+      ow[t] = op[(size_t)(2 * t + 1) * plane];
+    }
+    MFN_COMPILER_FENCE();   // all eighteen requested before the first is compared (deform_conv.h)
+    int same = 1;
+    MFN_UNROLL
+    for (int t = 1; t < 9; ++t) same &= (int)(oh[t] == oh[0]) & (int)(ow[t] == ow[0]);
+    shared = same != 0;
+    off_h = oh[0];
+    off_w = ow[0];
+  } else {
+    const float *fp = p.flow + (size_t)n * 2 * plane + (size_t)ho * W + wo;
+    off_h = fp[0] * p.flow_scale / p.flow_stride;       // MaskFlownet.py:230
+    off_w = fp[plane] * p.flow_scale / p.flow_stride;
+  }
+
+  // ---- geometry of the shared-offset path: per tap row / column the pair of weights on neighbourhood lines i, i + 1 ----------
+  float ya[3], yb[3], xa[3], xb[3];
+  int row0, col0;                  // unclamped first row / column of the 4x4 neighbourhood
+  bool regular = shared && p.allow_fast != 0;
+  {
+    // tap i sits on neighbourhood lines (i, i + 1) with weights (1 - l, l) when floor(i + off) = floor(off) + i.  In fp32 the sum
+    // i + off can round UP to the next integer (off a hair below one: floor(0 + off) = -1, 1 + off == 1.0f) -- the oracle then
+    // reads line i + 1 with weight 1 (l = 0), which is the same pair of lines with weights (0, 1): still the shared path
+    // (ONE such pixel in a level-2 batch used to send its whole tile to the per-tap path, 75 us instead of 25)
+    auto axis = [&](float off, int in0, int dim, float (&wa)[3], float (&wb)[3], int &first) {
+      int lo0 = 0;
+      MFN_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        bool v; int lo, hi; float l;
+        dc_axis(off, in0, i, dim, v, lo, hi, l);
+        v = v && px_valid;
+        const int ulo = (int)fminf(fmaxf(floorf((float)i + off), -1.0e6f), 1.0e6f);
+        if (i == 0) lo0 = ulo;
+        const bool up = ulo == lo0 + i + 1 && l == 0.f;   // rounded up to an integer
+        regular = regular && (ulo == lo0 + i || up);
+        wa[i] = v ? (up ? 0.f : 1.f - l) : 0.f;
+        wb[i] = v ? (up ? 1.f : l) : 0.f;
+      }
+      first = in0 + lo0;
+    };
+    axis(off_h, h_in, H, ya, yb, row0);
+    axis(off_w, w_in, W, xa, xb, col0);
+  }
+  const bool fast = __all(regular || !px_valid) != 0;   // wave-uniform; false: the per-tap column path
+
+  // ---- the wave's source window: the box of its lanes' neighbourhoods in the small shape where that fits, else the big one, and
+  // the lanes outside even that fetch from global memory ---------------------------------------------------------------------------
+  int wr0 = 0, wc0 = 0;
+  bool inwin = true;
+  unsigned xvoff[3] = {0xFFFFFF00u, 0xFFFFFF00u, 0xFFFFFF00u};
+  int gofs = 0;   // index into lds[] of this lane's first neighbourhood value inside slot 0: ONE address register, the 16 reads
+                  // are its immediates
+  auto setup_window = [&](auto win_c) {
+    using WN = decltype(win_c);
+    const int big = 1 << 28;
+    const bool use = px_valid && fast;
+    wr0 = mfn_wave_min_i32(use ? row0 : big);
+    wc0 = mfn_wave_min_i32(use ? col0 : big);
+    // one lane with a wild offset must not drag the window away from everybody else: never further up / left of the tile's
+    // centre lane than the window can reach back from it (rows / columns outside the image are zero-filled, wherever they are)
+    const int rc = mfn_readlane_i32(row0, 12), cc = mfn_readlane_i32(col0, 12);
+    wr0 = wr0 == big ? 0 : max(wr0, rc - (WN::ROWS - 4));
+    wc0 = (wc0 == big ? 0 : max(wc0, cc - (WN::COLS - 4))) & ~3;   // 16-byte aligned origin (two's complement: also negative)
+    inwin = !px_valid || (row0 >= wr0 && row0 - wr0 <= WN::ROWS - 4 && col0 >= wc0 && col0 - wc0 <= WN::COLS - 4);
+    MFN_UNROLL
+    for (int i = 0; i < WN::NI; ++i) {
+      const int slot = i * 64 + lane;                       // float4 slots: [channel 0/1][ROWS][C4 float4]
+      const int chs = slot / (WN::ROWS * WN::C4), rem = slot - chs * (WN::ROWS * WN::C4);
+      const int row = rem / WN::C4, c4 = rem - row * WN::C4;
+      const int r = wr0 + row, c = wc0 + 4 * c4;
+      xvoff[i] = (fast && chs < 2 && r >= 0 && r <= H - 1 && c >= 0 && c <= W - 4)
+                     ? (unsigned)(((size_t)n * p.Cin * plane + (size_t)chs * plane + (size_t)r * W + c) * 4)
+                     : 0xFFFFFF00u;                         // outside the image: never read, the transfer writes zeros
+    }
+    // lanes that are not in the window read the slot's first value (finite)
+    gofs = (px_valid && inwin && fast) ? kb * WN::CH + (row0 - wr0) * WN::COLS + (col0 - wc0) : 0;
+    gofs += G::XW_OFF + wave * (RING * DCM_XW_F);
+    MFN_OPAQUE(gofs);   // as an opaque sum: hipcc otherwise keeps XW_OFF apart and forms eight addresses per step
+  };
+  setup_window(DcmWin<false, RING>{});
+  bool all_in = __all(inwin) != 0;   // wave-uniform
+  const bool bigwin = fast && !all_in;
+  if (bigwin) {
+    setup_window(DcmWin<true, RING>{});
+    all_in = __all(inwin) != 0;
+  }
+  float *xwin = lds + G::XW_OFF + wave * (RING * DCM_XW_F);
+  const mfn_rsrc_t xrsrc = mfn_make_rsrc(p.x, (unsigned)((size_t)p.N * p.Cin * plane * 4));
+  const int cp_base = kw * gps * 8;    // first channel pair of this K slice
+  int buf_issue = 0;                   // ring slot of the next window transfer (uniform)
+  auto issue_x = [&](int kl, auto win_c) {   // window of the slice's pair kl -> ring slot kl % DEPTH
+    using WN = decltype(win_c);
+    const unsigned soff = (unsigned)((size_t)(2 * (cp_base + kl)) * plane * 4);
+    float *dst = xwin + buf_issue * WN::SLOT_F;
+    if (!(MFN_DCM_ABLATE & 4)) {
+      MFN_UNROLL
+      for (int i = 0; i < WN::NI; ++i) mfn_dma16_so(xrsrc, dst + i * 256, xvoff[i], soff);
+    }
+    buf_issue = buf_issue + 1 == WN::DEPTH ? 0 : buf_issue + 1;
+  };
+
+  // ---- prologue: what the steps before the first would have issued, in their order (chunks 0 .. NSTAGE - 2, windows 0 .. DEPTH - 1) ----
+  auto prologue = [&](auto win_c) {
+    using WN = decltype(win_c);
+    constexpr int U0 = -9 * 4;   // far enough back for every prefetch distance
+    MFN_UNROLL
+    for (int u = U0; u < 0; ++u) {
+      const int ss = ((u % 9) + 9) % 9;
+      const int kl = (u - ss) / 9 * 8 + ss;                                  // pair of step u (ss < 8)
+      if (ss % KC == 0 && (u - ss % KC) / KC + G::NSTAGE - 1 >= 0) issue_w((u - ss % KC) / KC + G::NSTAGE - 1);
+      if (ss < 8 && kl + WN::DEPTH >= 0) issue_x(kl + WN::DEPTH, win_c);
+    }
+  };
+  if (bigwin) prologue(DcmWin<true, RING>{}); else prologue(DcmWin<false, RING>{});
+
+  f32x16 acc[MT][NACC];
+  MFN_UNROLL
+  for (int mt = 0; mt < MT; ++mt)
+    MFN_UNROLL
+    for (int a = 0; a < NACC; ++a)
+      MFN_UNROLL
+      for (int r = 0; r < 16; ++r) acc[mt][a][r] = 0.f;
+
+  const float *xn = p.x + (size_t)n * p.Cin * plane;
+
+  // ---- column values of one (pixel, channel): the tiers ------------------------------------------------------------------------------
+  // window (small or big shape): 16 LDS reads at one address register + immediates; the big window with the lanes that are outside
+  // even that reading global memory at clamped rows / columns (their weights on lines outside the image are zero); per-tap offsets:
+  // pertap_pair below.
+  f32x2 vp[4][2];   // the 4x4 neighbourhood of the pair in preparation: vp[m][h] = columns 2h, 2h + 1 of row m (one ds_read2_b32)
+  int buf_read = 0;  // ring slot of the next pair to gather (uniform)
+  auto cols_gather = [&](int kn, auto win_c, auto out_c) {
+    using WN = decltype(win_c);
+    constexpr bool OUT = decltype(out_c)::value;
+    const float *xb_ = lds + (buf_read * WN::SLOT_F + gofs);
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m)
+      MFN_UNROLL
+      for (int h = 0; h < 2; ++h) {
+        vp[m][h].x = (MFN_DCM_ABLATE & 2) ? (float)(m + h + kn) : xb_[m * WN::COLS + 2 * h];
+        vp[m][h].y = (MFN_DCM_ABLATE & 2) ? (float)(m - h + kn) : xb_[m * WN::COLS + 2 * h + 1];
+      }
+    buf_read = buf_read + 1 == WN::DEPTH ? 0 : buf_read + 1;
+    if (OUT) {
+      if (!inwin) {
+        int r0 = row0, c0 = col0;
+        MFN_OPAQUE(r0);   // formed here, step by step: hoisted out of the loop the eight offsets would cost eight registers
+        MFN_OPAQUE(c0);
+        const int c = min(2 * (cp_base + kn) + kb, p.Cin - 1);   // (a prefetch past the last pair reads the last channel: unused)
+        const float *pl = xn + (size_t)c * plane;
+        int ro[4], co[4];
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m) {
+          ro[m] = min(max(r0 + m, 0), H - 1) * W;
+          co[m] = min(max(c0 + m, 0), W - 1);
+        }
+        MFN_UNROLL
+        for (int m = 0; m < 4; ++m)
+          MFN_UNROLL
+          for (int h = 0; h < 2; ++h) {
+            vp[m][h].x = pl[ro[m] + co[2 * h]];
+            vp[m][h].y = pl[ro[m] + co[2 * h + 1]];
+          }
+      }
+    }
+  };
+  // separable interpolation, y pass then x pass, in SCALAR fp32 instructions: taps 0..7 into x8 (the K elements of the lane's
+  // k-block), tap 8 beside them.  (Packed v_pk_mul_f32 / v_pk_fma_f32 on the register pairs the LDS reads deliver would be 12
+  // instructions fewer -- and measured 586 cycles per step for these 30 instructions against 171 for the 38 of the split: packed
+  // fp32 issued behind matrix instructions that are still in flight stalls, MI355X_MICROARCH.md "anti-lever beside MFMAs".)
+  auto cols_finish = [&](float (&x8)[8], float &c8) {
+    f32x2 ty[3][2];
+    if (MFN_DCM_ABLATE & 16) {
+      MFN_UNROLL
+      for (int e = 0; e < 8; ++e) x8[e] = e < 4 ? vp[e][0].x : vp[e - 4][1].y;
+      c8 = vp[0][0].y;
+      return;
+    }
+    MFN_UNROLL
+    for (int i = 0; i < 3; ++i)
+      MFN_UNROLL
+      for (int h = 0; h < 2; ++h) {
+        ty[i][h].x = fmaf(yb[i], vp[i + 1][h].x, ya[i] * vp[i][h].x);
+        ty[i][h].y = fmaf(yb[i], vp[i + 1][h].y, ya[i] * vp[i][h].y);
+      }
+    MFN_UNROLL
+    for (int i = 0; i < 3; ++i) {
+      const float t0 = ty[i][0].x, t1 = ty[i][0].y, t2 = ty[i][1].x, t3 = ty[i][1].y;
+      const float c0 = fmaf(xb[0], t1, xa[0] * t0), c1 = fmaf(xb[1], t2, xa[1] * t1), c2 = fmaf(xb[2], t3, xa[2] * t2);
+      if (i < 2) { x8[3 * i] = c0; x8[3 * i + 1] = c1; x8[3 * i + 2] = c2; }
+      else { x8[6] = c0; x8[7] = c1; c8 = c2; }
+    }
+  };
+  DcmB B;
+  // the six products of one K step against the MT filter tiles.  a_read: this step's [term][ft] blocks from the stage buffer --
+  // requested BEFORE the next pair's gather, so that the first matrix instruction waits for its own operand only (LDS returns in
+  // order: behind the gather it would wait for all sixteen neighbourhood values as well)
+  mfn_bf16x8 ah[MT], am[MT], al[MT];
+  auto a_read = [&](const float *a) {
+    MFN_UNROLL
+    for (int ft = 0; ft < MT; ++ft) {
+      if (MFN_DCM_ABLATE & 64) { ah[ft] = am[ft] = al[ft] = B.h; continue; }
+      al[ft] = mfn_read_bf16x8(a + (2 * MT + ft) * 256);
+      ah[ft] = mfn_read_bf16x8(a + (0 * MT + ft) * 256);
+      am[ft] = mfn_read_bf16x8(a + (1 * MT + ft) * 256);
+    }
+  };
+  auto mma_issue = [&](const DcmB &b) {
+    if (MFN_DCM_ABLATE & 1) {
+      MFN_UNROLL
+      for (int ft = 0; ft < MT; ++ft) acc[ft][0][0] += mfn_bf16_at(reinterpret_cast<const float *>(&ah[ft]), 0) + mfn_bf16_at(reinterpret_cast<const float *>(&al[ft]), 1) + mfn_bf16_at(reinterpret_cast<const float *>(&am[ft]), 2) + mfn_bf16_at(reinterpret_cast<const float *>(&b.l), 0);
+      return;
+    }
+#define MFN_DCM_(A_, B_, P_)                                                                      \
+  MFN_UNROLL                                                                                      \
+  for (int ft = 0; ft < MT; ++ft) acc[ft][(P_) % NACC] = MFN_MFMA_32x32x16_BF16(A_[ft], B_, acc[ft][(P_) % NACC]);
+    MFN_DCM_(al, b.h, 0)   // smallest products first: 2^-16 class, then 2^-8, then the leading one
+    MFN_DCM_(ah, b.l, 1)
+    MFN_DCM_(am, b.m, 0)
+    MFN_DCM_(am, b.h, 1)
+    MFN_DCM_(ah, b.m, 0)
+    MFN_DCM_(ah, b.h, 1)
+#undef MFN_DCM_
+  };
+
+  // Per-tap offsets (MXNet's general operator; the reference never calls it so): the pair of THIS step tap by tap -- geometry
+  // rebuilt per tap and per step (lean in registers, not fast), taps 0..7 against the fp32 sum of the weight's three terms on
+  // v_mfma_f32_32x32x2_f32 (exact), tap 8 into the left-over step's operand like everybody else's.
+  auto pertap_pair = [&](int kp, const float *a, float *t8dst) {
+    const int c = 2 * (cp_base + kp) + kb;
+    const float *pl = xn + (size_t)c * plane;
+    MFN_NOUNROLL
+    for (int t = 0; t < 9; ++t) {
+      float oh = off_h, ow = off_w;
+      if (p.offset) {
+        const float *op = p.offset + (size_t)n * 18 * plane + (size_t)ho * W + wo;
+        oh = op[(size_t)(2 * t) * plane];
+        ow = op[(size_t)(2 * t + 1) * plane];
+      }
+      const int ti = (t * 11) >> 5, tj = t - 3 * ti;
+      const DcTap tp = dc_make_tap(oh, ow, h_in, w_in, ti, tj, H, W, px_valid);
+      const int bb = tp.base & 0x3FFFFFFF, dwi = (tp.base >> 30) & 1;
+      const float v1 = pl[bb], v2 = pl[bb + dwi], v3 = pl[bb + tp.dhW], v4 = pl[bb + tp.dhW + dwi];
+      const float cvt = tp.w1 * v1 + tp.w2 * v2 + tp.w3 * v3 + tp.w4 * v4;
+      if (t < 8) {
+        MFN_UNROLL
+        for (int ft = 0; ft < MT; ++ft) {
+          const float wv = mfn_bf16_at(a + (0 * MT + ft) * 256, t) + mfn_bf16_at(a + (1 * MT + ft) * 256, t) + mfn_bf16_at(a + (2 * MT + ft) * 256, t);
+          acc[ft][0] = MFN_MFMA_32x32x2(wv, cvt, acc[ft][0]);
+        }
+      } else {
+        *t8dst = cvt;
+      }
+    }
+  };
+
+  // ---- B(0) ---------------------------------------------------------------------------------------------------------------------
+  float *xt8 = lds + G::T8_OFF + wave * 512 + lane;   // tap 8 of the group's eight pairs, [pair][lane]: the left-over step's K elements
+  auto first_operand = [&](auto win_c, auto out_c) {
+    using WN = decltype(win_c);
+    MFN_WAIT_VM((dcm_prologue_after_x0<KC, G::NSTAGE, WN::DEPTH, NIW, WN::NI>()));   // window 0 landed
+    float x8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c8 = 0.f;
+    if (fast) {
+      cols_gather(0, win_c, out_c);
+      cols_finish(x8, c8);
+    }
+    xt8[0] = c8;
+    mfn_split3x8(x8, B.h, B.m, B.l);
+  };
+
+  // ---- the K loop: 9 steps per 16-channel group.  Step t: the six products of B(t) against the MT filter tiles; under them
+  // B(t + 1) is gathered and interpolated, then split into the same registers (the matrix instructions read their operands at
+  // issue).  The tiers are INSTANCES of the loop, not branches inside one: a load hipcc knows about makes it wait -- at the join, for
+  // every wave -- with a vmcnt that also drains the window / weight transfers it does not know about; and with one site of matrix
+  // instructions per branch hipcc keeps the accumulators in two register sets and copies all of them at every join.
+  // Window tiers: the nine steps of a group UNROLLED (a rolled loop over the groups): the step number is a compile-time constant,
+  // so the waits, the chunk boundaries and the left-over step cost no scalar compare chain, and a step is straight-line code in
+  // which hipcc places the interpolation between the matrix instructions (rolled with uniform branches: 16.6 us of loop at level 2
+  // against 12.9).
+  auto run_groups = [&](auto win_c, auto out_c) {
+    using WN = decltype(win_c);
+    constexpr int CPG = 9 / KC;   // chunks per group
+    first_operand(win_c, out_c);
+    MFN_NOUNROLL
+    for (int g = 0; g < gps; ++g) {
+      mfn_static_for<9>([&](auto s_c) {
+        constexpr int S = decltype(s_c)::value;
+        constexpr int NWAIT = dcm_wait_count<KC, G::NSTAGE, WN::DEPTH, NIW, WN::NI>(S);
+        if (NWAIT < 1000) MFN_WAIT_VM(NWAIT < 63 ? NWAIT : 63);
+        const int ch = g * CPG + S / KC;
+        constexpr int kk = S % KC;
+        if (kk == 0) {   // this chunk's weights landed for every wave; everybody is done with the stage that is refilled now
+          MFN_WAIT_LGKM0();
+          if (!(MFN_DCM_ABLATE & 128)) MFN_RAW_BARRIER();
+          if (S == 0 && g == 0) MFN_STAMP(p.timeline, 1);
+          issue_w(ch + G::NSTAGE - 1);
+        }
+        if (S < 8) issue_x(g * 8 + S + WN::DEPTH, win_c);
+        const float *a = lds + (ch % G::NSTAGE) * G::STAGE_W + (size_t)(kw * KC + kk) * G::STEP_W + (kb * 32 + j) * 4;
+        float x8[8];
+        a_read(a);
+        if (S != 7) cols_gather(S == 8 ? (g + 1) * 8 : g * 8 + S + 1, win_c, out_c);
+        mma_issue(B);
+        if (S == 7) {   // the left-over step's operand: tap 8 of the eight pairs
+          MFN_UNROLL
+          for (int e = 0; e < 8; ++e) x8[e] = xt8[e * 64];
+        } else {
+          float c8;
+          cols_finish(x8, c8);
+          xt8[(S == 8 ? 0 : S + 1) * 64] = c8;   // the slot of the pair just formed inside ITS group
+        }
+#ifdef MFN_DCM_SPLIT_PACKED
+        if (!(MFN_DCM_ABLATE & 8)) mfn_split3x8(x8, B.h, B.m, B.l);
+#else
+        if (!(MFN_DCM_ABLATE & 8)) mfn_split3x8_scalar(x8, B.h, B.m, B.l);
+#endif
+        MFN_SCHED_BARRIER();
+      });
+    }
+  };
+  // Per-tap tier: one rolled loop, the step inside its group (s) a wave-uniform counter.
+  auto run_pertap = [&]() {
+    using WN = DcmWin<false, RING>;
+    first_operand(WN{}, std::false_type{});
+    const int nsteps = gps * 9;
+    int s = 0, kl = 0;   // step inside the group; pair of the step
+    MFN_NOUNROLL
+    for (int t = 0; t < nsteps; ++t) {
+      mfn_static_for<9>([&](auto s_c) {   // one test per distinct count: the steps that share it as a bit mask
+        constexpr int S = decltype(s_c)::value;
+        constexpr int NWAIT = dcm_wait_count<KC, G::NSTAGE, WN::DEPTH, NIW, WN::NI>(S);
+        constexpr unsigned MASK = dcm_wait_mask<KC, G::NSTAGE, WN::DEPTH, NIW, WN::NI>(S);   // 0 unless S is the first step with this count
+        if (NWAIT < 1000 && MASK != 0 && ((MASK >> s) & 1u)) MFN_WAIT_VM(NWAIT < 63 ? NWAIT : 63);
+      });
+      const int ch = t / KC, kk = t - ch * KC;
+      if (kk == 0) {
+        MFN_WAIT_LGKM0();
+        MFN_RAW_BARRIER();
+        if (t == 0) MFN_STAMP(p.timeline, 1);
+        issue_w(ch + G::NSTAGE - 1);
+      }
+      if (s < 8) issue_x(kl + WN::DEPTH, WN{});   // (zero-filled: keeps the transfer sequence, hence the counts, those of the window tiers)
+      const float *a = lds + (ch % G::NSTAGE) * G::STAGE_W + (size_t)(kw * KC + kk) * G::STEP_W + (kb * 32 + j) * 4;
+      if (s < 8) pertap_pair(kl, a, xt8 + (kl & 7) * 64);
+      else { a_read(a); mma_issue(B); }
+      if (s == 7) {
+        float x8[8];
+        MFN_UNROLL
+        for (int e = 0; e < 8; ++e) x8[e] = xt8[e * 64];
+        mfn_split3x8(x8, B.h, B.m, B.l);
+      }
+      if (s < 8) ++kl;
+      s = s == 8 ? 0 : s + 1;
+    }
+  };
+  if (!fast) run_pertap();
+  else if (!bigwin) run_groups(DcmWin<false, RING>{}, std::false_type{});
+  else if (all_in) run_groups(DcmWin<true, RING>{}, std::false_type{});
+  else run_groups(DcmWin<true, RING>{}, std::true_type{});
+  MFN_STAMP(p.timeline, 2);
+  MFN_STAMP_INFO(p.timeline, !fast ? 3 : (!bigwin ? 0 : (all_in ? 1 : 2)));   // the first wave's tier
+
+  // ---- K-slice reduction: tile mt is summed (slice order 0..KW-1, deterministic) and stored by slice mt % KW ------------------------
+  MFN_WAIT_VM(0);       // the prefetches past the end have landed: nothing is on its way into LDS any more
+  f32x16 fin[MT];
+  MFN_UNROLL
+  for (int mt = 0; mt < MT; ++mt)
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) fin[mt][r] = NACC == 2 ? acc[mt][0][r] + acc[mt][NACC - 1][r] : acc[mt][0][r];
+  if (KW > 1) {
+    MFN_WAIT_LGKM0();
+    MFN_RAW_BARRIER();  // every wave is out of the loop: the stage buffers are free
+    float *red = lds + (size_t)pt * (KW - 1) * 1024;
+    MFN_UNROLL
+    for (int mt = 0; mt < MT; ++mt) {
+      const int owner = mt % KW;
+      if (kw != owner) {
+        float *dst = red + (size_t)(kw < owner ? kw : kw - 1) * 1024 + lane;
+        MFN_UNROLL
+        for (int r = 0; r < 16; ++r) dst[r * 64] = fin[mt][r];
+      }
+      __syncthreads();
+      if (kw == owner) {
+        f32x16 sum;
+        MFN_UNROLL
+        for (int k = 0; k < KW; ++k) {
+          f32x16 part;
+          if (k == owner) part = fin[mt];
+          else {
+            const float *src = red + (size_t)(k < owner ? k : k - 1) * 1024 + lane;
+            MFN_UNROLL
+            for (int r = 0; r < 16; ++r) part[r] = src[r * 64];
+          }
+          MFN_UNROLL
+          for (int r = 0; r < 16; ++r) sum[r] = k == 0 ? part[r] : sum[r] + part[r];
+        }
+        fin[mt] = sum;
+      }
+      if (mt + 1 < MT) __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  D reg r of lane (j, kb): filter row (r&3) + 8*(r>>2) + 4*kb, pixel j.  The 32 x 32 tile is transposed through
+  // the wave's idle window ring so that a lane holds four adjacent pixels of one filter: 4 x 16-byte stores instead of 16 dword stores
+  constexpr int TS = 40;
+  float *tr = xwin;
+  const size_t oplane = plane;
+  const int quad = lane & 7, orow = lane >> 3;
+  const int px0 = quad * 4;
+  const int oy = tile_ho0 + (px0 >> 3), ox = tile_wo0 + (px0 & 7);
+  const bool st_ok = tile < p.ntiles && oy < H;
+  const bool ep = p.ep_mask || p.ep_add || p.ep_leaky;
+  const size_t pix0 = st_ok ? (size_t)n * oplane + (size_t)oy * W : 0;
+  int oxq[4];
+  MFN_UNROLL
+  for (int q = 0; q < 4; ++q) oxq[q] = st_ok ? min(ox + q, W - 1) : 0;
+  float sg[4] = {1.f, 1.f, 1.f, 1.f};
+  if (ep && p.ep_mask) {
+    float mv[4];
+    MFN_UNROLL
+    for (int q = 0; q < 4; ++q) mv[q] = p.ep_mask[pix0 + oxq[q]];
+    MFN_UNROLL
+    for (int q = 0; q < 4; ++q) sg[q] = 1.f / (1.f + expf(-mv[q]));
+  }
+  const size_t obatch = st_ok ? (size_t)n * p.Cout * oplane + (size_t)oy * W : 0;
+  float *obase = p.out + (size_t)n * p.Cout * oplane;
+  MFN_UNROLL
+  for (int mt = 0; mt < MT; ++mt) {
+    if (KW > 1 && kw != mt % KW) continue;
+    float bq[4], addv[4][4];
+    MFN_UNROLL
+    for (int i = 0; i < 4; ++i) bq[i] = p.bias ? p.bias[min(m0 + mt * 32 + i * 8 + orow, p.Cout - 1)] : 0.f;
+    if (ep && p.ep_add) {
+      MFN_UNROLL
+      for (int i = 0; i < 4; ++i) {
+        const size_t orow_off = obatch + (size_t)min(m0 + mt * 32 + i * 8 + orow, p.Cout - 1) * oplane;
+        MFN_UNROLL
+        for (int q = 0; q < 4; ++q) addv[i][q] = p.ep_add[orow_off + oxq[q]];
+      }
+    }
+    MFN_WAIT_LGKM0();   // the previous tile's reads are done (wave-private buffer: no barrier needed)
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * kb) * TS + j] = fin[mt][r];
+    MFN_WAIT_LGKM0();
+    MFN_UNROLL
+    for (int i = 0; i < 4; ++i) {
+      const int ol = i * 8 + orow;
+      const int o = m0 + mt * 32 + ol;
+      const float4 v = *reinterpret_cast<const float4 *>(tr + ol * TS + px0);
+      float e[4] = {v.x + bq[i], v.y + bq[i], v.z + bq[i], v.w + bq[i]};
+      if (ep) {
+        MFN_UNROLL
+        for (int q = 0; q < 4; ++q) {
+          if (p.ep_mask) e[q] = e[q] * sg[q];
+          if (p.ep_add) e[q] = e[q] + addv[i][q];
+          if (p.ep_leaky) e[q] = fmaxf(e[q], 0.1f * e[q]);
+        }
+      }
+      if (st_ok && o < p.Cout) {
+        float *dst = obase + (size_t)o * oplane + (size_t)oy * W + ox;
+        if (ox + 3 < W) {
+          mfn_store4_stream(dst, e[0], e[1], e[2], e[3], p.st_policy);
+        } else {
+          MFN_UNROLL
+          for (int q = 0; q < 4; ++q)
+            if (ox + q < W) dst[q] = e[q];
+        }
+      }
+    }
+  }
+  MFN_STAMP(p.timeline, 3);
+}
+
+template <int MT, int PT, int KW, int RING>
+inline int dc_mma_launch(const DeformParams &p, hipStream_t stream) {
+  using G = DcmGeom<MT, PT, KW, RING>;
+  const int bx = cdiv(p.ntiles, PT);
+  if (bx <= 0) return 0;
+  return launch("dc_mma", dc_mma_kernel<MT, PT, KW, RING>, dim3(bx, 1, p.mgroups), dim3(G::NTH), (size_t)G::LDS_W * sizeof(float), stream, p);
+}
+
+// what the kernel needs of a call: the network's operator shape, 16-byte rows, whole groups of 16 channels
+inline bool dcm_shape_ok(int N, int Cin, int H, int W, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                         int groups, int dg) {
+  return kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && groups == 1 && dg == 1 && Ho == H &&
+         Wo == W && W % 4 == 0 && W >= 8 && H >= 1 && Cin % 16 == 0 && (size_t)N * Cin * H * W < ((size_t)1 << 30);
+}
+
+}  // namespace mfn

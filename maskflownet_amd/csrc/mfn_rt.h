@@ -48,6 +48,7 @@ static inline void mfn_split3(float x, unsigned short &h, unsigned short &m, uns
 static inline void mfn_split3x8(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &m, mfn_bf16x8 &l) {
   for (int e = 0; e < 8; ++e) mfn_split3(x[e], h.v[e], m.v[e], l.v[e]);
 }
+#define mfn_split3x8_scalar mfn_split3x8   // (device: the residuals by scalar subtractions instead of v_pk_add_f32)
 // the same split one term at a time (the kernel places a matrix instruction between the stages)
 struct mfn_split_state { float r[8]; };
 static inline void mfn_split_stage_h(const float (&x)[8], mfn_bf16x8 &h, mfn_split_state &st) {
@@ -100,6 +101,7 @@ static inline float mfn_half_sum_top(float v) {
 // (in order): the free-running emulated lanes run the whole sequence one lane at a time instead -- same sums
 #define MFN_EMU_LOCK() (hipemu::t_block->mu.lock())
 #define MFN_EMU_UNLOCK() (hipemu::t_block->mu.unlock())
+static inline int mfn_readlane_i32(int v, int lane) { return __shfl(v, lane); }   // the value of one lane, wave-uniform
 MFN_WAVE_REDUCE_EMU(mfn_wave_min_i32, std::min)
 MFN_WAVE_REDUCE_EMU(mfn_wave_max_i32, std::max)
 // LDS-DMA emulation: synchronous copy (ordering of the real asynchronous engine is checked on the GPU)
@@ -226,6 +228,28 @@ __device__ __forceinline__ void mfn_split3x8(const float (&x)[8], mfn_bf16x8 &h,
   }
   h = __builtin_bit_cast(mfn_bf16x8, hw); m = __builtin_bit_cast(mfn_bf16x8, mw); l = __builtin_bit_cast(mfn_bf16x8, lw);
 }
+// the same with the residuals formed by scalar v_sub_f32 (46 instructions): packed fp32 arithmetic issued while matrix
+// instructions of the wave are in flight stalls (MI355X_MICROARCH.md, "anti-lever beside MFMAs"), so kernels that place the
+// split BETWEEN their matrix instructions use this form
+__device__ __forceinline__ void mfn_split3x8_scalar(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &m, mfn_bf16x8 &l) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hw, mw, lw;
+  _Pragma("unroll")
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+    float r0 = v.x - __builtin_bit_cast(float, hp << 16), r1 = v.y - __builtin_bit_cast(float, hp & 0xffff0000u);
+    asm volatile("" : "+v"(r0), "+v"(r1));   // keeps the two subtractions scalar (hipcc would pack them again)
+    const f32x2 rr = {r0, r1};
+    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf2));
+    float s0 = r0 - __builtin_bit_cast(float, mp << 16), s1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
+    asm volatile("" : "+v"(s0), "+v"(s1));
+    const f32x2 ss = {s0, s1};
+    hw[q] = hp; mw[q] = mp; lw[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(ss, bf2));
+  }
+  h = __builtin_bit_cast(mfn_bf16x8, hw); m = __builtin_bit_cast(mfn_bf16x8, mw); l = __builtin_bit_cast(mfn_bf16x8, lw);
+}
 // the same split one term at a time (4 + 16 + 16 VALU instructions; the kernel places a matrix instruction between the stages):
 // h: the hi terms, the state keeps the values; m: widen hi, first residual, mid terms; l: widen mid, second residual, lo terms
 struct mfn_split_state { f32x2 v[4]; unsigned hp[4], mp[4]; };
@@ -326,6 +350,7 @@ __device__ __forceinline__ int mfn_wave_min_i32(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(id, v, 0x143, 0xc, 0xf, false));
   return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int mfn_readlane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }   // wave-uniform
 #define MFN_WAVE_SYNC_EMU() ((void)0)
 #define MFN_EMU_LOCK() ((void)0)
 #define MFN_EMU_UNLOCK() ((void)0)

@@ -17,9 +17,11 @@
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
-//   dc.mma        1: the deformable convolution's GEMM as a bf16 x 3 operand split on the matrix cores (six products of
-//                 v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate; tap 8 stays on the fp32 MFMA) -- a measured
-//                 variant whose results differ from the exact-fp32 default in the last bits; 0 (default): exact fp32
+//   dc.mma        the deformable convolution's arithmetic: -1 (default) / 1: dc_mma_kernel (kernels/deform_conv_mma.h) wherever the
+//                 call has the network's operator shape -- the GEMM as a bf16 x 3 operand split on the matrix cores (six products of
+//                 v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate; error against fp64 not above the exact kernel's);
+//                 0: dc_lds_kernel everywhere (v_mfma_f32_32x32x2_f32, the bit pattern of an fp32 FMA chain)
+//   dc.mt         dc_mma_kernel only, together with dc.pt and dc.nw: 32-filter tiles per wave (the K slices per pixel tile are nw / pt)
 //   conv.mma      1: the same bf16 x 3 split for the 3x3 convolutions (and the 4x4 / stride-2 transposed convolution run as one)
 //   dc.pt         pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
 //   dc.ksb        K split across blocks (partial sums + reduce kernel); 0 = heuristic
@@ -40,8 +42,8 @@ namespace mfn {
 struct Tuning {
   int corr_variant = -1, corr_direct = 0, corr_rows = 0, corr_gram = -1;
   int store_policy = -1;
-  int dc_mma = 0, conv_mma = 0;
-  int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_off = 0;
+  int dc_mma = -1, conv_mma = 0;
+  int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_off = 0, dc_mt = 0;
   int path_generic = 0, bwd_off = 0;
   int conv_mt = 0, conv_pt = 0;
   int *slot(const char *key) {
@@ -53,6 +55,7 @@ struct Tuning {
     if (!strcmp(key, "corr.gram")) return &corr_gram;
     if (!strcmp(key, "store.policy")) return &store_policy;
     if (!strcmp(key, "dc.pt")) return &dc_pt;
+    if (!strcmp(key, "dc.mt")) return &dc_mt;
     if (!strcmp(key, "dc.ksb")) return &dc_ksb;
     if (!strcmp(key, "dc.nw")) return &dc_nw;
     if (!strcmp(key, "dc.off")) return &dc_off;

@@ -33,6 +33,7 @@ Two more passes are built from the same operators (BASELINE.json configs[3], con
 Launches go to a private stream; capture()/replay() wrap the ~14 launches in one hipGraph.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -150,7 +151,8 @@ def synth_inputs(N, H, W, seed=20260925, flow_model="smooth"):
             # piecewise-linear field.  Model: N(0, 2 level-px) noise three levels up (1/8 resolution),
             # upsampled 3x with the reference's Upsample(2), plus a global shift per sample.
             ch8, cw8 = max(1, (h + 7) // 8), max(1, (w + 7) // 8)
-            fl = rng.standard_normal((n, 2, ch8, cw8)) * 2.0 + rng.uniform(-3, 3, (n, 2, 1, 1))
+            # (MFN_DIAG_FLOW_NOISE: measurement sessions only -- the coarse field's sigma, e.g. 0.5 for flows whose windows all fit)
+            fl = rng.standard_normal((n, 2, ch8, cw8)) * float(os.environ.get("MFN_DIAG_FLOW_NOISE", 2.0)) + rng.uniform(-3, 3, (n, 2, 1, 1))
             for _ in range(3):
                 fl = upsample2(fl)
             fl = fl[:, :, :h, :w].astype(np.float32)

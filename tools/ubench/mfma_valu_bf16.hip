@@ -1,0 +1,65 @@
+// Microbenchmark: how v_mfma_f32_32x32x16_bf16 and plain fp32 VALU instructions of the SAME wave (and of co-resident waves) share
+// a SIMD -- the step of dc_mma_kernel is "6 matrix instructions, then ~40 VALU of interpolation, then ~40 VALU of operand split".
+//   mode 0: 6 MFMA only            mode 1: 42 v_fma only (6 independent chains)
+//   mode 2: 6 MFMA then 42 v_fma   mode 3: interleaved M, 7 v_fma, M, 7 v_fma, ...
+//   mode 4: as 2 with v_pk_fma_f32 (21 packed)     mode 5: as 3 with packed
+// Reported: shader cycles per iteration per wave (s_memtime), for 1 / 2 / 3 / 4 waves per SIMD (one block of 4*w waves per CU).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, int iters) {
+  f32x16 a0 = {0}, a1 = {0};
+  bf16x8 x, y;
+  for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(threadIdx.x * 0.001f + e); y[e] = (__bf16)(e * 0.5f); }
+  float v[6] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f};
+  f32x2 pv[6];
+  for (int i = 0; i < 6; ++i) pv[i] = (f32x2){(float)i, (float)i + 0.5f};
+  const float m = 1.0001f + threadIdx.x * 1e-9f;
+  const f32x2 pm = {m, m};
+  const unsigned long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#define MM(acc) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0)
+#define V7(j) do { _Pragma("unroll") for (int q = 0; q < 7; ++q) v[(j + q) % 6] = __builtin_fmaf(v[(j + q) % 6], m, 0.5f); } while (0)
+#define P7(j) do { _Pragma("unroll") for (int q = 0; q < 4; ++q) pv[(j + q) % 6] = __builtin_elementwise_fma(pv[(j + q) % 6], pm, pm); } while (0)
+    if (MODE == 0 || MODE == 2 || MODE == 4) { MM(a0); MM(a1); MM(a0); MM(a1); MM(a0); MM(a1); }
+    if (MODE == 1 || MODE == 2) { V7(0); V7(1); V7(2); V7(3); V7(4); V7(5); }
+    if (MODE == 4) { P7(0); P7(1); P7(2); P7(3); P7(4); P7(5); }
+    if (MODE == 3) { MM(a0); V7(0); MM(a1); V7(1); MM(a0); V7(2); MM(a1); V7(3); MM(a0); V7(4); MM(a1); V7(5); }
+    if (MODE == 5) { MM(a0); P7(0); MM(a1); P7(1); MM(a0); P7(2); MM(a1); P7(3); MM(a0); P7(4); MM(a1); P7(5); }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const unsigned long long t1 = clock64();
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += a0[i] + a1[i];
+  for (int i = 0; i < 6; ++i) s += v[i] + pv[i].x + pv[i].y;
+  if (s == 1.2345e30f) out[0] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+int main() {
+  float *out; unsigned long long *cyc;
+  hipMalloc(&out, 256); hipMalloc(&cyc, 256 * 16 * 8);
+  const int iters = 2000;
+  const char *names[] = {"6 MFMA", "42 v_fma", "6 MFMA, then 42 v_fma", "M,7v interleaved", "6 MFMA, then 24 v_pk_fma", "M,4pk interleaved"};
+  for (int mode = 0; mode < 6; ++mode)
+    for (int w : {1, 2, 3, 4}) {
+      for (int rep = 0; rep < 2; ++rep) {
+        switch (mode) {
+          case 0: hipLaunchKernelGGL(k<0>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
+          case 1: hipLaunchKernelGGL(k<1>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
+          case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
+          case 3: hipLaunchKernelGGL(k<3>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
+          case 4: hipLaunchKernelGGL(k<4>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
+          case 5: hipLaunchKernelGGL(k<5>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
+        }
+        hipDeviceSynchronize();
+      }
+      unsigned long long h[16];
+      hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+      double mean = 0; for (int i = 0; i < 4 * w; ++i) mean += (double)h[i]; mean /= 4 * w * iters;
+      printf("%-28s waves/SIMD %d: %7.1f cycles per iteration per wave  (%6.1f per SIMD-iteration)\n", names[mode], w, mean, mean / w);
+    }
+  return 0;
+}
