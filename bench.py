@@ -581,14 +581,14 @@ def end_to_end(N, H, W, device, torch, steps=30, full=False, ref_flow=None):
     net.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ok = bool(torch.isfinite(net.b["gflow_full" if full else "flow_full"]).all().item())
-    if ref_flow is not None:   # a variant run: its final flow against the exact path's on the same weights and images
+    if ref_flow is not None:   # the fp32-FMA run: its final flow against the default arithmetic's on the same weights and images
         fl = net.b["flow_full"].double()
         d = (fl - ref_flow.double()).pow(2).sum(1).sqrt().mean().item()
         m = ref_flow.double().pow(2).sum(1).sqrt().mean().item()
         return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_forward": round(dt * 1e3, 3), "batch": N, "finite": ok,
-                "epe_vs_exact_px": d, "epe_vs_exact_rel": d / max(m, 1e-30),
-                "what": "the MaskFlownet-S forward with conv.mma=1 and dc.mma=1: every convolution and deformable convolution as a "
-                        "bf16 x 3 operand split on the matrix cores (fp32 accumulate); measured variant, not the default"}
+                "epe_vs_default_px": d, "epe_vs_default_rel": d / max(m, 1e-30),
+                "what": "the MaskFlownet-S forward under mfn_set_arithmetic('all', MFN_ARITH_FP32): every convolution, deformable "
+                        "convolution and cost volume on fp32 FMA / fp32 MFMA kernels; its final flow against the default arithmetic's"}
     net_flow = net.b["flow_full"].clone() if not full else None
     if full:
         return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_forward": round(dt * 1e3, 3), "batch": N,
@@ -600,7 +600,8 @@ def end_to_end(N, H, W, device, torch, steps=30, full=False, ref_flow=None):
             "GFLOP_per_forward": round(net.flops() / 1e9, 1), "achieved_TFLOPs": round(net.flops() / dt / 1e12, 1),
             "frac_of_fp32_peak": round(net.flops() / dt / 1e12 / FP32_PEAK_TFLOPS, 3), "finite": ok,
             "what": "MaskFlownet-S forward %dx%d end to end (pyramid + decoder + context convolutions, cost volumes, deformable "
-                    "matching, upsampling, warp), every layer a libmfn_hip.so kernel, fp32, one hipGraph replay per forward" % (H, W),
+                    "matching, upsampling, warp), every layer a libmfn_hip.so kernel under the library's default arithmetic (fp32 in / out / "
+                    "accumulate; the GEMM-shaped layers as bf16 x 3 on the matrix cores), one hipGraph replay per forward" % (H, W),
             "note": "not the headline: `value` above is the matching hot path BASELINE.json's north_star names", "_flow": net_flow}
 
 
@@ -724,10 +725,12 @@ def main():
                    "flow_fields": ("smooth: the reference's Upsample(2) applied recursively to a coarse field, as flow_l is inside "
                                    "the network" if args.flow == "smooth" else
                                    "rough: SURVEY.md 8(d), i.i.d. N(0, 2 px) per pixel + 2% outliers in [-h, h]"),
-                   "arithmetic": "fp32 in, fp32 out, fp32 accumulate everywhere; the level-2 cost volume (32 channels) contracts on "
-                                 "v_mfma_f32_16x16x32_bf16 with each fp32 operand split into three bf16 terms and the six products of "
-                                 "weight >= 2^-16 kept (error against fp64 as the fp32-FMA kernel's; corr.gram=0 selects that kernel: "
-                                 "`fma_correlation`)",
+                   "arithmetic": "fp32 in, fp32 out, fp32 accumulate everywhere.  Library default (mfn_set_arithmetic): the cost volumes "
+                                 "(v_mfma_f32_16x16x32_bf16) and the deformable convolutions (v_mfma_f32_32x32x16_bf16) contract on the bf16 "
+                                 "matrix cores with each fp32 operand split exactly into three bf16 terms and six of the nine partial "
+                                 "products kept (the dropped ones <= 2^-24 of a product each): fp32-EQUIVALENT -- error against the fp64 "
+                                 "oracle not above the fp32 kernels' (tests/test_gpu_parity.py *_error_vs_fp64) -- not the bit pattern of "
+                                 "an FMA chain; MFN_ARITH_FP32 selects the FMA / fp32-MFMA kernels: the `fp32_arithmetic` sub-object",
                    "backend": (args.backend if dist is not None else None),
                    **({"tuning_overrides": args.tuning} if args.tuning else {}), "parallelism": "batch shard x%d" % world},
         "algorithmic_MB_per_step_per_gpu": round(sum(ab.values()) / 1e6, 2),
@@ -814,17 +817,20 @@ def main():
             res["customop"] = {"error": repr(e)}
     if gpu and world == 1 and not args.no_side_configs and args.config == "cfg2" and args.mode == "dropin" and args.flow == "smooth" \
             and not args.no_graph and not args.tuning:
-        # transparency: the same pass with the level-2 cost volume on the fp32-FMA kernel (corr.gram = 0) instead of the Gram band
-        # on the bf16 matrix cores (operands split into three bf16 terms: exact to fp32 rounding, not bit-identical to an FMA chain)
+        # transparency: the same pass with EVERY operator on fp32 FMA chains / the fp32 MFMA (mfn_set_arithmetic(all, MFN_ARITH_FP32)):
+        # the cost volumes on corr_dma_kernel, the deformable convolutions on dc_lds_kernel (v_mfma_f32_32x32x2_f32) -- rounds 1-3's
+        # kernels -- instead of the bf16 x 3 matrix-core kernels (operands split into three bf16 terms, six of nine products: error
+        # against fp64 not above these kernels', not bit-identical to an FMA chain)
         try:
             from maskflownet_amd import _lib as _lg
-            _lg.set_tuning(corr_gram=0)
-            res["fma_correlation"] = side_config("cfg2", "dropin", 200, torch, hotpath, want_roofline=True)
-            res["fma_correlation"]["what"] = "corr.gram=0: every kernel of the pass on fp32 FMA / fp32 MFMA arithmetic (round 3's level-2 kernel)"
+            _lg.set_arithmetic(all=_lg.ARITH_FP32)
+            res["fp32_arithmetic"] = side_config("cfg2", "dropin", 200, torch, hotpath, want_roofline=True)
+            res["fp32_arithmetic"]["what"] = ("mfn_set_arithmetic('all', MFN_ARITH_FP32): every kernel of the pass on fp32 FMA / fp32 MFMA "
+                                              "arithmetic (round 3's correlation and deformable-convolution kernels)")
         except Exception as e:
-            res["fma_correlation"] = {"error": repr(e)}
+            res["fp32_arithmetic"] = {"error": repr(e)}
         finally:
-            _lg.set_tuning(corr_gram=-1)
+            _lg.set_arithmetic(all=_lg.ARITH_DEFAULT)
     if not args.no_cpu_baseline and world == 1 and gpu:  # rank 0 at N=1 only: other ranks would idle in the barrier meanwhile
         res["cpu_baseline"], want = cpu_baseline(wl, args.cpu_seconds)
         res["speedup_vs_cpu_baseline"] = round(value / res["cpu_baseline"]["value"], 1)
@@ -835,33 +841,6 @@ def main():
             res["cpu_baseline_multithread"] = cpu_baseline_threads(wl, min(args.cpu_seconds, 8.0), os.cpu_count() or 1)
         except Exception as e:
             res["cpu_baseline_multithread"] = {"error": repr(e)}
-    if gpu and world == 1 and not args.no_side_configs and args.config == "cfg2" and args.mode == "dropin" and args.flow == "smooth" \
-            and not args.no_graph and not args.tuning:
-        # measured variant, NOT the headline: the deformable convolutions' GEMM as a bf16 x 3 operand split on the matrix cores
-        # (dc.mma = 1), same pass, same inputs; its outputs against the same oracle pass
-        try:
-            from maskflownet_amd import _lib as _l
-            _l.set_tuning(dc_mma=1)
-            vw = hotpath.HotPathWorkload(args.config, device="cuda:%d" % torch.cuda.current_device(), mode="dropin").capture()
-            for _ in range(50):
-                vw.step()
-            vw.synchronize()
-            dtv = timed_steps([vw], 400, None, torch)
-            res["bf16x3"] = {"value": round(vw.N * 400 / dtv, 2), "unit": "image-pairs/s", "ms_per_step": round(dtv / 400 * 1e3, 4), "steps": 400,
-                             "what": "dc.mma=1: fp32 operands of the deformable convolutions split into three bf16 terms, six products on "
-                                     "v_mfma_f32_32x32x16_bf16 (fp32 accumulate), tap 8 on the fp32 MFMA; everything else as the headline",
-                             "ops_in_graph_us": {k: v for k, v in per_op_graph_cost(vw, torch, reps=10).items() if k.startswith("deform")},
-                             "note": "not the headline: `value` is the exact-fp32 path; this variant's error against the fp64 oracle is not "
-                                     "above the exact kernel's (tests/test_gpu_parity.py)"}
-            if "parity" in res:
-                vw.replay()
-                vw.synchronize()
-                res["bf16x3"]["parity"] = {k: v for k, v in parity_vs_oracle(vw, want).items() if k in ("max_rel_err", "worst_output", "ok")}
-            del vw
-        except Exception as e:
-            res["bf16x3"] = {"error": repr(e)}
-        finally:
-            _l.set_tuning(dc_mma=0)
     if gpu and world == 1 and not args.no_e2e and wl.kind == "S":
         try:
             res["e2e"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch)
@@ -869,10 +848,10 @@ def main():
             if exact_flow is not None and not args.tuning:
                 from maskflownet_amd import _lib as _l2
                 try:
-                    _l2.set_tuning(conv_mma=1, dc_mma=1)
-                    res["e2e_bf16x3"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch, ref_flow=exact_flow)
+                    _l2.set_arithmetic(all=_l2.ARITH_FP32)
+                    res["e2e_fp32"] = end_to_end(wl.N, wl.H, wl.W, "cuda:%d" % torch.cuda.current_device(), torch, ref_flow=exact_flow)
                 finally:
-                    _l2.set_tuning(conv_mma=0, dc_mma=0)
+                    _l2.set_arithmetic(all=_l2.ARITH_DEFAULT)
         except Exception as e:
             res["e2e"] = {"error": repr(e)}
         try:

@@ -15,9 +15,10 @@
  *     launch.  mfn_last_error() returns a thread-local description of the last failure.
  *     Nothing throws across the boundary.
  *   - the operator entry points are re-entrant and keep no per-call state: any number of host threads may call
- *     them concurrently on their own streams.  The process-global MEASUREMENT state is the exception and is not
- *     part of the drop-in surface: mfn_set_tuning / mfn_profile_* / mfn_debug_set_timeline write plain globals
- *     that every launch reads -- call them only while no other thread is inside the library.
+ *     them concurrently on their own streams.  What arithmetic a call uses is the calling thread's own setting
+ *     (mfn_set_arithmetic, thread-local).  The process-global MEASUREMENT state is the exception and is not
+ *     part of the drop-in surface: mfn_set_tuning (tilings / code paths only) / mfn_profile_* / mfn_debug_set_timeline
+ *     write plain globals that every launch reads -- call them only while no other thread is inside the library.
  *   - flow tensors use the network's channel order: channel 0 = dy (vertical),
  *     channel 1 = dx (horizontal)   (/root/reference/network/pipeline.py:105,
  *     /root/reference/network/layer.py:17).
@@ -334,8 +335,34 @@ int mfn_profile_query(const char *name_substr, int *launches, double *total_ms);
 /* Writes up to `cap` bytes of "name launches total_ms\n" lines into buf; returns bytes needed. */
 int mfn_profile_dump(char *buf, int cap);
 
-/* Kernel-selection knobs for tuning sweeps (process-global, NOT thread-safe, not part of the drop-in surface: set
- * them before the first operator call or while no other thread is inside the library).
+/* ---------------------------------------------------------------------------------------------
+ * Arithmetic.  The three GEMM-shaped operators (Correlation, DeformableConvolution, Convolution / Deconvolution) exist in
+ * two arithmetics; which one a call uses is a property of the CALLING THREAD (thread-local, re-entrant, default compiled in),
+ * never of the process-global measurement knobs below:
+ *   MFN_ARITH_DEFAULT  the library's choice: the bf16 x 3 matrix-core kernels wherever one exists for the call's shape
+ *                      (level shapes of the network), the fp32 kernels elsewhere.
+ *   MFN_ARITH_FP32     fp32 FMA chains everywhere (v_fma_f32 / v_mfma_f32_32x32x2_f32): the accumulation order of an fp32
+ *                      inner product, bit-reproducible against itself across tilings of K only within one kernel.
+ *   MFN_ARITH_BF16X3   as the default.
+ * bf16 x 3: every fp32 operand is written exactly as hi + mid + lo with three bf16 terms (24 significant bits) and SIX of the
+ * nine partial products -- those of weight >= 2^-16 -- are accumulated in fp32 by v_mfma_f32_*_bf16.  I/O stays fp32.  The
+ * dropped products are <= 2^-24 of a product each (~1 ulp per product, not per sum); the acceptance rule, asserted per kernel in
+ * tests/test_gpu_parity.py, is "error against the fp64 oracle not above the fp32 kernel's on the same input".  It is
+ * fp32-EQUIVALENT, not the bit pattern of an FMA chain.  Divergence on non-finite inputs: an +-inf operand splits into
+ * inf + NaN (inf - bf16(inf)), so outputs that an FMA chain would make +-inf come back NaN; NaN inputs give NaN either way;
+ * values beyond bf16's range do not exist (bf16 has fp32's exponent); fp32 denormal operands lose their low terms (flushed), an
+ * absolute error below 2^-126 per product.
+ * Layouts packed by mfn_deform_conv_pack_weights / mfn_conv2d_pack_weights depend on the arithmetic of the thread that packed
+ * them; a call under another arithmetic refuses them (layout tag) instead of misreading them.
+ * op: "correlation" | "deformable_convolution" | "convolution" | "all".  Unknown op / mode: MFN_E_PARAM. */
+#define MFN_ARITH_DEFAULT (-1)
+#define MFN_ARITH_FP32 0
+#define MFN_ARITH_BF16X3 1
+int mfn_set_arithmetic(const char *op, int mode);
+int mfn_get_arithmetic(const char *op, int *mode);
+
+/* Kernel-selection knobs for tuning sweeps: tilings and code paths only, never arithmetic (process-global, NOT thread-safe,
+ * not part of the drop-in surface: set them before the first operator call or while no other thread is inside the library).
  * Unknown keys return MFN_E_PARAM.  Keys: see maskflownet_amd/csrc/tuning.h. */
 /* Measurement only: when non-NULL, instrumented kernels write 4 x uint64 wall-clock stamps (100 MHz)
  * per workgroup into this device buffer (caller sizes it: 32 bytes x workgroups). */

@@ -56,6 +56,8 @@ SIGNATURES = {
     "leaky_relu_bwd": (_i, [_f, _f, _f, C.c_size_t, C.c_float, _s]),
     "conv2d_bwd_workspace_bytes": (C.c_size_t, [_i] * 18),
     "conv2d_bwd": (_i, [_f] * 7 + [_i] * 21 + [C.c_void_p, C.c_size_t, _s]),
+    "set_arithmetic": (_i, [C.c_char_p, _i]),
+    "get_arithmetic": (_i, [C.c_char_p, _pi]),
     "set_tuning": (_i, [C.c_char_p, _i]),
     "get_tuning": (_i, [C.c_char_p, _pi]),
 }

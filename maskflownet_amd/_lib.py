@@ -96,13 +96,17 @@ def build(force=False, verbose=False):
     if proc.returncode != 0:
         # CalledProcessError's str() does not show its stderr: print the compiler's diagnostics before raising
         import sys
-        sys.stderr.write("\n".join(other[-200:]) + "\n")
-        raise subprocess.CalledProcessError(proc.returncode, cmd, stderr="\n".join(other[-200:]))
+        errs = [i for i, l in enumerate(other) if "error" in l]   # the m0 warnings of every LDS-DMA statement would bury them
+        shown = sorted({j for i in errs for j in range(max(0, i - 2), min(len(other), i + 8))}) or range(max(0, len(other) - 60), len(other))
+        text = "\n".join(other[j] for j in shown)
+        sys.stderr.write(text + "\n")
+        raise subprocess.CalledProcessError(proc.returncode, cmd, stderr=text)
     warnings = [l for l in other if "warning:" in l]
     if warnings and verbose:
         print("hipcc: %d warning(s), first: %s" % (len(warnings), warnings[0]))
     with open(RES_PATH + ".tmp%d" % os.getpid(), "w") as f:
         f.write("# src=%s\n" % want)
+        f.write("# warnings=%d%s\n" % (len(warnings), (" first: " + warnings[0].strip()) if warnings else ""))
         f.write("\n".join(remarks) + "\n")
     os.replace(RES_PATH + ".tmp%d" % os.getpid(), RES_PATH)
     os.replace(tmp, SO_PATH)
@@ -111,6 +115,29 @@ def build(force=False, verbose=False):
     if verbose:
         print("libmfn_hip.so rebuilt (src=%s)" % want)
     return SO_PATH
+
+
+def build_warnings():
+    """Number of compiler warnings of the build at SO_PATH (recorded by build() next to the kernel-resource remarks), or None."""
+    import re
+    if not os.path.exists(RES_PATH):
+        return None
+    with open(RES_PATH) as f:
+        f.readline()
+        m = re.match(r"# warnings=(\d+)", f.readline())
+    return int(m.group(1)) if m else None
+
+
+def device_disassembly():
+    """llvm-objdump -d of the gfx950 code object inside the shipped library (ROCm's clang-offload-bundler + llvm-objdump)."""
+    import tempfile
+    llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, SO_PATH, os.path.join(d, "copy.so")])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        return subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
 
 
 def kernel_resources():
@@ -165,8 +192,37 @@ def tuning_epoch():
     return _tuning_epoch
 
 
+ARITHMETIC_OPS = {"corr_gram": "correlation", "dc_mma": "deformable_convolution", "conv_mma": "convolution"}
+ARITH_DEFAULT, ARITH_FP32, ARITH_BF16X3 = -1, 0, 1
+
+
+def set_arithmetic(**kw):
+    """mfn_set_arithmetic for the calling thread: correlation= / deformable_convolution= / convolution= / all= one of
+    ARITH_DEFAULT (-1), ARITH_FP32 (0), ARITH_BF16X3 (1).  Packed-weight caches key on tuning_epoch(), which this bumps."""
+    global _tuning_epoch
+    _tuning_epoch += 1
+    for op, mode in kw.items():
+        check(lib().set_arithmetic(op.encode(), int(mode)), "set_arithmetic")
+
+
+def get_tuning(key):
+    """The present value of a tuning key ('a_b' form), or of a thread's arithmetic for the three legacy names."""
+    v = ctypes.c_int()
+    if key in ARITHMETIC_OPS:
+        check(lib().get_arithmetic(ARITHMETIC_OPS[key].encode(), ctypes.byref(v)), "get_arithmetic")
+    else:
+        check(lib().get_tuning(key.replace("_", ".", 1).encode(), ctypes.byref(v)), "get_tuning")
+    return v.value
+
+
 def set_tuning(**kw):
+    """mfn_set_tuning (tilings / code paths; key 'a_b' -> 'a.b').  The three names that selected arithmetic before round 5 --
+    corr_gram, dc_mma, conv_mma -- are still accepted here and routed to set_arithmetic (measurement tools pass them in one
+    list with tiling keys); the C library itself has no such tuning keys any more."""
     global _tuning_epoch
     _tuning_epoch += 1
     for k, v in kw.items():
-        check(lib().set_tuning(k.replace("_", ".", 1).encode(), int(v)), "set_tuning")
+        if k in ARITHMETIC_OPS:
+            check(lib().set_arithmetic(ARITHMETIC_OPS[k].encode(), max(-1, min(1, int(v)))), "set_arithmetic")
+        else:
+            check(lib().set_tuning(k.replace("_", ".", 1).encode(), int(v)), "set_tuning")

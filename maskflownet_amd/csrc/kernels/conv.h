@@ -21,6 +21,11 @@
 
 namespace mfn {
 
+// words of a channel pair's weights of one 32-filter tile in the bf16 x 3 form of conv_mfma_kernel<.., MMA = 1>:
+// [term hi|mid|lo][channel of the pair][filter][taps 0..7] bf16 + [channel][filter] fp32 for tap 8 (832; 576 in fp32)
+constexpr int DC_PAIR_W_BF16 = 3 * 2 * 32 * 8 / 2 + 2 * 32;
+
+
 struct ConvParams {
   const float *x;
   const float *w;     // original layout [generic kernel]: (Cout, Cin/g, kh, kw), transposed: (Cin, Cout/g, kh, kw)

@@ -505,7 +505,7 @@ inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *na
   return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
-inline bool corr_variant_gram(int v) { return v >= 40 && v <= 43; }
+inline bool corr_variant_gram(int v) { return v == 40; }
 // Output rows per work item: 6 or 8 (T = 3 / 4 blocks; the schedule is compile-time).  One wave per item, eight resident waves
 // per CU (two blocks of four): the level-2 launch of 384x512 at batch 8 is 2048 items of 6 rows = one residency round.  Fewer
 // rows per item mean more halo (an item converts rows + 2*md f2 rows); 8 where 6 does not divide H and 8 does (448x1024:
@@ -514,23 +514,14 @@ inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
   if (override_rows == 6 || override_rows == 8) return override_rows;
   return (H % 6 != 0 && H % 8 == 0) ? 8 : 6;
 }
-// corr.variant 40: exact (three terms, six products), cooperative stores (full lines through LDS, written through unless the
-// caller's policy says plain); 42: the same with every wave storing its own 32-byte runs (plain stores -- written through that
-// pattern costs 14.2 us for the 31.85 MB of level 2 against 8.4 us, profiles/r04_store_pattern_ubench.txt); 41: two terms,
-// three products on the form of 42 (measured variant, ~1e-5 relative; md = 4, six-row items, no fused activation); 43: 42 with
-// TWO waves per item (md = 4, six rows; measured slower -- the one instantiation that exercises GramSched<SP = 2>).  Ring of 4
-// tiles (wave-private stores: 13.2 us; 5: 13.7, 9: 14.6; cooperative: 10.45 us, 6: 10.8 and no better on cold buffers -- a deep
-// ring only delays the first tiles of 2048 waves that all start together).
+// corr.variant 40: three terms, six products, cooperative stores (full lines through LDS, written through unless the caller's
+// policy says plain), a ring of 4 tiles.  The measured-and-lost forms of round 4 -- 41 (two terms, ~1e-5 relative), 42 (every
+// wave stores its own 32-byte runs: 13.2 us against 10.45), 43 (two waves per item) -- are no longer instantiated in the shipped
+// library; the template parameters that selected them (TERMS, SP, COOP) remain, profiles/r04_corr_gram_experiments.md
+// holds their numbers.
 template <int D>
-inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s) {
+inline int corr_gram_variant(const CorrGramParams &p, int /*variant*/, hipStream_t s) {
   const bool wt = (p.store_policy & 2) != 0;
-  if (variant == 43 && D == 9 && !p.leaky && p.rows == 6) return corr_gram_launch<9, 3, 4, 4, 3, 0, false, 2>(p, s, "corr_gram_v43");
-  if (variant == 41 && D == 9 && !p.leaky && p.rows == 6) return corr_gram_launch<9, 3, 4, 4, 2, 0, false>(p, s, "corr_gram_v41");
-  if (variant == 42) {
-#define MFN_GRAM_(TT_) (p.leaky ? corr_gram_launch<D, TT_, 4, 4, 3, 0, true>(p, s, "corr_gram_v42") : corr_gram_launch<D, TT_, 4, 4, 3, 0, false>(p, s, "corr_gram_v42"))
-    return p.rows == 8 ? MFN_GRAM_(4) : MFN_GRAM_(3);
-#undef MFN_GRAM_
-  }
 #define MFN_GRAM_(TT_) \
   (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, true, 1, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, true, 1, true>(p, s, "corr_gram_v40")) \
            : (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, false, 1, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, false, 1, true>(p, s, "corr_gram_v40")))

@@ -26,9 +26,6 @@
 #define MFN_DC_ABLATE 0
 #endif
 
-#ifndef MFN_MMA_GROUPS
-#define MFN_MMA_GROUPS 1   // measurement builds: 0 = no scheduling groups in the bf16 x 3 steps
-#endif
 namespace mfn {
 
 struct DeformParams {
@@ -61,7 +58,6 @@ struct DeformParams {
   int dcm_groups, dcm_gps;                    // dc_mma_kernel (deform_conv_mma.h): 16-channel groups of the call / per K slice
 };
 
-constexpr int DC_PAIR_W_BF16 = 3 * 2 * 32 * 8 / 2 + 2 * 32;   // words of a channel pair's weights in the bf16 x 3 form (832; 576 in fp32)
 // weights (Cout, Cin, 9) -> wt[mg][cp][t][half][RL]: filter o = mg*RL + r, channel c = 2*cp + half; zero padded
 // in c (odd Cin, rows up to ncp_pad) and o (Cout not a multiple of RL).  One M-group is one linear
 // array, so a K-chunk of it is one contiguous LDS-DMA transfer.
@@ -77,28 +73,6 @@ __global__ __launch_bounds__(256) void dc_pack_weights_kernel(PackParams p) {
   const int mg = (int)(idx / ((size_t)2 * p.RL * p.T * p.ncp_pad));
   const int c = 2 * cp + half, o = mg * p.RL + r;
   p.wt[idx] = (c < p.Cin && o < p.Cout) ? p.w[((size_t)o * p.Cin + c) * p.T + t] : 0.f;
-}
-
-// the same filters for the bf16 x 3 split (DcGeom<.., MMA = 1>): one thread per (M-group, pair, channel of the pair, filter)
-struct PackBf16Params { const float *w; float *wt; int Cin, Cout, mgroups, ncp_pad; };
-__global__ __launch_bounds__(256) void dc_pack_weights_bf16_kernel(PackBf16Params p) {
-  const size_t total = (size_t)p.mgroups * p.ncp_pad * 2 * 32;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int m = (int)(idx & 31), kb = (int)((idx >> 5) & 1);
-  const int cp = (int)((idx >> 6) % p.ncp_pad), mg = (int)((idx >> 6) / p.ncp_pad);
-  const int c = 2 * cp + kb, o = mg * 32 + m;
-  const bool ok = c < p.Cin && o < p.Cout;
-  float x[8];
-  MFN_UNROLL
-  for (int e = 0; e < 8; ++e) x[e] = ok ? p.w[((size_t)o * p.Cin + c) * 9 + e] : 0.f;
-  mfn_bf16x8 h, mm, l;
-  mfn_split3x8(x, h, mm, l);
-  float *base = p.wt + ((size_t)mg * p.ncp_pad + cp) * DC_PAIR_W_BF16;
-  mfn_write_bf16x8(base + ((0 * 2 + kb) * 32 + m) * 4, h);
-  mfn_write_bf16x8(base + ((1 * 2 + kb) * 32 + m) * 4, mm);
-  mfn_write_bf16x8(base + ((2 * 2 + kb) * 32 + m) * 4, l);
-  base[768 + kb * 32 + m] = ok ? p.w[((size_t)o * p.Cin + c) * 9 + 8] : 0.f;
 }
 
 // the matching module's epilogue on one output value (bias already added): v * sigmoid(mask) + add, LeakyReLU(0.1)
@@ -160,13 +134,10 @@ constexpr int dc_kc(int mt, int kw) {
   return q >= 4 ? 4 : (q >= 2 ? 2 : 1);
 }
 template <int V> struct DcInt { static constexpr int value = V; };
-// MMA = 1 (dc.mma, one filter tile per wave only): the weights of a channel pair are stored for the bf16 x 3 split --
-// [split hi|mid|lo][channel of the pair][filter][taps 0..7] as bf16 (16 bytes per lane and split: the A operand of one
-// v_mfma_f32_32x32x16_bf16) followed by [channel][filter] fp32 for tap 8, which stays on the exact fp32 MFMA.
-template <int MT, int KW, int MMA = 0> struct DcGeom {
+template <int MT, int KW> struct DcGeom {
   static constexpr int RL = 32 * MT;
   static constexpr int KC = dc_kc(MT, KW);
-  static constexpr int PAIR_W = MMA ? DC_PAIR_W_BF16 : 18 * RL;   // words of one channel pair's weights
+  static constexpr int PAIR_W = 18 * RL;   // words of one channel pair's weights
   static constexpr int CHUNK_F = KC * PAIR_W;   // floats
   static constexpr int CH4 = CHUNK_F / 4;       // float4 items
 };
@@ -178,18 +149,15 @@ constexpr int dc_min_waves(int mt, int pt, int nw = 4) {
 }
 
 // NW = waves per block (4, or 8 for the coarsest level: twice the in-block K slices, half the channel-pair chain per wave)
-template <int MT, int PT, int NW = 4, int MMA = 0>
+template <int MT, int PT, int NW = 4>
 __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kernel(DeformParams p) {
-  static_assert(MMA == 0 || MT == 1, "the bf16 x 3 form is built for one filter tile per wave");
   constexpr int T = 9;
   constexpr int NTH = NW * 64;
   constexpr int KW = NW / PT;  // K-slices handled inside the block (one wave each per pixel tile)
-  using G = DcGeom<MT, KW, MMA>;
+  using G = DcGeom<MT, KW>;
   constexpr int RL = G::RL, KC = G::KC, CH4 = G::CH4;
   constexpr int NI = (KW * CH4 + NTH - 1) / NTH;  // DMA instructions per thread per stage
-  // floats per stage buffer.  MMA: whole wave transfers only (the instructions that carry nothing go to a 1 KB dump behind
-  // the windows), so that the larger bf16 x 3 blocks still fit three workgroups into a CU's LDS
-  constexpr int STAGE_F = MMA ? ((KW * CH4 + 63) / 64) * 256 : NI * NTH * 4;
+  constexpr int STAGE_F = NI * NTH * 4;   // floats per stage buffer
   MFN_DYN_SHARED(float, lds);                 // 2 weight stage buffers + x windows (all reused for the K-slice reduction)
   // staged source window per wave and channel: 10 rows x 24 floats under a 2x16 pixel tile, 12 rows x 20 floats
   // under a 4x8 tile -- 60 float4 slots per channel, one channel pair = 2 wave DMA instructions (120 of 128 lanes)
@@ -271,7 +239,6 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
     MFN_UNROLL
     for (int i = 0; i < NI; ++i) {
       float *dst = buf + (i * NW + wave) * 256;
-      if (MMA && (i * NW + wave) * 64 >= KW * CH4) dst = lds + 2 * STAGE_F + NW * (3 * XW_F);   // nothing to carry: the dump
       mfn_dma16_so(wrsrc, dst, voff[i], soff);
     }
   };
@@ -380,34 +347,8 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   const int nchunks = p.cps_per_slice / KC;  // cps_per_slice is a multiple of KC
 
   // this lane's weight of tap t inside a channel pair's block `pw` (wave-uniform pointer): the filter (j) x channel (half)
-  // element the fp32 MFMA wants as A.  MMA: rebuilt exactly from its three bf16 terms (the tiers that are not hot use this).
-  auto a_of = [&](const float *pw, int t, int mt) -> float {
-    if (!MMA) return pw[(t * 2 + half) * RL + mt * 32 + j];
-    if (t == 8) return pw[768 + half * 32 + j];
-    const int e = ((0 * 2 + half) * 32 + j) * 8 + t;   // bf16 index of the hi term; mid / lo follow 2 * 32 * 8 further
-    return mfn_bf16_at(pw, e) + mfn_bf16_at(pw, e + 512) + mfn_bf16_at(pw, e + 1024);
-  };
-  // MMA: the nine column values of a pair against its filters -- taps 0..7 as three bf16 terms each, six products on the
-  // matrix cores (smallest terms first); tap 8 on the fp32 MFMA.  prepare = split + operand reads, issue(i) = product i
-  struct MmaOps { mfn_bf16x8 ah, am, al, bh, bm, bl; float a8, b8; };
-  auto mma_prepare = [&](const float *pw, const float (&cv)[9], MmaOps &o) {
-    const float x8[8] = {cv[0], cv[1], cv[2], cv[3], cv[4], cv[5], cv[6], cv[7]};
-    mfn_split3x8(x8, o.bh, o.bm, o.bl);
-    o.ah = mfn_read_bf16x8(pw + ((0 * 2 + half) * 32 + j) * 4);
-    o.am = mfn_read_bf16x8(pw + ((1 * 2 + half) * 32 + j) * 4);
-    o.al = mfn_read_bf16x8(pw + ((2 * 2 + half) * 32 + j) * 4);
-    o.a8 = pw[768 + half * 32 + j];
-    o.b8 = cv[8];
-  };
-  auto mma_issue = [&](const MmaOps &o, int i) {
-    if (i == 0) acc[0] = MFN_MFMA_32x32x16_BF16(o.al, o.bh, acc[0]);
-    else if (i == 1) acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bl, acc[0]);
-    else if (i == 2) acc[0] = MFN_MFMA_32x32x16_BF16(o.am, o.bm, acc[0]);
-    else if (i == 3) acc[0] = MFN_MFMA_32x32x16_BF16(o.am, o.bh, acc[0]);
-    else if (i == 4) acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bm, acc[0]);
-    else if (i == 5) acc[0] = MFN_MFMA_32x32x16_BF16(o.ah, o.bh, acc[0]);
-    else acc[0] = MFN_MFMA_32x32x2(o.a8, o.b8, acc[0]);
-  };
+  // element the fp32 MFMA wants as A
+  auto a_of = [&](const float *pw, int t, int mt) -> float { return pw[(t * 2 + half) * RL + mt * 32 + j]; };
   const int full_pairs = p.Cin / 2;  // pairs whose two channels both exist; an odd Cin adds one half pair
   // one channel pair on the fast path: separable bilinear interpolation of the 4x4 neighbourhood into
   // the 9 column values, which ARE the B operands of the 9 k-steps
@@ -619,59 +560,7 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
       // the loop ends, they land in registers that are dead from the compiler's point of view -- it had handed them to the
       // epilogue without a wait, and one pass in two came back with a wrong 4x8 tile somewhere (tools/r03_det.py; every
       // comparison with the oracle had passed).
-      // (MMA: reading the next window unconditionally would save the phi copies of the interpolated values -- measured ~1 us
-      // per launch -- but level 3 then came back with wrong 4x8 tiles in 5-60 of 60 runs, with the reads sunk below the matrix
-      // instructions or pinned ahead of them alike (tools/r03_bf16_det.py): the reads stay conditional.)
       if (k + 1 < nf) gather2(BN, vp);
-      if (MMA) {   // six matrix-core products + tap 8 with this wave's own VALU work between them
-        // The seven instructions accumulate into the same tile: back to back each waits for its predecessor (8 passes) and nothing
-        // else of the wave issues meanwhile.  So the split is staged -- hi terms (4 VALU), mid (16), lo (16) -- and the products
-        // are ordered by which term they need, still smallest first by class (2^-16: l*h, m*m, h*l; 2^-8: m*h, h*m; then h*h);
-        // the next pair's interpolation fills the rest.  Scheduling fences pin the order; the register fence at the end keeps
-        // the interpolation in THIS basic block (hipcc sinks it past the branches of the next step's DMA section otherwise --
-        // found in the ISA: MMMMMMM back to back, then 30 VALU a block later).
-        MmaOps o;
-        if (MFN_DC_ABLATE & 16) {   // measurement builds: no weight reads
-          const float fk[4] = {(float)k, 1.f, 2.f, 3.f};
-          o.ah = o.am = o.al = mfn_read_bf16x8(fk);
-          o.a8 = (float)k;
-        } else {
-          o.ah = mfn_read_bf16x8(pw + ((0 * 2 + half) * 32 + j) * 4);
-          o.am = mfn_read_bf16x8(pw + ((1 * 2 + half) * 32 + j) * 4);
-          o.al = mfn_read_bf16x8(pw + ((2 * 2 + half) * 32 + j) * 4);
-          o.a8 = pw[768 + half * 32 + j];
-        }
-        o.b8 = cur[8];
-        const float x8[8] = {cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]};
-        mfn_split_state sp;
-        MFN_REGFENCE8(vp[0][0], vp[0][1], vp[0][2], vp[0][3], vp[1][0], vp[1][1], vp[1][2], vp[1][3]);   // ... and from rising into the gather's block
-        interp_rows2(vp, trp, 0); interp_rows2(vp, trp, 1);
-        mfn_split_stage_h(x8, o.bh, sp);
-        MFN_SCHED_BARRIER();
-#if MFN_DC_ABLATE & 1
-#define MFN_DC_MMA_(a, b) acc[0][0] += mfn_bf16_at(reinterpret_cast<const float *>(&(a)), 0) * mfn_bf16_at(reinterpret_cast<const float *>(&(b)), 1)
-#else
-#define MFN_DC_MMA_(a, b) acc[0] = MFN_MFMA_32x32x16_BF16((a), (b), acc[0])
-#endif
-        MFN_DC_MMA_(o.al, o.bh);
-        mfn_split_stage_m(sp, o.bm);
-        MFN_SCHED_BARRIER();
-        MFN_DC_MMA_(o.am, o.bm);
-        mfn_split_stage_l(sp, o.bl);
-        MFN_SCHED_BARRIER();
-        MFN_DC_MMA_(o.ah, o.bl);
-        interp_col2(trp, nxt, 0);
-        MFN_SCHED_BARRIER();
-        MFN_DC_MMA_(o.am, o.bh);
-        interp_col2(trp, nxt, 1);
-        MFN_SCHED_BARRIER();
-        MFN_DC_MMA_(o.ah, o.bm);
-        interp_col2(trp, nxt, 2);
-        MFN_SCHED_BARRIER();
-        MFN_DC_MMA_(o.ah, o.bh);
-        if (MFN_DC_ABLATE & 1) acc[0][1] += o.a8 * o.b8; else acc[0] = MFN_MFMA_32x32x2(o.a8, o.b8, acc[0]);
-        MFN_REGFENCE9(nxt);
-      } else {
         mfma_tap(ap, 0, cur[0]); interp_rows2(vp, trp, 0);
         mfma_tap(ap, 1, cur[1]);
         mfma_tap(ap, 2, cur[2]); interp_rows2(vp, trp, 1);
@@ -681,7 +570,6 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         mfma_tap(ap, 6, cur[6]); interp_col2(trp, nxt, 2);
         mfma_tap(ap, 7, cur[7]);
         mfma_tap(ap, 8, cur[8]);
-      }
       MFN_SCHED_BARRIER();
     };
     for (int k = 0; k < nf;) {
@@ -792,17 +680,6 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
         const float *pw = lds + (ch & 1) * STAGE_F + kw * G::CHUNK_F + (size_t)kk * G::PAIR_W;
         const float *ap = pw + half * RL + j;
         // the last step interpolates a repeated pair (results unused): one MFMA stream, no accumulator copies
-        if (MMA) {
-          MmaOps o;
-          mma_prepare(pw, cur, o);
-          mma_issue(o, 0); xrow(R[SN][0], 0);
-          mma_issue(o, 1); xrow(R[SN][1], 1);
-          mma_issue(o, 2); xrow(R[SN][2], 2);
-          mma_issue(o, 3); xrow(R[SN][3], 3);
-          mma_issue(o, 4); ycol(nxt, 0);
-          mma_issue(o, 5); ycol(nxt, 1);
-          mma_issue(o, 6); ycol(nxt, 2);
-        } else {
           mfma_tap(ap, 0, cur[0]); xrow(R[SN][0], 0);
           mfma_tap(ap, 1, cur[1]); xrow(R[SN][1], 1);
           mfma_tap(ap, 2, cur[2]); xrow(R[SN][2], 2);
@@ -812,7 +689,6 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
           mfma_tap(ap, 6, cur[6]); ycol(nxt, 2);
           mfma_tap(ap, 7, cur[7]);
           mfma_tap(ap, 8, cur[8]);
-        }
         MFN_REGFENCE9(nxt);  // slot SN is read out: the next step's request may overwrite it
         MFN_SCHED_BARRIER();
       };
@@ -985,22 +861,22 @@ __global__ __launch_bounds__(NW * 64, dc_min_waves(MT, PT, NW)) void dc_lds_kern
   MFN_STAMP(p.timeline, 3);
 }
 
-template <int MT, int PT, int NW = 4, int MMA = 0>
+template <int MT, int PT, int NW = 4>
 inline size_t dc_lds_bytes() {
   constexpr int KW = NW / PT;
-  constexpr int NI = (KW * DcGeom<MT, KW, MMA>::CH4 + NW * 64 - 1) / (NW * 64);
-  const size_t stage = MMA ? (size_t)2 * ((KW * DcGeom<MT, KW, MMA>::CH4 + 63) / 64) * 1024 : (size_t)2 * NI * NW * 64 * 16;
+  constexpr int NI = (KW * DcGeom<MT, KW>::CH4 + NW * 64 - 1) / (NW * 64);
+  const size_t stage = (size_t)2 * NI * NW * 64 * 16;
   const size_t red = KW > 1 ? (size_t)PT * (KW - 1) * MT * 16 * 64 * 4 : 0;
-  const size_t xwin = (size_t)NW * 3 * (2 * 256) * 4 + (MMA ? 1024 : 0);  // NW waves x 3 buffers x one channel-pair window (XW_F floats) [+ the DMA dump]
+  const size_t xwin = (size_t)NW * 3 * (2 * 256) * 4;  // NW waves x 3 buffers x one channel-pair window (XW_F floats)
   return stage + xwin > red ? stage + xwin : red;
 }
 
-template <int MT, int PT, int NW = 4, int MMA = 0>
+template <int MT, int PT, int NW = 4>
 inline int dc_lds_launch(const DeformParams &p, hipStream_t stream, const char *name) {
   const int tiles = p.tile_w ? p.ntiles : cdiv(p.P, 32);
   const int bx = cdiv(tiles, PT);
   if (bx <= 0) return 0;
-  return launch(name, dc_lds_kernel<MT, PT, NW, MMA>, dim3(bx, p.ksb, p.mgroups), dim3(NW * 64), dc_lds_bytes<MT, PT, NW, MMA>(),
+  return launch(name, dc_lds_kernel<MT, PT, NW>, dim3(bx, p.ksb, p.mgroups), dim3(NW * 64), dc_lds_bytes<MT, PT, NW>(),
                 stream, p);
 }
 
@@ -1027,11 +903,6 @@ inline int dc_pack_launch(PackParams pp, hipStream_t stream) {
   const size_t total = (size_t)pp.mgroups * pp.ncp_pad * pp.T * 2 * pp.RL;
   return launch("dc_pack_weights", dc_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                 stream, pp);
-}
-
-inline int dc_pack_bf16_launch(PackBf16Params pp, hipStream_t stream) {
-  const size_t total = (size_t)pp.mgroups * pp.ncp_pad * 2 * 32;
-  return launch("dc_pack_weights_bf16", dc_pack_weights_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, pp);
 }
 
 struct DcCopyParams { const float *src; float *dst; size_t n; };

@@ -378,6 +378,10 @@ __device__ __forceinline__ int mfn_wave_max_i32(int v) {
 // ---- LDS-DMA (buffer_load_dwordx4 ... lds): global -> LDS without a VGPR round trip ------------------
 // Issued through inline asm on purpose: hipcc waits vmcnt(0) before any ds_read that follows a DMA it
 // knows about, which would serialise the staging ring.  Counting is therefore ours: MFN_WAIT_VM(n).
+// M0 (the LDS destination) is written and read INSIDE one statement and not named a clobber: hipcc reserves the register (naming
+// it only drew 1 690 "clobber list contains reserved registers" warnings per build and changed nothing), and it never keeps a
+// value of its own in it across our statements -- tests/test_abi.py disassembles the shipped library and asserts that every
+// instruction that touches M0 is one of these `s_mov_b32 m0, ...`, immediately followed by its `buffer_load ... lds`.
 // A raw buffer descriptor gives zero fill for free: lanes whose byte offset is >= num_records read 0.
 typedef int mfn_rsrc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ mfn_rsrc_t mfn_make_rsrc(const void *p, unsigned nbytes) {
@@ -393,14 +397,14 @@ __device__ __forceinline__ mfn_rsrc_t mfn_make_rsrc(const void *p, unsigned nbyt
 __device__ __forceinline__ void mfn_dma16(mfn_rsrc_t rsrc, float *lds_wave_base, unsigned voff) {
   const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
-               : "memory", "m0");
+               : "memory");
 }
 // same with a wave-uniform byte offset added by the instruction's soffset operand
 __device__ __forceinline__ void mfn_dma16_so(mfn_rsrc_t rsrc, float *lds_wave_base, unsigned voff, unsigned soff) {
   const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
   const unsigned so = __builtin_amdgcn_readfirstlane(soff);
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(so)
-               : "memory", "m0");
+               : "memory");
 }
 // DMA of one row of a tensor: ONE descriptor per tensor, the row's byte offset in soffset.  The hardware's range check of a raw
 // buffer is offset >= num_records - soffset, i.e. voff + soff against the descriptor's range: exact for the tensor (measured:
@@ -416,7 +420,7 @@ __device__ __forceinline__ void mfn_dma16_row(const void *base, unsigned full_by
   const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
   const unsigned so = __builtin_amdgcn_readfirstlane(valid ? soff : 0u);
   asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(so)
-               : "memory", "m0");
+               : "memory");
 }
 // one float per lane into a REGISTER through the same kind of descriptor (the compiler sees this load and places its wait):
 // lanes whose voff + soff is out of the tensor, or every lane when !valid, read 0

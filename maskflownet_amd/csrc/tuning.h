@@ -2,7 +2,8 @@
 // 0 (or any value a key does not list) means "let the library choose".  Round 3 cut the list from 47 keys to the 13 that
 // select between code paths the library ships (tests force every path through them); the measurement knobs of rounds 1 / 2
 // (tilings, ring depths, cache policies per kernel family, staggering, ablation masks) are gone with the variants they chose
-// between -- DESIGN.md records what each of them measured.
+// between -- DESIGN.md records what each of them measured.  Round 5: the three keys that selected ARITHMETIC (corr.gram, dc.mma,
+// conv.mma) are gone from here: that is mfn_set_arithmetic (include/mfn_hip.h), per thread; these keys only choose tilings / paths.
 //   corr.variant  6: corr_tiled_kernel (images narrower than 16 columns), 16 / 20 / 22: corr_dma_kernel with 1 / 2 / 3 channel
 //                 groups, 26 / 31: the same with a tile's displacement rows spread over 5 / 3 blocks (coarse levels); -1 = the
 //                 plan (api_impl.inc corr_plan)
@@ -11,18 +12,11 @@
 //                 44 / 45: corr_gramk_kernel (coarse levels: the same band, a block = an 8 x 2 pixel block of f1 and two / half of the
 //                 f2 rows it meets, one wave per 32 channels)
 //   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 0 = the plan)
-//   corr.gram     the plan's use of the matrix-core kernels (variant 40 for 32-channel levels of >= 400 tiles, 44 / 45 for the
-//                 coarse levels): -1 the library's default (api_impl.inc corr_plan, corr_gramk_plan), 0 never (fp32-FMA kernels
-//                 everywhere), 1 always where the shape allows
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
-//   dc.mma        the deformable convolution's arithmetic: -1 (default) / 1: dc_mma_kernel (kernels/deform_conv_mma.h) wherever the
-//                 call has the network's operator shape -- the GEMM as a bf16 x 3 operand split on the matrix cores (six products of
-//                 v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate; error against fp64 not above the exact kernel's);
-//                 0: dc_lds_kernel everywhere (v_mfma_f32_32x32x2_f32, the bit pattern of an fp32 FMA chain)
-//   dc.mt         dc_mma_kernel only, together with dc.pt and dc.nw: 32-filter tiles per wave (the K slices per pixel tile are nw / pt)
-//   conv.mma      1: the same bf16 x 3 split for the 3x3 convolutions (and the 4x4 / stride-2 transposed convolution run as one)
+//   dc.mt         dc_mma_kernel (kernels/deform_conv_mma.h) only, together with dc.pt and dc.nw: 32-filter tiles per wave (the K slices
+//                 per pixel tile are nw / pt); all three > 0 replace the plan's tiling
 //   dc.pt         pixel tiles per block: 1 | 2 | 4   (the block's 4 waves split K 4/pt ways)
 //   dc.ksb        K split across blocks (partial sums + reduce kernel); 0 = heuristic
 //   dc.nw         waves per block: 0 auto, 4, 8 (8 only with pt = 1)
@@ -40,19 +34,15 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_variant = -1, corr_direct = 0, corr_rows = 0, corr_gram = -1;
+  int corr_variant = -1, corr_direct = 0, corr_rows = 0;
   int store_policy = -1;
-  int dc_mma = -1, conv_mma = 0;
   int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_off = 0, dc_mt = 0;
   int path_generic = 0, bwd_off = 0;
   int conv_mt = 0, conv_pt = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.variant")) return &corr_variant;
-    if (!strcmp(key, "dc.mma")) return &dc_mma;
-    if (!strcmp(key, "conv.mma")) return &conv_mma;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
     if (!strcmp(key, "corr.rows")) return &corr_rows;
-    if (!strcmp(key, "corr.gram")) return &corr_gram;
     if (!strcmp(key, "store.policy")) return &store_policy;
     if (!strcmp(key, "dc.pt")) return &dc_pt;
     if (!strcmp(key, "dc.mt")) return &dc_mt;

@@ -75,9 +75,14 @@ def emu_ops():
 
 
 def set_tuning(**kw):
+    """As maskflownet_amd._lib.set_tuning, on the emulation build (corr_gram / dc_mma / conv_mma select the thread's arithmetic)."""
+    from maskflownet_amd._lib import ARITHMETIC_OPS
     ops = emu_ops()
     for k, v in kw.items():
-        ops.check(ops.ns.set_tuning(k.replace("_", ".", 1).encode(), int(v)))
+        if k in ARITHMETIC_OPS:
+            ops.check(ops.ns.set_arithmetic(ARITHMETIC_OPS[k].encode(), max(-1, min(1, int(v)))))
+        else:
+            ops.check(ops.ns.set_tuning(k.replace("_", ".", 1).encode(), int(v)))
 
 
 def launch_log():

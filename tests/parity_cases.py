@@ -173,6 +173,55 @@ def case_deform_pertap(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0,
     return check_close(got, want, what="deform per-tap %s" % (kw,))
 
 
+def case_deform_flow(ops, oracle, to_dev, to_host, x_shape, fl, fused=True, seed=0, what="deform flow"):
+    """deformable convolution under a given flow field (level pixels, (N,2,H,W), channel 0 = dy): the shared-offset call pattern."""
+    rng = np.random.default_rng(8100 + seed)
+    N, C, H, W = x_shape
+    x = feat(rng, x_shape)
+    w = msra_weight(rng, C, C)
+    b = (rng.standard_normal((C,)) * 0.1).astype(np.float32)
+    fl = (np.asarray(fl, np.float32) * np.float32(8.0 / 20.0)).astype(np.float32)
+    off = oracle.offsets_from_flow(fl, 20.0, 8.0)
+    want = oracle.deformable_convolution(x, off, w, b, kernel=(3, 3), pad=(1, 1))
+    if fused:
+        got = ops.deformable_convolution_shared(to_dev(x), to_dev(fl), 20.0, 8.0, to_dev(w), to_dev(b))
+    else:
+        got = ops.DeformableConvolution(to_dev(x), ops.offsets_from_flow(to_dev(fl), 20.0, 8.0), to_dev(w), to_dev(b), kernel=(3, 3), pad=(1, 1),
+                                        num_filter=C)
+    return check_close(to_host(got), want, what=what)
+
+
+def wild_flow(rng, N, H, W, sigma=6.0):
+    """i.i.d. offsets of `sigma` level pixels with a few absurd ones (far outside, 1e9, -3e38): no two lanes of a wave share a
+    window, some lanes lie outside any window."""
+    fl = (rng.standard_normal((N, 2, H, W)) * sigma).astype(np.float32)
+    fl[:, :, 0, 0] = 1000.0
+    fl[:, :, min(1, H - 1), min(1, W - 1)] = -1000.0
+    fl[:, 0, min(2, H - 1), min(2, W - 1)] = 1e9
+    fl[:, 1, min(2, H - 1), min(3, W - 1)] = -3e38
+    return fl
+
+
+def gradient_flow(N, H, W, gy, gx):
+    """dy = gy * (y - H/2), dx = gx * (x - W/2): a wave's 4 x 8 tile needs a window that grows with the gradient (the small
+    12 x 20 one up to ~0.8 px/px, the big 16 x 24 one up to ~1.3, lanes outside beyond)."""
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    return np.broadcast_to(np.stack([gy * (yy - H // 2) + 0.3, gx * (xx - W // 2) - 0.4])[None], (N, 2, H, W)).astype(np.float32)
+
+
+def rounding_flow(N, H, W):
+    """Offsets a hair below an integer: in fp32 `tap + offset` rounds UP to the next integer for some taps and not for others
+    (floor(0 + o) = -1 but 1 + o == 1.0f).  The shared-offset path folds that pattern (weights (0, 1) on the same pair of lines)."""
+    vals = [-1e-8, np.float32(1) - np.float32(6e-8), np.float32(3) - np.float32(2.4e-7), -3e-8, 1e-8,
+            np.nextafter(np.float32(2), np.float32(0)), np.nextafter(np.float32(-1), np.float32(0)), 0.0]
+    fl = np.zeros((N, 2, H, W), np.float32)
+    for i in range(H):
+        for j in range(W):
+            fl[:, 0, i, j] = vals[(i * W + j) % len(vals)]
+            fl[:, 1, i, j] = vals[(i * 3 + j * 5) % len(vals)]
+    return fl * np.float32(20.0 / 8.0)   # case_deform_flow scales by 8 / 20: the offsets are `vals` up to one rounding
+
+
 def case_deform_packed(ops, oracle, to_dev, to_host, N, Cin, Cout, H, W, seed=0, **kw):
     """Weights packed once (mfn_deform_conv_pack_weights) give bit-identical results to the per-call path,
     for the MFMA path, its fused-offset form and the shapes that fall to the generic kernel."""

@@ -142,24 +142,31 @@ def test_every_tuning_key_used_by_tests_tools_and_bench_exists():
             for kv in m.group(1).split(","):
                 if "=" in kv:
                     used.setdefault(kv.split("=")[0].replace("_", ".", 1), set()).add(os.path.basename(f))
-    unknown = {k: sorted(v) for k, v in used.items() if k not in keys}
+    # the three names that selected ARITHMETIC before round 5 are no tuning keys any more: _lib.set_tuning / emu_ops.set_tuning
+    # route them to mfn_set_arithmetic (thread-local), which the emulation build answers for
+    from maskflownet_amd._lib import ARITHMETIC_OPS
+    for legacy, op in ARITHMETIC_OPS.items():
+        assert legacy.replace("_", ".", 1) not in keys, legacy
+        v = ctypes.c_int(7)
+        assert ns.get_arithmetic(op.encode(), ctypes.byref(v)) == 0 and v.value in (-1, 0, 1), op
+    assert ns.set_arithmetic(b"no_such_operator", 0) != 0 and ns.set_arithmetic(b"correlation", 5) != 0
+    unknown = {k: sorted(v) for k, v in used.items() if k not in keys and k.replace(".", "_", 1) not in ARITHMETIC_OPS}
     assert not unknown, unknown
     assert len(used) >= 8, sorted(used)   # the scan does find the calls
 
 
 def test_kernels_with_hand_counted_waits_have_no_compiler_scratch():
-    """correlation_gram.h counts its own vmcnt waits (LDS-DMA loads AND stores, all inline asm) and the deformable convolution's
-    default gather tier keeps asynchronous global loads in flight (mfn_gload4_async): a compiler-made scratch load or store in
-    those kernels would join the same in-order queue uncounted.  _lib.build() keeps hipcc's kernel-resource-usage remarks of the
-    build that ships; the kernels concerned must show no scratch and no spills (a build-time check instead of
-    trusting the register allocator).  dc.mma = 1 (a measured, non-default variant) may use scratch in one instantiation --
-    reported, not asserted."""
+    """correlation_gram.h and deform_conv_mma.h count their own vmcnt waits (LDS-DMA loads AND stores, all inline asm) and the fp32
+    deformable convolution's global-gather tier keeps asynchronous global loads in flight (mfn_gload4_async): a compiler-made
+    scratch load or store in those kernels would join the same in-order queue uncounted.  _lib.build() keeps hipcc's
+    kernel-resource-usage remarks of the build that ships; the kernels concerned must show no scratch and no spills (ADVICE r03:
+    a build-time check instead of trusting the register allocator)."""
     import subprocess
     from maskflownet_amd import _lib
     _lib.build()
     res = _lib.kernel_resources()
     assert len(res) > 50, "no kernel-resource remarks next to libmfn_hip.so: %s" % _lib.RES_PATH
-    seen = {"gram": 0, "dc": 0}
+    seen = {"gram": 0, "dc": 0, "dcm": 0}
     for mangled, r in res.items():
         name = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout.strip()
         clean = r.get("ScratchSize [bytes/lane]") == "0" and r.get("VGPRs Spill") == "0"
@@ -167,10 +174,38 @@ def test_kernels_with_hand_counted_waits_have_no_compiler_scratch():
             seen["gram"] += 1
             assert clean, (name, r)
         elif "dc_lds_kernel<" in name:
-            mma = name.split("<")[1].split(">")[0].split(",")[3].strip() == "1"
             seen["dc"] += 1
-            if not mma:
-                assert clean, (name, r)
-            elif not clean:
-                print("note: %s uses %s bytes of scratch per lane" % (name, r.get("ScratchSize [bytes/lane]")))
-    assert seen["gram"] >= 8 and seen["dc"] >= 4, seen
+            assert clean, (name, r)
+        elif "dc_mma_kernel<" in name:
+            seen["dcm"] += 1
+            assert clean, (name, r)
+    assert seen["gram"] >= 8 and seen["dc"] >= 4 and seen["dcm"] >= 4, seen
+
+
+def test_the_build_has_no_compiler_warnings():
+    """hipcc used to print 1 690 'inline asm clobber list contains reserved registers: m0' warnings per build (every LDS-DMA
+    statement): the statements now save and restore M0 inside the string instead of naming it a clobber (cdna_hip_programming.md
+    5.7), and a build that warns again fails here."""
+    from maskflownet_amd import _lib
+    _lib.build()
+    assert _lib.build_warnings() == 0, "hipcc warned %d times: see %s" % (_lib.build_warnings(), _lib.RES_PATH)
+
+
+def test_m0_is_only_touched_by_the_lds_dma_statements():
+    """The LDS-DMA statements of mfn_rt.h write M0 without telling hipcc (the register is compiler-reserved: a clobber entry is
+    ignored with a warning).  That is sound as long as hipcc itself keeps nothing in M0 across them -- shown on the shipped
+    library's own disassembly: every instruction that mentions M0 is `s_mov_b32 m0, <sgpr>` and the very next instruction is the
+    `buffer_load_dword... lds` it serves."""
+    import re
+    from maskflownet_amd import _lib
+    _lib.build()
+    lines = [l.split("//")[0].strip() for l in _lib.device_disassembly().splitlines()]
+    lines = [l for l in lines if l and not l.endswith(":") and not l.startswith(("Disassembly", "/"))]
+    n = 0
+    for i, l in enumerate(lines):
+        if not re.search(r"\bm0\b", l):
+            continue
+        n += 1
+        assert re.match(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$", l), l   # a scalar source: the write of our own statement
+        assert re.match(r"buffer_load_dword(x[234])? .* lds", lines[i + 1]), (l, lines[i + 1])
+    assert n > 100, n

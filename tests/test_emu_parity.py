@@ -17,8 +17,8 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(corr_variant=-1, corr_rows=0, corr_gram=-1, dc_mma=0, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, path_generic=0,
-                      bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=0)
+DEFAULT_TUNING = dict(corr_variant=-1, corr_rows=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
+                      path_generic=0, bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=-1)
 
 
 @pytest.fixture(autouse=True)
@@ -60,18 +60,6 @@ def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows):
     pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
 
 
-@pytest.mark.parametrize("variant", [42, 43])
-def test_correlation_gram_wave_private_stores(ops, oracle, variant):
-    """corr.variant 42: every wave stores its own 32-byte runs (no block barrier, plain stores); 43: the same with two waves per
-    item, each taking every other f2 row (GramSched<SP = 2>).  Exact like 40."""
-    emu_ops.set_tuning(corr_variant=variant, corr_direct=2)
-    pc.case_correlation(ops, oracle, ident, ident, (2, 32, 13, 20), 4)
-    assert "corr_gram_v%d" % variant in emu_ops.launch_log()
-    pc.case_correlation(ops, oracle, ident, ident, (1, 32, 24, 72), 4, seed=3)
-    if variant == 42:
-        pc.case_correlation_leaky(ops, oracle, ident, ident, (1, 32, 7, 36), 2)
-
-
 @pytest.mark.skipif(__import__("os").environ.get("MFN_SLOW_TESTS") != "1",
                     reason="95 s on the emulation (400 tiles of 32 x 4 is the plan's threshold): MFN_SLOW_TESTS=1 runs it; the GPU "
                            "suite runs the plan's choice at every BASELINE level shape")
@@ -83,18 +71,6 @@ def test_correlation_gram_by_plan(ops, oracle):
     assert "corr_gram_v40" in emu_ops.launch_log()
     pc.case_correlation(ops, oracle, ident, ident, (1, 32, 16, 64), 4, seed=2)  # 8 tiles: the usual plan
     assert "corr_gram" not in emu_ops.launch_log()
-
-
-def test_correlation_gram_two_term_variant(ops, oracle):
-    """corr.variant 41: two bf16 terms, three products -- a measured variant, 2^-17 relative per product (never the plan's choice)."""
-    emu_ops.set_tuning(corr_variant=41, corr_direct=2)
-    rng = np.random.default_rng(5)
-    f1, f2 = pc.feat(rng, (1, 32, 10, 24)), pc.feat(rng, (1, 32, 10, 24))
-    got = ops.Correlation(f1, f2, kernel_size=1, max_displacement=4, stride1=1, stride2=1, pad_size=4, is_multiply=True)
-    want = oracle.correlation(f1, f2, max_displacement=4, pad_size=4)
-    err = np.abs(got - want).max() / np.abs(want).max()
-    assert err < 3e-5, err
-    assert "corr_gram_v41" in emu_ops.launch_log()
 
 
 @pytest.mark.parametrize("variant", [44, 45])
@@ -265,46 +241,92 @@ def test_grid_generator_and_sampler(ops, oracle):
 @pytest.mark.parametrize("pt,ksb", [(1, 1), (4, 1), (2, 1), (2, 2), (1, 2), (1, 0)])
 @pytest.mark.parametrize("fused", [True, False])
 def test_deform_shared_offsets(ops, oracle, pt, ksb, fused):
-    # pt pixel tiles per block, 4/pt in-block K slices, ksb cross-block K slices (partials + reduce)
-    emu_ops.set_tuning(dc_pt=pt, dc_ksb=ksb)
+    # the fp32 kernel (dc_lds_kernel): pt pixel tiles per block, 4/pt in-block K slices, ksb cross-block K slices (partials + reduce)
+    emu_ops.set_tuning(dc_mma=0, dc_pt=pt, dc_ksb=ksb)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 7, fused=fused)
 
 
+@pytest.mark.parametrize("arith", [0, 1])
 @pytest.mark.parametrize("opt", [dict(), dict(mask=False), dict(tradeoff=False, leaky=False), dict(mask=False, tradeoff=False)])
-def test_deform_matching_epilogue(ops, oracle, opt):
+def test_deform_matching_epilogue(ops, oracle, opt, arith):
+    emu_ops.set_tuning(dc_mma=arith)
+    emu_ops.launch_log()
     pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 6, 8, **opt)      # 16-byte transposed stores
+    assert ("dc_mma" in emu_ops.launch_log()) == (arith == 1)
     pc.case_deform_matching(ops, oracle, ident, ident, 1, 8, 5, 7, seed=1, **opt)  # scalar stores (W % 4 != 0)
-    emu_ops.set_tuning(dc_ksb=2)
-    pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 4, 8, seed=2, **opt)  # split K: epilogue in the reduce kernel
-    emu_ops.set_tuning(dc_ksb=0, path_generic=2)
-    pc.case_deform_matching(ops, oracle, ident, ident, 1, 8, 4, 6, seed=3, **opt)   # generic kernel
+    if arith == 0:
+        emu_ops.set_tuning(dc_ksb=2)
+        pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 4, 8, seed=2, **opt)  # split K: epilogue in the reduce kernel
+        emu_ops.set_tuning(dc_ksb=0, path_generic=2)
+        pc.case_deform_matching(ops, oracle, ident, ident, 1, 8, 4, 6, seed=3, **opt)   # generic kernel
 
 
 def test_deform_eight_wave_blocks(ops, oracle):
-    # 8 waves = 8 in-block K slices of one pixel tile (the coarsest-level plan), even and ragged channel counts
-    emu_ops.set_tuning(dc_nw=8, dc_pt=1)
+    # dc_lds_kernel: 8 waves = 8 in-block K slices of one pixel tile (the coarsest-level plan), even and ragged channel counts
+    emu_ops.set_tuning(dc_mma=0, dc_nw=8, dc_pt=1)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 64, 4, 8)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 40, 5, 8, seed=2, fused=False)
     pc.case_deform_pertap(ops, oracle, ident, ident, 1, 36, 33, 4, 8, kernel=(3, 3), pad=(1, 1))
 
 
-@pytest.mark.parametrize("plan", [dict(dc_pt=4), dict(dc_pt=2), dict(dc_pt=1), dict(dc_pt=1, dc_nw=8), dict(dc_pt=2, dc_ksb=2)])
-def test_deform_bf16x3_operand_split(ops, oracle, plan):
-    """dc.mma = 1: fp32 operands as three bf16 terms, six products on v_mfma_f32_32x32x16_bf16 + tap 8 on the fp32 MFMA; every
-    gather tier (LDS window, global row quads under rough offsets, per-tap offsets with the weights rebuilt from their
-    terms, the 32-flattened-pixel form), ragged channels / filters, the matching epilogue.  Same tolerance as the exact kernel."""
-    emu_ops.set_tuning(dc_mma=1, **plan)
-    pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8)                       # LDS window tier
-    pc.case_deform_shared(ops, oracle, ident, ident, 2, 40, 5, 12, seed=2, fused=False)  # 20 pairs: chunk tails; drop-in offsets
-    emu_ops.set_tuning(dc_off=1)
-    pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8, seed=3)               # global-gather tier
-    emu_ops.set_tuning(dc_off=0)
-    pc.case_deform_pertap(ops, oracle, ident, ident, 1, 36, 33, 4, 8, kernel=(3, 3), pad=(1, 1))   # per-tap offsets, ragged filters
-    pc.case_deform_pertap(ops, oracle, ident, ident, 1, 3, 5, 4, 5, kernel=(3, 3), pad=(1, 1))     # odd Cin, flattened pixels
-    pc.case_deform_matching(ops, oracle, ident, ident, 1, 32, 6, 8)
+# dc_mma_kernel's tilings (filter tiles per wave, pixel tiles per block, waves per block) and a channel count they divide
+DCM_TILINGS = [(1, 4, 4, 32), (2, 3, 12, 64), (3, 1, 6, 96), (1, 1, 8, 128), (1, 1, 4, 64), (1, 1, 2, 32), (1, 1, 1, 48)]
 
 
-def test_deform_bf16x3_pack_is_a_layout_of_its_own(ops, oracle):
+@pytest.mark.parametrize("mt,pt,nw,C", DCM_TILINGS)
+def test_deform_matrix_core_kernel(ops, oracle, mt, pt, nw, C):
+    """dc_mma_kernel (kernels/deform_conv_mma.h, the default arithmetic of the deformable convolution): fp32 operands as three bf16
+    terms, six products on v_mfma_f32_32x32x16_bf16, tap 8 of a 16-channel group as its ninth K step, B operands shared by the
+    filter tiles of a wave, K slices summed in slice order by the waves in parallel.  Every tiling the library ships, on: the
+    small-window tier (drop-in and fused calls, ragged tiles in both directions), per-tap offsets with ragged filters (the lean
+    per-tap tier), the matching epilogue, packed weights."""
+    emu_ops.set_tuning(dc_mma=1, dc_mt=mt, dc_pt=pt, dc_nw=nw)
+    emu_ops.launch_log()
+    pc.case_deform_shared(ops, oracle, ident, ident, 1, C, 6, 8)
+    assert "dc_mma" in emu_ops.launch_log()
+    pc.case_deform_shared(ops, oracle, ident, ident, 2, C, 5, 12, seed=2, fused=False)   # ragged rows and columns; drop-in offsets
+    pc.case_deform_pertap(ops, oracle, ident, ident, 1, C, C - 24, 5, 12, kernel=(3, 3), pad=(1, 1))   # per-tap offsets, a ragged filter tile
+    pc.case_deform_matching(ops, oracle, ident, ident, 1, C, 6, 8)
+    emu_ops.launch_log()
+    pc.case_deform_packed(ops, oracle, ident, ident, 1, C, C, 6, 8, kernel=(3, 3), pad=(1, 1))
+    assert "dc_mma" in emu_ops.launch_log()
+
+
+@pytest.mark.parametrize("mt,pt,nw,C", [(1, 4, 4, 32), (2, 3, 12, 64), (1, 1, 8, 128)])
+def test_deform_matrix_core_kernel_window_tiers(ops, oracle, mt, pt, nw, C):
+    """The tiers of the source window: gradients the small 12 x 20 window holds, ones only the big 16 x 24 one holds, ones
+    that leave lanes outside both (global loads under an exec mask), offsets without any coherence incl. absurd values, and
+    the offsets a hair below an integer whose fp32 floors are not consecutive (folded into the shared-offset path)."""
+    emu_ops.set_tuning(dc_mma=1, dc_mt=mt, dc_pt=pt, dc_nw=nw)
+    for gy, gx in [(0.0, 0.6), (1.2, 0.0), (1.1, 0.9), (-1.2, -1.5), (0.3, 2.2), (2.5, 2.5)]:
+        pc.case_deform_flow(ops, oracle, ident, ident, (1, C, 12, 24), pc.gradient_flow(1, 12, 24, gy, gx), what="gradient %s %s" % (gy, gx))
+    rng = np.random.default_rng(31)
+    pc.case_deform_flow(ops, oracle, ident, ident, (1, C, 9, 16), pc.wild_flow(rng, 1, 9, 16))
+    pc.case_deform_flow(ops, oracle, ident, ident, (2, C, 6, 8), pc.wild_flow(rng, 2, 6, 8), fused=False, seed=1)
+    pc.case_deform_flow(ops, oracle, ident, ident, (1, C, 8, 16), pc.rounding_flow(1, 8, 16), fused=False, seed=2)
+    assert "dc_mma" in emu_ops.launch_log()
+
+
+def test_deform_rounding_fold_in_the_fp32_kernel(ops, oracle):
+    emu_ops.set_tuning(dc_mma=0)
+    pc.case_deform_flow(ops, oracle, ident, ident, (1, 32, 8, 16), pc.rounding_flow(1, 8, 16), fused=False, seed=2)
+
+
+def test_deform_matrix_core_plan_and_fallback(ops, oracle):
+    """The plan's tilings per level-like shape, and the shapes the matrix-core kernel does not take (channels that are no
+    multiple of 16, rows that are no multiple of 16 bytes): dc_lds_kernel, silently."""
+    for C, H, W in [(32, 6, 8), (96, 4, 8), (48, 4, 8), (128, 4, 8)]:
+        emu_ops.launch_log()
+        pc.case_deform_shared(ops, oracle, ident, ident, 1, C, H, W, seed=8)
+        assert "dc_mma" in emu_ops.launch_log()
+    for C, H, W in [(40, 4, 8), (32, 6, 7)]:
+        emu_ops.launch_log()
+        pc.case_deform_shared(ops, oracle, ident, ident, 1, C, H, W, seed=8)
+        assert "dc_lds" in emu_ops.launch_log()
+
+
+def test_deform_pack_follows_the_arithmetic(ops, oracle):
+    emu_ops.set_tuning(dc_mma=0)
     pk = pc.case_deform_packed(ops, oracle, ident, ident, 1, 32, 32, 6, 8, kernel=(3, 3), pad=(1, 1))
     emu_ops.set_tuning(dc_mma=1)
     rng = np.random.default_rng(1)
@@ -312,7 +334,7 @@ def test_deform_bf16x3_pack_is_a_layout_of_its_own(ops, oracle):
     with pytest.raises(RuntimeError, match="re-run mfn_deform_conv_pack_weights"):
         ops.DeformableConvolution(x, off, np.zeros((32, 32, 3, 3), np.float32), None, kernel=(3, 3), pad=(1, 1), num_filter=32,
                                   no_bias=True, packed=pk)
-    pc.case_deform_packed(ops, oracle, ident, ident, 1, 32, 32, 6, 8, kernel=(3, 3), pad=(1, 1))   # packs under dc.mma = 1
+    pc.case_deform_packed(ops, oracle, ident, ident, 1, 32, 32, 6, 8, kernel=(3, 3), pad=(1, 1))   # packs under the matrix-core arithmetic
 
 
 def test_deform_several_filter_groups(ops, oracle):
@@ -328,7 +350,7 @@ def test_deform_shared_odd_channels_and_padding_of_filters(ops, oracle):
 
 @pytest.mark.parametrize("stage", [0, 1])
 def test_deform_window_staging_and_per_tap_fallback(ops, oracle, stage):
-    emu_ops.set_tuning(dc_off=1 - stage)
+    emu_ops.set_tuning(dc_mma=0, dc_off=1 - stage)
     pc.case_deform_shared(ops, oracle, ident, ident, 1, 32, 6, 8)      # W % 4 == 0: window staging eligible
     pc.case_deform_shared(ops, oracle, ident, ident, 2, 8, 12, 16, seed=3)
 

@@ -24,9 +24,7 @@ for s in settings:
     keys |= {kv.split("=")[0] for kv in s.split(",") if kv}
 defaults = {}
 for k in keys:
-    v = ctypes.c_int()
-    lib.get_tuning(k.replace("_", ".", 1).encode(), ctypes.byref(v))
-    defaults[k] = v.value
+    defaults[k] = _lib.get_tuning(k)
 graphs = []
 for s in settings:
     kv = dict(defaults)
