@@ -37,9 +37,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "tiny", "tiny_full", "tiny_train"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "tiny", "tiny_full", "tiny_train", "e2e_train"],
                     help="cfg2 (default, the headline) / cfg3: MaskFlownet-S forward; cfg4: full model (S + cascade) forward; "
-                         "cfg5: S forward + backward + gradient all-reduce; tiny*: 2 x 64x128 smoke shapes (not a BASELINE config)")
+                         "cfg5: S forward + backward + gradient all-reduce; tiny*: 2 x 64x128 smoke shapes (not a BASELINE config); "
+                         "e2e_train: the whole MaskFlownet-S training step (every layer on the library), batch 8 per GPU, its 142 "
+                         "gradients exchanged in four flat buckets from the autograd hooks (informational, not a BASELINE line)")
     ap.add_argument("--mode", default="dropin", choices=["dropin", "fused"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--repack", action="store_true",
@@ -321,14 +323,16 @@ def side_config(cfg, mode, steps, torch, hotpath, want_roofline=False, want_domi
     return out
 
 
-def customop_leg(wl, steps, torch, hotpath):
+def customop_leg(wl, steps, torch, hotpath, fused=False):
     """The pass as the REFERENCE would run it (SURVEY.md 8b "Threading"): every operator through
     maskflownet_amd.mxnet_ops -- mx.nd.Correlation / contrib.DeformableConvolution / GridGenerator + BilinearSampler routed by
-    install() to mx.nd.Custom(op_type='mfn_*'), each CustomOp.forward doing hipSetDevice, a launch on the NULL stream and
-    hipDeviceSynchronize -- over the MXNet stub of tests/fake_mxnet (MXNet has no ROCm build; the stub implements the CustomOp
-    protocol over torch tensors, its Python overhead is inside the number).  11 Custom calls per pass (5 + 4 + 2); the offset
-    tensors are built as network/MaskFlownet.py:230 builds them (repeat / expand_dims / reshape: MXNet's own operators, torch in
-    the stub).  Reports pairs/s and what one call costs on top of its kernels."""
+    install() to mx.nd.Custom(op_type='mfn_*'), each CustomOp.forward doing hipSetDevice (on a device change), a launch on the
+    NULL stream and hipStreamSynchronize -- over the MXNet stub of tests/fake_mxnet (MXNet has no ROCm build; the stub implements
+    the CustomOp protocol over torch tensors, its Python overhead is inside the number).  11 Custom calls per pass (5 + 4 + 2); the
+    offset tensors are built as network/MaskFlownet.py:230 builds them (repeat / expand_dims / reshape: MXNet's own operators,
+    torch in the stub).  fused=True: a pyramid level's offsets + deformable convolution + cost volume as ONE Custom call
+    (mfn_matching_level, the six-line edit of INTEGRATION.md) and the warp as mfn_warp: 6 calls per pass, no offset tensors.
+    Reports pairs/s and what one call costs on top of its kernels."""
     import importlib
     import time
     fake = os.path.join(ROOT, "tests", "fake_mxnet")
@@ -336,6 +340,7 @@ def customop_leg(wl, steps, torch, hotpath):
     sys.path.insert(0, fake)
     try:
         import mxnet as mx
+        import mxnet.ndarray as mxnd
         import maskflownet_amd.mxnet_ops as m
         if m.mx is not mx:
             m = importlib.reload(m)
@@ -359,36 +364,57 @@ def customop_leg(wl, steps, torch, hotpath):
             outs.append(F.BilinearSampler(A["img2"], grid))
             return outs
 
+        def one_pass_fused():
+            outs = [F.Correlation(A["c1_6"], A["c2_6"], **ck)]
+            for l in (5, 4, 3, 2):
+                corr, _warp = F.Custom(A["c1_%d" % l], A["c2_%d" % l], A["flow_%d" % l], A["w_%d" % l], A["b_%d" % l], op_type="mfn_matching_level",
+                                       scale=hotpath.SCALE, stride=hotpath.STRIDES[l], max_displacement=hotpath.MD, activation="none",
+                                       corr_activation="none")
+                outs.append(corr)
+            outs.append(F.Custom(A["img2"], A["flow_full"], op_type="mfn_warp", clip_grid=0))
+            return outs
+
+        run = one_pass_fused if fused else one_pass
         for _ in range(5):
-            outs = one_pass()
+            outs = run()
         torch.cuda.synchronize()
         worst = 0.0   # the adapter's outputs against the pass the headline timed (same inputs, same library)
         for got, name in zip(outs, ["corr6", "corr5", "corr4", "corr3", "corr2", "warp"]):
             ref = wl.o[name]
             worst = max(worst, float((got._tensor - ref).abs().max() / ref.abs().max().clamp_min(1e-30)))
+        mxnd.POISON_EMPTY = False   # the stub fills every fresh array with NaN (a launch per allocation MXNet's pool does not make)
         t0 = time.perf_counter()
         for _ in range(steps):
-            one_pass()
+            run()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        mxnd.POISON_EMPTY = True
         m.uninstall()
     finally:
         sys.path.remove(fake)
         for k in [k for k in sys.modules if k == "mxnet" or k.startswith("mxnet.")]:
             del sys.modules[k]
         sys.modules.update(saved)
-    ncalls = 11
+    ncalls = 6 if fused else 11
     us_pass = dt / steps * 1e6
     kern = per_kernel_breakdown(wl, 10, torch)
-    us_kernels = sum(v["us_per_pass"] for v in kern.values())
+    us_kernels = sum(v["us_per_pass"] for k, v in kern.items() if not (fused and k.startswith("offsets")))
     return {"value": round(wl.N * steps / dt, 2), "unit": "image-pairs/s", "ms_per_step": round(us_pass / 1e3, 4), "steps": steps,
             "custom_calls_per_pass": ncalls, "kernel_us_per_pass": round(us_kernels, 1),
             "overhead_us_per_call": round((us_pass - us_kernels) / ncalls, 1),
             "max_rel_diff_vs_headline_outputs": worst,
-            "what": "the cfg2 pass through maskflownet_amd.mxnet_ops CustomOps (install()) over tests/fake_mxnet: per call hipSetDevice "
-                    "+ NULL-stream launch + hipDeviceSynchronize + the stub's Python; offsets built with the framework's own "
-                    "repeat/expand_dims/reshape as MaskFlownet.py:230 does",
+            "what": ("the cfg2 pass through maskflownet_amd.mxnet_ops CustomOps over tests/fake_mxnet, a pyramid level per call "
+                     "(mfn_matching_level: offsets + deformable convolution + cost volume, two launches and one drain) and mfn_warp: "
+                     "per call hipSetDevice on a device change + NULL-stream launches + hipStreamSynchronize + the stub's Python"
+                     if fused else
+                     "the cfg2 pass through maskflownet_amd.mxnet_ops CustomOps (install()) over tests/fake_mxnet: per call hipSetDevice "
+                     "on a device change + NULL-stream launch + hipStreamSynchronize + the stub's Python; offsets built with the "
+                     "framework's own repeat/expand_dims/reshape as MaskFlownet.py:230 does (three torch kernels per level in the stub)"),
             "note": "not the headline: `value` above is the same kernels behind the C ABI as one hipGraph replay"}
+
+
+def customop_fused_leg(wl, steps, torch, hotpath):
+    return customop_leg(wl, steps, torch, hotpath, fused=True)
 
 
 def per_kernel_breakdown(wl, iters, torch):
@@ -530,33 +556,58 @@ def network_epe_delta(H, W, device):
             "seconds": round(time.perf_counter() - t0, 1)}
 
 
-def end_to_end_train(N, H, W, device, torch, steps=5):
+def end_to_end_train(N, H, W, device, torch, steps=5, dist=None, world=1, rank=0, barrier_timing=False):
     """Informational: one training step of the whole MaskFlownet-S (pipeline.py:89-114) -- forward, MultiscaleEpe loss, backward,
-    Adam step -- with every layer's forward AND backward a libmfn_hip.so kernel (maskflownet_amd/training.py); eager, driven by
-    torch's autograd tape as the reference's is by MXNet's."""
+    the gradient exchange, Adam step -- with every layer's forward AND backward a libmfn_hip.so kernel (maskflownet_amd/training.py);
+    eager, driven by torch's autograd tape as the reference's is by MXNet's.  The 142 parameter gradients live in four flat buckets
+    (training.GradientBuckets); with a process group each bucket is all-reduced (RCCL) from the autograd hook of its last gradient,
+    overlapping the rest of backward; N is the PER-GPU batch, the optimizer sees sum / (N * world) as trainer.step(batch_size) does."""
     from maskflownet_amd import network, training
     torch.cuda.set_device(torch.device(device))
     net = training.MaskFlownetSTrainable(network.random_params(seed=1)).to(device)
     loss_fn = training.MultiscaleEpe()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-    g = torch.Generator(device="cpu").manual_seed(3)
+    buckets = training.GradientBuckets(net.parameters(), n_buckets=4, dist=dist)
+    g = torch.Generator(device="cpu").manual_seed(3 + 1000 * rank)   # every rank its own shard of the global batch
     im1 = (torch.rand(N, 3, H, W, generator=g) - 0.5).to(device)
     im2 = (torch.rand(N, 3, H, W, generator=g) - 0.5).to(device)
     label = (torch.randn(N, 2, H, W, generator=g) * 3.0).to(device)
     mask = torch.ones(N, 1, H, W, device=device)
     for _ in range(2):
-        loss = training.train_step(net, loss_fn, opt, im1, im2, label, mask)
+        loss = training.train_step(net, loss_fn, opt, im1, im2, label, mask, buckets=buckets, global_batch=N * world)
     torch.cuda.synchronize()
+    if barrier_timing and dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = training.train_step(net, loss_fn, opt, im1, im2, label, mask)
+        loss = training.train_step(net, loss_fn, opt, im1, im2, label, mask, buckets=buckets, global_batch=N * world)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(N / dt, 1), "unit": "image-pairs/s", "ms_per_step": round(dt * 1e3, 2), "batch": N, "steps": steps,
-            "finite": bool(torch.isfinite(loss).all().item()),
-            "what": "MaskFlownet-S training step 384x512 end to end (forward, multiscale EPE loss, backward, Adam): every layer's forward "
-                    "and backward a libmfn_hip.so kernel (142 parameter tensors), eager under torch's autograd tape; concat / gating / "
-                    "loss arithmetic and the optimizer are torch element-wise kernels",
+    if barrier_timing and dist is not None:
+        dist.barrier()
+    dt_local = time.perf_counter() - t0
+    dt_max = dt_local
+    if dist is not None:
+        tm = torch.tensor([dt_local], dtype=torch.float64, device=device)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt_max = float(tm.item())
+    dt = dt_max / steps
+    # the ranks must hold identical parameters after identical updates: a 2-float record of them, compared across ranks
+    ck = torch.stack([sum(p.detach().double().abs().sum() for p in net.parameters()), torch.tensor(float(sum(p.numel() for p in net.parameters())),
+                                                                                                   dtype=torch.float64, device=device)])
+    same = True
+    if dist is not None:
+        every = [torch.zeros_like(ck) for _ in range(world)]
+        dist.all_gather(every, ck)
+        same = all(bool(torch.equal(e, every[0])) for e in every)
+    return {"value": round(N * world / dt, 1), "unit": "image-pairs/s", "ms_per_step": round(dt * 1e3, 2), "batch_per_gpu": N, "n_gpus": world,
+            "steps": steps, "finite": bool(torch.isfinite(loss).all().item()),
+            "gradient_exchange": {"buckets": len(buckets.buckets), "MB": round(buckets.nbytes() / 1e6, 2),
+                                  "launch_order": list(buckets.launch_order), "collective": "all_reduce(sum) per bucket, async from the "
+                                  "autograd hook of the bucket's last gradient" if dist is not None else "none (one device): 1/batch only",
+                                  "parameters_identical_across_ranks": same},
+            "what": "MaskFlownet-S training step 384x512 end to end (forward, multiscale EPE loss, backward, gradient exchange, Adam): every "
+                    "layer's forward and backward a libmfn_hip.so kernel (142 parameter tensors), eager under torch's autograd tape; concat / "
+                    "gating / loss arithmetic and the optimizer are torch element-wise kernels",
             "note": "not the headline; the hot path's own training pass (graph replay, flat gradient bucket) is `train`"}
 
 
@@ -638,6 +689,27 @@ def main():
         dist = dist_mod
     elif gpu:
         torch.cuda.set_device(0)
+
+    if args.config == "e2e_train":
+        # the whole-network training step, batch sharded over the ranks (weak scaling: 8 pairs per GPU), gradients in four flat buckets
+        if not gpu:
+            sys.exit("bench.py: --config e2e_train runs on the GPU only")
+        r = end_to_end_train(8, 384, 512, "cuda:%d" % torch.cuda.current_device(), torch, steps=max(1, min(args.steps, 50)), dist=dist,
+                             world=world, rank=rank, barrier_timing=True)
+        if rank == 0:
+            line = {"metric": "image-pairs/s MaskFlownet-S 384x512 training step end to end (informational)", "value": r["value"],
+                    "unit": "image-pairs/s", "n_gpus": world, "steps": r["steps"], "warmup": 2, "ms_per_step": r["ms_per_step"],
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": "MaskFlownet-S train step, batch=8 synthetic 384x512 per GPU", "per_gpu_batch": 8,
+                               "global_batch": 8 * world, "parallelism": "batch shard x%d, 4 gradient buckets" % world},
+                    "distributed": {"world_size_env": world,
+                                    "process_group": ({"world_size": dist.get_world_size(), "backend": dist.get_backend()} if dist is not None else None)},
+                    **{k: r[k] for k in ("gradient_exchange", "finite", "what")}}
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from maskflownet_amd import hotpath
     from maskflownet_amd.dist import allreduce_checksum
@@ -815,6 +887,10 @@ def main():
             res["customop"] = customop_leg(wl, 200, torch, hotpath)
         except Exception as e:
             res["customop"] = {"error": repr(e)}
+        try:
+            res["customop_fused"] = customop_fused_leg(wl, 200, torch, hotpath)
+        except Exception as e:
+            res["customop_fused"] = {"error": repr(e)}
     if gpu and world == 1 and not args.no_side_configs and args.config == "cfg2" and args.mode == "dropin" and args.flow == "smooth" \
             and not args.no_graph and not args.tuning:
         # transparency: the same pass with EVERY operator on fp32 FMA chains / the fp32 MFMA (mfn_set_arithmetic(all, MFN_ARITH_FP32)):

@@ -42,23 +42,31 @@ _REQ = {"null": 0, "write": 1, "inplace": 1, "add": 3}  # -> MFN_REQ_* (include/
 
 
 class _HipRuntime:
-    """hipSetDevice / hipDeviceSynchronize around every operator call (see module docstring)."""
+    """hipSetDevice (only when the thread's device changes) / hipStreamSynchronize(NULL stream) around every operator call (see
+    module docstring)."""
 
     def __init__(self):
+        import threading
         self._hip = ctypes.CDLL("libamdhip64.so")
+        self._hip.hipSetDevice.argtypes = [ctypes.c_int]
+        self._hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        self._tls = threading.local()
 
     def enter(self, ctx):
         if ctx.device_type != "gpu":
             raise mx.base.MXNetError("mfn_* operators run on the MI355X only: array lives on %s "
                                      "(there is no CPU implementation behind them)" % (ctx,))
-        rc = self._hip.hipSetDevice(int(ctx.device_id))
-        if rc != 0:
-            raise mx.base.MXNetError("hipSetDevice(%d) failed: %d" % (ctx.device_id, rc))
+        dev = int(ctx.device_id)
+        if getattr(self._tls, "dev", None) != dev:   # MXNet's custom-op worker stays on one device between calls of one model
+            rc = self._hip.hipSetDevice(dev)
+            if rc != 0:
+                raise mx.base.MXNetError("hipSetDevice(%d) failed: %d" % (ctx.device_id, rc))
+            self._tls.dev = dev
 
     def sync(self):
-        rc = self._hip.hipDeviceSynchronize()
+        rc = self._hip.hipStreamSynchronize(None)   # the launches went to the NULL stream: nothing else has to drain
         if rc != 0:
-            raise mx.base.MXNetError("hipDeviceSynchronize failed: %d" % rc)
+            raise mx.base.MXNetError("hipStreamSynchronize failed: %d" % rc)
 
 
 _rt = None   # tests substitute a host runtime
@@ -82,12 +90,44 @@ def _check(status):
 
 
 def _ptr(nd):
+    """Device address of an array.  No wait_to_read(): MXNet runs a CustomOp's forward / backward only when the engine has
+    the inputs complete on the device and hands it the output buffers to write, and the launch goes to the NULL stream, which
+    is ordered behind every blocking stream's earlier work anyway."""
     if nd is None:
         return None
-    nd.wait_to_read()
     p = ctypes.c_void_p()
     mx.base.check_call(mx.base._LIB.MXNDArrayGetData(nd.handle, ctypes.byref(p)))
     return p.value
+
+
+# Scratch of the operator calls, one growing buffer per device: imperative mx.nd.Custom builds a new CustomOp per call (a
+# per-instance buffer would be allocated on every call), and every call ends with its stream drained, so two calls never
+# use the buffer at once on one device.
+_scratch = {}
+
+
+_need = {}
+
+
+def _bytes(lib, query, *dims):
+    """A workspace-size query of the library, remembered per (query, tuning epoch, shape): pure functions of their integer
+    arguments and of the thread's arithmetic / the tuning state."""
+    key = (query, _lib.tuning_epoch()) + dims   # set_tuning / set_arithmetic bump the epoch
+    v = _need.get(key)
+    if v is None:
+        v = _need[key] = getattr(lib, query)(*dims)
+    return v
+
+
+def _workspace(need, ctx):
+    """(pointer, bytes) of at least `need` bytes on ctx, or (None, 0)."""
+    if not need:
+        return None, 0
+    key = (ctx.device_type, ctx.device_id)
+    buf = _scratch.get(key)
+    if buf is None or buf.size * 4 < need:
+        buf = _scratch[key] = mx.nd.empty(((int(need * 1.25) + 3) // 4,), ctx=ctx)
+    return _ptr(buf), buf.size * 4
 
 
 def _bool(s):
@@ -139,10 +179,7 @@ if mx is not None:
             lib = self._begin(in_data[0])
             out = _Out(self, out_data[0], req[0])
             # scratch for the channel-sliced kernels of the coarse levels (0 bytes where the plan does not slice)
-            need = lib.correlation_workspace_bytes(n, c, h, w, *self.a)
-            if need and (self.ws is None or self.ws.size * 4 < need or self.ws.context != in_data[0].context):
-                self.ws = mx.nd.empty(((need + 3) // 4,), ctx=in_data[0].context)
-            wsp, wsn = (_ptr(self.ws), self.ws.size * 4) if need else (None, 0)
+            wsp, wsn = _workspace(_bytes(lib, "correlation_workspace_bytes", n, c, h, w, *self.a), in_data[0].context)
             _check(lib.correlation_fwd_act(_ptr(in_data[0]), _ptr(in_data[1]), _ptr(out.buf), n, c, h, w, *self.a,
                                            self.act, wsp, wsn, None))
             self._end()
@@ -366,11 +403,6 @@ if mx is not None:
             return (n, cin, h, wd, in_data[2].shape[0], p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"], p["dh"],
                     p["dw"], p["g"], p["dg"])
 
-        def _workspace(self, need, ctx):
-            if need and (self.ws is None or self.ws.size * 4 < need or self.ws.context != ctx):
-                self.ws = mx.nd.empty(((need + 3) // 4,), ctx=ctx)
-            return self.ws if need else None
-
         def forward(self, is_train, req, in_data, out_data, aux):
             if req[0] == "null":
                 return
@@ -378,9 +410,8 @@ if mx is not None:
             b = in_data[3] if len(in_data) > 3 else None
             dims = self._dims(in_data)
             lib = self._begin(x)
-            ws = self._workspace(lib.deform_conv_workspace_bytes(*dims), x.context)
+            wsp, wsn = _workspace(_bytes(lib, "deform_conv_workspace_bytes", *dims), x.context)
             out = _Out(self, out_data[0], req[0])
-            wsp, wsn = (_ptr(ws), ws.size * 4) if ws is not None else (None, 0)
             # The call lays the weights out in its workspace every time, training or not.  A layout cached across calls
             # would have to be keyed on the weight array's device address -- and Gluon's Trainer updates parameters in
             # place at the same address while the reference validates between training steps (main.py:542-556): every
@@ -399,11 +430,10 @@ if mx is not None:
             lib = self._begin(x)
             # one int per 2x16-pixel strip: lets strips whose nine taps share one offset (MaskFlownet.py:230) take
             # all taps in one pass
-            ws = self._workspace(lib.deform_conv_bwd_workspace_bytes(*dims), x.context)
+            wsp, wsn = _workspace(lib.deform_conv_bwd_workspace_bytes(*dims), x.context)
             g = [_ptr(in_grad[i]) if i < len(in_grad) and rq[i] else None for i in range(4)]
             _check(lib.deform_conv_bwd(_ptr(out_grad[0]), _ptr(x), _ptr(off), _ptr(w), g[0], g[1], g[2], g[3], *dims,
-                                       rq[0], rq[1], rq[2], rq[3], _ptr(ws) if ws is not None else None,
-                                       ws.size * 4 if ws is not None else 0, None))
+                                       rq[0], rq[1], rq[2], rq[3], wsp, wsn, None))
             self._end()
 
     @mx.operator.register("mfn_deform_conv")
@@ -448,6 +478,83 @@ if mx is not None:
         def create_operator(self, ctx, shapes, dtypes):
             return _DeformConv(self.p)
 
+    # ---- one pyramid level of the matching module in ONE Custom call (MaskFlownet.py:227-236: offsets from the flow, the
+    # deformable convolution, [gating by sigmoid(mask) + trade-off], LeakyReLU, cost volume against the other image's features,
+    # LeakyReLU).  Outputs: the cost volume and the warped features (the decoder reads both).  Two launches, one drain -- against
+    # three Custom calls' worth of host protocol plus the framework's own repeat / expand_dims / reshape kernels that build the
+    # 9x-redundant offset tensor.  INTEGRATION.md shows the six lines of MaskFlownet.py it replaces.
+    class _MatchingLevel(_Op):
+        def __init__(self, scale, stride, md, gated, tradeoff, act_warp, act_corr):
+            self.scale, self.stride, self.md = scale, stride, md
+            self.gated, self.tradeoff, self.act_warp, self.act_corr = gated, tradeoff, act_warp, act_corr
+
+        def forward(self, is_train, req, in_data, out_data, aux):
+            c1, c2, flow, w, b = in_data[:5]
+            rest = list(in_data[5:])
+            mask = rest.pop(0) if self.gated else None
+            trade = rest.pop(0) if self.tradeoff else None
+            n, c, h, wd = c2.shape
+            cout = w.shape[0]
+            lib = self._begin(c2)
+            warp = _Out(self, out_data[1], req[1] if req[1] != "null" else "write")   # the cost volume needs it either way
+            corr = _Out(self, out_data[0], req[0])
+            dims = (n, c, h, wd, cout, 3, 3, 1, 1, 1, 1, 1)
+            a = (self.md, 1, 1, 1, self.md, 1)
+            # one scratch buffer for both launches, asked for BEFORE the first: the filter bank's layout in front, behind it the
+            # channel-sliced cost-volume kernels' partial sums (coarse levels) -- growing the buffer between the launches would
+            # free what the first one is still reading
+            need1 = (_bytes(lib, "deform_conv_workspace_bytes", n, c, h, wd, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1) + 255) // 256 * 256
+            need2 = _bytes(lib, "correlation_workspace_bytes", n, cout, h, wd, *a) if req[0] != "null" else 0
+            wsp, wsn = _workspace(need1 + need2, c2.context)
+            _check(lib.deform_conv_matching_fwd(_ptr(c2), _ptr(flow), self.scale, self.stride, _ptr(w), None, 0, 0, _ptr(b),
+                                                _ptr(mask), _ptr(trade), self.act_warp, _ptr(warp.buf), *dims, wsp, need1, None))
+            if req[0] != "null":
+                _check(lib.correlation_fwd_act(_ptr(c1), _ptr(warp.buf), _ptr(corr.buf), n, cout, h, wd, *a, self.act_corr,
+                                               (wsp + need1) if need2 else None, need2, None))
+            self._end()
+            corr.finish()
+            warp.finish()
+
+        def backward(self, req, out_grad, in_data, out_data, in_grad, aux):
+            raise NotImplementedError("mfn_matching_level is the inference form of a pyramid level (--valid / --predict); training "
+                                      "goes through mfn_correlation and mfn_deform_conv, whose backward passes exist")
+
+    @mx.operator.register("mfn_matching_level")
+    class _MatchingLevelProp(mx.operator.CustomOpProp):
+        def __init__(self, scale="20.0", stride="1.0", max_displacement="4", gated="False", tradeoff="False", activation="leaky",
+                     corr_activation="leaky"):
+            super().__init__(need_top_grad=True)
+            self.scale, self.stride, self.md = float(scale), float(stride), int(max_displacement)
+            self.gated, self.tradeoff = _bool(gated), _bool(tradeoff)
+            for a in (activation, corr_activation):
+                if a not in ("none", "None", "leaky"):
+                    raise ValueError("mfn_matching_level: activations must be 'none' or 'leaky'")
+            self.act_warp, self.act_corr = int(activation == "leaky"), int(corr_activation == "leaky")
+            if self.stride == 0.0:
+                raise ValueError("mfn_matching_level: stride must be non-zero")
+
+        def list_arguments(self):
+            return ["data1", "data2", "flow", "weight", "bias"] + (["mask"] if self.gated else []) + (["tradeoff"] if self.tradeoff else [])
+
+        def list_outputs(self):
+            return ["corr", "warp"]
+
+        def infer_shape(self, in_shape):
+            n, c, h, w = in_shape[1]
+            cout = in_shape[3][0] if len(in_shape[3]) == 4 and in_shape[3][0] else c
+            if list(in_shape[0]) != [n, cout, h, w]:
+                raise ValueError("mfn_matching_level: data1 must be %s, got %s" % ((n, cout, h, w), tuple(in_shape[0])))
+            shapes = [tuple(in_shape[0]), (n, c, h, w), (n, 2, h, w), (cout, c, 3, 3), (cout,)]
+            if self.gated:
+                shapes.append((n, 1, h, w))
+            if self.tradeoff:
+                shapes.append((n, cout, h, w))
+            d = 2 * self.md + 1
+            return shapes, [(n, d * d, h, w), (n, cout, h, w)], []
+
+        def create_operator(self, ctx, shapes, dtypes):
+            return _MatchingLevel(self.scale, self.stride, self.md, self.gated, self.tradeoff, self.act_warp, self.act_corr)
+
     # ---- Convolution / Deconvolution (Gluon nn.Conv2D / nn.Conv2DTranspose of MaskFlownet.py:79-163) ----
     class _Conv(_Op):
         def __init__(self, p, transposed):
@@ -466,12 +573,9 @@ if mx is not None:
             dims = (n, cin, h, wd, cout, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"], p["dh"], p["dw"], p["g"],
                     int(self.transposed))
             lib = self._begin(x)
-            need = lib.conv2d_workspace_bytes(*dims)
-            if need and (self.ws is None or self.ws.size * 4 < need or self.ws.context != x.context):
-                self.ws = mx.nd.empty(((need + 3) // 4,), ctx=x.context)
+            wsp, wsn = _workspace(lib.conv2d_workspace_bytes(*dims), x.context)
             out = _Out(self, out_data[0], req[0])
-            _check(lib.conv2d_fwd(_ptr(x), 0, _ptr(w), None, 0, 0, _ptr(b), _ptr(out.buf), 0, *dims, p["ah"], p["aw"], 0,
-                                  _ptr(self.ws) if need else None, self.ws.size * 4 if need else 0, None))
+            _check(lib.conv2d_fwd(_ptr(x), 0, _ptr(w), None, 0, 0, _ptr(b), _ptr(out.buf), 0, *dims, p["ah"], p["aw"], 0, wsp, wsn, None))
             self._end()
             out.finish()
 
@@ -486,12 +590,9 @@ if mx is not None:
             dims = (n, cin, h, wd, cout, p["kh"], p["kw"], p["sh"], p["sw"], p["ph"], p["pw"], p["dh"], p["dw"], p["g"],
                     int(self.transposed), p["ah"], p["aw"], 0)
             lib = self._begin(x)
-            need = lib.conv2d_bwd_workspace_bytes(*dims)
-            if need and (self.bws is None or self.bws.size * 4 < need or self.bws.context != x.context):
-                self.bws = mx.nd.empty(((need + 3) // 4,), ctx=x.context)
+            wsp, wsn = _workspace(lib.conv2d_bwd_workspace_bytes(*dims), x.context)
             g = [_ptr(in_grad[i]) if i < len(in_grad) and rq[i] else None for i in range(3)]
-            _check(lib.conv2d_bwd(_ptr(out_grad[0]), _ptr(x), _ptr(w), None, g[0], g[1], g[2], *dims, rq[0], rq[1], rq[2],
-                                  _ptr(self.bws) if need else None, self.bws.size * 4 if need else 0, None))
+            _check(lib.conv2d_bwd(_ptr(out_grad[0]), _ptr(x), _ptr(w), None, g[0], g[1], g[2], *dims, rq[0], rq[1], rq[2], wsp, wsn, None))
             self._end()
 
     class _ConvPropBase(mx.operator.CustomOpProp):

@@ -232,11 +232,100 @@ class MultiscaleEpe(nn.Module):
         return total
 
 
-def train_step(net, loss_fn, opt, im1, im2, label, mask):
-    """pipeline.py:95-114 for one device: forward, loss, backward, optimizer step.  Returns the per-sample loss."""
-    opt.zero_grad(set_to_none=True)
+class GradientBuckets:
+    """The training step's gradient exchange (/root/reference/network/pipeline.py:27 kvstore='device', :95 batch
+    shards, :114 `trainer.step(batch_size)`): every parameter gradient of the network (142 tensors, 42.06 MB for MaskFlownet-S)
+    lives in one of `n_buckets` flat fp32 buffers -- `p.grad` is a VIEW into its bucket, autograd accumulates in place -- laid
+    out in REVERSE registration order, which is roughly the order backward completes them (context network and decoders first,
+    the image pyramid last).  A post-accumulate hook per parameter counts its bucket down; the bucket whose last gradient
+    arrives is all-reduced (sum) at once with async_op=True, so the collective of the decoders' gradients travels over
+    RCCL / xGMI while backward is still in the pyramid.  finish() waits for the handles and applies 1 / global_batch.
+    Four buckets of ~10.5 MB: large enough for xGMI's per-link bandwidth, few enough launches, early enough first launch.
+    Without a process group (or world 1) only the 1 / global_batch remains."""
+
+    def __init__(self, params, n_buckets=4, dist=None):
+        params = [p for p in params if p.requires_grad]
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        order = list(reversed(params))
+        total = sum(p.numel() for p in order)
+        target = (total + n_buckets - 1) // max(1, n_buckets)
+        groups, cur, size = [], [], 0
+        for p in order:
+            cur.append(p)
+            size += p.numel()
+            if size >= target and len(groups) < n_buckets - 1:
+                groups.append(cur)
+                cur, size = [], 0
+        if cur:
+            groups.append(cur)
+        self.buckets, self.members, self._of, self._hooks = [], groups, {}, []
+        for bi, grp in enumerate(groups):
+            flat = torch.zeros(sum(p.numel() for p in grp), dtype=grp[0].dtype, device=grp[0].device)
+            off = 0
+            for p in grp:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self._of[p] = bi
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._arrived))
+            self.buckets.append(flat)
+        self._left = [len(g) for g in groups]
+        self._handles = []
+        self.launch_order = []   # bucket indices in the order their all-reduce was launched by the last backward (tests read it)
+
+    def zero(self):
+        """Before a step's backward (instead of opt.zero_grad(set_to_none=True), which would drop the views)."""
+        for b in self.buckets:
+            b.zero_()
+        self._left = [len(g) for g in self.members]
+        self._handles, self.launch_order = [], []
+
+    def _arrived(self, p):
+        bi = self._of[p]
+        b = self.buckets[bi]
+        if p.grad is None or not (b.data_ptr() <= p.grad.data_ptr() < b.data_ptr() + b.numel() * b.element_size()):
+            raise RuntimeError("a parameter's .grad no longer views its gradient bucket (zero the buckets with GradientBuckets.zero())")
+        self._left[bi] -= 1
+        if self._left[bi] == 0:
+            self.launch_order.append(bi)
+            if self.dist is not None:
+                self._handles.append(self.dist.all_reduce(self.buckets[bi], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self, global_batch):
+        """Behind backward: every bucket reduced (whatever arrived late is launched now), then trainer.step's 1 / batch_size."""
+        for bi, left in enumerate(self._left):
+            if left > 0:   # parameters that took no gradient this step (frozen branches): their bucket still has to travel
+                self._left[bi] = 0
+                self.launch_order.append(bi)
+                if self.dist is not None:
+                    self._handles.append(self.dist.all_reduce(self.buckets[bi], op=self.dist.ReduceOp.SUM, async_op=True))
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        for b in self.buckets:
+            b.mul_(1.0 / float(global_batch))
+
+    def nbytes(self):
+        return sum(b.numel() * b.element_size() for b in self.buckets)
+
+
+def train_step(net, loss_fn, opt, im1, im2, label, mask, buckets=None, global_batch=None):
+    """pipeline.py:95-114: forward, loss, `loss.backward()` (the per-sample losses summed), the gradient exchange, and
+    `trainer.step(batch_size)` -- the optimizer sees (sum over the GLOBAL batch of the per-sample gradients) / global_batch.
+    buckets: a GradientBuckets over net.parameters() (its all-reduces start inside backward); None = one device, the gradients
+    scaled in place.  global_batch defaults to this call's batch (one device).  Returns the per-sample loss of the local shard."""
+    gb = int(global_batch if global_batch is not None else im1.shape[0])
+    if buckets is not None:
+        buckets.zero()
+    else:
+        opt.zero_grad(set_to_none=True)
     preds, _ = net(im1, im2)
     loss = loss_fn(label, mask, *preds)
     loss.sum().backward()
+    if buckets is not None:
+        buckets.finish(gb)
+    else:
+        for p in net.parameters():
+            if p.grad is not None:
+                p.grad.mul_(1.0 / gb)
     opt.step()
     return loss.detach()

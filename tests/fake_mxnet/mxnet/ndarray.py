@@ -119,6 +119,9 @@ class NDArray:
         return "<stub NDArray %s @%s>" % ("x".join(map(str, self.shape)), self._ctx)
 
 
+POISON_EMPTY = True   # tests: on.  A timing run may switch the fill (a kernel launch per allocation MXNet does not do) off
+
+
 def _ctx_of(ctx):
     return ctx if ctx is not None else cpu()
 
@@ -127,7 +130,7 @@ def empty(shape, ctx=None, dtype=np.float32):
     ctx = _ctx_of(ctx)
     shape = (shape,) if isinstance(shape, int) else tuple(shape)
     t = torch.empty(shape, dtype=_DTYPES[np.dtype(dtype)], device=ctx.torch_device())
-    if t.dtype.is_floating_point:
+    if t.dtype.is_floating_point and POISON_EMPTY:
         t.fill_(float("nan"))  # poisoned: an operator that forgets to write is caught
     return NDArray(t, ctx)
 

@@ -415,6 +415,44 @@ def test_upsample_and_fused_leaky_correlation_train(cpu_binding, oracle):
 
 
 # ---- the reference's own source files, unmodified, through install() ---------------------------------------------
+def _matching_level(mx, oracle, ctx, N, C, H, W, stride, gated, seed=0):
+    """mfn_matching_level against the operator chain of MaskFlownet.py:227-236 stated on the oracle."""
+    rng = np.random.default_rng(600 + seed)
+    c1, c2 = pc.feat(rng, (N, C, H, W)), pc.feat(rng, (N, C, H, W))
+    w = pc.msra_weight(rng, C, C)
+    b = (rng.standard_normal((C,)) * 0.1).astype(np.float32)
+    fl = (pc.flow_field(rng, N, H, W, sigma=2.0) * np.float32(stride / 20.0)).astype(np.float32)
+    mask = (rng.standard_normal((N, 1, H, W)) * 2).astype(np.float32)
+    trade = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    warp = oracle.deformable_convolution(c2, oracle.offsets_from_flow(fl, 20.0, stride), w, b, kernel=(3, 3), pad=(1, 1))
+    if gated:
+        warp = warp * (np.float32(1) / (np.float32(1) + np.exp(-mask, dtype=np.float32))) + trade
+    warp = np.where(warp > 0, warp, np.float32(0.1) * warp).astype(np.float32)
+    corr = oracle.correlation(c1, warp, max_displacement=4, pad_size=4)
+    corr = np.where(corr > 0, corr, np.float32(0.1) * corr).astype(np.float32)
+    a = lambda v: mx.nd.array(v, ctx=ctx)
+    ins = [a(c1), a(c2), a(fl), a(w), a(b)] + ([a(mask), a(trade)] if gated else [])
+    got_corr, got_warp = mx.nd.Custom(*ins, op_type="mfn_matching_level", scale=20.0, stride=stride, max_displacement=4,
+                                      gated=gated, tradeoff=gated)
+    pc.check_close(got_warp.asnumpy(), warp, what="matching level: warped features")
+    pc.check_close(got_corr.asnumpy(), corr, what="matching level: cost volume")
+
+
+@pytest.mark.parametrize("gated", [False, True])
+def test_matching_level_in_one_custom_call(cpu_binding, oracle, gated):
+    """One pyramid level (offsets from the flow + deformable convolution [+ gating, trade-off] + LeakyReLU + cost volume +
+    LeakyReLU) as a single mx.nd.Custom call with two outputs; a coarse shape whose cost volume wants scratch as well."""
+    mx, m = cpu_binding
+    _matching_level(mx, oracle, mx.cpu(), 1, 32, 6, 8, 8.0, gated)
+    _matching_level(mx, oracle, mx.cpu(), 2, 48, 4, 8, 16.0, gated, seed=1)
+    prop = mx.operator.get_registered("mfn_matching_level")(scale="20.0", stride="8", gated="True", tradeoff="True")
+    assert prop.list_arguments() == ["data1", "data2", "flow", "weight", "bias", "mask", "tradeoff"] and prop.list_outputs() == ["corr", "warp"]
+    assert prop.infer_shape([[2, 32, 6, 8], [2, 32, 6, 8], [2, 2, 6, 8], [32, 32, 3, 3], [32], [2, 1, 6, 8], [2, 32, 6, 8]])[1] == \
+        [(2, 81, 6, 8), (2, 32, 6, 8)]
+    with pytest.raises(ValueError, match="stride"):
+        mx.operator.get_registered("mfn_matching_level")(stride="0")
+
+
 def _reference_modules():
     pkg = types.ModuleType("mfn_refnet")
     pkg.__path__ = [REF_NET]   # a bare namespace: network/__init__.py (pipeline, trainer, ...) is not executed
@@ -571,3 +609,12 @@ def test_gpu_chain_and_warp_custom_ops(gpu_binding, oracle):
     grid = mx.nd.GridGenerator(data=FL.flip(axis=1), transform_type="warp")
     pc.check_close(mx.nd.BilinearSampler(X, grid).asnumpy(), want)
     pc.check_close(mx.nd.Custom(X, FL, op_type="mfn_warp", clip_grid=0).asnumpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [5, 3, 2])
+def test_gpu_matching_level_custom_op(gpu_binding, oracle, level):
+    mx, m = gpu_binding
+    C = {5: 128, 4: 96, 3: 64, 2: 32}[level]
+    s = {5: 32, 4: 16, 3: 8, 2: 4}[level]
+    _matching_level(mx, oracle, mx.gpu(0), 2, C, 384 // s, 512 // s, float(s), gated=(level == 3), seed=level)
