@@ -88,7 +88,10 @@ template <int MT, int PT, int KW, int RING> struct DcmGeom {
   static constexpr int NI = (WI_TOTAL + NW - 1) / NW;  // ... per wave at most; a wave whose last one would be past WI_TOTAL issues one fewer
   static constexpr int NI_MIN = WI_TOTAL / NW;         // ... at least: the waits count with this (a wave that issued one more waits for it too)
   static constexpr int STAGE_W = WI_TOTAL * 256;       // words per stage buffer
-  static constexpr int RED_W = KW > 1 ? PT * (KW - 1) * 1024 : 0;   // K-slice reduction: one 32 x 32 tile per non-owner slice
+  // K-slice reduction through the (then idle) stage buffers: every slice's MT tiles at once where they fit -- one barrier --, else
+  // tile by tile (one 32 x 32 tile per non-owner slice, two barriers per tile)
+  static constexpr bool RED_ALL = KW > 1 && PT * KW * MT * 1024 <= NSTAGE * STAGE_W;
+  static constexpr int RED_W = KW > 1 ? (RED_ALL ? PT * KW * MT * 1024 : PT * (KW - 1) * 1024) : 0;
   static constexpr int XW_OFF = NSTAGE * STAGE_W > RED_W ? NSTAGE * STAGE_W : RED_W;
   static constexpr int T8_OFF = XW_OFF + NW * RING * DCM_XW_F;      // tap 8 of a group's eight pairs: [wave][pair][lane]
   static constexpr int DUMP_OFF = T8_OFF + NW * 512;
@@ -186,6 +189,11 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   using G = DcmGeom<MT, PT, KW, RING>;
   constexpr int NW = G::NW, KC = G::KC, NI = G::NI, NIW = G::NI_MIN;
   constexpr int NACC = MT == 1 ? 2 : 1;   // MT = 1: two accumulators take the products alternately (no dependent MFMA pair)
+  // One pixel tile per block: every wave is a K slice of its own and nobody shares its weights -- each wave then transfers exactly
+  // its own slice's blocks into its part of the stage buffers and the K loop needs NO block barrier (a wave's own program order
+  // says when a stage is free).  With several pixel tiles the waves of a K slice share one copy, staged cooperatively.
+  constexpr bool PRIVATE_W = PT == 1;
+  static_assert(!PRIVATE_W || G::NI * NW == G::WI_TOTAL, "one pixel tile: the slices' blocks divide evenly over the waves");
   static_assert(9 % KC == 0, "chunk boundaries at fixed steps of a group");
   static_assert(RING >= 3 && RING * DCM_XW_F >= 32 * 40, "the epilogue transposes a tile through the wave's window ring");
   MFN_DYN_SHARED(float, lds);
@@ -210,17 +218,18 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   unsigned voffW[NI];
   MFN_UNROLL
   for (int i = 0; i < NI; ++i) {
-    const int ii = i * NW + wave;
+    const int ii = PRIVATE_W ? wave * (KC * 3 * MT) + i : i * NW + wave;   // PRIVATE_W: the wave's own slice (ii / (KC 3 MT) == kw)
     const int k = ii / (KC * 3 * MT), rem = ii - k * (KC * 3 * MT);
     voffW[i] = ii < G::WI_TOTAL ? (unsigned)((((size_t)k * gps * 9) * G::STEP_W + (size_t)rem * 256) * 4) + (unsigned)lane * 16u : 0xFFFFFF00u;
   }
   auto issue_w = [&](int ch) {   // chunk ch of every K slice of the block -> stage ch % NSTAGE
     float *buf = lds + (ch % G::NSTAGE) * G::STAGE_W;
-    const unsigned soff = (unsigned)((size_t)ch * KC * G::STEP_W * 4);
+    // a chunk past the slice's last step (the unconditional prefetch) is requested out of range: zero fill, no memory access
+    const unsigned soff = ch * KC < gps * 9 ? (unsigned)((size_t)ch * KC * G::STEP_W * 4) : 0x7FFFFF00u;
     if (MFN_DCM_ABLATE & 32) return;
     MFN_UNROLL
     for (int i = 0; i < NI; ++i) {
-      const int ii = i * NW + wave;
+      const int ii = PRIVATE_W ? wave * (KC * 3 * MT) + i : i * NW + wave;
       if (ii < G::WI_TOTAL) mfn_dma16_so(wrsrc, buf + ii * 256, voffW[i], soff);   // wave-uniform
     }
   };
@@ -270,6 +279,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     off_w = fp[plane] * p.flow_scale / p.flow_stride;
   }
 
+  MFN_STAMP2(p.timeline, 0);   // offsets requested and compared
   // ---- geometry of the shared-offset path: per tap row / column the pair of weights on neighbourhood lines i, i + 1 ----------
   float ya[3], yb[3], xa[3], xb[3];
   int row0, col0;                  // unclamped first row / column of the 4x4 neighbourhood
@@ -300,6 +310,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   }
   const bool fast = __all(regular || !px_valid) != 0;   // wave-uniform; false: the per-tap column path
 
+  MFN_STAMP2(p.timeline, 1);   // geometry
   // ---- the wave's source window: the box of its lanes' neighbourhoods in the small shape where that fits, else the big one, and
   // the lanes outside even that fetch from global memory ---------------------------------------------------------------------------
   int wr0 = 0, wc0 = 0;
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   int buf_issue = 0;                   // ring slot of the next window transfer (uniform)
   auto issue_x = [&](int kl, auto win_c) {   // window of the slice's pair kl -> ring slot kl % DEPTH
     using WN = decltype(win_c);
-    const unsigned soff = (unsigned)((size_t)(2 * (cp_base + kl)) * plane * 4);
+    const unsigned soff = kl < gps * 8 ? (unsigned)((size_t)(2 * (cp_base + kl)) * plane * 4) : 0x7FFFFF00u;   // past the slice: out of range
     float *dst = xwin + buf_issue * WN::SLOT_F;
     if (!(MFN_DCM_ABLATE & 4)) {
       MFN_UNROLL
@@ -368,7 +379,9 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
       if (ss < 8 && kl + WN::DEPTH >= 0) issue_x(kl + WN::DEPTH, win_c);
     }
   };
+  MFN_STAMP2(p.timeline, 2);   // window box
   if (bigwin) prologue(DcmWin<true, RING>{}); else prologue(DcmWin<false, RING>{});
+  MFN_STAMP2(p.timeline, 3);   // prologue transfers issued
 
   f32x16 acc[MT][NACC];
   MFN_UNROLL
@@ -437,8 +450,12 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     for (int i = 0; i < 3; ++i)
       MFN_UNROLL
       for (int h = 0; h < 2; ++h) {
+#ifdef MFN_DCM_INTERP_PACKED   // measurement builds
+        ty[i][h] = mfn_fma2(mfn_f2(yb[i], yb[i]), vp[i + 1][h], mfn_mul2(mfn_f2(ya[i], ya[i]), vp[i][h]));
+#else
         ty[i][h].x = fmaf(yb[i], vp[i + 1][h].x, ya[i] * vp[i][h].x);
         ty[i][h].y = fmaf(yb[i], vp[i + 1][h].y, ya[i] * vp[i][h].y);
+#endif
       }
     MFN_UNROLL
     for (int i = 0; i < 3; ++i) {
@@ -523,6 +540,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     }
     xt8[0] = c8;
     mfn_split3x8(x8, B.h, B.m, B.l);
+    MFN_STAMP2(p.timeline, 4);   // first operand formed (window 0 landed)
   };
 
   // ---- the K loop: 9 steps per 16-channel group.  Step t: the six products of B(t) against the MT filter tiles; under them
@@ -548,7 +566,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
         constexpr int kk = S % KC;
         if (kk == 0) {   // this chunk's weights landed for every wave; everybody is done with the stage that is refilled now
           MFN_WAIT_LGKM0();
-          if (!(MFN_DCM_ABLATE & 128)) MFN_RAW_BARRIER();
+          if (!PRIVATE_W && !(MFN_DCM_ABLATE & 128)) MFN_RAW_BARRIER();
           if (S == 0 && g == 0) MFN_STAMP(p.timeline, 1);
           issue_w(ch + G::NSTAGE - 1);
         }
@@ -592,7 +610,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
       const int ch = t / KC, kk = t - ch * KC;
       if (kk == 0) {
         MFN_WAIT_LGKM0();
-        MFN_RAW_BARRIER();
+        if (!PRIVATE_W) MFN_RAW_BARRIER();
         if (t == 0) MFN_STAMP(p.timeline, 1);
         issue_w(ch + G::NSTAGE - 1);
       }
@@ -617,6 +635,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   MFN_STAMP(p.timeline, 2);
   MFN_STAMP_INFO(p.timeline, !fast ? 3 : (!bigwin ? 0 : (all_in ? 1 : 2)));   // the first wave's tier
 
+  MFN_STAMP2(p.timeline, 5);
   // ---- K-slice reduction: tile mt is summed (slice order 0..KW-1, deterministic) and stored by slice mt % KW ------------------------
   MFN_WAIT_VM(0);       // the prefetches past the end have landed: nothing is on its way into LDS any more
   f32x16 fin[MT];
@@ -627,24 +646,26 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   if (KW > 1) {
     MFN_WAIT_LGKM0();
     MFN_RAW_BARRIER();  // every wave is out of the loop: the stage buffers are free
-    float *red = lds + (size_t)pt * (KW - 1) * 1024;
-    MFN_UNROLL
-    for (int mt = 0; mt < MT; ++mt) {
-      const int owner = mt % KW;
-      if (kw != owner) {
-        float *dst = red + (size_t)(kw < owner ? kw : kw - 1) * 1024 + lane;
-        MFN_UNROLL
-        for (int r = 0; r < 16; ++r) dst[r * 64] = fin[mt][r];
-      }
+    if (G::RED_ALL) {   // every slice's tiles at once: [pt][kw][mt][16][64]
+      float *mine = lds + (size_t)((pt * KW + kw) * MT) * 1024 + lane;
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt)
+        if (kw != mt % KW) {
+          MFN_UNROLL
+          for (int r = 0; r < 16; ++r) mine[mt * 1024 + r * 64] = fin[mt][r];
+        }
       __syncthreads();
-      if (kw == owner) {
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt) {
+        const int owner = mt % KW;
+        if (kw != owner) continue;
         f32x16 sum;
         MFN_UNROLL
         for (int k = 0; k < KW; ++k) {
           f32x16 part;
           if (k == owner) part = fin[mt];
           else {
-            const float *src = red + (size_t)(k < owner ? k : k - 1) * 1024 + lane;
+            const float *src = lds + (size_t)((pt * KW + k) * MT + mt) * 1024 + lane;
             MFN_UNROLL
             for (int r = 0; r < 16; ++r) part[r] = src[r * 64];
           }
@@ -653,10 +674,39 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
         }
         fin[mt] = sum;
       }
-      if (mt + 1 < MT) __syncthreads();
+    } else {
+      float *red = lds + (size_t)pt * (KW - 1) * 1024;
+      MFN_UNROLL
+      for (int mt = 0; mt < MT; ++mt) {
+        const int owner = mt % KW;
+        if (kw != owner) {
+          float *dst = red + (size_t)(kw < owner ? kw : kw - 1) * 1024 + lane;
+          MFN_UNROLL
+          for (int r = 0; r < 16; ++r) dst[r * 64] = fin[mt][r];
+        }
+        __syncthreads();
+        if (kw == owner) {
+          f32x16 sum;
+          MFN_UNROLL
+          for (int k = 0; k < KW; ++k) {
+            f32x16 part;
+            if (k == owner) part = fin[mt];
+            else {
+              const float *src = red + (size_t)(k < owner ? k : k - 1) * 1024 + lane;
+              MFN_UNROLL
+              for (int r = 0; r < 16; ++r) part[r] = src[r * 64];
+            }
+            MFN_UNROLL
+            for (int r = 0; r < 16; ++r) sum[r] = k == 0 ? part[r] : sum[r] + part[r];
+          }
+          fin[mt] = sum;
+        }
+        if (mt + 1 < MT) __syncthreads();
+      }
     }
   }
 
+  MFN_STAMP2(p.timeline, 6);   // K slices reduced
   // ---- epilogue.  D reg r of lane (j, kb): filter row (r&3) + 8*(r>>2) + 4*kb, pixel j.  The 32 x 32 tile is transposed through
   // the wave's idle window ring so that a lane holds four adjacent pixels of one filter: 4 x 16-byte stores instead of 16 dword stores
   constexpr int TS = 40;

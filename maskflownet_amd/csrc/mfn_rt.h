@@ -160,6 +160,7 @@ static inline void mfn_wait_vm_dyn(unsigned) { hipemu::wave().bar.arrive_and_wai
 #define MFN_LDS_BARRIER() __syncthreads()
 #define MFN_COMPILER_FENCE() ((void)0)
 #define MFN_STAMP(buf, k) ((void)0)
+#define MFN_STAMP2(buf, k) ((void)0)
 #define MFN_STAMP_INFO(buf, val) ((void)0)
 #define MFN_CYCLES() 0ull
 #else
@@ -514,6 +515,7 @@ __device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_u
 #endif
 #if !MFN_TIMELINE
 #define MFN_STAMP(buf, k) ((void)0)
+#define MFN_STAMP2(buf, k) ((void)0)
 #define MFN_STAMP_INFO(buf, val) ((void)0)
 #else
 // one more word per block behind the stamps of 16384 blocks (tools/timeline_dc_blocks.py): bits 0..15 the caller's value,
@@ -526,6 +528,16 @@ __device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_u
       const unsigned long long xcc_ = (unsigned)__builtin_amdgcn_s_getreg(63508) & 0xFu;                    \
       b_[65536 + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =                 \
           ((unsigned long long)(val) & 0xFFFFull) | (hw_ << 16) | (xcc_ << 32);                             \
+    }                                                                                                       \
+  } while (0)
+// eight more stamps per block behind those (set-up phases): [3 * 65536 + block * 8 + k]
+#define MFN_STAMP2(buf, k)                                                                                  \
+  do {                                                                                                      \
+    if ((buf) && threadIdx.x == 0) {                                                                        \
+      const bool cyc_ = ((unsigned long long)(buf)) & 1ull;                                                 \
+      unsigned long long *b_ = (unsigned long long *)(((unsigned long long)(buf)) & ~1ull);                 \
+      b_[3 * 65536 + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] =  \
+          cyc_ ? (unsigned long long)clock64() : (unsigned long long)wall_clock64();                        \
     }                                                                                                       \
   } while (0)
 #define MFN_STAMP(buf, k)                                                                                   \

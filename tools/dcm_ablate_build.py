@@ -11,7 +11,14 @@ from maskflownet_amd import _lib
 BUILD = os.path.join(ROOT, "tools", "ablate_build")
 os.makedirs(BUILD, exist_ok=True)
 procs = []
-for mask in [int(a) for a in sys.argv[1:]]:
+for a in sys.argv[1:]:
+    if not a.isdigit():   # NAME=-DFLAG,-DFLAG : a variant build (tools/ablate_build/libmfn_dcm_NAME.so)
+        name, _, flags = a.partition("=")
+        out = os.path.join(BUILD, "libmfn_dcm_%s.so" % name)
+        procs.append((out, subprocess.Popen(["hipcc"] + _lib.HIPCC_FLAGS + [f for f in flags.split(",") if f] + ["-o", out, os.path.join(_lib.CSRC, "api.hip")],
+                                            stderr=subprocess.DEVNULL)))
+        continue
+    mask = int(a)
     out = os.path.join(BUILD, "libmfn_dcm_%d.so" % mask)
     procs.append((out, subprocess.Popen(["hipcc"] + _lib.HIPCC_FLAGS + ["-DMFN_DCM_ABLATE=%d" % mask, "-DMFN_DCM_CONFIGS(X)=X(1,4,1) X(2,3,4) X(1,1,8) X(3,1,6) X(1,1,1)", "-o", out, os.path.join(_lib.CSRC, "api.hip")],
                                         stderr=subprocess.DEVNULL)))

@@ -16,7 +16,7 @@ wl.run_eager()
 NB = 16384
 for l in (5, 4, 3, 2):
     fn = calls["deform%d" % l]
-    tl = torch.zeros(65536 + NB, dtype=torch.int64, device="cuda")
+    tl = torch.zeros(3 * 65536 + NB * 8, dtype=torch.int64, device="cuda")
     with torch.cuda.stream(wl.stream):
         for _ in range(3): fn()
         wl.stream.synchronize()
@@ -24,8 +24,10 @@ for l in (5, 4, 3, 2):
     a = tl.cpu().numpy()
     t = a[:NB * 4].reshape(NB, 4).astype(np.float64) * 0.01
     info = a[65536:65536 + NB]
+    t2 = a[3 * 65536:3 * 65536 + NB * 8].reshape(NB, 8).astype(np.float64) * 0.01
     m = t[:, 0] > 0
-    t, info = t[m], info[m]
+    t, info, t2 = t[m], info[m], t2[m]
+    t2 -= (a[:NB * 4].reshape(NB, 4).astype(np.float64) * 0.01)[m][:, 0].min()
     t -= t[:, 0].min()
     mode = info & 0xFFFF
     cu = (info >> 16) & 0xFFFF
@@ -35,3 +37,7 @@ for l in (5, 4, 3, 2):
         print("  tier %d: %4d blocks | setup %.2f | loop med %.2f p90 %.2f max %.2f | epilogue %.2f | end med %.2f max %.2f" % (
             md, q.sum(), np.median(t[q, 1] - t[q, 0]), np.median(t[q, 2] - t[q, 1]), np.percentile(t[q, 2] - t[q, 1], 90), (t[q, 2] - t[q, 1]).max(),
             np.median(t[q, 3] - t[q, 2]), np.median(t[q, 3]), t[q, 3].max()))
+        names = ["offsets", "geometry", "window box", "prologue issue", "first operand", "(loop: stamp 1..2)", "K-slice reduce", "epilogue"]
+        seq = [t[q, 0], t2[q, 0], t2[q, 1], t2[q, 2], t2[q, 3], t2[q, 4], t[q, 1], t[q, 2], t2[q, 6], t[q, 3]]
+        lab = ["offsets", "geometry", "window box", "prologue issue", "first operand", "first barrier", "LOOP", "K-slice reduce", "epilogue"]
+        print("          " + "  ".join("%s %.2f" % (lab[i], np.median(seq[i + 1] - seq[i])) for i in range(len(lab))))
