@@ -104,7 +104,9 @@ template <int MT, int PT, int KW, int RING> struct DcmGeom {
 // transfers of pair k + RING if s < 8].  Needed at the wait: the window of the next pair step (gathered in this step; none in
 // step 7) and, at a chunk boundary, this step's weight chunk.  Transfers complete in issue order, so the count is the number
 // issued after the youngest needed one.  1000 = nothing needed.
-template <int KC, int NSTAGE, int RING, int NI, int XW_NI> constexpr int dcm_wait_count(int s) {
+// REQ: requests of the lanes outside the window (the tier that has them), issued behind the step's transfers by every step that
+// prepares a pair (all but step 7) -- they join the same in-order queue.
+template <int KC, int NSTAGE, int RING, int NI, int XW_NI, int REQ = 0> constexpr int dcm_wait_count(int s) {
   int issued = 0, result = 1000;
   int stampW[64] = {}, stampX[80] = {};
   for (int u = 0; u < 45; ++u) {
@@ -120,6 +122,23 @@ template <int KC, int NSTAGE, int RING, int NI, int XW_NI> constexpr int dcm_wai
     }
     if (ss % KC == 0) { issued += NI; stampW[u / KC + NSTAGE - 1] = issued; }
     if (ss < 8) { issued += XW_NI; stampX[8 * grp + ss + RING] = issued; }
+    if (ss != 7) issued += REQ;
+  }
+  return result;
+}
+// ... and the count with which a preparing step (s != 7) waits for the requests it consumes -- those of the PREVIOUS preparing
+// step --, at the point behind its own transfers and requests: everything issued since
+template <int KC, int NSTAGE, int RING, int NI, int XW_NI, int REQ> constexpr int dcm_landed_count(int s) {
+  int issued = 0, last_req = 0, result = 0;
+  for (int u = 0; u < 45; ++u) {
+    const int ss = u % 9;
+    if (ss % KC == 0) issued += NI;
+    if (ss < 8) issued += XW_NI;
+    if (ss != 7) {
+      issued += REQ;
+      if (u == 36 + s) result = issued - last_req;
+      last_req = issued;
+    }
   }
   return result;
 }
@@ -399,9 +418,8 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   // pertap_pair below.
   f32x2 vp[4][2];   // the 4x4 neighbourhood of the pair in preparation: vp[m][h] = columns 2h, 2h + 1 of row m (one ds_read2_b32)
   int buf_read = 0;  // ring slot of the next pair to gather (uniform)
-  auto cols_gather = [&](int kn, auto win_c, auto out_c) {
+  auto cols_gather = [&](int kn, auto win_c) {
     using WN = decltype(win_c);
-    constexpr bool OUT = decltype(out_c)::value;
     const float *xb_ = lds + (buf_read * WN::SLOT_F + gofs);
     MFN_UNROLL
     for (int m = 0; m < 4; ++m)
@@ -411,27 +429,50 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
         vp[m][h].y = (MFN_DCM_ABLATE & 2) ? (float)(m - h + kn) : xb_[m * WN::COLS + 2 * h + 1];
       }
     buf_read = buf_read + 1 == WN::DEPTH ? 0 : buf_read + 1;
-    if (OUT) {
-      if (!inwin) {
-        int r0 = row0, c0 = col0;
-        MFN_OPAQUE(r0);   // formed here, step by step: hoisted out of the loop the eight offsets would cost eight registers
-        MFN_OPAQUE(c0);
-        const int c = min(2 * (cp_base + kn) + kb, p.Cin - 1);   // (a prefetch past the last pair reads the last channel: unused)
-        const float *pl = xn + (size_t)c * plane;
-        int ro[4], co[4];
+  };
+  // Lanes whose neighbourhood lies outside the (big) window read it from global memory: rows clamped to the image, the four
+  // columns as they are (immediate offsets of ONE address per row) -- every tap that touches a row or column outside the image has
+  // weight zero (dc_axis: a valid tap's two lines are inside), so what is read there only has to be finite, and past either end of
+  // the tensor the descriptor's range check returns 0.  The requests are statements hipcc does not count (one it knows about makes
+  // it wait with a vmcnt that also drains the window / weight transfers of later steps, at every step), issued behind the step's
+  // transfers under an exec mask of the outside lanes (mfn_bload1x4_async: the addresser's time goes with the ACTIVE lanes), TWO
+  // preparations ahead: two register sets, vq[e & 1] for the e-th preparation of a group (eight per group: steps 0..6 and 8).
+  // The waits count them (dcm_wait_count's REQ, dcm_landed_count).  Per step: 16 requests + 16 selects.
+  // History on SURVEY 8(d)'s i.i.d. flow (sigma 2 px at EVERY level + 2 % wild: ~4 of a wave's 64 lanes outside), level-4 loop of a
+  // block with such lanes against 7.1 us without: 10.8 (16 clamped addresses per step inside a divergent branch, known loads)
+  // -> 11.3 (unknown loads, all lanes) -> 10.5 (two sets ahead) -> 9.2 us (exec mask); whole pass 42.3k -> 43.1k pairs/s.
+  float vq[2][16];
+  unsigned rbo[4] = {0u, 0u, 0u, 0u};   // set by the tier that uses them
+  unsigned long long lanes_out = 0ull;
+  auto lanes_setup = [&]() {
+    lanes_out = __ballot(!inwin);
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m)
+      rbo[m] = inwin ? 0xFFFFF000u
+                     : (unsigned)(((n * p.Cin + kb) * H + min(max(row0 + m, 0), H - 1)) * W + col0) * 4u;   // (wraps below the tensor: out of range)
+  };
+  auto lanes_request = [&](int kn, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    const unsigned soff = kn < gps * 8 ? (unsigned)((size_t)(2 * (cp_base + kn)) * plane * 4) : 0x7FFFFF00u;   // past the slice: out of range
+    MFN_UNROLL
+    for (int m = 0; m < 4; ++m)
+      mfn_bload1x4_async(vq[SET][4 * m], vq[SET][4 * m + 1], vq[SET][4 * m + 2], vq[SET][4 * m + 3], xrsrc, rbo[m], soff, lanes_out);
+  };
+  auto lanes_landed = [&](auto set_c, auto nafter_c) {
+    constexpr int SET = decltype(set_c)::value;
+    constexpr int NAFTER = decltype(nafter_c)::value < 63 ? decltype(nafter_c)::value : 63;
+    MFN_LANDED4(vq[SET][0], vq[SET][1], vq[SET][2], vq[SET][3], NAFTER);
+    MFN_REGFENCE4(vq[SET][4], vq[SET][5], vq[SET][6], vq[SET][7]);
+    MFN_REGFENCE4(vq[SET][8], vq[SET][9], vq[SET][10], vq[SET][11]);
+    MFN_REGFENCE4(vq[SET][12], vq[SET][13], vq[SET][14], vq[SET][15]);
+    if (!inwin) {
+      MFN_UNROLL
+      for (int m = 0; m < 4; ++m)
         MFN_UNROLL
-        for (int m = 0; m < 4; ++m) {
-          ro[m] = min(max(r0 + m, 0), H - 1) * W;
-          co[m] = min(max(c0 + m, 0), W - 1);
+        for (int h = 0; h < 2; ++h) {
+          vp[m][h].x = vq[SET][4 * m + 2 * h];
+          vp[m][h].y = vq[SET][4 * m + 2 * h + 1];
         }
-        MFN_UNROLL
-        for (int m = 0; m < 4; ++m)
-          MFN_UNROLL
-          for (int h = 0; h < 2; ++h) {
-            vp[m][h].x = pl[ro[m] + co[2 * h]];
-            vp[m][h].y = pl[ro[m] + co[2 * h + 1]];
-          }
-      }
     }
   };
   // separable interpolation, y pass then x pass, in SCALAR fp32 instructions: taps 0..7 into x8 (the K elements of the lane's
@@ -535,7 +576,14 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     MFN_WAIT_VM((dcm_prologue_after_x0<KC, G::NSTAGE, WN::DEPTH, NIW, WN::NI>()));   // window 0 landed
     float x8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c8 = 0.f;
     if (fast) {
-      cols_gather(0, win_c, out_c);
+      if (decltype(out_c)::value) lanes_request(0, std::integral_constant<int, 1>{});
+      cols_gather(0, win_c);
+      if (decltype(out_c)::value) {
+        lanes_landed(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        // the pair the loop's first step prepares.  (The wait above was for EVERYTHING the prologue issued: the loop's counts
+        // assume the steady sequence, requests included, which the prologue does not replay.)
+        lanes_request(1, std::integral_constant<int, 0>{});
+      }
       cols_finish(x8, c8);
     }
     xt8[0] = c8;
@@ -555,15 +603,19 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   auto run_groups = [&](auto win_c, auto out_c) {
     using WN = decltype(win_c);
     constexpr int CPG = 9 / KC;   // chunks per group
+    if (decltype(out_c)::value) lanes_setup();
     first_operand(win_c, out_c);
     MFN_NOUNROLL
     for (int g = 0; g < gps; ++g) {
       mfn_static_for<9>([&](auto s_c) {
         constexpr int S = decltype(s_c)::value;
-        constexpr int NWAIT = dcm_wait_count<KC, G::NSTAGE, WN::DEPTH, NIW, WN::NI>(S);
+        constexpr bool OUT = decltype(out_c)::value;
+        constexpr int NWAIT = dcm_wait_count<KC, G::NSTAGE, WN::DEPTH, NIW, WN::NI, OUT ? 16 : 0>(S);
         if (NWAIT < 1000) MFN_WAIT_VM(NWAIT < 63 ? NWAIT : 63);
         const int ch = g * CPG + S / KC;
         constexpr int kk = S % KC;
+        const int kn = S == 8 ? (g + 1) * 8 : g * 8 + S + 1;   // the pair in preparation under this step's products
+        constexpr int E = S == 8 ? 7 : S;   // the group's E-th preparation (steps 0..6 and 8)
         if (kk == 0) {   // this chunk's weights landed for every wave; everybody is done with the stage that is refilled now
           MFN_WAIT_LGKM0();
           if (!PRIVATE_W && !(MFN_DCM_ABLATE & 128)) MFN_RAW_BARRIER();
@@ -571,11 +623,16 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
           issue_w(ch + G::NSTAGE - 1);
         }
         if (S < 8) issue_x(g * 8 + S + WN::DEPTH, win_c);
+        // the lanes outside the window: preparation E asks for the pair of preparation E + 1, into the other register set
+        if (OUT && S != 7) lanes_request(S == 8 ? g * 8 + 9 : g * 8 + S + 2, std::integral_constant<int, (E + 1) & 1>{});
         const float *a = lds + (ch % G::NSTAGE) * G::STAGE_W + (size_t)(kw * KC + kk) * G::STEP_W + (kb * 32 + j) * 4;
         float x8[8];
         a_read(a);
-        if (S != 7) cols_gather(S == 8 ? (g + 1) * 8 : g * 8 + S + 1, win_c, out_c);
+        if (S != 7) cols_gather(kn, win_c);
         mma_issue(B);
+        if (OUT && S != 7)
+          lanes_landed(std::integral_constant<int, E & 1>{},
+                       std::integral_constant<int, dcm_landed_count<KC, G::NSTAGE, WN::DEPTH, NIW, WN::NI, 16>(S)>{});
         if (S == 7) {   // the left-over step's operand: tap 8 of the eight pairs
           MFN_UNROLL
           for (int e = 0; e < 8; ++e) x8[e] = xt8[e * 64];

@@ -146,6 +146,17 @@ static inline void mfn_dma16_row(const void *base, unsigned full_bytes, unsigned
 static inline void mfn_gload4_async(f32x4_emu &dst, const float *base_uniform, unsigned byteoff) {
   memcpy(&dst, (const char *)base_uniform + byteoff, 16);
 }
+// four consecutive floats, one request each, through a raw buffer descriptor: out of range reads 0.  Synchronous here.
+static inline void mfn_bload1x4_async(float &d0, float &d1, float &d2, float &d3, mfn_rsrc_t r, unsigned voff, unsigned soff,
+                                      unsigned long long lanes) {
+  if (!((lanes >> hipemu::t_lane) & 1ull)) return;
+  float *d[4] = {&d0, &d1, &d2, &d3};
+  for (int k = 0; k < 4; ++k) {
+    const unsigned off = voff + 4u * k;
+    if ((unsigned long long)off + soff + 4 <= r.nrec) memcpy(d[k], r.base + off + soff, 4);
+    else *d[k] = 0.f;
+  }
+}
 #define MFN_LANDED4(a, b, c, d, n) ((void)0)
 #define MFN_REGFENCE4(a, b, c, d) ((void)0)
 #define MFN_REGFENCE9(v) ((void)0)
@@ -487,6 +498,23 @@ __device__ __forceinline__ void mfn_gload4_async(f32x4 &dst, const float *base_u
   // s_nop 4: the base may have been written by a v_readfirstlane just before (VALU-written SGPR -> VMEM: 5 wait states,
   // and hipcc pads nothing inside an asm statement)
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byteoff), "s"(sb) : "memory");
+}
+// Four consecutive floats -- four requests, the instruction's immediate offsets 0, 4, 8, 12 -- through a raw buffer descriptor with a
+// wave-uniform soffset, unknown to hipcc like mfn_gload4_async, for the lanes of the (wave-uniform) mask only: the texture
+// addresser spends a cycle per ACTIVE lane on a dword request whose lanes do not share cache lines, so sixteen full-wave requests
+// are ~1000 cycles of its time per step whoever needed them (measured: level 4, 7.1 -> 10.5 us of loop with 4 of 64 lanes outside
+// the window).  The other lanes' registers keep their contents; with an empty mask the requests still issue and still count.
+// Lanes whose offset is out of the descriptor's range get 0 and touch no memory.  Early-clobber destinations: the address
+// register is read by the later requests.
+__device__ __forceinline__ void mfn_bload1x4_async(float &d0, float &d1, float &d2, float &d3, mfn_rsrc_t rsrc, unsigned voff, unsigned soff,
+                                                   unsigned long long lanes) {
+  const unsigned so = __builtin_amdgcn_readfirstlane(soff);
+  unsigned long long saved;
+  asm volatile("s_and_saveexec_b64 %4, %8\n\ts_nop 4\n\t"
+               "buffer_load_dword %0, %5, %6, %7 offen\n\tbuffer_load_dword %1, %5, %6, %7 offen offset:4\n\t"
+               "buffer_load_dword %2, %5, %6, %7 offen offset:8\n\tbuffer_load_dword %3, %5, %6, %7 offen offset:12\n\t"
+               "s_mov_b64 exec, %4"
+               : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&s"(saved) : "v"(voff), "s"(rsrc), "s"(so), "s"(lanes) : "memory", "scc");
 }
 #define MFN_LANDED4(a, b, c, d, n) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n) : "memory")
 // the same in two parts, for waits whose count is chosen by a (uniform) branch: MFN_WAIT_VM(n) in the branches, then ONE
