@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile session (round 5): the bench logs, rocprofv3 kernel stats of the bench command and of the training pass, SQ counter sets
-# of dc_mma_kernel at levels 2 and 3, HBM traffic passes of the level-2 correlation; summaries -> profiles/ by tools/make_profiles.py r05.
+# of dc_mma_kernel at levels 2..5, HBM traffic passes of the level-2 correlation; summaries -> profiles/ by tools/make_profiles.py r05.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 G=gpurun_out
@@ -18,7 +18,7 @@ fi
 timeout 600 rocprofv3 --kernel-trace --stats -d $G/prof_bench -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-side-configs --no-e2e > $G/r05p/prof_bench.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $G/prof_cfg5 -o cfg5 -- python bench.py --config cfg5 --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-e2e --no-side-configs > $G/r05p/prof_cfg5.log 2>&1
 : > $G/r05p/dc_pmc.txt
-for lvl in 2 3; do
+for lvl in 2 3 4 5; do
   i=0
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
