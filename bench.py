@@ -246,14 +246,24 @@ def roofline_of_dominant_kernel(wl, iters, torch, md=4):
 
 
 FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+BF16_PEAK_TFLOPS = 2500.0  # ... dense bf16 MFMA peak (the 5 PFLOP/s headline includes 2:1 sparsity)
 
 
 def compute_roofline(wl, per_op, hotpath):
-    """The kernels that dominate the step are the deformable convolutions (fp32 ALU bound: the exact-fp32 MFMA and the
-    VALU share the ALUs): GEMM flops of each level (2*N*h*w*Cout*Cin*9) / the time of that call's kernels
-    inside the profiled pass, against 157.3 TFLOP/s."""
+    """The kernels that dominate the step are the deformable convolutions: GEMM flops of each level (2*N*h*w*Cout*Cin*9,
+    SURVEY.md 8d) / the time of that call's kernels inside the profiled pass.  Under the library's default arithmetic they run as
+    dc_mma_kernel -- every fp32 product as SIX bf16 products on v_mfma_f32_32x32x16_bf16 --, so the matrix-core roofline of the
+    ALGORITHMIC flops is the dense bf16 peak / 6; under MFN_ARITH_FP32 (dc_lds_kernel, v_mfma_f32_32x32x2_f32) it is the fp32
+    peak.  `frac_of_fp32_peak` is kept in both cases: it is the figure rounds 2-4 reported as `frac`."""
     shp = hotpath.level_shapes(wl.N, wl.H, wl.W)
-    levels, tot_f, tot_s = {}, 0.0, 0.0
+    levels, tot_f, tot_s, names = {}, 0.0, 0.0, set()
+    for l in (5, 4, 3, 2):
+        recs = per_op.get("deform%d" % l, [])
+        if not recs:
+            continue
+        names.update(r[0] for r in recs)
+    bf16x3 = any(n.startswith("dc_mma") for n in names)
+    peak = BF16_PEAK_TFLOPS / 6.0 if bf16x3 else FP32_PEAK_TFLOPS
     for l in (5, 4, 3, 2):
         recs = per_op.get("deform%d" % l, [])
         if not recs:
@@ -265,13 +275,22 @@ def compute_roofline(wl, per_op, hotpath):
         tot_f += flops
         tot_s += sec
         levels["L%d" % l] = {"kernels": [r[0] for r in recs], "us": round(sec * 1e6, 2), "GFLOP": round(flops / 1e9, 3),
-                             "achieved": round(flops / sec / 1e12, 1), "frac": round(flops / sec / 1e12 / FP32_PEAK_TFLOPS, 3)}
+                             "achieved": round(flops / sec / 1e12, 1), "frac": round(flops / sec / 1e12 / peak, 3),
+                             "frac_of_fp32_peak": round(flops / sec / 1e12 / FP32_PEAK_TFLOPS, 3)}
     if not tot_s:
         return None
-    return {"bound": "mfma", "kernel": "dc_lds_kernel (DeformableConvolution, fused gather + fp32 MFMA GEMM), all four levels",
-            "achieved": round(tot_f / tot_s / 1e12, 1), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tot_f / tot_s / 1e12 / FP32_PEAK_TFLOPS, 3), "us_per_pass": round(tot_s * 1e6, 1), "levels": levels,
-            "note": "fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: bit-exact fmaf chain); interpolation flops not counted"}
+    ach = tot_f / tot_s / 1e12
+    return {"bound": "mfma",
+            "kernel": ("dc_mma_kernel (DeformableConvolution: fused gather + interpolation + three-term split, six bf16 products per fp32 product "
+                       "on v_mfma_f32_32x32x16_bf16), all four levels" if bf16x3 else
+                       "dc_lds_kernel (DeformableConvolution, fused gather + fp32 MFMA GEMM), all four levels"),
+            "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 3),
+            "peak_is": ("dense bf16 matrix peak %.0f TFLOP/s / 6 products (MI355X_MICROARCH.md); executed matrix flops = 6 x achieved = %.0f TFLOP/s"
+                        % (BF16_PEAK_TFLOPS, 6 * ach)) if bf16x3 else "fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md)",
+            "frac_of_fp32_peak": round(ach / FP32_PEAK_TFLOPS, 3), "us_per_pass": round(tot_s * 1e6, 1), "levels": levels,
+            "note": ("algorithmic GEMM flops, fp32-equivalent arithmetic (error vs fp64 <= the fp32 kernel's); interpolation flops not counted; the "
+                     "kernel is bound by the VALU work that forms the B operand, not by the matrix cores (profiles/r05_dc_pmc.md)") if bf16x3 else
+                    "fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32: bit-exact fmaf chain); interpolation flops not counted"}
 
 
 def warp_roofline(wl, hotpath):
@@ -852,8 +871,9 @@ def main():
             dtr = timed_steps([rw], steps_r, None, torch)
             res["rough_flow"] = {"value": round(rw.N * steps_r / dtr, 2), "unit": "image-pairs/s",
                                  "ms_per_step": round(dtr / steps_r * 1e3, 4), "steps": steps_r,
-                                 "flow_fields": "i.i.d. N(0, 2 px) per pixel + 2% outliers in [-h, h] (SURVEY.md 8d): no wave shares "
-                                                "a source window, every tile takes the row-gather / per-pixel tiers",
+                                 "flow_fields": "i.i.d. N(0, 2 px) per pixel + 2% outliers in [-h, h] (SURVEY.md 8d), at EVERY level: the deformable "
+                                                "convolution's tiles take the 16 x 24 window and ~half of them the tier whose outside lanes read "
+                                                "global memory; the warp its per-pixel gathers",
                                  "ops_in_graph_us": {k: v for k, v in per_op_graph_cost(rw, torch, reps=10).items()
                                                      if k.startswith(("deform", "warp"))},
                                  "note": "not the headline: inside the network flow_l is Upsample(2) of the coarser level's flow"}
