@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run one kernel a few times (for rocprofv3 --pmc / --kernel-trace).  usage: prof_one.py corr|deform|warp [level]
-env: MFN_TUNE="corr_variant=20,dc_off=1" ITERS=20"""
+env: MFN_TUNE="corr_variant=20,dc_off=1" ITERS=20 ROTATE=1 (corr: inputs and outputs rotate through 7 buffer sets, > 256 MiB:
+the cache-cold case of bench.py's `hbm_rotated`)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +17,17 @@ level = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 iters = int(os.environ.get("ITERS", "20"))
 wl = hotpath.HotPathWorkload("cfg2", mode="fused")
 t, o = wl.t, wl.o
+if what == "corr" and os.environ.get("ROTATE"):
+    nsets = 7
+    f1s = [t["c1_%d" % level].clone() for _ in range(nsets)]
+    f2s = [t["c2_%d" % level].clone() for _ in range(nsets)]
+    outs = [torch.empty_like(o["corr%d" % level]) for _ in range(nsets)]
+    for it in range(iters):
+        i = it % nsets
+        ops.Correlation(f1s[i], f2s[i], 1, 4, 1, 1, 4, True, out=outs[i])
+    torch.cuda.synchronize()
+    print("done", what, level, "rotated over", nsets, "sets")
+    sys.exit(0)
 for _ in range(iters):
     if what == "corr":
         ops.Correlation(t["c1_%d" % level], t["c2_%d" % level], 1, 4, 1, 1, 4, True, out=o["corr%d" % level])

@@ -49,9 +49,18 @@ int main() {
     double u4 = timeit(s, [&] { copy_k<float4><<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, s>>>((const float4*)a, (float4*)b, n4); }, K);
     double ur = timeit(s, [&] { read_k<<<dim3((unsigned)((2 * n4 + 255) / 256)), 256, 0, s>>>((const float4*)a, sink, 2 * n4 > maxb / 16 ? maxb / 16 : 2 * n4); }, K);
     double uw = timeit(s, [&] { write_k<<<dim3((unsigned)((2 * n4 + 255) / 256)), 256, 0, s>>>((float4*)b, 2 * n4 > maxb / 16 ? maxb / 16 : 2 * n4); }, K);
+    // the same float4 copy with every launch of the graph on its own slice of the 1 GB buffers (K * half <= 1 GB): what a launch of this
+    // size costs when neither its input nor its output is in the 256 MB Infinity Cache (bench.py's hbm_rotated case)
+    double urot = -1.0;
+    if ((size_t)K * half <= maxb) {
+      int it = 0;
+      urot = timeit(s, [&] { const size_t o = (size_t)(it++ % K) * (half / 16);
+                             copy_k<float4><<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, s>>>((const float4*)a + o, (float4*)b + o, n4); }, K);
+    }
     const double bytes = 2.0 * half;
     printf("%10.1f %16.2f %10.2f %16.2f %10.2f %10.2f %8.2f %10.2f %8.2f\n", bytes / 1e6, u1, bytes / u1 / 1e6, u4, bytes / u4 / 1e6,
            ur, bytes / ur / 1e6, uw, bytes / uw / 1e6);
+    if (urot > 0) printf("%10s %16s %10s %16.2f %10.2f   <- float4 copy, every launch on its own slice (cache-cold)\n", "", "", "", urot, bytes / urot / 1e6);
   }
   return 0;
 }
