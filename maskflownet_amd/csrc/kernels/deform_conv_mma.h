@@ -49,9 +49,16 @@ namespace mfn {
 constexpr int DCM_XW_F = 512;      // floats of a ring slot of the small window
 template <bool BIG, int RING> struct DcmWin {
   static constexpr int ROWS = BIG ? 16 : 12, COLS = BIG ? 24 : 20, C4 = COLS / 4, CH = ROWS * COLS;
+  // floats between the slot's two channels.  Small window: 268 = 12 mod 64 -- a wave's 32 pixels (4 rows x 8 columns, 20 floats per
+  // row) read banks {0..7, 20..27, 40..47, 60..3} for the lanes of channel 0; channel 1 at + 240 (= 48 mod 64) lands on
+  // {48..55, 4..11, 24..31, 44..51}, half of it on banks of channel 0 (profiles/r05_dc_pmc.md: 38 % of the LDS cycles were bank
+  // conflicts); at + 268 it reads {12..19, 32..39, 52..59, 8..15}: nothing shared with channel 0.  The 28 floats between are 7 of the
+  // transfer's 128 float4 slots (2 x 60 + 7 <= 128: still two instructions).  (Launch times did not move: LDS waits were 6 % of the
+  // wave cycles before.)
+  static constexpr int CHS = BIG ? CH : 268;
   static constexpr int NI = BIG ? 3 : 2, SLOT_F = BIG ? 768 : 512;
   static constexpr int DEPTH = BIG ? (RING * DCM_XW_F) / 768 : RING;   // slots = how many pairs ahead a window is requested
-  static_assert(2 * CH <= SLOT_F && 2 * ROWS * C4 <= NI * 64 && DEPTH >= 2, "the pair's window fits its slot and its transfers");
+  static_assert(CHS % 4 == 0 && CHS >= CH && CHS + CH <= SLOT_F && CHS + CH <= NI * 256 && DEPTH >= 2, "the pair's window fits its slot and its transfers");
 };
 
 // K steps per weight chunk (= block barrier period).  One M-group's step is 3 * MT KB per K slice.
@@ -352,15 +359,15 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     MFN_UNROLL
     for (int i = 0; i < WN::NI; ++i) {
       const int slot = i * 64 + lane;                       // float4 slots: [channel 0/1][ROWS][C4 float4]
-      const int chs = slot / (WN::ROWS * WN::C4), rem = slot - chs * (WN::ROWS * WN::C4);
+      const int chs = slot / (WN::CHS / 4), rem = slot - chs * (WN::CHS / 4);   // (rem past the channel's rows: the padding, or the slot's end)
       const int row = rem / WN::C4, c4 = rem - row * WN::C4;
       const int r = wr0 + row, c = wc0 + 4 * c4;
-      xvoff[i] = (fast && chs < 2 && r >= 0 && r <= H - 1 && c >= 0 && c <= W - 4)
+      xvoff[i] = (fast && chs < 2 && row < WN::ROWS && r >= 0 && r <= H - 1 && c >= 0 && c <= W - 4)
                      ? (unsigned)(((size_t)n * p.Cin * plane + (size_t)chs * plane + (size_t)r * W + c) * 4)
                      : 0xFFFFFF00u;                         // outside the image: never read, the transfer writes zeros
     }
     // lanes that are not in the window read the slot's first value (finite)
-    gofs = (px_valid && inwin && fast) ? kb * WN::CH + (row0 - wr0) * WN::COLS + (col0 - wc0) : 0;
+    gofs = (px_valid && inwin && fast) ? kb * WN::CHS + (row0 - wr0) * WN::COLS + (col0 - wc0) : 0;
     gofs += G::XW_OFF + wave * (RING * DCM_XW_F);
     MFN_OPAQUE(gofs);   // as an opaque sum: hipcc otherwise keeps XW_OFF apart and forms eight addresses per step
   };
