@@ -56,6 +56,8 @@ struct DeformParams {
                                              // tile_w == 0: 32 consecutive pixels of the flattened (n,ho,wo) index
   float *partial;                             // ksb > 1: raw partial sums [ksb][N][Cout][Ho][Wo]
   int dcm_groups, dcm_gps;                    // dc_mma_kernel (deform_conv_mma.h): 16-channel groups of the call / per K slice
+  size_t x_nstride, out_nstride;              // dc_mma_kernel: elements between consecutive images of x / out (0: dense) -- channel slices
+                                              // of a concat buffer (the plain-convolution form, mfn_conv2d_fwd)
 };
 
 // weights (Cout, Cin, 9) -> wt[mg][cp][t][half][RL]: filter o = mg*RL + r, channel c = 2*cp + half; zero padded

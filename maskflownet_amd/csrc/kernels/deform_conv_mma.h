@@ -61,6 +61,17 @@ template <bool BIG, int RING> struct DcmWin {
   static_assert(CHS % 4 == 0 && CHS >= CH && CHS + CH <= SLOT_F && CHS + CH <= NI * 256 && DEPTH >= 2, "the pair's window fits its slot and its transfers");
 };
 
+// Plain 3x3 / stride 1 / pad 1 convolution (dc_mma_kernel<.., CONV = true>, mfn_conv2d_fwd): every tap sits ON a pixel, so the window is
+// the tile's 4 x 8 pixels + a one-pixel border -- 6 rows x 16 columns from the 16-byte aligned column 4 left of the tile -- and a pair
+// is ONE transfer instruction (2 x 24 float4 slots of its 64).  The two channels lie 104 floats apart: channel 0's lanes then read
+// banks {3..10, 19..26, 35..42, 51..58} and channel 1's + 8 of that: no bank shared.  Six slots fit the wave's ring: six pairs ahead.
+template <int RING> struct DcmWinConv {
+  static constexpr int ROWS = 6, COLS = 16, C4 = 4, CH = ROWS * COLS, CHS = 104;
+  static constexpr int NI = 1, SLOT_F = 256;
+  static constexpr int DEPTH = (RING * DCM_XW_F) / SLOT_F;
+  static_assert(CHS % 4 == 0 && CHS >= CH && CHS + CH <= SLOT_F && DEPTH >= 2, "the pair's window fits one transfer");
+};
+
 // K steps per weight chunk (= block barrier period).  One M-group's step is 3 * MT KB per K slice.
 constexpr int dcm_kc(int mt, int kw) { return mt * kw == 1 ? 3 : 1; }
 // stage buffers of the weight ring: chunk c + NSTAGE - 1 is requested when chunk c opens (KC = 1: two steps of latency cover,
@@ -210,7 +221,10 @@ inline int dcm_pack_launch(DcmPackParams pp, hipStream_t stream) {
 
 struct DcmB { mfn_bf16x8 h, m, l; };
 
-template <int MT, int PT, int KW, int RING>
+// CONV: the plain 3x3 / stride 1 / pad 1 convolution on the same machinery (no offsets: the nine taps ARE the 3 x 3 pixels around the
+// output pixel, read straight from the window; Cin need not be a multiple of 16 -- the packed weights of the missing channels are
+// zero and their window transfers are suppressed; x and out may be channel slices of concat buffers).
+template <int MT, int PT, int KW, int RING, bool CONV = false>
 __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mma_kernel(DeformParams p) {
   using G = DcmGeom<MT, PT, KW, RING>;
   constexpr int NW = G::NW, KC = G::KC, NI = G::NI, NIW = G::NI_MIN;
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   const int m0 = mg * MT * 32;
   const int H = p.H, W = p.W;
   const size_t plane = (size_t)H * W;
+  const size_t xns = p.x_nstride ? p.x_nstride : (size_t)p.Cin * plane;   // elements between the images of x
 
   // ---- weight staging plan ------------------------------------------------------------------------------------------
   const int gps = p.dcm_gps;   // groups per K slice
@@ -282,9 +297,10 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   const int h_in = ho - 1, w_in = wo - 1;   // stride 1, pad 1
 
   // ---- offsets: one (dy, dx) per pixel (flow mode), or the eighteen of the operator's tensor, which qualify when equal --------
-  float off_h, off_w;
+  float off_h = 0.f, off_w = 0.f;
   bool shared = true;
-  if (p.offset) {
+  if (CONV) {
+  } else if (p.offset) {
     const float *op = p.offset + (size_t)n * 18 * plane + (size_t)ho * W + wo;
     float oh[9], ow[9];
     MFN_UNROLL
@@ -331,10 +347,17 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
       }
       first = in0 + lo0;
     };
-    axis(off_h, h_in, H, ya, yb, row0);
-    axis(off_w, w_in, W, xa, xb, col0);
+    if (CONV) {   // the nine taps are the pixels (h_in + i, w_in + j): nothing to interpolate, rows / columns outside the image read
+      row0 = h_in;  // the window's zeros
+      col0 = w_in;
+      MFN_UNROLL
+      for (int i = 0; i < 3; ++i) { ya[i] = xa[i] = 1.f; yb[i] = xb[i] = 0.f; }
+    } else {
+      axis(off_h, h_in, H, ya, yb, row0);
+      axis(off_w, w_in, W, xa, xb, col0);
+    }
   }
-  const bool fast = __all(regular || !px_valid) != 0;   // wave-uniform; false: the per-tap column path
+  const bool fast = CONV || __all(regular || !px_valid) != 0;   // wave-uniform; false: the per-tap column path
 
   MFN_STAMP2(p.timeline, 1);   // geometry
   // ---- the wave's source window: the box of its lanes' neighbourhoods in the small shape where that fits, else the big one, and
@@ -363,7 +386,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
       const int row = rem / WN::C4, c4 = rem - row * WN::C4;
       const int r = wr0 + row, c = wc0 + 4 * c4;
       xvoff[i] = (fast && chs < 2 && row < WN::ROWS && r >= 0 && r <= H - 1 && c >= 0 && c <= W - 4)
-                     ? (unsigned)(((size_t)n * p.Cin * plane + (size_t)chs * plane + (size_t)r * W + c) * 4)
+                     ? (unsigned)(((size_t)n * xns + (size_t)chs * plane + (size_t)r * W + c) * 4)
                      : 0xFFFFFF00u;                         // outside the image: never read, the transfer writes zeros
     }
     // lanes that are not in the window read the slot's first value (finite)
@@ -371,24 +394,46 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     gofs += G::XW_OFF + wave * (RING * DCM_XW_F);
     MFN_OPAQUE(gofs);   // as an opaque sum: hipcc otherwise keeps XW_OFF apart and forms eight addresses per step
   };
-  setup_window(DcmWin<false, RING>{});
-  bool all_in = __all(inwin) != 0;   // wave-uniform
-  const bool bigwin = fast && !all_in;
-  if (bigwin) {
-    setup_window(DcmWin<true, RING>{});
-    all_in = __all(inwin) != 0;
+  unsigned xvoff_c0 = 0xFFFFFF00u;   // CONV: the transfer's lanes of channel 0 only (the last pair of an odd channel count)
+  bool all_in = true, bigwin = false;
+  if (CONV) {
+    using WN = DcmWinConv<RING>;
+    wr0 = tile_ho0 - 1;
+    wc0 = tile_wo0 - 4;
+    const int chs = lane / (WN::CHS / 4), rem = lane - chs * (WN::CHS / 4);
+    const int row = rem / WN::C4, c4 = rem - row * WN::C4;
+    const int r = wr0 + row, c = wc0 + 4 * c4;
+    const bool ok = chs < 2 && row < WN::ROWS && r >= 0 && r <= H - 1 && c >= 0 && c <= W - 4;
+    xvoff[0] = ok ? (unsigned)(((size_t)n * xns + (size_t)chs * plane + (size_t)r * W + c) * 4) : 0xFFFFFF00u;
+    xvoff_c0 = chs == 0 ? xvoff[0] : 0xFFFFFF00u;
+    gofs = kb * WN::CHS + (row0 - wr0) * WN::COLS + (col0 - wc0);
+    gofs += G::XW_OFF + wave * (RING * DCM_XW_F);
+    MFN_OPAQUE(gofs);
+  } else {
+    setup_window(DcmWin<false, RING>{});
+    all_in = __all(inwin) != 0;   // wave-uniform
+    bigwin = fast && !all_in;
+    if (bigwin) {
+      setup_window(DcmWin<true, RING>{});
+      all_in = __all(inwin) != 0;
+    }
   }
   float *xwin = lds + G::XW_OFF + wave * (RING * DCM_XW_F);
-  const mfn_rsrc_t xrsrc = mfn_make_rsrc(p.x, (unsigned)((size_t)p.N * p.Cin * plane * 4));
+  const mfn_rsrc_t xrsrc = mfn_make_rsrc(p.x, (unsigned)((size_t)p.N * xns * 4));
   const int cp_base = kw * gps * 8;    // first channel pair of this K slice
   int buf_issue = 0;                   // ring slot of the next window transfer (uniform)
   auto issue_x = [&](int kl, auto win_c) {   // window of the slice's pair kl -> ring slot kl % DEPTH
     using WN = decltype(win_c);
-    const unsigned soff = kl < gps * 8 ? (unsigned)((size_t)(2 * (cp_base + kl)) * plane * 4) : 0x7FFFFF00u;   // past the slice: out of range
+    const int c0 = 2 * (cp_base + kl);   // CONV: channels past Cin (the zero-padded tail of the last 16-channel group) are not read --
+                                         // behind a concat slice lies the next image's memory, written or not
+    const unsigned soff = (kl < gps * 8 && (!CONV || c0 < p.Cin)) ? (unsigned)((size_t)c0 * plane * 4) : 0x7FFFFF00u;   // past the slice: out of range
     float *dst = xwin + buf_issue * WN::SLOT_F;
     if (!(MFN_DCM_ABLATE & 4)) {
-      MFN_UNROLL
-      for (int i = 0; i < WN::NI; ++i) mfn_dma16_so(xrsrc, dst + i * 256, xvoff[i], soff);
+      if (CONV) mfn_dma16_so(xrsrc, dst, c0 + 1 < p.Cin ? xvoff[0] : xvoff_c0, soff);
+      else {
+        MFN_UNROLL
+        for (int i = 0; i < WN::NI; ++i) mfn_dma16_so(xrsrc, dst + i * 256, xvoff[i], soff);
+      }
     }
     buf_issue = buf_issue + 1 == WN::DEPTH ? 0 : buf_issue + 1;
   };
@@ -406,7 +451,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     }
   };
   MFN_STAMP2(p.timeline, 2);   // window box
-  if (bigwin) prologue(DcmWin<true, RING>{}); else prologue(DcmWin<false, RING>{});
+  if (CONV) prologue(DcmWinConv<RING>{}); else if (bigwin) prologue(DcmWin<true, RING>{}); else prologue(DcmWin<false, RING>{});
   MFN_STAMP2(p.timeline, 3);   // prologue transfers issued
 
   f32x16 acc[MT][NACC];
@@ -417,7 +462,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
       MFN_UNROLL
       for (int r = 0; r < 16; ++r) acc[mt][a][r] = 0.f;
 
-  const float *xn = p.x + (size_t)n * p.Cin * plane;
+  const float *xn = p.x + (size_t)n * xns;
 
   // ---- column values of one (pixel, channel): the tiers ------------------------------------------------------------------------------
   // window (small or big shape): 16 LDS reads at one address register + immediates; the big window with the lanes that are outside
@@ -428,6 +473,16 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   auto cols_gather = [&](int kn, auto win_c) {
     using WN = decltype(win_c);
     const float *xb_ = lds + (buf_read * WN::SLOT_F + gofs);
+    if (CONV) {   // the 3 x 3 pixels: columns 0, 1 as a pair, column 2 alone
+      MFN_UNROLL
+      for (int m = 0; m < 3; ++m) {
+        vp[m][0].x = xb_[m * WN::COLS];
+        vp[m][0].y = xb_[m * WN::COLS + 1];
+        vp[m][1].x = xb_[m * WN::COLS + 2];
+      }
+      buf_read = buf_read + 1 == WN::DEPTH ? 0 : buf_read + 1;
+      return;
+    }
     MFN_UNROLL
     for (int m = 0; m < 4; ++m)
       MFN_UNROLL
@@ -456,7 +511,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     MFN_UNROLL
     for (int m = 0; m < 4; ++m)
       rbo[m] = inwin ? 0xFFFFF000u
-                     : (unsigned)(((n * p.Cin + kb) * H + min(max(row0 + m, 0), H - 1)) * W + col0) * 4u;   // (wraps below the tensor: out of range)
+                     : (unsigned)((size_t)n * xns + ((size_t)kb * H + min(max(row0 + m, 0), H - 1)) * W + col0) * 4u;   // (wraps below the tensor: out of range)
   };
   auto lanes_request = [&](int kn, auto set_c) {
     constexpr int SET = decltype(set_c)::value;
@@ -487,6 +542,12 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   // instructions fewer -- and measured 586 cycles per step for these 30 instructions against 171 for the 38 of the split: packed
   // fp32 issued behind matrix instructions that are still in flight stalls, MI355X_MICROARCH.md "anti-lever beside MFMAs".)
   auto cols_finish = [&](float (&x8)[8], float &c8) {
+    if (CONV) {
+      x8[0] = vp[0][0].x; x8[1] = vp[0][0].y; x8[2] = vp[0][1].x;
+      x8[3] = vp[1][0].x; x8[4] = vp[1][0].y; x8[5] = vp[1][1].x;
+      x8[6] = vp[2][0].x; x8[7] = vp[2][0].y; c8 = vp[2][1].x;
+      return;
+    }
     f32x2 ty[3][2];
     if (MFN_DCM_ABLATE & 16) {
       MFN_UNROLL
@@ -692,10 +753,13 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
       s = s == 8 ? 0 : s + 1;
     }
   };
-  if (!fast) run_pertap();
-  else if (!bigwin) run_groups(DcmWin<false, RING>{}, std::false_type{});
-  else if (all_in) run_groups(DcmWin<true, RING>{}, std::false_type{});
-  else run_groups(DcmWin<true, RING>{}, std::true_type{});
+  if constexpr (CONV) run_groups(DcmWinConv<RING>{}, std::false_type{});
+  else {
+    if (!fast) run_pertap();
+    else if (!bigwin) run_groups(DcmWin<false, RING>{}, std::false_type{});
+    else if (all_in) run_groups(DcmWin<true, RING>{}, std::false_type{});
+    else run_groups(DcmWin<true, RING>{}, std::true_type{});
+  }
   MFN_STAMP(p.timeline, 2);
   MFN_STAMP_INFO(p.timeline, !fast ? 3 : (!bigwin ? 0 : (all_in ? 1 : 2)));   // the first wave's tier
 
@@ -794,7 +858,7 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     for (int q = 0; q < 4; ++q) sg[q] = 1.f / (1.f + expf(-mv[q]));
   }
   const size_t obatch = st_ok ? (size_t)n * p.Cout * oplane + (size_t)oy * W : 0;
-  float *obase = p.out + (size_t)n * p.Cout * oplane;
+  float *obase = p.out + (size_t)n * (p.out_nstride ? p.out_nstride : (size_t)p.Cout * oplane);
   MFN_UNROLL
   for (int mt = 0; mt < MT; ++mt) {
     if (KW > 1 && kw != mt % KW) continue;
@@ -842,12 +906,17 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
   MFN_STAMP(p.timeline, 3);
 }
 
-template <int MT, int PT, int KW, int RING>
-inline int dc_mma_launch(const DeformParams &p, hipStream_t stream) {
+template <int MT, int PT, int KW, int RING, bool CONV = false>
+inline int dc_mma_launch(const DeformParams &p, hipStream_t stream, const char *name = "dc_mma") {
   using G = DcmGeom<MT, PT, KW, RING>;
   const int bx = cdiv(p.ntiles, PT);
   if (bx <= 0) return 0;
-  return launch("dc_mma", dc_mma_kernel<MT, PT, KW, RING>, dim3(bx, 1, p.mgroups), dim3(G::NTH), (size_t)G::LDS_W * sizeof(float), stream, p);
+  return launch(name, dc_mma_kernel<MT, PT, KW, RING, CONV>, dim3(bx, 1, p.mgroups), dim3(G::NTH), (size_t)G::LDS_W * sizeof(float), stream, p);
+}
+// the plain-convolution form: 3x3 / stride 1 / pad 1 / dilation 1, one group, 16-byte rows; any channel count
+inline bool dcm_conv_shape_ok(int N, size_t x_nstride, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int groups) {
+  return kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && groups == 1 && W % 4 == 0 && W >= 8 &&
+         H >= 1 && (size_t)N * x_nstride < ((size_t)1 << 30);
 }
 
 // what the kernel needs of a call: the network's operator shape, 16-byte rows, whole groups of 16 channels

@@ -7,8 +7,7 @@
 //   corr.variant  6: corr_tiled_kernel (images narrower than 16 columns), 16 / 20 / 22: corr_dma_kernel with 1 / 2 / 3 channel
 //                 groups, 26 / 31: the same with a tile's displacement rows spread over 5 / 3 blocks (coarse levels); -1 = the
 //                 plan (api_impl.inc corr_plan)
-//                 40 / 41: corr_gram_kernel (32-channel levels: the band of the Gram matrix on the bf16 matrix cores with the
-//                 operands split into three / two bf16 terms -- 40 is exact fp32, 41 a measured variant, 43 = 40 with two waves per item)
+//                 40: corr_gram_kernel (32-channel levels: the band of the Gram matrix on the bf16 matrix cores, operands as three bf16 terms)
 //                 44 / 45: corr_gramk_kernel (coarse levels: the same band, a block = an 8 x 2 pixel block of f1 and two / half of the
 //                 f2 rows it meets, one wave per 32 channels)
 //   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 0 = the plan)
@@ -30,6 +29,9 @@
 //                 every level)
 //   conv.mt / conv.pt  32-filter tiles per wave (1..4) / pixel tiles per block (4, or 1 = four in-block K slices); 0 = plan (the plan
 //                 only picks pt = 4 and mt > 2 for images of >= 1024 pixel tiles: the CPU emulation tests reach those kernels through these)
+//   conv.dcm      plain 3x3 / stride 1 / pad 1 convolutions on dc_mma_kernel<.., CONV> (kernels/deform_conv_mma.h): 0 = the plan (filter counts
+//                 that are multiples of 32 on images of >= 384 pixel tiles, default arithmetic), 1 = never, 2 = whatever the tile count
+//                 (the CPU emulation tests reach the kernel through this)
 #pragma once
 #include <string.h>
 namespace mfn {
@@ -38,7 +40,7 @@ struct Tuning {
   int store_policy = -1;
   int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_off = 0, dc_mt = 0;
   int path_generic = 0, bwd_off = 0;
-  int conv_mt = 0, conv_pt = 0;
+  int conv_mt = 0, conv_pt = 0, conv_dcm = 0;
   int *slot(const char *key) {
     if (!strcmp(key, "corr.variant")) return &corr_variant;
     if (!strcmp(key, "corr.direct")) return &corr_direct;
@@ -53,6 +55,7 @@ struct Tuning {
     if (!strcmp(key, "bwd.off")) return &bwd_off;
     if (!strcmp(key, "conv.mt")) return &conv_mt;
     if (!strcmp(key, "conv.pt")) return &conv_pt;
+    if (!strcmp(key, "conv.dcm")) return &conv_dcm;
     return nullptr;
   }
 };

@@ -17,7 +17,7 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(corr_variant=-1, corr_rows=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
+DEFAULT_TUNING = dict(conv_dcm=0, corr_variant=-1, corr_rows=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
                       path_generic=0, bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=-1)
 
 
@@ -624,6 +624,34 @@ def test_conv3x3_bf16x3_operand_split(ops, oracle, mt, pt):
     pc.case_conv(ops, oracle, ident, ident, 1, 20, 130, 5, 16, pad=(2, 2), dilate=(2, 2), seed=1)   # five filter tiles, dilation
     pc.case_conv(ops, oracle, ident, ident, 1, 6, 10, 11, 19, pad=(1, 1), stride=(2, 2), seed=2)
     pc.case_deconv(ops, oracle, ident, ident, 2, 9, 16, 5, 8, leaky=True)                       # upfeat as a 3x3 convolution
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W", [(21, 32, 6, 16), (40, 64, 7, 12), (19, 96, 5, 8), (64, 64, 4, 24), (35, 128, 4, 8)])
+def test_conv3x3_on_the_matrix_core_deformable_kernel(ops, oracle, Cin, Cout, H, W):
+    """dc_mma_kernel<.., CONV = true> (kernels/deform_conv_mma.h): 3x3 / stride 1 / pad 1 convolutions whose filter count is a multiple
+    of 32 -- channel counts that are no multiple of 16 (zero-padded last group, an odd count's last pair with one channel), ragged pixel
+    tiles, one / two / three filter tiles per wave, two M-groups, the K-split tiling (64 filters, groups % 4 == 0), fused LeakyReLU,
+    packed weights, a concat slice as input and as output."""
+    emu_ops.set_tuning(conv_dcm=2)
+    emu_ops.launch_log()
+    pc.case_conv(ops, oracle, ident, ident, 2, Cin, Cout, H, W, pad=(1, 1), leaky=True)
+    assert "conv3x3_dcm" in emu_ops.launch_log()
+    rng = np.random.default_rng(77)
+    x = pc.feat(rng, (2, Cin, H, W))
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    # x = concat(conv(x), x): the input is the channel suffix of a buffer whose prefix is NOT written yet (NaN: must never be read)
+    buf = np.full((2, Cout + Cin, H, W), np.float32(np.nan))
+    buf[:, Cout:] = x
+    pk = ops.pack_conv_weights(w, x.shape, kernel=(3, 3), pad=(1, 1))
+    ops.Convolution(buf[:, Cout:], w, b, pad=(1, 1), num_filter=Cout, out=buf[:, :Cout], packed=pk)
+    pc.check_close(buf[:, :Cout], oracle.convolution(x, w, b, pad=(1, 1)))
+    np.testing.assert_array_equal(buf[:, Cout:], x)
+    emu_ops.set_tuning(conv_dcm=1)
+    emu_ops.launch_log()
+    with pytest.raises(Exception, match="laid out for|do not match"):
+        ops.Convolution(x, w, b, pad=(1, 1), num_filter=Cout, packed=pk)   # packed for the other kernel family
+    assert "conv3x3_dcm" not in emu_ops.launch_log()
 
 
 @pytest.mark.parametrize("kw", [dict(pad=(1, 1), stride=(2, 2)), dict(pad=(2, 2), dilate=(2, 2)), dict(pad=(4, 4), dilate=(4, 4)),

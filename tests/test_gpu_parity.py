@@ -1,6 +1,7 @@
 """GPU parity tests proper: the HIP kernels, called through the C ABI, against the CPU oracle on
 the same seeded inputs at the BASELINE.json shapes, plus size-independent
 properties at full size.  Tolerance: north_star's 1e-4 relative (asserted 10x tighter)."""
+import ctypes
 import numpy as np
 import pytest
 
@@ -298,6 +299,44 @@ def test_conv_bf16x3_operand_split_error_vs_fp64(ops, T, dev, case):
         err[mma] = float(np.abs(got - want).max() / np.abs(want).max())
     print("conv %s: max rel err vs fp64  exact fp32 %.3e   bf16x3 %.3e" % ((N, Cin, Cout, H, W), err[0], err[1]))
     assert err[1] <= 1e-5 and err[1] <= 2.0 * err[0] + 2e-7, err
+
+
+@pytest.mark.parametrize("case", [dict(N=8, Cin=131, Cout=128, H=96, W=128),    # conv2_0: odd channel count, two M-groups of two tiles
+                                  dict(N=8, Cin=387, Cout=96, H=96, W=128),     # conv2_2: three filter tiles per wave
+                                  dict(N=8, Cin=547, Cout=32, H=96, W=128),     # conv2_4
+                                  dict(N=8, Cin=64, Cout=64, H=48, W=64),       # conv3b: the K-split tiling
+                                  dict(N=8, Cin=291, Cout=128, H=48, W=64),     # conv3_1
+                                  dict(N=4, Cin=483, Cout=64, H=112, W=256)])   # conv2_3 at 448x1024
+def test_conv_on_the_matrix_core_deformable_kernel_error_vs_fp64(ops, T, dev, case):
+    """dc_mma_kernel<.., CONV> (the plan's kernel for 3x3 / stride 1 / pad 1 layers with whole 32-filter tiles at levels 2 and 3): its
+    error against torch's fp64 convolution must not exceed the fp32-MFMA kernel's by more than a rounding -- the acceptance rule of
+    every bf16 x 3 kernel --, reading a concat buffer's channel suffix whose prefix is NaN (never to be read) and writing that prefix."""
+    from maskflownet_amd import _lib
+    N, Cin, Cout, H, W = (case[k] for k in ("N", "Cin", "Cout", "H", "W"))
+    g = T.Generator(device="cuda").manual_seed(5)
+    x = T.randn(N, Cin, H, W, device="cuda", generator=g)
+    w = T.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * float(np.sqrt(2.0 / (1.01 * Cin * 9)))
+    b = T.randn(Cout, device="cuda", generator=g) * 0.1
+    want = T.nn.functional.leaky_relu(T.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1), 0.1)
+    scale = float(want.abs().max())
+    err = {}
+    for arith, name in ((0, "conv3x3_mfma"), (-1, "conv3x3_dcm")):
+        _lib.set_arithmetic(convolution=arith)
+        buf = T.full((N, Cout + Cin, H, W), float("nan"), device="cuda")
+        buf[:, Cout:] = x
+        _lib.lib().profile_reset(); _lib.lib().profile_enable(1)
+        ops.Convolution(buf[:, Cout:], w, b, pad=(1, 1), num_filter=Cout, activation="leaky", out=buf[:, :Cout])
+        T.cuda.synchronize()
+        _lib.lib().profile_enable(0)
+        cnt, ms = ctypes.c_int(0), ctypes.c_double(0)
+        _lib.lib().profile_query(name.encode(), ctypes.byref(cnt), ctypes.byref(ms))
+        assert cnt.value == 1, (name, cnt.value)
+        assert bool(T.isfinite(buf[:, :Cout]).all())
+        assert bool((buf[:, Cout:] == x).all())
+        err[arith] = float((buf[:, :Cout].double() - want).abs().max()) / scale
+    _lib.set_arithmetic(convolution=-1)
+    print("conv %s: max rel err vs fp64  fp32 MFMA %.3e   dc_mma CONV %.3e" % ((N, Cin, Cout, H, W), err[0], err[-1]))
+    assert err[-1] <= 1e-5 and err[-1] <= 2.0 * err[0] + 2e-7, err
 
 
 @pytest.mark.parametrize("tiling", [(1, 4, 4, 32), (2, 3, 12, 64), (3, 1, 6, 96), (1, 1, 8, 128), (1, 1, 4, 64), (1, 1, 2, 32), (1, 1, 1, 48)])
