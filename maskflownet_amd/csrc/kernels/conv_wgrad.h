@@ -153,6 +153,105 @@ __global__ __launch_bounds__(64) void conv_wgrad_kernel(ConvWgradParams p) {
     for (int r = 0; r < 16; ++r) sl[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = acc[t][r];
 }
 
+// The same gradient for dilation 1 on v_mfma_f32_32x32x16_bf16, fp32-EQUIVALENT (the library's default arithmetic; conv_wgrad_kernel
+// is MFN_ARITH_FP32's): both operands as three bf16 terms, six of the nine partial products, fp32 accumulate -- 6 matrix instructions
+// of 32 cycles per 16 pixels and tap against 8 of 64.  K = 16 pixels of one image row: lane (col, half) owns pixels 8 half .. 8 half + 7
+// of the run -- two aligned quads of its filter's gradient plane, and per input row the four quads from 4 pixels left of them.  The ten
+// values x[-1 .. 8] of a row are split ONCE, as five pairs (55 instructions): the operands of the taps kx = 0 and kx = 2 are four
+// consecutive words of the five as they are, the one of kx = 1 starts at an odd element -- four v_alignbit_b32 per term.  Per run and
+// wave: 14 loads of 16 bytes, ~250 VALU instructions, 54 matrix instructions (1 728 cycles; the fp32 form: 72 of 64 = 4 608).
+// Masks are out-of-range offsets (zeros from the hardware), as in conv_wgrad_kernel.  Tile / slice / slab layout and the reduce are conv_wgrad_kernel's.
+__global__ __launch_bounds__(64) void conv_wgrad_mma_kernel(ConvWgradParams p) {
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 31, half = lane >> 5;
+  const int slice = blockIdx.x, tc = blockIdx.y, to = blockIdx.z;
+  const int H = p.H, W = p.W;
+  const int plane = H * W, wr = W / 16;
+  const int o = to * 32 + col, c = tc * 32 + col;
+  const bool o_ok = o < p.Cout, c_ok = c < p.Cin;
+  f32x16 acc[9];
+  MFN_UNROLL
+  for (int t = 0; t < 9; ++t)
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int r0 = slice * p.runs_per_slice, r1 = min(p.runs, r0 + p.runs_per_slice);
+  constexpr unsigned OOR = 0xFFFFFF00u;
+  const unsigned gbytes = (unsigned)(p.Cout * plane) * 4u, xbytes = (unsigned)(p.Cin * plane) * 4u;
+  // software pipeline over (run, input row) as in conv_wgrad_kernel: the quads of step s + 1 are requested before the 18 matrix
+  // instructions of step s; two register sets (126 -> ~100 registers beside the 144 accumulators: two waves per SIMD)
+  f32x4 A[2][2], C[2][4];   // [set][quad] of the gradient; [set][quad L, C0, C1, R] of one input row
+  auto coords = [&](int run, bool &live, int &y, int &n, int &x0) {
+    live = run < r1;
+    const int rr = live ? run : r0;
+    const int xr = rr % wr, row = rr / wr;
+    y = row % H; n = MFN_UNIFORM(row / H);
+    x0 = xr * 16 + 8 * half;
+  };
+  auto issue = [&](int run, int ky, f32x4 (&Cb)[4], f32x4 (&Ab)[2]) {
+    bool live; int y, n, x0;
+    coords(run, live, y, n, x0);
+    if (ky == 0) {
+      const float *gimg = p.g + (size_t)n * p.Cout * plane;
+      const unsigned go = (unsigned)(o * plane + y * W + x0) * 4u;
+      Ab[0] = mfn_bload4(gimg, gbytes, (o_ok && live) ? go : OOR);
+      Ab[1] = mfn_bload4(gimg, gbytes, (o_ok && live) ? go + 16u : OOR);
+    }
+    const float *ximg = p.x + (size_t)n * p.Cin * plane;
+    const int yy = y + ky - 1;
+    const bool rok = live && c_ok && yy >= 0 && yy < H;
+    const unsigned xo = (unsigned)(c * plane + yy * W + x0) * 4u;
+    Cb[0] = mfn_bload4(ximg, xbytes, (rok && x0 >= 4) ? xo - 16u : OOR);
+    Cb[1] = mfn_bload4(ximg, xbytes, rok ? xo : OOR);
+    Cb[2] = mfn_bload4(ximg, xbytes, rok ? xo + 16u : OOR);
+    Cb[3] = mfn_bload4(ximg, xbytes, (rok && x0 + 8 < W) ? xo + 32u : OOR);
+  };
+  mfn_bf16x8 ah, am, al;
+  auto work = [&](int ky, const f32x4 (&Cb)[4], const f32x4 (&Ab)[2]) {
+    if (ky == 0) {
+      const float a8[8] = {Ab[0][0], Ab[0][1], Ab[0][2], Ab[0][3], Ab[1][0], Ab[1][1], Ab[1][2], Ab[1][3]};
+      mfn_split3x8_scalar(a8, ah, am, al);
+    }
+    const float v[10] = {Cb[0][3], Cb[1][0], Cb[1][1], Cb[1][2], Cb[1][3], Cb[2][0], Cb[2][1], Cb[2][2], Cb[2][3], Cb[3][0]};   // x[-1 .. 8]
+    unsigned wh[5], wm[5], wl[5];
+    mfn_split3_pairs<5>(v, wh, wm, wl);
+    MFN_UNROLL
+    for (int kx = 0; kx < 3; ++kx) {
+      mfn_bf16x8 bh, bm, bl;
+      if (kx == 1) {   // elements 1 .. 8: every word straddles two pairs
+        bh = mfn_words_to_bf16x8(mfn_alignbit16(wh[1], wh[0]), mfn_alignbit16(wh[2], wh[1]), mfn_alignbit16(wh[3], wh[2]), mfn_alignbit16(wh[4], wh[3]));
+        bm = mfn_words_to_bf16x8(mfn_alignbit16(wm[1], wm[0]), mfn_alignbit16(wm[2], wm[1]), mfn_alignbit16(wm[3], wm[2]), mfn_alignbit16(wm[4], wm[3]));
+        bl = mfn_words_to_bf16x8(mfn_alignbit16(wl[1], wl[0]), mfn_alignbit16(wl[2], wl[1]), mfn_alignbit16(wl[3], wl[2]), mfn_alignbit16(wl[4], wl[3]));
+      } else {         // elements 0 .. 7 (kx = 0) / 2 .. 9 (kx = 2): four of the five words
+        const int w0 = kx == 0 ? 0 : 1;
+        bh = mfn_words_to_bf16x8(wh[w0], wh[w0 + 1], wh[w0 + 2], wh[w0 + 3]);
+        bm = mfn_words_to_bf16x8(wm[w0], wm[w0 + 1], wm[w0 + 2], wm[w0 + 3]);
+        bl = mfn_words_to_bf16x8(wl[w0], wl[w0 + 1], wl[w0 + 2], wl[w0 + 3]);
+      }
+      f32x16 &d = acc[ky * 3 + kx];
+      d = MFN_MFMA_32x32x16_BF16(al, bh, d);
+      d = MFN_MFMA_32x32x16_BF16(ah, bl, d);
+      d = MFN_MFMA_32x32x16_BF16(am, bm, d);
+      d = MFN_MFMA_32x32x16_BF16(am, bh, d);
+      d = MFN_MFMA_32x32x16_BF16(ah, bm, d);
+      d = MFN_MFMA_32x32x16_BF16(ah, bh, d);
+    }
+  };
+  issue(r0, 0, C[0], A[0]);
+  for (int run = r0; run < r1; run += 2) {
+    issue(run, 1, C[1], A[0]);     MFN_SCHED_BARRIER(); work(0, C[0], A[0]); MFN_SCHED_BARRIER();
+    issue(run, 2, C[0], A[0]);     MFN_SCHED_BARRIER(); work(1, C[1], A[0]); MFN_SCHED_BARRIER();
+    issue(run + 1, 0, C[1], A[1]); MFN_SCHED_BARRIER(); work(2, C[0], A[0]); MFN_SCHED_BARRIER();
+    issue(run + 1, 1, C[0], A[1]); MFN_SCHED_BARRIER(); work(0, C[1], A[1]); MFN_SCHED_BARRIER();
+    issue(run + 1, 2, C[1], A[1]); MFN_SCHED_BARRIER(); work(1, C[0], A[1]); MFN_SCHED_BARRIER();
+    issue(run + 2, 0, C[0], A[0]); MFN_SCHED_BARRIER(); work(2, C[1], A[1]); MFN_SCHED_BARRIER();
+  }
+  float *sl = p.slabs + (((size_t)slice * p.tiles_o + to) * p.tiles_c + tc) * (9 * 1024);
+  MFN_UNROLL
+  for (int t = 0; t < 9; ++t)
+    MFN_UNROLL
+    for (int r = 0; r < 16; ++r) sl[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + col] = acc[t][r];
+}
+
 // gw (Cout, Cin, 3, 3) (+)= the slices' partial tiles.  A block = 32 consecutive slab elements x 8 slice groups: thread (element, group
 // g) adds slices g, g+8, ... (four requests in flight), the groups meet in LDS and are added in group order -- a fixed order, and
 // 1/8 of the serial chain a thread per element had (a one-tile layer such as conv1b has 1300 slices: 300 of its 396 us were this sum).
@@ -192,10 +291,12 @@ inline bool conv_wgrad_shape_ok(int Cin, int Cout, int H, int W, int kh, int kw,
          W % 8 == 0 && (size_t)Cin * H * W < ((size_t)1 << 30) && (size_t)Cout * H * W < ((size_t)1 << 30);
 }
 struct ConvWgradPlan { int qpl, tiles_o, tiles_c, slices, runs, runs_per_slice; size_t slab_bytes; };
-inline ConvWgradPlan conv_wgrad_plan(int N, int Cin, int Cout, int H, int W) {
+// mma: conv_wgrad_mma_kernel's runs of 16 pixels (dilation 1, W % 16 == 0, the default arithmetic)
+inline bool conv_wgrad_mma_ok(int W, int dil) { return dil == 1 && W % 16 == 0; }
+inline ConvWgradPlan conv_wgrad_plan(int N, int Cin, int Cout, int H, int W, bool mma = false) {
   ConvWgradPlan q;
   q.tiles_o = cdiv(Cout, 32); q.tiles_c = cdiv(Cin, 32);
-  q.qpl = W % 32 == 0 ? 4 : 1;
+  q.qpl = mma ? 2 : (W % 32 == 0 ? 4 : 1);
   q.runs = N * H * (W / (8 * q.qpl));
   int s = cdiv(2048, q.tiles_o * q.tiles_c);       // ~2 k waves: two per SIMD
   const size_t tile_bytes = (size_t)q.tiles_o * q.tiles_c * 9 * 1024 * sizeof(float);
@@ -208,11 +309,18 @@ inline ConvWgradPlan conv_wgrad_plan(int N, int Cin, int Cout, int H, int W) {
   return q;
 }
 inline int conv_wgrad_launch(const float *g, const float *x, float *gw, void *slabs, int N, int Cin, int Cout, int H, int W, int dil,
-                             int add, hipStream_t s) {
-  const ConvWgradPlan q = conv_wgrad_plan(N, Cin, Cout, H, W);
+                             int add, hipStream_t s, bool mma = false) {
+  mma = mma && conv_wgrad_mma_ok(W, dil);
+  const ConvWgradPlan q = conv_wgrad_plan(N, Cin, Cout, H, W, mma);
   ConvWgradParams p{g, x, (float *)slabs, N, Cin, Cout, H, W, dil, q.tiles_o, q.tiles_c, q.slices, q.runs, q.runs_per_slice};
   const dim3 grid((unsigned)q.slices, (unsigned)q.tiles_c, (unsigned)q.tiles_o);
   int rc;
+  if (mma) {
+    if ((rc = launch("conv_wgrad_bf16x3", conv_wgrad_mma_kernel, grid, dim3(64), 0, s, p))) return rc;
+    ConvWgradReduceParams rp{(const float *)slabs, gw, Cin, Cout, q.tiles_o, q.tiles_c, q.slices, add};
+    const size_t per_slice = (size_t)q.tiles_o * q.tiles_c * 9 * 1024;
+    return launch("conv_wgrad_reduce", conv_wgrad_reduce_kernel, dim3((unsigned)(per_slice / 32)), dim3(256), 256 * sizeof(float), s, rp);
+  }
 #define MFN_WG_(DM_) (q.qpl == 4 ? launch("conv_wgrad", conv_wgrad_kernel<DM_, 4>, grid, dim3(64), 0, s, p) \
                                  : launch("conv_wgrad", conv_wgrad_kernel<DM_, 1>, grid, dim3(64), 0, s, p))
   rc = dil == 1 ? MFN_WG_(1) : (dil == 2 ? MFN_WG_(2) : MFN_WG_(4));

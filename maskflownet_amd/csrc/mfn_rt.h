@@ -49,6 +49,20 @@ static inline void mfn_split3x8(const float (&x)[8], mfn_bf16x8 &h, mfn_bf16x8 &
   for (int e = 0; e < 8; ++e) mfn_split3(x[e], h.v[e], m.v[e], l.v[e]);
 }
 #define mfn_split3x8_scalar mfn_split3x8   // (device: the residuals by scalar subtractions instead of v_pk_add_f32)
+// NP pairs of values -> NP words per term (low half = the pair's first value); words back into a matrix operand; a word from two neighbours
+template <int NP> static inline void mfn_split3_pairs(const float (&x)[2 * NP], unsigned (&h)[NP], unsigned (&m)[NP], unsigned (&l)[NP]) {
+  for (int q = 0; q < NP; ++q) {
+    unsigned short h0, m0, l0, h1, m1, l1;
+    mfn_split3(x[2 * q], h0, m0, l0);
+    mfn_split3(x[2 * q + 1], h1, m1, l1);
+    h[q] = (unsigned)h0 | ((unsigned)h1 << 16); m[q] = (unsigned)m0 | ((unsigned)m1 << 16); l[q] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+}
+static inline mfn_bf16x8 mfn_words_to_bf16x8(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+  const unsigned w[4] = {w0, w1, w2, w3};
+  mfn_bf16x8 v; memcpy(&v, w, 16); return v;
+}
+static inline unsigned mfn_alignbit16(unsigned hi, unsigned lo) { return (lo >> 16) | (hi << 16); }
 // the same split one term at a time (the kernel places a matrix instruction between the stages)
 struct mfn_split_state { float r[8]; };
 static inline void mfn_split_stage_h(const float (&x)[8], mfn_bf16x8 &h, mfn_split_state &st) {
@@ -262,6 +276,30 @@ __device__ __forceinline__ void mfn_split3x8_scalar(const float (&x)[8], mfn_bf1
   }
   h = __builtin_bit_cast(mfn_bf16x8, hw); m = __builtin_bit_cast(mfn_bf16x8, mw); l = __builtin_bit_cast(mfn_bf16x8, lw);
 }
+// NP pairs of values -> NP words per term (low half = the pair's first value), residuals by scalar subtractions: 11 instructions per pair
+template <int NP> __device__ __forceinline__ void mfn_split3_pairs(const float (&x)[2 * NP], unsigned (&h)[NP], unsigned (&m)[NP], unsigned (&l)[NP]) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  _Pragma("unroll")
+  for (int q = 0; q < NP; ++q) {
+    const f32x2 v = {x[2 * q], x[2 * q + 1]};
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+    float r0 = v.x - __builtin_bit_cast(float, hp << 16), r1 = v.y - __builtin_bit_cast(float, hp & 0xffff0000u);
+    asm volatile("" : "+v"(r0), "+v"(r1));
+    const f32x2 rr = {r0, r1};
+    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, bf2));
+    float s0 = r0 - __builtin_bit_cast(float, mp << 16), s1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
+    asm volatile("" : "+v"(s0), "+v"(s1));
+    const f32x2 ss = {s0, s1};
+    h[q] = hp; m[q] = mp; l[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(ss, bf2));
+  }
+}
+__device__ __forceinline__ mfn_bf16x8 mfn_words_to_bf16x8(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 w = {w0, w1, w2, w3};
+  return __builtin_bit_cast(mfn_bf16x8, w);
+}
+// the word made of the high half of `lo` and the low half of `hi` (one v_alignbit_b32): a pair that starts at an odd element
+__device__ __forceinline__ unsigned mfn_alignbit16(unsigned hi, unsigned lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 // the same split one term at a time (4 + 16 + 16 VALU instructions; the kernel places a matrix instruction between the stages):
 // h: the hi terms, the state keeps the values; m: widen hi, first residual, mid terms; l: widen mid, second residual, lo terms
 struct mfn_split_state { f32x2 v[4]; unsigned hp[4], mp[4]; };

@@ -25,6 +25,8 @@ CONV_CASES = [
     dict(N=1, Cin=4, Cout=4, H=8, W=8, req=("null", "write", "null")),
     dict(N=2, Cin=4, Cout=6, H=40, W=52, leaky=True),            # 4160 (n, pixel) terms per channel: the bias gradient in two slices
     dict(N=1, Cin=1, Cout=3, H=65, W=65, req=("null", "null", "add")),   # odd plane: scalar loads in the slices; accumulate
+    dict(N=2, Cin=40, Cout=33, H=9, W=32, leaky=True, req=("write", "add", "write")),  # W % 16 == 0: the bf16 x 3 weight gradient, two tiles each way, odd H
+    dict(N=3, Cin=35, Cout=64, H=5, W=16, seed=4),                                     # ... one run per row, an odd number of runs per slice
 ]
 
 
@@ -37,6 +39,28 @@ def emu():
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_backward_emulated(emu, case):
     pc.case_conv_backward(emu, ident, ident, **case)
+
+
+def test_conv_weight_gradient_kernels_follow_the_arithmetic(emu):
+    """Dilation 1 and W % 16 == 0: conv_wgrad_mma_kernel (bf16 x 3 on the matrix cores) under the default arithmetic, conv_wgrad_kernel
+    (fp32 MFMA) under MFN_ARITH_FP32; other widths / dilations: conv_wgrad_kernel always."""
+    from tests.emu import emu_ops
+    case = dict(N=1, Cin=8, Cout=32, H=8, W=16)
+    try:
+        emu_ops.launch_log()
+        pc.case_conv_backward(emu, ident, ident, **case)
+        assert "conv_wgrad_bf16x3" in emu_ops.launch_log()
+        emu_ops.set_tuning(conv_mma=0)
+        emu_ops.launch_log()
+        pc.case_conv_backward(emu, ident, ident, **case)
+        log = emu_ops.launch_log()
+        assert "conv_wgrad_bf16x3" not in log and "conv_wgrad" in log
+        emu_ops.set_tuning(conv_mma=-1)
+        emu_ops.launch_log()
+        pc.case_conv_backward(emu, ident, ident, N=1, Cin=8, Cout=32, H=8, W=24)
+        assert "conv_wgrad_bf16x3" not in emu_ops.launch_log()
+    finally:
+        emu_ops.set_tuning(conv_mma=-1)
 
 
 @pytest.mark.parametrize("shape,factor", [((1, 2, 3, 4), 2), ((2, 1, 4, 5), 4), ((1, 1, 1, 1), 2), ((1, 2, 5, 3), 1),
