@@ -626,10 +626,10 @@ def test_conv3x3_bf16x3_operand_split(ops, oracle, mt, pt):
     pc.case_deconv(ops, oracle, ident, ident, 2, 9, 16, 5, 8, leaky=True)                       # upfeat as a 3x3 convolution
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W", [(21, 32, 6, 16), (40, 64, 7, 12), (19, 96, 5, 8), (64, 64, 4, 24), (35, 128, 4, 8)])
+@pytest.mark.parametrize("Cin,Cout,H,W", [(21, 32, 6, 16), (40, 64, 7, 12), (19, 96, 5, 8), (64, 64, 4, 24), (35, 128, 4, 8),
+                                          (32, 70, 5, 8), (16, 133, 4, 8)])   # filter counts that pad the last M-group (data gradients)
 def test_conv3x3_on_the_matrix_core_deformable_kernel(ops, oracle, Cin, Cout, H, W):
-    """dc_mma_kernel<.., CONV = true> (kernels/deform_conv_mma.h): 3x3 / stride 1 / pad 1 convolutions whose filter count is a multiple
-    of 32 -- channel counts that are no multiple of 16 (zero-padded last group, an odd count's last pair with one channel), ragged pixel
+    """dc_mma_kernel<.., CONV = true> (kernels/deform_conv_mma.h): 3x3 / stride 1 / pad 1 convolutions with at least 32 filters -- channel counts that are no multiple of 16 (zero-padded last group, an odd count's last pair with one channel), ragged pixel
     tiles, one / two / three filter tiles per wave, two M-groups, the K-split tiling (64 filters, groups % 4 == 0), fused LeakyReLU,
     packed weights, a concat slice as input and as output."""
     emu_ops.set_tuning(conv_dcm=2)

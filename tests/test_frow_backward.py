@@ -41,6 +41,19 @@ def test_conv_backward_emulated(emu, case):
     pc.case_conv_backward(emu, ident, ident, **case)
 
 
+def test_conv_data_gradient_on_the_matrix_core_convolution(emu):
+    """The data gradient of a 3x3 / stride 1 convolution is a convolution with the flipped weights and Cin filters: with >= 32 of them
+    it takes dc_mma_kernel<.., CONV> like the forward (forced here: the plan asks for >= 384 pixel tiles)."""
+    from tests.emu import emu_ops
+    try:
+        emu_ops.set_tuning(conv_dcm=2)
+        emu_ops.launch_log()
+        pc.case_conv_backward(emu, ident, ident, N=2, Cin=37, Cout=32, H=6, W=16, leaky=True)
+        assert emu_ops.launch_log().count("conv3x3_dcm") >= 2   # the forward and the data gradient
+    finally:
+        emu_ops.set_tuning(conv_dcm=0)
+
+
 def test_conv_weight_gradient_kernels_follow_the_arithmetic(emu):
     """Dilation 1 and W % 16 == 0: conv_wgrad_mma_kernel (bf16 x 3 on the matrix cores) under the default arithmetic, conv_wgrad_kernel
     (fp32 MFMA) under MFN_ARITH_FP32; other widths / dilations: conv_wgrad_kernel always."""
