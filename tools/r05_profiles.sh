@@ -4,7 +4,8 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 G=gpurun_out
-rm -rf $G/prof_bench $G/prof_cfg5 $G/pmc_FETCH_SIZE $G/pmc_WRITE_SIZE $G/r05p
+rm -rf $G/prof_bench $G/prof_cfg5 $G/pmc_FETCH_SIZE $G/pmc_WRITE_SIZE
+[ -z "$SKIP_PMC" ] && rm -rf $G/r05p
 rm -f $G/bench*.log
 mkdir -p $G/r05p
 if [ -z "$SKIP_BENCH" ]; then
@@ -17,8 +18,9 @@ python bench.py --flow rough --no-side-configs --no-e2e --no-epe --no-cpu-baseli
 fi
 timeout 600 rocprofv3 --kernel-trace --stats -d $G/prof_bench -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-side-configs --no-e2e > $G/r05p/prof_bench.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $G/prof_cfg5 -o cfg5 -- python bench.py --config cfg5 --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-e2e --no-side-configs > $G/r05p/prof_cfg5.log 2>&1
-: > $G/r05p/dc_pmc.txt
-for lvl in 2 3 4 5; do
+[ -z "$SKIP_PMC" ] && : > $G/r05p/dc_pmc.txt
+[ -n "$SKIP_PMC" ] && LEVELS="" || LEVELS="2 3 4 5"
+for lvl in $LEVELS; do
   i=0
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
              "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
@@ -35,4 +37,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $c --kernel-trace -d $G/pmc_$c -o r -- python tools/prof_one.py corr 2 > $G/r05p/pmc_$c.log 2>&1
 done
 ls -la $G/prof_bench $G/prof_cfg5 | head
-tail -40 $G/r05p/dc_pmc.txt
+[ -z "$SKIP_PMC" ] && tail -40 $G/r05p/dc_pmc.txt
