@@ -80,7 +80,8 @@ constexpr int dcm_kc(int mt, int kw) { return mt * kw == 1 ? 3 : 1; }
 constexpr int dcm_nstage(int mt, int pt, int kw, int ring) {
   if (dcm_kc(mt, kw) != 1) return 2;
   const int words3 = 3 * kw * 3 * mt * 256 + pt * kw * (ring * DCM_XW_F + 512) + 256;
-  return words3 * 4 <= 160 * 1024 ? 3 : 2;
+  const int budget = pt * kw <= 4 ? 80 * 1024 : 160 * 1024;   // blocks of four waves are meant to run (at least) two per CU
+  return words3 * 4 <= budget ? 3 : 2;
 }
 // waves per SIMD the register allocator is held to: what one block needs to fit a CU at all (nw / 4), and three / two / one for
 // one / two / more filter tiles per wave (level 2: three 4-wave blocks per CU = the whole launch in one residency round)

@@ -270,7 +270,7 @@ def test_deform_eight_wave_blocks(ops, oracle):
 
 
 # dc_mma_kernel's tilings (filter tiles per wave, pixel tiles per block, waves per block) and a channel count they divide
-DCM_TILINGS = [(1, 4, 4, 32), (2, 3, 12, 64), (3, 1, 6, 96), (1, 1, 8, 128), (1, 1, 4, 64), (1, 1, 2, 32), (1, 1, 1, 48)]
+DCM_TILINGS = [(1, 4, 4, 32), (2, 3, 12, 64), (2, 2, 4, 64), (3, 1, 6, 96), (1, 1, 8, 128), (1, 1, 4, 64), (1, 1, 2, 32), (1, 1, 1, 48)]
 
 
 @pytest.mark.parametrize("mt,pt,nw,C", DCM_TILINGS)

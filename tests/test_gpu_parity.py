@@ -339,7 +339,7 @@ def test_conv_on_the_matrix_core_deformable_kernel_error_vs_fp64(ops, T, dev, ca
     assert err[-1] <= 1e-5 and err[-1] <= 2.0 * err[0] + 2e-7, err
 
 
-@pytest.mark.parametrize("tiling", [(1, 4, 4, 32), (2, 3, 12, 64), (3, 1, 6, 96), (1, 1, 8, 128), (1, 1, 4, 64), (1, 1, 2, 32), (1, 1, 1, 48)])
+@pytest.mark.parametrize("tiling", [(1, 4, 4, 32), (2, 3, 12, 64), (2, 2, 4, 64), (3, 1, 6, 96), (1, 1, 8, 128), (1, 1, 4, 64), (1, 1, 2, 32), (1, 1, 1, 48)])
 def test_deform_mma_tilings_and_window_tiers(ops, oracle, dev, tiling):
     """Every tiling of dc_mma_kernel the library ships (filter tiles per wave, pixel tiles per block, waves per block) on the
     hardware: the small-window tier, gradients only the big window holds, gradients that leave lanes outside both, offsets with no
