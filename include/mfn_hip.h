@@ -272,15 +272,20 @@ int mfn_offsets_from_flow(const float *flow_yx, float *offset, int N, int H, int
  *   Convolution:   out[n,o,y,x] = b[o] + sum_{c,i,j} w[o,c,i,j] * x[n,c, y*sh-ph+i*dh, x*sw-pw+j*dw]      (zero outside)
  *   Deconvolution: out[n,o,y,x] = b[o] + sum_{c,i,j} w[c,o,i,j] * x[n,c,(y+ph-i*dh)/sh,(x+pw-j*dw)/sw]   (exact divisions only)
  * x: (N,Cin,H,W); w: (Cout,Cin/groups,kh,kw), transposed: (Cin,Cout/groups,kh,kw); out: (N,Cout,Ho,Wo) from
- * mfn_conv2d_out_shape.  3x3 convolutions and 4x4 transposed convolutions with groups == 1 run fused gather + fp32-MFMA
- * implicit GEMM kernels (no im2col buffer); every other parameter set runs a generic kernel.
+ * mfn_conv2d_out_shape.  3x3 convolutions and 4x4 transposed convolutions with groups == 1 run fused gather + matrix-core
+ * implicit GEMM kernels (no im2col buffer; arithmetic per mfn_set_arithmetic("convolution", ..): the default is fp32-EQUIVALENT --
+ * operands as three bf16 terms, see "Arithmetic" --, MFN_ARITH_FP32 the bit-exact fp32 MFMA chain); every other parameter set
+ * runs a generic kernel.
  * activation: MFN_ACT_NONE | MFN_ACT_LEAKY_0_1 (fused, bit-identical to the separate elementwise op).
  * out_batch_stride / in_batch_stride: elements between consecutive output / input images (0 = dense): a layer writes
  * straight into its channel slice of the decoder's concat buffer and the next layer reads the buffer's channel suffix
  * (x = concat(conv(x), x), MaskFlownet.py:219-223) -- no concat copies.
  * Weights: give `w` (re-laid-out into `workspace` on every call, mfn_conv2d_workspace_bytes) or a buffer made once by
  * mfn_conv2d_pack_weights + its layout tag (mfn_conv2d_packed_weight_bytes; a tag that does not match the plan of the
- * current shape / tuning is refused, never silently used).
+ * current shape / tuning is refused, never silently used).  3x3 / stride 1 / pad 1 layers with >= 32 filters on large images are
+ * packed for the deformable convolution's matrix-core kernel (kernels/deform_conv_mma.h, CONV form): a call with such a buffer needs
+ * x and out 16-byte aligned and batch strides that are multiples of 4 elements (MFN_E_ALIGN otherwise; a call that gives `w` picks
+ * the other kernel by itself).
  * ------------------------------------------------------------------------------------------- */
 int mfn_conv2d_out_shape(int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int transposed,
                          int adj_h, int adj_w, int *Ho, int *Wo);
