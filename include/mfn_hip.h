@@ -356,7 +356,11 @@ int mfn_profile_dump(char *buf, int cap);
  * fp32-EQUIVALENT, not the bit pattern of an FMA chain.  Divergence on non-finite inputs: an +-inf operand splits into
  * inf + NaN (inf - bf16(inf)), so outputs that an FMA chain would make +-inf come back NaN; NaN inputs give NaN either way;
  * values beyond bf16's range do not exist (bf16 has fp32's exponent); fp32 denormal operands lose their low terms (flushed), an
- * absolute error below 2^-126 per product.
+ * absolute error below 2^-126 per product.  Which OUTPUTS a non-finite input pixel reaches: under the default arithmetic the
+ * deformable convolution's taps outside the image read zeros, so exactly the outputs whose valid taps touch the pixel (MXNet's
+ * set); the fp32 kernel (MFN_ARITH_FP32, dc_lds_kernel) multiplies border-clamped reads by zero weights, so a non-finite pixel
+ * within three rows / columns of the border also poisons neighbouring outputs whose taps fall outside the image
+ * (tests/test_gpu_parity.py::test_deform_numeric_range_edge_cases).
  * Layouts packed by mfn_deform_conv_pack_weights / mfn_conv2d_pack_weights depend on the arithmetic of the thread that packed
  * them; a call under another arithmetic refuses them (layout tag) instead of misreading them.
  * op: "correlation" | "deformable_convolution" | "convolution" | "all".  Unknown op / mode: MFN_E_PARAM. */

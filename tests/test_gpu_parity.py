@@ -159,6 +159,52 @@ def test_correlation_numeric_range_edge_cases(ops, oracle, dev):
             assert np.array_equal(got[inf], want[inf])
 
 
+def test_deform_numeric_range_edge_cases(ops, oracle, dev):
+    """The deformable convolution under both arithmetics on features spanning 1e-12 ... 1e12 across the channels, fp32 denormals, and
+    +-inf / NaN in single input pixels: finite inputs agree with the oracle (to 1e-5 of the largest entry); wherever the oracle's
+    result is non-finite so is the kernel's (bf16 x 3 may turn an inf into NaN: include/mfn_hip.h "Arithmetic"), and every output
+    the oracle keeps finite stays finite and right -- a poisoned pixel reaches exactly the outputs whose taps read it."""
+    from maskflownet_amd import _lib, hotpath
+    rng = np.random.default_rng(78)
+    N, C, H, W = 2, 32, 24, 32
+    x = pc.feat(rng, (N, C, H, W))
+    w = pc.msra_weight(rng, C, C)
+    b = (rng.standard_normal((C,)) * 0.1).astype(np.float32)
+    fl = (pc.flow_field(rng, N, H, W, sigma=2.0) * np.float32(4.0 / 20.0)).astype(np.float32)
+    off = oracle.offsets_from_flow(fl, 20.0, 4.0)
+    mag = (10.0 ** np.linspace(-12, 12, C)).astype(np.float32)[None, :, None, None]
+    xr = (x * mag).astype(np.float32)
+    xr[0, :, 3, 5] = np.float32(1e-41)       # denormals
+    xr[1, 4, 7, 9] = np.float32(-3e-42)
+    want = oracle.deformable_convolution(xr, off, w, b, kernel=(3, 3), pad=(1, 1))
+    for arith in (0, -1):
+        _lib.set_arithmetic(deformable_convolution=arith)
+        got = host(ops.DeformableConvolution(dev(xr), dev(off), dev(w), dev(b), kernel=(3, 3), pad=(1, 1), num_filter=C))
+        pc.check_close(got, want, what="wide dynamic range, arithmetic %d" % arith)
+    xn = x.copy()
+    xn[0, 3, 10, 11] = np.inf
+    xn[0, 7, 12, 20] = -np.inf
+    xn[1, 0, 2, 2] = np.nan
+    want = oracle.deformable_convolution(xn, off, w, b, kernel=(3, 3), pad=(1, 1))
+    bad = ~np.isfinite(want)
+    assert bad.any() and not bad.all()
+    for arith in (0, -1):
+        _lib.set_arithmetic(deformable_convolution=arith)
+        got = host(ops.DeformableConvolution(dev(xn), dev(off), dev(w), dev(b), kernel=(3, 3), pad=(1, 1), num_filter=C))
+        assert not np.isfinite(got[bad]).any(), "arithmetic %d: a non-finite result came back finite" % arith
+        fin = np.isfinite(got)
+        if arith == -1:   # the default kernel: taps outside the image read the window's zeros -- exactly the oracle's set
+            assert fin[~bad].all(), "a finite result was poisoned"
+        else:             # dc_lds_kernel multiplies border-CLAMPED reads by zero weights: a non-finite pixel within three columns / rows
+            extra = ~fin & ~bad      # of the border also reaches outputs next to it whose taps fall outside (include/mfn_hip.h "Arithmetic")
+            near = np.zeros_like(extra)
+            near[1, :, :7, :7] = True      # around the NaN at (1, 0, 2, 2); the two infinities sit in the interior
+            assert not (extra & ~near).any(), "a finite result far from the border pixel was poisoned"
+        ok = fin & ~bad
+        assert np.abs(got[ok] - want[ok]).max() <= 1e-5 * np.abs(want[ok]).max()
+    _lib.set_arithmetic(deformable_convolution=-1)
+
+
 @pytest.mark.parametrize("variant", [44, 45])
 @pytest.mark.parametrize("shape,md", [((8, 196, 6, 8), 4), ((8, 128, 12, 16), 4), ((8, 96, 24, 32), 4), ((8, 64, 48, 64), 4),   # levels 6..3 of configs[1]
                                       ((4, 196, 7, 16), 4), ((4, 128, 14, 32), 4),                                          # configs[2]: odd heights
