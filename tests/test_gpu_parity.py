@@ -318,7 +318,7 @@ def test_deform_mma_error_vs_fp64(ops, oracle, dev, level, flow, cfg):
         np.testing.assert_array_equal(fused, got)
         res[mma] = float(np.abs(got.astype(np.float64) - want64).max() / np.abs(want64).max())
     print("%s level %d %s: max rel err vs fp64  fp32 kernel %.3e   bf16x3 %.3e" % (cfg, 6 - level, flow, res[0], res[1]))
-    assert res[1] <= 1e-5 and res[1] <= 2.0 * res[0] + 2e-7, res
+    assert res[1] <= 1e-5 and res[1] <= 1.25 * res[0] + 1e-7, res   # observed 0.70 ... 1.10 x (profiles/r05_fp64_errors.txt)
 
 
 @pytest.mark.parametrize("case", [dict(N=2, Cin=128, Cout=128, H=48, W=64, dilate=(2, 2), pad=(2, 2)),     # four filter tiles per wave
