@@ -354,7 +354,7 @@ inline int corr_tiled_launch(CorrParams p, hipStream_t stream, const char *name)
 // 4-channel stages, no register prefetch, >= 4 waves per SIMD -- the kernel of images narrower than 32 columns
 // (corr.variant 6).  Rounds 1 / 2 swept eight points and a half-wave form (corr_hw_kernel); none of them is selected by a plan.
 constexpr int kCorrVariants = 48;  // valid values of corr.variant: 6 (corr_tiled_kernel), 16 / 20 / 22 / 26 / 31 (corr_dma_kernel), 40 / 41 / 42 / 43 (corr_gram_kernel), 44 / 45 (corr_gramk_kernel)
-inline bool corr_variant_known(int v) { return v == 6 || v == 16 || v == 20 || v == 22 || v == 26 || v == 31 || (v >= 40 && v <= 45); }
+inline bool corr_variant_known(int v) { return v == 6 || v == 16 || v == 20 || v == 22 || v == 26 || v == 31 || (v >= 40 && v <= 48); }
 template <int D, int TW>
 inline int corr_tiled_variant(const CorrParams &p, int /*variant*/, hipStream_t s) {
   return corr_tiled_launch<D, TW, 1, 4, 1, false, 4>(p, s, "corr_tiled_v6");

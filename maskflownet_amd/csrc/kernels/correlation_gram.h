@@ -60,15 +60,24 @@ struct CorrGramParams {
   int rows;               // output rows per work item (even)
   int strips, segs;       // ceil(W / 8), ceil(H / rows)
   int bx_per_row;         // blocks along x: ceil(strips / waves per block)
+  unsigned bx_magic, segs_magic;   // mfn_make_magic of bx_per_row / segs: block id -> (strip group, segment, image) by two
+                                   // s_mul_hi_u32 instead of two runtime divisions (~40 scalar instructions in front of the first DMA)
   size_t out_nstride;     // elements between images of `out` (a channel slice of a concat buffer when > D*D*H*W)
   int store_policy;       // mfn_bstore4
   int leaky;              // fused LeakyReLU(0.1)
-  int xcd_swizzle;
+  int xcd_swizzle;        // 0, or the number of blocks of the launch (mfn_xcd_remap's range: no second, dependent kernarg load for gridDim)
+  int prio;               // measurement (corr.prio): how the younger block of a CU is helped against the age arbitration
   float inv_c;            // 1/32, folded into the f1 operand before the split (a power of two: exact)
   unsigned long long *timeline;  // measurement builds only (-DMFN_TIMELINE=1): 4 stamps per block, or NULL
 };
 
 struct GramOp { mfn_bf16x8 h, m, l; };
+// TERMS == 1: the raw fp32 values themselves -- value j is channel 4j + lane/16 of the lane's pixel, which is exactly the A / B
+// operand of K step j of v_mfma_f32_16x16x4_f32 (lane = pixel + 16 k): no conversion at all, eight fp32 matrix instructions per
+// chain (an fmaf chain over the channels in order, bitwise) instead of six bf16 ones.
+struct GramOpF { float r[8]; };
+template <int TERMS> struct GramOpSel { typedef GramOp type; };
+template <> struct GramOpSel<1> { typedef GramOpF type; };
 
 // One PAIR of fp32 values -> word q of the three bf16 terms (mfn_split3x8 / mfn_split2x8 of mfn_rt.h, a quarter at a time, so that
 // the kernel can place the nine VALU instructions of a pair behind one matrix instruction).
@@ -106,6 +115,56 @@ __device__ __forceinline__ void gram_words_to_op(const GramWords &w, GramOp &o) 
   const u32x4_ h = {w.h[0], w.h[1], w.h[2], w.h[3]}, m = {w.m[0], w.m[1], w.m[2], w.m[3]}, l = {w.l[0], w.l[1], w.l[2], w.l[3]};
   o.h = __builtin_bit_cast(mfn_bf16x8, h); o.m = __builtin_bit_cast(mfn_bf16x8, m); o.l = __builtin_bit_cast(mfn_bf16x8, l);
 #endif
+}
+
+// TERMS == 4: the same three terms, the residuals formed ON THE MATRIX CORES (round 6).  The operand split of TERMS == 3 is nine
+// VALU instructions per pair of values: three v_cvt_pk_bf16_f32 and, to get each residual x - float(bf16(x)), a shift, a mask and a
+// packed subtract -- 646 of a wave's 912 VALU instructions at level 2, on a SIMD whose issue slots are what bounds the kernel
+// (profiles/r04_corr_pmc.md).  But the accumulator layout of v_mfma_f32_16x16x32_bf16 (lane = column n + 16 g, register i = row
+// 4 g + i) IS the operand layout (lane = column + 16 k-block, eight K values) when rows are read as K slots: with the eight raw
+// values of a lane held as two accumulator tiles C0 = raw[0..3], C1 = raw[4..7] and their bf16 roundings as a B operand Hb,
+//   C0 <- Sel0 * Hb + C0,   Sel0[r][k] = -1 if k == 8 (r / 4) + r % 4 else 0     (Sel1: ... + 4)
+// subtracts from every register exactly the bf16 value the SAME lane holds in K slot i (i + 4): the residual, exact in fp32
+// (products -1 * h and 0 * h are exact, the sum has one non-zero term and x - h is representable).  A tile's split is then
+// 3 x 4 v_cvt_pk_bf16_f32 + 2 x 2 matrix instructions on a pipe that idles 78 % of the time, instead of 36 VALU instructions;
+// the terms are bit-identical to TERMS == 3's (same roundings).  Non-finite inputs: 0 * inf = NaN spreads an inf to the residuals
+// of the pixel's other channels of the tile -- every output that pixel takes part in is NaN (TERMS == 3: NaN as well, through
+// inf - inf in the channel itself): the documented behaviour (include/mfn_hip.h "Arithmetic") is unchanged.
+struct GramSel { mfn_bf16x8 s0, s1; };
+__device__ __forceinline__ GramSel gram_make_sel(int lane) {
+  const int m = lane & 15, kb = lane >> 4;
+  const bool on = kb == (m >> 2);
+  const unsigned one = 0xBF80u << (16 * (m & 1));          // -1.0 as bf16, in K slot m % 4 of the lane's k-block
+  const unsigned w0 = (on && (m & 2) == 0) ? one : 0u, w1 = (on && (m & 2) != 0) ? one : 0u;
+  GramSel r;
+  r.s0 = mfn_words_to_bf16x8(w0, w1, 0u, 0u);
+  r.s1 = mfn_words_to_bf16x8(0u, 0u, w0, w1);
+  return r;
+}
+// eight fp32 values (two accumulator tiles) -> their bf16 roundings as one operand: 4 x v_cvt_pk_bf16_f32
+__device__ __forceinline__ mfn_bf16x8 gram_cvt8(const f32x4 &a, const f32x4 &b) {
+#if defined(MFN_EMU)
+  unsigned w[4];
+  for (int q = 0; q < 2; ++q) {
+    w[q] = (unsigned)hipemu_f32_to_bf16(a[2 * q]) | ((unsigned)hipemu_f32_to_bf16(a[2 * q + 1]) << 16);
+    w[2 + q] = (unsigned)hipemu_f32_to_bf16(b[2 * q]) | ((unsigned)hipemu_f32_to_bf16(b[2 * q + 1]) << 16);
+  }
+  return mfn_words_to_bf16x8(w[0], w[1], w[2], w[3]);
+#else
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  const f32x2 p0 = {a[0], a[1]}, p1 = {a[2], a[3]}, p2 = {b[0], b[1]}, p3 = {b[2], b[3]};
+  return mfn_words_to_bf16x8(__builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf2)), __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf2)),
+                             __builtin_bit_cast(unsigned, __builtin_convertvector(p2, bf2)), __builtin_bit_cast(unsigned, __builtin_convertvector(p3, bf2)));
+#endif
+}
+// one stage of the matrix-core split of a tile held as (x0, x1): even stages round the present residual into term st / 2,
+// odd stages subtract that term
+__device__ __forceinline__ void gram_msplit_stage(int st, const GramSel &sel, f32x4 &x0, f32x4 &x1, mfn_bf16x8 (&term)[3]) {
+  if ((st & 1) == 0) term[st >> 1] = gram_cvt8(x0, x1);
+  else {
+    x0 = MFN_MFMA_16x16x32_BF16(sel.s0, term[st >> 1], x0);
+    x1 = MFN_MFMA_16x16x32_BF16(sel.s1, term[st >> 1], x1);
+  }
 }
 
 // The static schedule of a wave.  D = 2*md+1; T = f1 blocks (8 x 2 px) per work item: the item's rows are 2T.  Step
@@ -157,6 +216,15 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   constexpr int XOFF = 4;            // the f2 segment starts XOFF columns left of the strip (16-byte aligned, >= MD)
   constexpr unsigned INVALID = 0xFFFFFF00u;
   static_assert(MD >= 1 && MD <= 4 && T >= 1 && NSLOT >= 3 && NSLOT <= TT, "band wider than the 16-px segment / ring deeper than the item");
+  // TERMS: 1 fp32 matrix instructions on the raw values; 2 / 3 bf16 terms split on the VALU; 4 three terms split on the matrix
+  // cores (MSPLIT); 5 the same with the results' way out pipelined one step behind the chains (PIPE, cooperative form only):
+  // step j's matrix instructions cover the de-skew + staging of step j-1's accumulators and the read-back + stores of step
+  // j-2's lines, so that a step is [operand reads] [matrix instructions with everything else between them] [DMA issue] [barrier]
+  // instead of ending in a serial tail (row shifts that wait for the last matrix instruction, five masked 16-byte LDS writes,
+  // barrier, read-back, stores) that nothing covered.
+  constexpr bool MSPLIT = TERMS >= 4;
+  constexpr bool PIPE = TERMS == 5;
+  static_assert(!PIPE || (COOP && MFN_GRAM_ABLATE == 0), "the pipelined way out is the cooperative form's");
 
   const int H = p.H, W = p.W;
   const int plane = H * W;
@@ -172,9 +240,13 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   unsigned voffN[2], voffM[2];
   {
     const int xq = x0 - XOFF + 4 * (lane & 3);
-    const bool okN = xq >= 0 && xq < W;
+    bool okN = xq >= 0 && xq < W;
     const int xm = x0 + 4 * (lane & 1);
-    const bool okM = xm < W;
+    bool okM = xm < W;
+    // measurement (corr.prio bits; wrong results): 8 = only the two middle quads of an f2 segment are fetched, 16 = no f2 fetch, 32 = no f1 fetch
+    if ((p.prio & 8) && ((lane & 3) == 0 || (lane & 3) == 3)) okN = false;
+    if (p.prio & 16) okN = false;
+    if (p.prio & 32) okM = false;
     MFN_UNROLL
     for (int j = 0; j < 2; ++j) {
       const int c = (lane >> 2) + 16 * j;
@@ -225,19 +297,40 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     stamp[k] = n_issued;
   };
   auto wait_tile = [&](int k) { mfn_wait_vm_dyn(n_issued - stamp[k]); };
+  // prologue: the first NSLOT tiles go out BEFORE the store-side geometry below is computed (round 6: ~230 instructions, two of
+  // them runtime divisions, used to stand between the kernel's entry and its first load); tiles 0 (block 0) and 1 (the f2 row
+  // of own step 0) become the first operands
+  mfn_static_for<NSLOT>([&](auto k_c) __attribute__((always_inline)) { issue_tile(k_c); });
+  MFN_SCHED_BARRIER();
   float raw[8];
   auto read_raw = [&](int k) {
     const float *su = ring + (k % NSLOT) * SLOT_F + rdoff;
     MFN_UNROLL
     for (int j = 0; j < 8; ++j) raw[j] = su[64 * j];
   };
-  GramOp Mreg[T];
-  GramOp Ncur;
-  auto convert = [&](GramOp &o, float scale) {
-    GramWords w;
-    MFN_UNROLL
-    for (int q = 0; q < 4; ++q) gram_split_pair<TERMS>(raw[2 * q] * scale, raw[2 * q + 1] * scale, w, q);
-    gram_words_to_op(w, o);
+  typedef typename GramOpSel<(TERMS == 1 ? 1 : 3)>::type Op;
+  Op Mreg[T];
+  Op Ncur;
+  GramSel sel;
+  if constexpr (MSPLIT) sel = gram_make_sel(lane);
+  auto convert = [&](Op &o, float scale) {
+    if constexpr (MSPLIT) {
+      f32x4 x0, x1;
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) { x0[q] = raw[q] * scale; x1[q] = raw[4 + q] * scale; }
+      mfn_bf16x8 term[3];
+      MFN_UNROLL
+      for (int st = 0; st < 5; ++st) gram_msplit_stage(st, sel, x0, x1, term);
+      o.h = term[0]; o.m = term[1]; o.l = term[2];
+    } else if constexpr (TERMS == 1) {
+      MFN_UNROLL
+      for (int q = 0; q < 8; ++q) o.r[q] = raw[q] * scale;
+    } else {
+      GramWords w;
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) gram_split_pair<TERMS>(raw[2 * q] * scale, raw[2 * q + 1] * scale, w, q);
+      gram_words_to_op(w, o);
+    }
   };
   // per block: descriptor of its output rows and the store offsets with the rows a short last segment does not have masked
   mfn_rsrc_t rs[T];
@@ -292,8 +385,6 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     for (int t = 0; t < T; ++t) rowok_bits |= (2 * t < R ? 1u : 0u) << (2 * t) | (2 * t + 1 < R ? 1u : 0u) << (2 * t + 1);
   }
 
-  // prologue: the first NSLOT tiles; tiles 0 (block 0) and 1 (the f2 row of own step 0) -> operands; two more tiles
-  mfn_static_for<NSLOT>([&](auto k_c) __attribute__((always_inline)) { issue_tile(k_c); });
   wait_tile(1);
   MFN_STAMP(p.timeline, 1);
   read_raw(0); convert(Mreg[0], p.inv_c);
@@ -330,6 +421,26 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     }
   };
 
+  // de-skew + stage chain ci (block t_hi - ci) of step s out of a[] into sbuf: the cooperative form's way out of the registers
+  auto stage_chain = [&](int s, int ci, const f32x4 *a, float *sbuf, unsigned &valid_bits) __attribute__((always_inline)) {
+    const int t = Ch::hi(s) - ci;
+    const int e = s - 2 * t;
+    f32x4 v;
+    v[0] = a[t][0];
+    v[1] = mfn_dpp_row_shl<1>(a[t][1], a[t][1]);
+    v[2] = mfn_dpp_row_shl<2>(a[t][2], a[t][2]);
+    v[3] = mfn_dpp_row_shl<3>(a[t][3], a[t][3]);
+    if (LEAKY) {
+      MFN_UNROLL
+      for (int i = 0; i < 4; ++i) v[i] = mfn_leaky01(v[i]);
+    }
+    if (e < D) valid_bits |= ((rowok_bits >> (2 * t)) & 1u) << (ci * 2);
+    if (e >= 1) valid_bits |= ((rowok_bits >> (2 * t + 1)) & 1u) << (ci * 2 + 1);
+    if (stw[ci] >= 0) *reinterpret_cast<f32x4 *>(sbuf + stw[ci]) = v;
+  };
+  f32x4 accP[T];                    // PIPE: the previous step's accumulators
+  unsigned valid_staged = 0;        // PIPE: valid_bits of the lines staged during the previous step
+
   mfn_static_for<J>([&](auto j_c) __attribute__((always_inline)) {
     constexpr int j = decltype(j_c)::value;
     constexpr int s = SC::step(j);
@@ -339,7 +450,7 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     constexpr bool moreM = tM >= 0;
     constexpr int kN = more ? SC::seqN(j + 1) : 0;
     if (more) wait_tile(kN);
-    GramOp Nnext;
+    Op Nnext;
     // raw tiles of the next step out of LDS first: their conversion (VALU) hides behind this step's matrix instructions
     float rawM[8], rawN[8];
     if (moreM) { read_raw(kN - 1); MFN_UNROLL for (int i = 0; i < 8; ++i) rawM[i] = raw[i] * p.inv_c; }
@@ -350,22 +461,59 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     // and the conversion of the next step's operands is spread between them pair by pair (MFN_GRAM_SCHED pins that order with
     // scheduling fences; measured: 13.85 us with, 13.75 us without -- the wave is bound by its VALU / VMEM issue, not by
     // the order, profiles/r04_corr_gram_experiments.md).
-    constexpr int NPROD = TERMS == 3 ? 6 : 3;
-    constexpr int npairs = (moreM ? 4 : 0) + (more ? 4 : 0);
+    constexpr int NPROD = TERMS >= 3 ? 6 : (TERMS == 1 ? 8 : 3);
+    constexpr int npairs = (TERMS == 1 || MSPLIT) ? 0 : (moreM ? 4 : 0) + (more ? 4 : 0);
+    // MSPLIT: the next step's tiles as accumulator tiles; five split stages spread between this step's chains
+    f32x4 xM0, xM1, xN0, xN1;
+    mfn_bf16x8 cM[3], cN[3];
+    int next_stage = 0;
+    if constexpr (MSPLIT) {
+      MFN_UNROLL
+      for (int q = 0; q < 4; ++q) {
+        if (moreM) { xM0[q] = rawM[q]; xM1[q] = rawM[4 + q]; }
+        if (more) { xN0[q] = rawN[q]; xN1[q] = rawN[4 + q]; }
+      }
+    }
+    auto split_stage = [&]() {
+      if constexpr (MSPLIT) {
+        if (moreM) gram_msplit_stage(next_stage, sel, xM0, xM1, cM);
+        if (more) gram_msplit_stage(next_stage, sel, xN0, xN1, cN);
+        ++next_stage;
+      }
+    };
     int done_pairs = 0, unit = 0, nunits = 0;
     MFN_UNROLL
     for (int t = 0; t < T; ++t) if (s - 2 * t >= 0 && s - 2 * t <= 2 * MD + 1) nunits += NPROD;
     auto convert_next_pair = [&]() {
-      if (done_pairs < npairs) {
-        const int q = done_pairs & 3;
-        if (moreM && done_pairs < 4) gram_split_pair<TERMS>(rawM[2 * q], rawM[2 * q + 1], wM, q);
-        else gram_split_pair<TERMS>(rawN[2 * q], rawN[2 * q + 1], wN, q);
-        ++done_pairs;
+      if constexpr (TERMS != 1 && !MSPLIT) {
+        if (done_pairs < npairs) {
+          const int q = done_pairs & 3;
+          if (moreM && done_pairs < 4) gram_split_pair<TERMS>(rawM[2 * q], rawM[2 * q + 1], wM, q);
+          else gram_split_pair<TERMS>(rawN[2 * q], rawN[2 * q + 1], wN, q);
+          ++done_pairs;
+        }
       }
     };
     f32x4 acc[T];
     MFN_UNROLL
     for (int t = 0; t < T; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+    // PIPE: what leaves the registers behind this step's matrix instructions -- the chains of step j-1 (accP) into staging buffer
+    // (j-1) & 1 and, read back first, the lines of step j-2 out of buffer j & 1 (staged during step j-1, barrier at its end)
+    constexpr int sP = j > 0 ? SC::step(j > 0 ? j - 1 : 0) : 0;
+    constexpr int nchP = (PIPE && j > 0) ? Ch::hi(sP) - Ch::lo(sP) + 1 : 0;
+    constexpr int nsjPP = (PIPE && j > 1) ? Ch::per_wave(SC::step(j > 1 ? j - 2 : 0)) : 0;
+    f32x4 vpp[nsjPP > 0 ? nsjPP : 1];
+    if constexpr (PIPE && j > 1) {
+      const float *pbuf = stg + (j & 1) * STG_F;
+      MFN_UNROLL
+      for (int jj = 0; jj < nsjPP; ++jj) vpp[jj] = *reinterpret_cast<const f32x4 *>(pbuf + (wave + 4 * jj) * 256 + strd_off);
+    }
+    unsigned valid_bitsP = 0;
+    int post_done = 0;
+    auto post_chain = [&]() {
+      stage_chain(sP, post_done, accP, stg + ((j + 1) & 1) * STG_F, valid_bitsP);
+      ++post_done;
+    };
     if (!(MFN_GRAM_ABLATE & 1)) {
       MFN_UNROLL
       for (int k = 0; k < NPROD; ++k) {
@@ -373,11 +521,20 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
         for (int t = 0; t < T; ++t) {
           const int e = s - 2 * t;
           if (e >= 0 && e <= 2 * MD + 1) {
-            const GramOp &Mo = Mreg[t];
-            // smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h (two terms: l*h, h*l, h*h)
-            const mfn_bf16x8 &a = TERMS == 3 ? (k == 0 ? Mo.l : (k == 2 || k == 3 ? Mo.m : Mo.h)) : (k == 0 ? Mo.l : Mo.h);
-            const mfn_bf16x8 &b = TERMS == 3 ? (k == 1 ? Ncur.l : (k == 2 || k == 4 ? Ncur.m : Ncur.h)) : (k == 1 ? Ncur.l : Ncur.h);
-            acc[t] = MFN_MFMA_16x16x32_BF16(a, b, acc[t]);
+            const Op &Mo = Mreg[t];
+            if constexpr (TERMS == 1) {
+              acc[t] = MFN_MFMA_16x16x4(Mo.r[k], Ncur.r[k], acc[t]);   // channels 4k .. 4k+3
+            } else {
+              // smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h (two terms: l*h, h*l, h*h)
+              const mfn_bf16x8 &a = TERMS >= 3 ? (k == 0 ? Mo.l : (k == 2 || k == 3 ? Mo.m : Mo.h)) : (k == 0 ? Mo.l : Mo.h);
+              const mfn_bf16x8 &b = TERMS >= 3 ? (k == 1 ? Ncur.l : (k == 2 || k == 4 ? Ncur.m : Ncur.h)) : (k == 1 ? Ncur.l : Ncur.h);
+              acc[t] = MFN_MFMA_16x16x32_BF16(a, b, acc[t]);
+            }
+            if constexpr (MSPLIT) {   // stage i behind unit floor(i * nunits / 5)
+              while (more && next_stage < 5 && next_stage * nunits <= unit * 5) split_stage();
+              if constexpr (PIPE) while (post_done < nchP && post_done * nunits <= unit * nchP) post_chain();
+              MFN_SCHED_BARRIER();
+            }
             if (MFN_GRAM_SCHED) {   // pair i behind unit floor(i * nunits / npairs)
               while (done_pairs < npairs && done_pairs * nunits <= unit * npairs) convert_next_pair();
               MFN_SCHED_BARRIER();
@@ -388,8 +545,17 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
       }
     }
     while (done_pairs < npairs) convert_next_pair();
-    if (moreM) gram_words_to_op(wM, Mreg[moreM ? tM : 0]);
-    if (more) gram_words_to_op(wN, Nnext);
+    if constexpr (MSPLIT) {
+      while (more && next_stage < 5) split_stage();
+      if (moreM) { Mreg[moreM ? tM : 0].h = cM[0]; Mreg[moreM ? tM : 0].m = cM[1]; Mreg[moreM ? tM : 0].l = cM[2]; }
+      if (more) { Nnext.h = cN[0]; Nnext.m = cN[1]; Nnext.l = cN[2]; }
+    } else if constexpr (TERMS == 1) {
+      if (moreM) { MFN_UNROLL for (int i = 0; i < 8; ++i) Mreg[moreM ? tM : 0].r[i] = rawM[i]; }
+      if (more) { MFN_UNROLL for (int i = 0; i < 8; ++i) Nnext.r[i] = rawN[i]; }
+    } else {
+      if (moreM) gram_words_to_op(wM, Mreg[moreM ? tM : 0]);
+      if (more) gram_words_to_op(wN, Nnext);
+    }
     MFN_WAIT_LGKM0();                      // the ring slots of the tiles just read are free: the next tiles of the sequence go there
     {
       constexpr int consumed = more ? kN + 1 : TT;       // tiles read so far
@@ -399,7 +565,17 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
         if constexpr (more && decltype(i_c)::value < (moreM ? 2 : 1) && k < TT) issue_tile(std::integral_constant<int, k>{});
       });
     }
-    if (!(MFN_GRAM_ABLATE & 1)) {
+    if constexpr (PIPE) {
+      while (post_done < nchP) post_chain();
+      if constexpr (j > 1) store_lines(std::integral_constant<int, (j > 1 ? j - 2 : 0)>{}, vpp, valid_staged);
+      valid_staged = valid_bitsP;
+      if ((p.prio & 7) >= 2) {   // measurement: the younger block of the CU gets the higher priority in (prio - 1) of every 4 steps
+        if (MFN_HW_WAVE_SLOT() != 0 && (j & 3) < (p.prio & 7) - 1) MFN_SETPRIO(1); else MFN_SETPRIO(0);
+      }
+      MFN_LDS_BARRIER();              // step j-1's lines are staged (read back in step j+1); buffer j & 1 is free for step j's
+      MFN_UNROLL
+      for (int t = 0; t < T; ++t) accP[t] = acc[t];
+    } else if (!(MFN_GRAM_ABLATE & 1)) {
       // active chains of this step, highest block first (ci = 0, 1, ...): t_hi = min(T-1, s/2) downwards while e = s - 2t <= 2MD+1
       constexpr int t_hi = chains_hi(s);
       constexpr int nch = t_hi - chains_lo(s) + 1;
@@ -448,7 +624,30 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     if (j == J / 2 - 1) MFN_STAMP(p.timeline, 2);
     MFN_SCHED_BARRIER();
   });
-  if (COOP && !(MFN_GRAM_ABLATE & 1)) {   // the last step's lines
+  if constexpr (PIPE) {   // what is still on its way: step J-1 in the registers, step J-2 in staging buffer J & 1
+    constexpr int sL = SC::step(J - 1);
+    constexpr int nchL = Ch::hi(sL) - Ch::lo(sL) + 1;
+    unsigned valid_last = 0;
+    MFN_UNROLL
+    for (int ci = 0; ci < nchL; ++ci) stage_chain(sL, ci, accP, stg + ((J - 1) & 1) * STG_F, valid_last);
+    {
+      constexpr int nsj = Ch::per_wave(SC::step(J - 2));
+      f32x4 v2[nsj];
+      const float *pbuf = stg + (J & 1) * STG_F;
+      MFN_UNROLL
+      for (int jj = 0; jj < nsj; ++jj) v2[jj] = *reinterpret_cast<const f32x4 *>(pbuf + (wave + 4 * jj) * 256 + strd_off);
+      store_lines(std::integral_constant<int, J - 2>{}, v2, valid_staged);
+    }
+    MFN_LDS_BARRIER();
+    {
+      constexpr int nsj = Ch::per_wave(sL);
+      f32x4 v1[nsj];
+      const float *pbuf = stg + ((J - 1) & 1) * STG_F;
+      MFN_UNROLL
+      for (int jj = 0; jj < nsj; ++jj) v1[jj] = *reinterpret_cast<const f32x4 *>(pbuf + (wave + 4 * jj) * 256 + strd_off);
+      store_lines(std::integral_constant<int, J - 1>{}, v1, valid_last);
+    }
+  } else if (COOP && !(MFN_GRAM_ABLATE & 1)) {   // the last step's lines
     constexpr int nsj = Ch::per_wave(SC::step(J - 1));
     f32x4 vlast[nsj];
     MFN_LDS_BARRIER();
@@ -474,20 +673,24 @@ __global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p
   const int wave = MFN_UNIFORM(threadIdx.x >> 6);
   float *ring = lds_all + (size_t)wave * NSLOT * 512;
   MFN_STAMP(p.timeline, 0);
+  if ((p.prio & 7) == 1 && MFN_HW_WAVE_SLOT() != 0) MFN_SETPRIO(1);
   int bid = blockIdx.x;
-  if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, gridDim.x);
-  const int bxs = bid % p.bx_per_row;
-  int rest = bid / p.bx_per_row;
+  if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)p.xcd_swizzle);
+  // exact for bid < 2^32 / divisor (the launch checks it): q = floor(bid * ceil(2^32 / d) / 2^32)
+  int rest = (int)mfn_div_magic((unsigned)bid, p.bx_magic);
+  const int bxs = bid - rest * p.bx_per_row;
   const int par = rest % SP;
   rest /= SP;
-  const int seg = rest % p.segs;
-  const int n = rest / p.segs;
+  const int n = (int)mfn_div_magic((unsigned)rest, p.segs_magic);
+  const int seg = rest - n * p.segs;
   const int sx = bxs * NWV + wave;
   if (!COOP && sx >= p.strips) return;   // COOP: a wave past the last strip keeps the block's barriers company (its lanes are all masked)
   const int x0 = sx * 8, ys = seg * (2 * T);
-  if (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * 512, wave, bxs * NWV * 8);
-  else if (SP == 1 || par == 0) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, 0>(p, ring, lane, n, ys, x0);
-  else corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, SP - 1>(p, ring, lane, n, ys, x0);
+  if constexpr (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * 512, wave, bxs * NWV * 8);
+  else {
+    if (SP == 1 || par == 0) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, 0>(p, ring, lane, n, ys, x0);
+    else corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, SP - 1>(p, ring, lane, n, ys, x0);
+  }
 }
 
 template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP = 1, bool COOP = false>
@@ -500,18 +703,22 @@ inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *na
   p.bx_per_row = cdiv(p.strips, NWV);
   const long nblk = (long)p.N * p.segs * SP * p.bx_per_row;
   if (nblk <= 0) return 0;
+  if (nblk * (long)(p.bx_per_row > p.segs ? p.bx_per_row : p.segs) >= (1L << 32)) return -1;   // the magic divisions' range
+  if (p.xcd_swizzle) p.xcd_swizzle = (int)nblk;
+  p.bx_magic = mfn_make_magic((unsigned)p.bx_per_row);
+  p.segs_magic = mfn_make_magic((unsigned)p.segs);
   constexpr int NSJ_MAX = ((MAXCH * 2 * D + 7) / 8 + 3) / 4;
   const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? 2 * NSJ_MAX * 4 * 8 * 32 : 0)) * sizeof(float);
   return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
-inline bool corr_variant_gram(int v) { return v == 40; }
+inline bool corr_variant_gram(int v) { return v == 40 || v == 46 || v == 48; }
 // Output rows per work item: 6 or 8 (T = 3 / 4 blocks; the schedule is compile-time).  One wave per item, eight resident waves
 // per CU (two blocks of four): the level-2 launch of 384x512 at batch 8 is 2048 items of 6 rows = one residency round.  Fewer
 // rows per item mean more halo (an item converts rows + 2*md f2 rows); 8 where 6 does not divide H and 8 does (448x1024:
 // 112 rows).  corr.rows overrides.
 inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
-  if (override_rows == 6 || override_rows == 8) return override_rows;
+  if (override_rows == 4 || override_rows == 6 || override_rows == 8) return override_rows;   // 4: variant 48 only
   return (H % 6 != 0 && H % 8 == 0) ? 8 : 6;
 }
 // corr.variant 40: three terms, six products, cooperative stores (full lines through LDS, written through unless the caller's
@@ -520,13 +727,19 @@ inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
 // library; the template parameters that selected them (TERMS, SP, COOP) remain, profiles/r04_corr_gram_experiments.md
 // holds their numbers.
 template <int D>
-inline int corr_gram_variant(const CorrGramParams &p, int /*variant*/, hipStream_t s) {
+inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s, int ring = 0) {
   const bool wt = (p.store_policy & 2) != 0;
-#define MFN_GRAM_(TT_) \
-  (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, true, 1, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, true, 1, true>(p, s, "corr_gram_v40")) \
-           : (wt ? corr_gram_launch<D, TT_, 4, 4, 3, 2, false, 1, true>(p, s, "corr_gram_v40") : corr_gram_launch<D, TT_, 4, 4, 3, 0, false, 1, true>(p, s, "corr_gram_v40")))
-  return p.rows == 8 ? MFN_GRAM_(4) : MFN_GRAM_(3);
+#define MFN_GRAM_R(TT_, TERMS_, NAME_, NS_) \
+  (p.leaky ? (wt ? corr_gram_launch<D, TT_, NS_, 4, TERMS_, 2, true, 1, true>(p, s, NAME_) : corr_gram_launch<D, TT_, NS_, 4, TERMS_, 0, true, 1, true>(p, s, NAME_)) \
+           : (wt ? corr_gram_launch<D, TT_, NS_, 4, TERMS_, 2, false, 1, true>(p, s, NAME_) : corr_gram_launch<D, TT_, NS_, 4, TERMS_, 0, false, 1, true>(p, s, NAME_)))
+#define MFN_GRAM_(TT_, TERMS_, NAME_) MFN_GRAM_R(TT_, TERMS_, NAME_, 4)
+  if (variant == 46) return p.rows == 8 ? MFN_GRAM_(4, 1, "corr_gram_v46") : MFN_GRAM_(3, 1, "corr_gram_v46");
+  if (variant == 40) return p.rows == 8 ? MFN_GRAM_(4, 3, "corr_gram_v40") : MFN_GRAM_(3, 3, "corr_gram_v40");
+  if (p.rows == 6 && ring == 6) return MFN_GRAM_R(3, 5, "corr_gram_v48", 6);
+  if (p.rows == 6 && ring == 8) return MFN_GRAM_R(3, 5, "corr_gram_v48", 8);
+  return p.rows == 8 ? MFN_GRAM_(4, 5, "corr_gram_v48") : (p.rows == 4 ? MFN_GRAM_(2, 5, "corr_gram_v48") : MFN_GRAM_(3, 5, "corr_gram_v48"));
 #undef MFN_GRAM_
+#undef MFN_GRAM_R
 }
 
 }  // namespace mfn

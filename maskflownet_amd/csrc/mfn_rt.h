@@ -183,6 +183,8 @@ static inline void mfn_bload1x4_async(float &d0, float &d1, float &d2, float &d3
 static inline void mfn_wait_vm_dyn(unsigned) { hipemu::wave().bar.arrive_and_wait(); }
 #define MFN_RAW_BARRIER() __syncthreads()
 #define MFN_LDS_BARRIER() __syncthreads()
+#define MFN_SETPRIO(n) ((void)0)
+#define MFN_HW_WAVE_SLOT() 0
 #define MFN_COMPILER_FENCE() ((void)0)
 #define MFN_STAMP(buf, k) ((void)0)
 #define MFN_STAMP2(buf, k) ((void)0)
@@ -571,6 +573,10 @@ __device__ __forceinline__ void mfn_bload1x4_async(float &d0, float &d1, float &
 // block barrier for data handed over through LDS: this wave's LDS operations are complete before it, and the compiler keeps
 // every memory access on its side of it (the bare s_barrier builtin does not stop hipcc from hoisting later LDS reads above it)
 #define MFN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// issue priority of the wave (0..3; arbitration on a SIMD is by priority, then age) and the wave's slot on its SIMD (HW_ID bits 3:0:
+// the k-th wave a SIMD was given that is still resident has slot k -- 0 for the first block of a CU, 1 for the one dispatched behind it)
+#define MFN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define MFN_HW_WAVE_SLOT() ((int)(__builtin_amdgcn_s_getreg(63492) & 0xFu))
 // measurement only: constant-rate (100 MHz) wall clock stamps, one writer per block
 #define MFN_CYCLES() ((unsigned long long)clock64())
 // measurement only: bit 0 of the buffer address selects the shader-cycle counter instead of the 100 MHz wall clock.
@@ -670,6 +676,11 @@ __device__ __forceinline__ void mfn_store1_stream(float *dst, float v, int polic
 // neighbouring tiles read overlapping data remap their block id with this so that XCD k works on one contiguous
 // range of tiles, [k*q + min(k, r), ...) with q = nb / 8, r = nb % 8: the overlap is then served by one L2
 // instead of being fetched over the fabric by several (full-resolution warp: 15.2 -> 11.6 us).
+// x / d for a divisor the host knows: magic = ceil(2^32 / d) (0 for d == 1), exact while x * d < 2^32
+__host__ __device__ __forceinline__ unsigned mfn_div_magic(unsigned x, unsigned magic) {
+  return magic ? (unsigned)(((unsigned long long)x * magic) >> 32) : x;
+}
+inline unsigned mfn_make_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)(((1ULL << 32) + d - 1) / d); }
 __host__ __device__ __forceinline__ unsigned mfn_xcd_remap(unsigned b, unsigned nb) {
   const unsigned q = nb >> 3, r = nb & 7u, xcd = b & 7u, i = b >> 3;
   return xcd * q + (xcd < r ? xcd : r) + i;

@@ -17,7 +17,7 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(conv_dcm=0, corr_variant=-1, corr_rows=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
+DEFAULT_TUNING = dict(conv_dcm=0, corr_variant=-1, corr_rows=0, corr_form=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
                       path_generic=0, bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=-1)
 
 
@@ -49,13 +49,15 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
                                            ((1, 32, 7, 36), 2, 6),      # md = 2 (25 channels), 5 strips = 2 blocks, a 1-row last item
                                            ((1, 32, 24, 8), 4, 0),      # 24 % 6 == 0 -> 6 rows; one strip: the f2 segment hangs over both image borders
                                            ((1, 32, 16, 16), 2, 0)])    # 16 % 6 != 0, 16 % 8 == 0 -> the plan picks 8-row items
-def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows):
+@pytest.mark.parametrize("variant", [40, 46, 48])
+def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows, variant):
     """corr.variant 40: the band of the Gram matrix on the bf16 matrix cores, operands split into three bf16 terms (six
     products): exact fp32 to the tolerance of every other cost-volume kernel.  Wave-private LDS-DMA rings, counted waits,
-    row-shift de-skew, range-checked band stores; LeakyReLU and the concat-slice form."""
-    emu_ops.set_tuning(corr_variant=40, corr_direct=2, corr_rows=rows)
+    row-shift de-skew, range-checked band stores; LeakyReLU and the concat-slice form.  corr.variant 46: the same band on
+    the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, raw operands, an fmaf chain over the channels)."""
+    emu_ops.set_tuning(corr_variant=variant, corr_direct=2, corr_rows=rows)
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
-    assert "corr_gram_v40" in emu_ops.launch_log()
+    assert "corr_gram_v%d" % variant in emu_ops.launch_log()
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
     pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
 
@@ -68,7 +70,7 @@ def test_correlation_gram_by_plan(ops, oracle):
     emu_ops.set_tuning(corr_gram=1)
     emu_ops.launch_log()
     pc.case_correlation(ops, oracle, ident, ident, (4, 32, 1, 3200), 4)        # 4 x 100 x 1 = 400 tiles of 32 x 4
-    assert "corr_gram_v40" in emu_ops.launch_log()
+    assert "corr_gram_v48" in emu_ops.launch_log()
     pc.case_correlation(ops, oracle, ident, ident, (1, 32, 16, 64), 4, seed=2)  # 8 tiles: the usual plan
     assert "corr_gram" not in emu_ops.launch_log()
 

@@ -36,7 +36,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_variant=-1, corr_rows=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
+    _lib.set_tuning(corr_variant=-1, corr_rows=0, corr_form=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
                     path_generic=0, bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=-1)
 
 
@@ -71,12 +71,15 @@ def test_correlation_every_variant(ops, oracle, dev, variant):
                                            ((8, 32, 96, 128), 2, 0), ((4, 32, 112, 256), 2, 6),     # the cascade's md = 2; a short last item
                                            ((8, 32, 96, 128), 4, 8),                                # the other item height
                                            ((2, 32, 37, 76), 4, 6), ((1, 32, 9, 20), 2, 8)])        # ragged strips, odd heights
-def test_correlation_gram_band_on_matrix_cores(ops, oracle, dev, shape, md, rows):
-    """corr.variant 40 (correlation_gram.h): the band of the Gram matrix on the bf16 matrix cores with the operands split
-    into three bf16 terms -- exact fp32 to the tolerance of every other cost-volume kernel; plain, with the fused LeakyReLU
-    and written into a concat slice."""
+@pytest.mark.parametrize("variant", [48, 46, 40])
+def test_correlation_gram_band_on_matrix_cores(ops, oracle, dev, shape, md, rows, variant):
+    """corr.variant 48 (correlation_gram.h, the plan's choice at 32-channel levels): the band of the Gram matrix on the bf16
+    matrix cores with the operands split into three bf16 terms ON the matrix cores and the results leaving one step behind the
+    chains -- exact fp32 to the tolerance of every other cost-volume kernel; plain, with the fused LeakyReLU and written into a
+    concat slice.  46: the same band on the fp32 matrix instruction (raw operands); 40: round 4's VALU split (kept as the
+    reference the new split is bit-identical to)."""
     from maskflownet_amd import _lib
-    _lib.set_tuning(corr_variant=40, corr_rows=rows)
+    _lib.set_tuning(corr_variant=variant, corr_rows=rows)
     pc.case_correlation(ops, oracle, dev, host, shape, md)
     pc.case_correlation_leaky(ops, oracle, dev, host, shape, md)
     if shape[0] <= 4:
@@ -92,11 +95,22 @@ def test_correlation_gram_is_deterministic_and_matches_the_fma_kernel(ops, T):
     f2 = T.randn(8, 32, 96, 128, device="cuda", generator=g)
     _lib.set_tuning(corr_variant=16)
     ref = ops.Correlation(f1, f2, 1, 4, 1, 1, 4)
-    _lib.set_tuning(corr_variant=40)
+    _lib.set_tuning(corr_variant=48)
     first = ops.Correlation(f1, f2, 1, 4, 1, 1, 4)
     for _ in range(30):
         assert T.equal(ops.Correlation(f1, f2, 1, 4, 1, 1, 4), first)
     assert (first - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    # the split on the matrix cores forms the same three terms as the VALU split: bit-identical cost volumes, also on features whose
+    # channels span 36 orders of magnitude and at the other item heights
+    mag = (10.0 ** T.linspace(-18, 18, 32, device="cuda"))[None, :, None, None]
+    for a, b in ((f1, f2), (f1 * mag, f2 * mag)):
+        for rows in (0, 8):
+            _lib.set_tuning(corr_variant=40, corr_rows=rows)
+            want = ops.Correlation(a, b, 1, 4, 1, 1, 4).clone()
+            _lib.set_tuning(corr_variant=48, corr_rows=rows)
+            assert T.equal(ops.Correlation(a, b, 1, 4, 1, 1, 4), want)
+    _lib.set_tuning(corr_variant=48, corr_rows=4)
+    assert T.equal(ops.Correlation(f1, f2, 1, 4, 1, 1, 4), first)
 
 
 @pytest.mark.parametrize("shape", CFG2 + CFG3)
