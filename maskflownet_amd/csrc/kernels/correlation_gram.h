@@ -37,6 +37,7 @@
 // moves, 24 + 8 LDS reads, 10 stores -- against 1440 VALU lane-ops and 288 16-byte LDS reads per pixel before.
 #pragma once
 #include "../mfn_rt.h"
+#include "msplit.h"
 
 // measurement builds only (tools/gram_ablate_build.py): bit 1 no matrix instructions / de-skew / stores (DMA, LDS reads and
 // conversions remain), 2 no stores, 4 no conversions (operands are the raw bits), 8 no DMA (the ring is never filled)
@@ -59,6 +60,7 @@ struct CorrGramParams {
   int N, H, W;            // C == 32
   int rows;               // output rows per work item (even)
   int strips, segs;       // ceil(W / 8), ceil(H / rows)
+  int segs_blk;           // row segments per image in units of a block's cooperative groups: ceil(segs / groups per block)
   int bx_per_row;         // blocks along x: ceil(strips / waves per block)
   unsigned bx_magic, segs_magic;   // mfn_make_magic of bx_per_row / segs: block id -> (strip group, segment, image) by two
                                    // s_mul_hi_u32 instead of two runtime divisions (~40 scalar instructions in front of the first DMA)
@@ -115,56 +117,6 @@ __device__ __forceinline__ void gram_words_to_op(const GramWords &w, GramOp &o) 
   const u32x4_ h = {w.h[0], w.h[1], w.h[2], w.h[3]}, m = {w.m[0], w.m[1], w.m[2], w.m[3]}, l = {w.l[0], w.l[1], w.l[2], w.l[3]};
   o.h = __builtin_bit_cast(mfn_bf16x8, h); o.m = __builtin_bit_cast(mfn_bf16x8, m); o.l = __builtin_bit_cast(mfn_bf16x8, l);
 #endif
-}
-
-// TERMS == 4: the same three terms, the residuals formed ON THE MATRIX CORES (round 6).  The operand split of TERMS == 3 is nine
-// VALU instructions per pair of values: three v_cvt_pk_bf16_f32 and, to get each residual x - float(bf16(x)), a shift, a mask and a
-// packed subtract -- 646 of a wave's 912 VALU instructions at level 2, on a SIMD whose issue slots are what bounds the kernel
-// (profiles/r04_corr_pmc.md).  But the accumulator layout of v_mfma_f32_16x16x32_bf16 (lane = column n + 16 g, register i = row
-// 4 g + i) IS the operand layout (lane = column + 16 k-block, eight K values) when rows are read as K slots: with the eight raw
-// values of a lane held as two accumulator tiles C0 = raw[0..3], C1 = raw[4..7] and their bf16 roundings as a B operand Hb,
-//   C0 <- Sel0 * Hb + C0,   Sel0[r][k] = -1 if k == 8 (r / 4) + r % 4 else 0     (Sel1: ... + 4)
-// subtracts from every register exactly the bf16 value the SAME lane holds in K slot i (i + 4): the residual, exact in fp32
-// (products -1 * h and 0 * h are exact, the sum has one non-zero term and x - h is representable).  A tile's split is then
-// 3 x 4 v_cvt_pk_bf16_f32 + 2 x 2 matrix instructions on a pipe that idles 78 % of the time, instead of 36 VALU instructions;
-// the terms are bit-identical to TERMS == 3's (same roundings).  Non-finite inputs: 0 * inf = NaN spreads an inf to the residuals
-// of the pixel's other channels of the tile -- every output that pixel takes part in is NaN (TERMS == 3: NaN as well, through
-// inf - inf in the channel itself): the documented behaviour (include/mfn_hip.h "Arithmetic") is unchanged.
-struct GramSel { mfn_bf16x8 s0, s1; };
-__device__ __forceinline__ GramSel gram_make_sel(int lane) {
-  const int m = lane & 15, kb = lane >> 4;
-  const bool on = kb == (m >> 2);
-  const unsigned one = 0xBF80u << (16 * (m & 1));          // -1.0 as bf16, in K slot m % 4 of the lane's k-block
-  const unsigned w0 = (on && (m & 2) == 0) ? one : 0u, w1 = (on && (m & 2) != 0) ? one : 0u;
-  GramSel r;
-  r.s0 = mfn_words_to_bf16x8(w0, w1, 0u, 0u);
-  r.s1 = mfn_words_to_bf16x8(0u, 0u, w0, w1);
-  return r;
-}
-// eight fp32 values (two accumulator tiles) -> their bf16 roundings as one operand: 4 x v_cvt_pk_bf16_f32
-__device__ __forceinline__ mfn_bf16x8 gram_cvt8(const f32x4 &a, const f32x4 &b) {
-#if defined(MFN_EMU)
-  unsigned w[4];
-  for (int q = 0; q < 2; ++q) {
-    w[q] = (unsigned)hipemu_f32_to_bf16(a[2 * q]) | ((unsigned)hipemu_f32_to_bf16(a[2 * q + 1]) << 16);
-    w[2 + q] = (unsigned)hipemu_f32_to_bf16(b[2 * q]) | ((unsigned)hipemu_f32_to_bf16(b[2 * q + 1]) << 16);
-  }
-  return mfn_words_to_bf16x8(w[0], w[1], w[2], w[3]);
-#else
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  const f32x2 p0 = {a[0], a[1]}, p1 = {a[2], a[3]}, p2 = {b[0], b[1]}, p3 = {b[2], b[3]};
-  return mfn_words_to_bf16x8(__builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf2)), __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf2)),
-                             __builtin_bit_cast(unsigned, __builtin_convertvector(p2, bf2)), __builtin_bit_cast(unsigned, __builtin_convertvector(p3, bf2)));
-#endif
-}
-// one stage of the matrix-core split of a tile held as (x0, x1): even stages round the present residual into term st / 2,
-// odd stages subtract that term
-__device__ __forceinline__ void gram_msplit_stage(int st, const GramSel &sel, f32x4 &x0, f32x4 &x1, mfn_bf16x8 (&term)[3]) {
-  if ((st & 1) == 0) term[st >> 1] = gram_cvt8(x0, x1);
-  else {
-    x0 = MFN_MFMA_16x16x32_BF16(sel.s0, term[st >> 1], x0);
-    x1 = MFN_MFMA_16x16x32_BF16(sel.s1, term[st >> 1], x1);
-  }
 }
 
 // The static schedule of a wave.  D = 2*md+1; T = f1 blocks (8 x 2 px) per work item: the item's rows are 2T.  Step
@@ -415,7 +367,7 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     const unsigned soff = (unsigned)((sp - 2 * th) * D * plane + 2 * th * W) * 4u;
     MFN_UNROLL
     for (int jj = 0; jj < nsj; ++jj) {
-      const unsigned vo = (valid & (unsigned)cbit[jj]) ? cvoff[jj] : INVALID;
+      const unsigned vo = ((valid & (unsigned)cbit[jj]) && !(p.prio & 64)) ? cvoff[jj] : INVALID;   // (corr.prio bit 64, measurement: nothing is written)
       if (MFN_GRAM_ABLATE & 2) { if (v[jj][0] == 1.2345e30f) mfn_bstore4_so(rs_item, vo, soff, v[jj], POL); }
       else { mfn_bstore4_so(rs_item, vo, soff, v[jj], POL); n_issued += 1; }
     }
@@ -666,11 +618,18 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
 // One wave per (image, row segment, strip, step parity); NWV adjacent strips per block.  COOP (NWV = 4, SP = 1): the block's
 // waves exchange their results through LDS (one barrier per step) and store full 128-byte lines.
 template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP, bool COOP>
-__global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p) {
-  static_assert(!COOP || (NWV == 4 && SP == 1), "cooperative stores: four strips = one 128-byte line, one wave per item");
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 2) void corr_gram_kernel(CorrGramParams p) {
+  static_assert(!COOP || ((NWV == 4 || NWV == 8) && SP == 1), "cooperative stores: four strips = one 128-byte line, one wave per item");
+  // NWV == 8 (round 6): TWO cooperative groups of four strips -- the row segments 2k and 2k + 1 of the same 32 columns -- in one block: all
+  // eight waves of the CU meet at every step's barrier, so neither group can fall behind the other (with two independent 4-wave
+  // blocks per CU the one dispatched second ends ~1.4 us after the first inside the pass: profiles/r06_corr_timeline_inpass.txt)
+  constexpr int NG = COOP ? NWV / 4 : 1;
+  constexpr int MDk = (D - 1) / 2, MAXCHk = T < MDk + 1 ? T : MDk + 1;
+  constexpr int STG_GROUP_F = 2 * (((MAXCHk * 2 * D + 7) / 8 + 3) / 4) * 4 * 8 * 32;   // floats of one group's two staging buffers
   MFN_DYN_SHARED(float, lds_all);
   const int lane = threadIdx.x & 63;
   const int wave = MFN_UNIFORM(threadIdx.x >> 6);
+  const int grp = COOP ? wave >> 2 : 0, w4 = COOP ? (wave & 3) : wave;
   float *ring = lds_all + (size_t)wave * NSLOT * 512;
   MFN_STAMP(p.timeline, 0);
   if ((p.prio & 7) == 1 && MFN_HW_WAVE_SLOT() != 0) MFN_SETPRIO(1);
@@ -682,11 +641,11 @@ __global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p
   const int par = rest % SP;
   rest /= SP;
   const int n = (int)mfn_div_magic((unsigned)rest, p.segs_magic);
-  const int seg = rest - n * p.segs;
-  const int sx = bxs * NWV + wave;
+  const int seg = (rest - n * p.segs_blk) * NG + grp;   // (a group past the last segment keeps the barriers company: every row masked)
+  const int sx = bxs * (COOP ? 4 : NWV) + w4;
   if (!COOP && sx >= p.strips) return;   // COOP: a wave past the last strip keeps the block's barriers company (its lanes are all masked)
   const int x0 = sx * 8, ys = seg * (2 * T);
-  if constexpr (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * 512, wave, bxs * NWV * 8);
+  if constexpr (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * 512 + (size_t)grp * STG_GROUP_F, w4, bxs * 32);
   else {
     if (SP == 1 || par == 0) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, 0>(p, ring, lane, n, ys, x0);
     else corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, SP - 1>(p, ring, lane, n, ys, x0);
@@ -700,15 +659,17 @@ inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *na
   p.rows = 2 * T;
   p.strips = cdiv(p.W, 8);
   p.segs = cdiv(p.H, p.rows);
-  p.bx_per_row = cdiv(p.strips, NWV);
-  const long nblk = (long)p.N * p.segs * SP * p.bx_per_row;
+  constexpr int NG = COOP ? NWV / 4 : 1;
+  p.bx_per_row = cdiv(p.strips, COOP ? 4 : NWV);
+  p.segs_blk = cdiv(p.segs, NG);
+  const long nblk = (long)p.N * p.segs_blk * SP * p.bx_per_row;
   if (nblk <= 0) return 0;
-  if (nblk * (long)(p.bx_per_row > p.segs ? p.bx_per_row : p.segs) >= (1L << 32)) return -1;   // the magic divisions' range
+  if (nblk * (long)(p.bx_per_row > p.segs_blk ? p.bx_per_row : p.segs_blk) >= (1L << 32)) return -1;   // the magic divisions' range
   if (p.xcd_swizzle) p.xcd_swizzle = (int)nblk;
   p.bx_magic = mfn_make_magic((unsigned)p.bx_per_row);
-  p.segs_magic = mfn_make_magic((unsigned)p.segs);
+  p.segs_magic = mfn_make_magic((unsigned)p.segs_blk);
   constexpr int NSJ_MAX = ((MAXCH * 2 * D + 7) / 8 + 3) / 4;
-  const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? 2 * NSJ_MAX * 4 * 8 * 32 : 0)) * sizeof(float);
+  const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? NG * 2 * NSJ_MAX * 4 * 8 * 32 : 0)) * sizeof(float);
   return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
@@ -735,6 +696,9 @@ inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s
 #define MFN_GRAM_(TT_, TERMS_, NAME_) MFN_GRAM_R(TT_, TERMS_, NAME_, 4)
   if (variant == 46) return p.rows == 8 ? MFN_GRAM_(4, 1, "corr_gram_v46") : MFN_GRAM_(3, 1, "corr_gram_v46");
   if (variant == 40) return p.rows == 8 ? MFN_GRAM_(4, 3, "corr_gram_v40") : MFN_GRAM_(3, 3, "corr_gram_v40");
+  if (p.rows == 6 && ring == 84)   // measurement: eight-wave blocks (two cooperative groups)
+    return p.leaky ? (wt ? corr_gram_launch<D, 3, 4, 8, 5, 2, true, 1, true>(p, s, "corr_gram_v48w8") : corr_gram_launch<D, 3, 4, 8, 5, 0, true, 1, true>(p, s, "corr_gram_v48w8"))
+                   : (wt ? corr_gram_launch<D, 3, 4, 8, 5, 2, false, 1, true>(p, s, "corr_gram_v48w8") : corr_gram_launch<D, 3, 4, 8, 5, 0, false, 1, true>(p, s, "corr_gram_v48w8"));
   if (p.rows == 6 && ring == 6) return MFN_GRAM_R(3, 5, "corr_gram_v48", 6);
   if (p.rows == 6 && ring == 8) return MFN_GRAM_R(3, 5, "corr_gram_v48", 8);
   return p.rows == 8 ? MFN_GRAM_(4, 5, "corr_gram_v48") : (p.rows == 4 ? MFN_GRAM_(2, 5, "corr_gram_v48") : MFN_GRAM_(3, 5, "corr_gram_v48"));

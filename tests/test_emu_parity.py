@@ -17,7 +17,7 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(conv_dcm=0, corr_variant=-1, corr_rows=0, corr_form=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
+DEFAULT_TUNING = dict(conv_dcm=0, corr_variant=-1, corr_rows=0, corr_form=0, corr_ring=0, corr_prio=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
                       path_generic=0, bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=-1)
 
 
@@ -60,6 +60,16 @@ def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows, var
     assert "corr_gram_v%d" % variant in emu_ops.launch_log()
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
     pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
+
+
+@pytest.mark.parametrize("shape,md", [((1, 32, 18, 40), 4), ((2, 32, 13, 24), 2)])
+def test_correlation_gram_eight_wave_blocks(ops, oracle, shape, md):
+    """corr.ring 84: two cooperative groups (row segments 2k, 2k + 1 of the same 32 columns) in one 8-wave block -- an odd number of
+    segments leaves the last block's second group with nothing but the barriers."""
+    emu_ops.set_tuning(corr_variant=48, corr_direct=2, corr_rows=6, corr_ring=84)
+    pc.case_correlation(ops, oracle, ident, ident, shape, md)
+    assert "corr_gram_v48w8" in emu_ops.launch_log()
+    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
 
 
 @pytest.mark.skipif(__import__("os").environ.get("MFN_SLOW_TESTS") != "1",

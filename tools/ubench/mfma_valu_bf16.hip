@@ -3,15 +3,20 @@
 //   mode 0: 6 MFMA only            mode 1: 42 v_fma only (6 independent chains)
 //   mode 2: 6 MFMA then 42 v_fma   mode 3: interleaved M, 7 v_fma, M, 7 v_fma, ...
 //   mode 4: as 2 with v_pk_fma_f32 (21 packed)     mode 5: as 3 with packed
+//   mode 6: the waves of a SIMD in two ROLES -- even residents (wave / 4 even) issue only the 6 MFMA, odd ones only the 42 v_fma: do matrix
+//           and vector instructions of DIFFERENT waves of one SIMD run side by side?  (2 and 4 waves per SIMD; cycles per role)
+//   mode 7: as 6 with v_mfma_f32_16x16x32_bf16 (12 per iteration: the same matrix-pipe time)
 // Reported: shader cycles per iteration per wave (s_memtime), for 1 / 2 / 3 / 4 waves per SIMD (one block of 4*w waves per CU).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, int iters) {
   f32x16 a0 = {0}, a1 = {0};
+  f32x4 b0 = {0}, b1 = {0}, b2 = {0}, b3 = {0};
   bf16x8 x, y;
   for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(threadIdx.x * 0.001f + e); y[e] = (__bf16)(e * 0.5f); }
   float v[6] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f};
@@ -29,11 +34,21 @@ __global__ __launch_bounds__(1024) void k(float *out, unsigned long long *cyc, i
     if (MODE == 4) { P7(0); P7(1); P7(2); P7(3); P7(4); P7(5); }
     if (MODE == 3) { MM(a0); V7(0); MM(a1); V7(1); MM(a0); V7(2); MM(a1); V7(3); MM(a0); V7(4); MM(a1); V7(5); }
     if (MODE == 5) { MM(a0); P7(0); MM(a1); P7(1); MM(a0); P7(2); MM(a1); P7(3); MM(a0); P7(4); MM(a1); P7(5); }
+    if (MODE == 6) {
+      if (((threadIdx.x >> 8) & 1) == 0) { MM(a0); MM(a1); MM(a0); MM(a1); MM(a0); MM(a1); }
+      else { V7(0); V7(1); V7(2); V7(3); V7(4); V7(5); }
+    }
+    if (MODE == 7) {
+#define M16(acc) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, acc, 0, 0, 0)
+      if (((threadIdx.x >> 8) & 1) == 0) { M16(b0); M16(b1); M16(b2); M16(b3); M16(b0); M16(b1); M16(b2); M16(b3); M16(b0); M16(b1); M16(b2); M16(b3); }
+      else { V7(0); V7(1); V7(2); V7(3); V7(4); V7(5); }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   const unsigned long long t1 = clock64();
   float s = 0;
   for (int i = 0; i < 16; ++i) s += a0[i] + a1[i];
+  for (int i = 0; i < 4; ++i) s += b0[i] + b1[i] + b2[i] + b3[i];
   for (int i = 0; i < 6; ++i) s += v[i] + pv[i].x + pv[i].y;
   if (s == 1.2345e30f) out[0] = s;
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
@@ -42,9 +57,11 @@ int main() {
   float *out; unsigned long long *cyc;
   hipMalloc(&out, 256); hipMalloc(&cyc, 256 * 16 * 8);
   const int iters = 2000;
-  const char *names[] = {"6 MFMA", "42 v_fma", "6 MFMA, then 42 v_fma", "M,7v interleaved", "6 MFMA, then 24 v_pk_fma", "M,4pk interleaved"};
-  for (int mode = 0; mode < 6; ++mode)
+  const char *names[] = {"6 MFMA", "42 v_fma", "6 MFMA, then 42 v_fma", "M,7v interleaved", "6 MFMA, then 24 v_pk_fma", "M,4pk interleaved",
+                         "roles: 6 MFMA | 42 v_fma", "roles: 12 MFMA16 | 42 v_fma"};
+  for (int mode = 0; mode < 8; ++mode)
     for (int w : {1, 2, 3, 4}) {
+      if (mode >= 6 && (w & 1)) continue;
       for (int rep = 0; rep < 2; ++rep) {
         switch (mode) {
           case 0: hipLaunchKernelGGL(k<0>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
@@ -53,11 +70,20 @@ int main() {
           case 3: hipLaunchKernelGGL(k<3>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
           case 4: hipLaunchKernelGGL(k<4>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
           case 5: hipLaunchKernelGGL(k<5>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
+          case 6: hipLaunchKernelGGL(k<6>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
+          case 7: hipLaunchKernelGGL(k<7>, dim3(256), dim3(256 * w), 0, 0, out, cyc, iters); break;
         }
         hipDeviceSynchronize();
       }
       unsigned long long h[16];
       hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+      if (mode >= 6) {
+        double mm = 0, mv = 0;
+        for (int i = 0; i < 4 * w; ++i) ((i >> 2) & 1 ? mv : mm) += (double)h[i];
+        mm /= 2 * w * iters; mv /= 2 * w * iters;
+        printf("%-28s waves/SIMD %d: matrix-role waves %7.1f, vector-role waves %7.1f cycles per iteration per wave\n", names[mode], w, mm, mv);
+        continue;
+      }
       double mean = 0; for (int i = 0; i < 4 * w; ++i) mean += (double)h[i]; mean /= 4 * w * iters;
       printf("%-28s waves/SIMD %d: %7.1f cycles per iteration per wave  (%6.1f per SIMD-iteration)\n", names[mode], w, mean, mean / w);
     }
