@@ -197,7 +197,7 @@ ARITH_DEFAULT, ARITH_FP32, ARITH_BF16X3 = -1, 0, 1
 
 
 def set_arithmetic(**kw):
-    """mfn_set_arithmetic for the calling thread: correlation= / deformable_convolution= / convolution= / all= one of
+    """mfn_set_arithmetic (one setting per process, read by every thread's calls): correlation= / deformable_convolution= / convolution= / all= one of
     ARITH_DEFAULT (-1), ARITH_FP32 (0), ARITH_BF16X3 (1).  Packed-weight caches key on tuning_epoch(), which this bumps."""
     global _tuning_epoch
     _tuning_epoch += 1
@@ -206,7 +206,7 @@ def set_arithmetic(**kw):
 
 
 def get_tuning(key):
-    """The present value of a tuning key ('a_b' form), or of a thread's arithmetic for the three legacy names."""
+    """The present value of a tuning key ('a_b' form), or of the process's arithmetic for the three legacy names."""
     v = ctypes.c_int()
     if key in ARITHMETIC_OPS:
         check(lib().get_arithmetic(ARITHMETIC_OPS[key].encode(), ctypes.byref(v)), "get_arithmetic")

@@ -3,6 +3,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>

@@ -60,7 +60,6 @@ struct CorrGramParams {
   int N, H, W;            // C == 32
   int rows;               // output rows per work item (even)
   int strips, segs;       // ceil(W / 8), ceil(H / rows)
-  int segs_blk;           // row segments per image in units of a block's cooperative groups: ceil(segs / groups per block)
   int bx_per_row;         // blocks along x: ceil(strips / waves per block)
   unsigned bx_magic, segs_magic;   // mfn_make_magic of bx_per_row / segs: block id -> (strip group, segment, image) by two
                                    // s_mul_hi_u32 instead of two runtime divisions (~40 scalar instructions in front of the first DMA)
@@ -68,7 +67,6 @@ struct CorrGramParams {
   int store_policy;       // mfn_bstore4
   int leaky;              // fused LeakyReLU(0.1)
   int xcd_swizzle;        // 0, or the number of blocks of the launch (mfn_xcd_remap's range: no second, dependent kernarg load for gridDim)
-  int prio;               // measurement (corr.prio): how the younger block of a CU is helped against the age arbitration
   float inv_c;            // 1/32, folded into the f1 operand before the split (a power of two: exact)
   unsigned long long *timeline;  // measurement builds only (-DMFN_TIMELINE=1): 4 stamps per block, or NULL
 };
@@ -192,13 +190,9 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   unsigned voffN[2], voffM[2];
   {
     const int xq = x0 - XOFF + 4 * (lane & 3);
-    bool okN = xq >= 0 && xq < W;
+    const bool okN = xq >= 0 && xq < W;
     const int xm = x0 + 4 * (lane & 1);
-    bool okM = xm < W;
-    // measurement (corr.prio bits; wrong results): 8 = only the two middle quads of an f2 segment are fetched, 16 = no f2 fetch, 32 = no f1 fetch
-    if ((p.prio & 8) && ((lane & 3) == 0 || (lane & 3) == 3)) okN = false;
-    if (p.prio & 16) okN = false;
-    if (p.prio & 32) okM = false;
+    const bool okM = xm < W;
     MFN_UNROLL
     for (int j = 0; j < 2; ++j) {
       const int c = (lane >> 2) + 16 * j;
@@ -367,7 +361,7 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     const unsigned soff = (unsigned)((sp - 2 * th) * D * plane + 2 * th * W) * 4u;
     MFN_UNROLL
     for (int jj = 0; jj < nsj; ++jj) {
-      const unsigned vo = ((valid & (unsigned)cbit[jj]) && !(p.prio & 64)) ? cvoff[jj] : INVALID;   // (corr.prio bit 64, measurement: nothing is written)
+      const unsigned vo = (valid & (unsigned)cbit[jj]) ? cvoff[jj] : INVALID;
       if (MFN_GRAM_ABLATE & 2) { if (v[jj][0] == 1.2345e30f) mfn_bstore4_so(rs_item, vo, soff, v[jj], POL); }
       else { mfn_bstore4_so(rs_item, vo, soff, v[jj], POL); n_issued += 1; }
     }
@@ -521,9 +515,6 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
       while (post_done < nchP) post_chain();
       if constexpr (j > 1) store_lines(std::integral_constant<int, (j > 1 ? j - 2 : 0)>{}, vpp, valid_staged);
       valid_staged = valid_bitsP;
-      if ((p.prio & 7) >= 2) {   // measurement: the younger block of the CU gets the higher priority in (prio - 1) of every 4 steps
-        if (MFN_HW_WAVE_SLOT() != 0 && (j & 3) < (p.prio & 7) - 1) MFN_SETPRIO(1); else MFN_SETPRIO(0);
-      }
       MFN_LDS_BARRIER();              // step j-1's lines are staged (read back in step j+1); buffer j & 1 is free for step j's
       MFN_UNROLL
       for (int t = 0; t < T; ++t) accP[t] = acc[t];
@@ -618,21 +609,13 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
 // One wave per (image, row segment, strip, step parity); NWV adjacent strips per block.  COOP (NWV = 4, SP = 1): the block's
 // waves exchange their results through LDS (one barrier per step) and store full 128-byte lines.
 template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP, bool COOP>
-__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 2) void corr_gram_kernel(CorrGramParams p) {
-  static_assert(!COOP || ((NWV == 4 || NWV == 8) && SP == 1), "cooperative stores: four strips = one 128-byte line, one wave per item");
-  // NWV == 8 (round 6): TWO cooperative groups of four strips -- the row segments 2k and 2k + 1 of the same 32 columns -- in one block: all
-  // eight waves of the CU meet at every step's barrier, so neither group can fall behind the other (with two independent 4-wave
-  // blocks per CU the one dispatched second ends ~1.4 us after the first inside the pass: profiles/r06_corr_timeline_inpass.txt)
-  constexpr int NG = COOP ? NWV / 4 : 1;
-  constexpr int MDk = (D - 1) / 2, MAXCHk = T < MDk + 1 ? T : MDk + 1;
-  constexpr int STG_GROUP_F = 2 * (((MAXCHk * 2 * D + 7) / 8 + 3) / 4) * 4 * 8 * 32;   // floats of one group's two staging buffers
+__global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p) {
+  static_assert(!COOP || (NWV == 4 && SP == 1), "cooperative stores: four strips = one 128-byte line, one wave per item");
   MFN_DYN_SHARED(float, lds_all);
   const int lane = threadIdx.x & 63;
   const int wave = MFN_UNIFORM(threadIdx.x >> 6);
-  const int grp = COOP ? wave >> 2 : 0, w4 = COOP ? (wave & 3) : wave;
   float *ring = lds_all + (size_t)wave * NSLOT * 512;
   MFN_STAMP(p.timeline, 0);
-  if ((p.prio & 7) == 1 && MFN_HW_WAVE_SLOT() != 0) MFN_SETPRIO(1);
   int bid = blockIdx.x;
   if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)p.xcd_swizzle);
   // exact for bid < 2^32 / divisor (the launch checks it): q = floor(bid * ceil(2^32 / d) / 2^32)
@@ -641,11 +624,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 2 : 2) void corr_gram_kernel(C
   const int par = rest % SP;
   rest /= SP;
   const int n = (int)mfn_div_magic((unsigned)rest, p.segs_magic);
-  const int seg = (rest - n * p.segs_blk) * NG + grp;   // (a group past the last segment keeps the barriers company: every row masked)
-  const int sx = bxs * (COOP ? 4 : NWV) + w4;
+  const int seg = rest - n * p.segs;
+  const int sx = bxs * NWV + wave;
   if (!COOP && sx >= p.strips) return;   // COOP: a wave past the last strip keeps the block's barriers company (its lanes are all masked)
   const int x0 = sx * 8, ys = seg * (2 * T);
-  if constexpr (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * 512 + (size_t)grp * STG_GROUP_F, w4, bxs * 32);
+  if constexpr (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * 512, wave, bxs * NWV * 8);
   else {
     if (SP == 1 || par == 0) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, 0>(p, ring, lane, n, ys, x0);
     else corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, SP - 1>(p, ring, lane, n, ys, x0);
@@ -659,17 +642,15 @@ inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *na
   p.rows = 2 * T;
   p.strips = cdiv(p.W, 8);
   p.segs = cdiv(p.H, p.rows);
-  constexpr int NG = COOP ? NWV / 4 : 1;
-  p.bx_per_row = cdiv(p.strips, COOP ? 4 : NWV);
-  p.segs_blk = cdiv(p.segs, NG);
-  const long nblk = (long)p.N * p.segs_blk * SP * p.bx_per_row;
+  p.bx_per_row = cdiv(p.strips, NWV);
+  const long nblk = (long)p.N * p.segs * SP * p.bx_per_row;
   if (nblk <= 0) return 0;
-  if (nblk * (long)(p.bx_per_row > p.segs_blk ? p.bx_per_row : p.segs_blk) >= (1L << 32)) return -1;   // the magic divisions' range
+  if (nblk * (long)(p.bx_per_row > p.segs ? p.bx_per_row : p.segs) >= (1L << 32)) return -1;   // the magic divisions' range
   if (p.xcd_swizzle) p.xcd_swizzle = (int)nblk;
   p.bx_magic = mfn_make_magic((unsigned)p.bx_per_row);
-  p.segs_magic = mfn_make_magic((unsigned)p.segs_blk);
+  p.segs_magic = mfn_make_magic((unsigned)p.segs);
   constexpr int NSJ_MAX = ((MAXCH * 2 * D + 7) / 8 + 3) / 4;
-  const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? NG * 2 * NSJ_MAX * 4 * 8 * 32 : 0)) * sizeof(float);
+  const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? 2 * NSJ_MAX * 4 * 8 * 32 : 0)) * sizeof(float);
   return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
@@ -679,7 +660,7 @@ inline bool corr_variant_gram(int v) { return v == 40 || v == 46 || v == 48; }
 // rows per item mean more halo (an item converts rows + 2*md f2 rows); 8 where 6 does not divide H and 8 does (448x1024:
 // 112 rows).  corr.rows overrides.
 inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
-  if (override_rows == 4 || override_rows == 6 || override_rows == 8) return override_rows;   // 4: variant 48 only
+  if (override_rows == 6 || override_rows == 8) return override_rows;
   return (H % 6 != 0 && H % 8 == 0) ? 8 : 6;
 }
 // corr.variant 40: three terms, six products, cooperative stores (full lines through LDS, written through unless the caller's
@@ -688,22 +669,15 @@ inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
 // library; the template parameters that selected them (TERMS, SP, COOP) remain, profiles/r04_corr_gram_experiments.md
 // holds their numbers.
 template <int D>
-inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s, int ring = 0) {
+inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s) {
   const bool wt = (p.store_policy & 2) != 0;
-#define MFN_GRAM_R(TT_, TERMS_, NAME_, NS_) \
-  (p.leaky ? (wt ? corr_gram_launch<D, TT_, NS_, 4, TERMS_, 2, true, 1, true>(p, s, NAME_) : corr_gram_launch<D, TT_, NS_, 4, TERMS_, 0, true, 1, true>(p, s, NAME_)) \
-           : (wt ? corr_gram_launch<D, TT_, NS_, 4, TERMS_, 2, false, 1, true>(p, s, NAME_) : corr_gram_launch<D, TT_, NS_, 4, TERMS_, 0, false, 1, true>(p, s, NAME_)))
-#define MFN_GRAM_(TT_, TERMS_, NAME_) MFN_GRAM_R(TT_, TERMS_, NAME_, 4)
+#define MFN_GRAM_(TT_, TERMS_, NAME_) \
+  (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, TERMS_, 2, true, 1, true>(p, s, NAME_) : corr_gram_launch<D, TT_, 4, 4, TERMS_, 0, true, 1, true>(p, s, NAME_)) \
+           : (wt ? corr_gram_launch<D, TT_, 4, 4, TERMS_, 2, false, 1, true>(p, s, NAME_) : corr_gram_launch<D, TT_, 4, 4, TERMS_, 0, false, 1, true>(p, s, NAME_)))
   if (variant == 46) return p.rows == 8 ? MFN_GRAM_(4, 1, "corr_gram_v46") : MFN_GRAM_(3, 1, "corr_gram_v46");
   if (variant == 40) return p.rows == 8 ? MFN_GRAM_(4, 3, "corr_gram_v40") : MFN_GRAM_(3, 3, "corr_gram_v40");
-  if (p.rows == 6 && ring == 84)   // measurement: eight-wave blocks (two cooperative groups)
-    return p.leaky ? (wt ? corr_gram_launch<D, 3, 4, 8, 5, 2, true, 1, true>(p, s, "corr_gram_v48w8") : corr_gram_launch<D, 3, 4, 8, 5, 0, true, 1, true>(p, s, "corr_gram_v48w8"))
-                   : (wt ? corr_gram_launch<D, 3, 4, 8, 5, 2, false, 1, true>(p, s, "corr_gram_v48w8") : corr_gram_launch<D, 3, 4, 8, 5, 0, false, 1, true>(p, s, "corr_gram_v48w8"));
-  if (p.rows == 6 && ring == 6) return MFN_GRAM_R(3, 5, "corr_gram_v48", 6);
-  if (p.rows == 6 && ring == 8) return MFN_GRAM_R(3, 5, "corr_gram_v48", 8);
-  return p.rows == 8 ? MFN_GRAM_(4, 5, "corr_gram_v48") : (p.rows == 4 ? MFN_GRAM_(2, 5, "corr_gram_v48") : MFN_GRAM_(3, 5, "corr_gram_v48"));
+  return p.rows == 8 ? MFN_GRAM_(4, 5, "corr_gram_v48") : MFN_GRAM_(3, 5, "corr_gram_v48");
 #undef MFN_GRAM_
-#undef MFN_GRAM_R
 }
 
 }  // namespace mfn

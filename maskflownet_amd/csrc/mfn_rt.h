@@ -183,8 +183,6 @@ static inline void mfn_bload1x4_async(float &d0, float &d1, float &d2, float &d3
 static inline void mfn_wait_vm_dyn(unsigned) { hipemu::wave().bar.arrive_and_wait(); }
 #define MFN_RAW_BARRIER() __syncthreads()
 #define MFN_LDS_BARRIER() __syncthreads()
-#define MFN_SETPRIO(n) ((void)0)
-#define MFN_HW_WAVE_SLOT() 0
 #define MFN_COMPILER_FENCE() ((void)0)
 #define MFN_STAMP(buf, k) ((void)0)
 #define MFN_STAMP2(buf, k) ((void)0)
@@ -573,10 +571,6 @@ __device__ __forceinline__ void mfn_bload1x4_async(float &d0, float &d1, float &
 // block barrier for data handed over through LDS: this wave's LDS operations are complete before it, and the compiler keeps
 // every memory access on its side of it (the bare s_barrier builtin does not stop hipcc from hoisting later LDS reads above it)
 #define MFN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// issue priority of the wave (0..3; arbitration on a SIMD is by priority, then age) and the wave's slot on its SIMD (HW_ID bits 3:0:
-// the k-th wave a SIMD was given that is still resident has slot k -- 0 for the first block of a CU, 1 for the one dispatched behind it)
-#define MFN_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
-#define MFN_HW_WAVE_SLOT() ((int)(__builtin_amdgcn_s_getreg(63492) & 0xFu))
 // measurement only: constant-rate (100 MHz) wall clock stamps, one writer per block
 #define MFN_CYCLES() ((unsigned long long)clock64())
 // measurement only: bit 0 of the buffer address selects the shader-cycle counter instead of the 100 MHz wall clock.

@@ -13,7 +13,7 @@
 //   corr.form     the form the PLAN gives a 32-channel level (0 = 48; 40 / 46 / 48): unlike corr.variant it leaves the other levels' plan alone
 //                 44 / 45: corr_gramk_kernel (coarse levels: the same band, a block = an 8 x 2 pixel block of f1 and two / half of the
 //                 f2 rows it meets, one wave per 32 channels)
-//   corr.rows     output rows per work item of corr_gram_kernel (6 or 8, form 48 also 4; 0 = the plan)
+//   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 0 = the plan)
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt
@@ -39,7 +39,7 @@
 #include <string.h>
 namespace mfn {
 struct Tuning {
-  int corr_variant = -1, corr_direct = 0, corr_rows = 0, corr_form = 0, corr_ring = 0, corr_prio = 0;
+  int corr_variant = -1, corr_direct = 0, corr_rows = 0, corr_form = 0;
   int store_policy = -1;
   int dc_pt = 0, dc_ksb = 0, dc_nw = 0, dc_off = 0, dc_mt = 0;
   int path_generic = 0, bwd_off = 0;
@@ -49,8 +49,6 @@ struct Tuning {
     if (!strcmp(key, "corr.direct")) return &corr_direct;
     if (!strcmp(key, "corr.rows")) return &corr_rows;
     if (!strcmp(key, "corr.form")) return &corr_form;
-    if (!strcmp(key, "corr.ring")) return &corr_ring;
-    if (!strcmp(key, "corr.prio")) return &corr_prio;
     if (!strcmp(key, "store.policy")) return &store_policy;
     if (!strcmp(key, "dc.pt")) return &dc_pt;
     if (!strcmp(key, "dc.mt")) return &dc_mt;

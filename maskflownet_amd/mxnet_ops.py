@@ -16,10 +16,18 @@ Two ways to use it inside the reference:
 
 CustomOp protocol notes (MXNet 1.5 python/mxnet/operator.py):
   * every keyword reaches CustomOpProp.__init__ as a STRING ("(3, 3)", "False", "NCHW");
-  * forward/backward run on MXNet's custom-op worker thread, which has no access to MXNet's stream: each
-    call waits for its inputs (wait_to_read), hipSetDevice()s to the arrays' context (the reference drives
-    several GPUs from one process, pipeline.py:95), launches on the NULL stream and hipDeviceSynchronize()s
-    before returning;
+  * forward/backward run on MXNet's custom-op worker threads (a pool: MXNET_CUSTOM_OP_NUM_THREADS, 16 by default
+    from 1.3 on), which have no access to MXNet's stream: each call hipSetDevice()s to the arrays' context when
+    the thread's device changes (the reference drives several GPUs from one process, pipeline.py:95), launches on
+    the NULL stream and drains it (hipStreamSynchronize(NULL)) before returning.  There is no wait_to_read(): the
+    engine schedules a CustomOp only when its inputs are complete on the device, and the NULL stream is ordered
+    behind every blocking stream's earlier work (an assumption no test here can check -- there is no MXNet to
+    run against; tests/fake_mxnet honours it by construction);
+  * two operators may run AT THE SAME TIME on two worker threads (ctypes releases the GIL inside a call): the
+    workspace of a call is therefore per (thread, device), never shared, and a buffer that a larger request
+    replaces stays referenced until the call that may still read it has drained its stream;
+  * the arithmetic (mfn_set_arithmetic) is ONE process-wide setting: whatever the user's thread selected is what
+    the worker threads' launches use;
   * `req` is honoured per output / gradient: 'null' skips, 'write' / 'inplace' let the kernel write straight
     into the framework's buffer (no temporary, no copy), 'add' uses the library's MFN_REQ_ADD for gradients
     and a temporary + self.assign for forward outputs;
@@ -100,34 +108,52 @@ def _ptr(nd):
     return p.value
 
 
-# Scratch of the operator calls, one growing buffer per device: imperative mx.nd.Custom builds a new CustomOp per call (a
-# per-instance buffer would be allocated on every call), and every call ends with its stream drained, so two calls never
-# use the buffer at once on one device.
-_scratch = {}
+# Scratch of the operator calls: one growing buffer per (THREAD, device).  Imperative mx.nd.Custom builds a new CustomOp per call
+# (a per-instance buffer would be allocated on every call); MXNet runs CustomOps on a pool of worker threads and ctypes releases
+# the GIL inside a library call, so two operators -- the im1 and the im2 pyramid's convolutions, say -- can be between their
+# "pack the weights" and "run" launches at the same time: a process-wide buffer would let one read the other's packed weights
+# (ADVICE r05).  Within one thread a call ends with its stream drained before the next begins.
+import threading
+
+_tls = threading.local()
 
 
-_need = {}
+def _thread_state():
+    st = getattr(_tls, "st", None)
+    if st is None:
+        st = _tls.st = {"scratch": {}, "need": {}, "retired": []}
+    return st
 
 
 def _bytes(lib, query, *dims):
-    """A workspace-size query of the library, remembered per (query, tuning epoch, shape): pure functions of their integer
-    arguments and of the thread's arithmetic / the tuning state."""
-    key = (query, _lib.tuning_epoch()) + dims   # set_tuning / set_arithmetic bump the epoch
-    v = _need.get(key)
+    """A workspace-size query of the library, remembered per thread and per (query, tuning epoch, shape): pure functions of their
+    integer arguments and of the process's arithmetic / tuning state (set_tuning / set_arithmetic bump the epoch)."""
+    need = _thread_state()["need"]
+    key = (query, _lib.tuning_epoch()) + dims
+    v = need.get(key)
     if v is None:
-        v = _need[key] = getattr(lib, query)(*dims)
+        v = need[key] = getattr(lib, query)(*dims)
     return v
 
 
 def _workspace(need, ctx):
-    """(pointer, bytes) of at least `need` bytes on ctx, or (None, 0)."""
+    """(pointer, bytes) of at least `need` bytes on ctx for the calling thread, or (None, 0).  A buffer that is replaced by a
+    larger one is kept alive until _release_retired() -- after the stream has been drained -- : a kernel launched earlier in
+    the same call may still be reading it."""
     if not need:
         return None, 0
+    st = _thread_state()
     key = (ctx.device_type, ctx.device_id)
-    buf = _scratch.get(key)
+    buf = st["scratch"].get(key)
     if buf is None or buf.size * 4 < need:
-        buf = _scratch[key] = mx.nd.empty(((int(need * 1.25) + 3) // 4,), ctx=ctx)
+        if buf is not None:
+            st["retired"].append(buf)
+        buf = st["scratch"][key] = mx.nd.empty(((int(need * 1.25) + 3) // 4,), ctx=ctx)
     return _ptr(buf), buf.size * 4
+
+
+def _release_retired():
+    del _thread_state()["retired"][:]
 
 
 def _bool(s):
@@ -165,6 +191,7 @@ if mx is not None:
 
         def _end(self):
             _runtime().sync()
+            _release_retired()
 
     # ---- Correlation (network/MaskFlownet.py:193-195, :440-441) ------------------------------------
     class _Correlation(_Op):

@@ -143,7 +143,7 @@ def test_every_tuning_key_used_by_tests_tools_and_bench_exists():
                 if "=" in kv:
                     used.setdefault(kv.split("=")[0].replace("_", ".", 1), set()).add(os.path.basename(f))
     # the three names that selected ARITHMETIC before round 5 are no tuning keys any more: _lib.set_tuning / emu_ops.set_tuning
-    # route them to mfn_set_arithmetic (thread-local), which the emulation build answers for
+    # route them to mfn_set_arithmetic (one setting per process), which the emulation build answers for
     from maskflownet_amd._lib import ARITHMETIC_OPS
     for legacy, op in ARITHMETIC_OPS.items():
         assert legacy.replace("_", ".", 1) not in keys, legacy
@@ -209,3 +209,76 @@ def test_m0_is_only_touched_by_the_lds_dma_statements():
         assert re.match(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$", l), l   # a scalar source: the write of our own statement
         assert re.match(r"buffer_load_dword(x[234])? .* lds", lines[i + 1]), (l, lines[i + 1])
     assert n > 100, n
+
+
+def _function_bodies(text):
+    """{name: [body, ...]} of the function definitions of a C++ source (brace matching from `name(...) {` at nesting depth 0 or inside
+    `namespace mfn {`; templates and attributes in front do not matter).  Good enough for this tree's headers."""
+    import re
+    out = {}
+    # strip comments and string literals
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r'"(\\.|[^"\\])*"', '""', text)
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text):
+        name = m.group(1)
+        if name in ("if", "for", "while", "switch", "return", "sizeof", "static_assert", "defined", "decltype", "alignas", "__launch_bounds__", "__attribute__"):
+            continue
+        # find the matching ')' then expect (qualifiers) '{'
+        i, depth = m.end(), 1
+        while i < len(text) and depth:
+            depth += text[i] == "("
+            depth -= text[i] == ")"
+            i += 1
+        j = i
+        while j < len(text) and text[j] in " \t\n":
+            j += 1
+        k = j
+        while text.startswith(("const", "noexcept", "__attribute__", "->"), k) or (k < len(text) and text[k] in " \t\n"):
+            k += 1 if text[k] in " \t\n" else len(re.match(r"const|noexcept|__attribute__\(\([^)]*\)\)|->\s*[A-Za-z_:<>0-9 ]+", text[k:]).group(0))
+        if k >= len(text) or text[k] != "{":
+            continue
+        b, depth = k + 1, 1
+        while b < len(text) and depth:
+            depth += text[b] == "{"
+            depth -= text[b] == "}"
+            b += 1
+        out.setdefault(name, []).append(text[k:b])
+    return out
+
+
+def test_every_kernel_is_reachable_from_the_c_abi():
+    """no `__global__` entry point without a launch that the C ABI's dispatch (api_impl.inc) can reach -- a
+    static walk: start from the bodies of the exported functions (MFN_API(...)) and follow every identifier that names a function
+    defined in csrc/; every kernel has to turn up.  Superseded generations that nothing launches any more fail here."""
+    import re
+    csrc = os.path.join(ROOT, "maskflownet_amd", "csrc")
+    files = [os.path.join(csrc, "api_impl.inc"), os.path.join(csrc, "api.hip"), os.path.join(csrc, "mfn_rt.h")] + \
+            [os.path.join(csrc, "kernels", f) for f in sorted(os.listdir(os.path.join(csrc, "kernels"))) if f.endswith(".h")]
+    text = "\n".join(open(f).read() for f in files)
+    kernels = set(re.findall(r"__global__(?:\s+__launch_bounds__\([^)]*\)\))?[^;{(]*?\bvoid\s+([A-Za-z_0-9]+)\s*\(", re.sub(r"__launch_bounds__\((?:[^()]|\([^()]*\))*\)", "", text)))
+    assert len(kernels) >= 50, sorted(kernels)
+    bodies = _function_bodies(text)
+    api = open(os.path.join(csrc, "api_impl.inc")).read()
+    # roots: the bodies of the exported entry points
+    roots = [m.group(1) for m in re.finditer(r"MFN_API\(([a-z0-9_]+)\)\s*\(", api)]
+    reached, todo = set(), []
+    for m in re.finditer(r"MFN_API\([a-z0-9_]+\)\s*\([^)]*\)\s*\{", api):
+        b, depth = m.end(), 1
+        while b < len(api) and depth:
+            depth += api[b] == "{"
+            depth -= api[b] == "}"
+            b += 1
+        todo.append(api[m.end():b])
+    assert len(todo) >= 40, len(todo)
+    ident = re.compile(r"\b([A-Za-z_][A-Za-z0-9_]*)\b")
+    while todo:
+        body = todo.pop()
+        for name in set(ident.findall(body)):
+            if name in reached:
+                continue
+            if name in bodies or name in kernels:
+                reached.add(name)
+                todo.extend(bodies.get(name, []))
+    missing = sorted(kernels - reached)
+    assert not missing, "kernels no exported function can reach: %s" % missing

@@ -17,7 +17,7 @@ def ops():
     return emu_ops.emu_ops()
 
 
-DEFAULT_TUNING = dict(conv_dcm=0, corr_variant=-1, corr_rows=0, corr_form=0, corr_ring=0, corr_prio=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
+DEFAULT_TUNING = dict(conv_dcm=0, corr_variant=-1, corr_rows=0, corr_form=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
                       path_generic=0, bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=-1)
 
 
@@ -44,32 +44,27 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 32), 2, seed=2)
 
 
-@pytest.mark.parametrize("shape,md,rows", [((1, 32, 10, 24), 4, 0),     # 6-row items: a full and a 4-row item per strip, three strips (one block)
-                                           ((2, 32, 13, 20), 4, 8),     # 8-row items, odd H (a 5-row last item: half-filled last block), ragged last strip
-                                           ((1, 32, 7, 36), 2, 6),      # md = 2 (25 channels), 5 strips = 2 blocks, a 1-row last item
-                                           ((1, 32, 24, 8), 4, 0),      # 24 % 6 == 0 -> 6 rows; one strip: the f2 segment hangs over both image borders
-                                           ((1, 32, 16, 16), 2, 0)])    # 16 % 6 != 0, 16 % 8 == 0 -> the plan picks 8-row items
-@pytest.mark.parametrize("variant", [40, 46, 48])
+# every shape on the plan's form (48); the other two forms share everything but the arithmetic of a step (46: raw operands on the fp32
+# matrix instruction; 40: the VALU split, results staged behind the chains) and run two shapes each -- the suite has a time budget
+@pytest.mark.parametrize("variant,shape,md,rows", [
+    (48, (1, 32, 10, 24), 4, 0),     # 6-row items: a full and a 4-row item per strip, three strips (one block)
+    (48, (2, 32, 13, 20), 4, 8),     # 8-row items, odd H (a 5-row last item: half-filled last block), ragged last strip
+    (48, (1, 32, 7, 36), 2, 6),      # md = 2 (25 channels), 5 strips = 2 blocks, a 1-row last item
+    (48, (1, 32, 24, 8), 4, 0),      # 24 % 6 == 0 -> 6 rows; one strip: the f2 segment hangs over both image borders
+    (48, (1, 32, 16, 16), 2, 0),     # 16 % 6 != 0, 16 % 8 == 0 -> the plan picks 8-row items
+    (46, (2, 32, 13, 20), 4, 8), (46, (1, 32, 7, 36), 2, 6),
+    (40, (1, 32, 10, 24), 4, 0), (40, (1, 32, 7, 36), 2, 6)])
 def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows, variant):
-    """corr.variant 40: the band of the Gram matrix on the bf16 matrix cores, operands split into three bf16 terms (six
-    products): exact fp32 to the tolerance of every other cost-volume kernel.  Wave-private LDS-DMA rings, counted waits,
-    row-shift de-skew, range-checked band stores; LeakyReLU and the concat-slice form.  corr.variant 46: the same band on
-    the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, raw operands, an fmaf chain over the channels)."""
+    """corr.variant 48 (the plan's): the band of the Gram matrix on the bf16 matrix cores, operands split into three bf16 terms
+    (six products) with the residuals formed by selector matrix instructions (kernels/msplit.h) and the results leaving one step
+    behind the chains: exact fp32 to the tolerance of every other cost-volume kernel.  Wave-private LDS-DMA rings, counted waits,
+    row-shift de-skew, cooperative full-line stores; LeakyReLU and the concat-slice form.  40: round 4's VALU split; 46: the same
+    band on the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, raw operands, an fmaf chain over the channels)."""
     emu_ops.set_tuning(corr_variant=variant, corr_direct=2, corr_rows=rows)
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
     assert "corr_gram_v%d" % variant in emu_ops.launch_log()
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
     pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
-
-
-@pytest.mark.parametrize("shape,md", [((1, 32, 18, 40), 4), ((2, 32, 13, 24), 2)])
-def test_correlation_gram_eight_wave_blocks(ops, oracle, shape, md):
-    """corr.ring 84: two cooperative groups (row segments 2k, 2k + 1 of the same 32 columns) in one 8-wave block -- an odd number of
-    segments leaves the last block's second group with nothing but the barriers."""
-    emu_ops.set_tuning(corr_variant=48, corr_direct=2, corr_rows=6, corr_ring=84)
-    pc.case_correlation(ops, oracle, ident, ident, shape, md)
-    assert "corr_gram_v48w8" in emu_ops.launch_log()
-    pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
 
 
 @pytest.mark.skipif(__import__("os").environ.get("MFN_SLOW_TESTS") != "1",

@@ -36,7 +36,7 @@ def host(t):
 def _reset_tuning():
     from maskflownet_amd import _lib
     yield
-    _lib.set_tuning(corr_variant=-1, corr_rows=0, corr_form=0, corr_ring=0, corr_prio=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
+    _lib.set_tuning(corr_variant=-1, corr_rows=0, corr_form=0, corr_gram=-1, dc_mma=-1, corr_direct=0, store_policy=-1, dc_pt=0, dc_ksb=0, dc_nw=0, dc_off=0, dc_mt=0,
                     path_generic=0, bwd_off=0, conv_mt=0, conv_pt=0, conv_mma=-1)
 
 
@@ -109,8 +109,6 @@ def test_correlation_gram_is_deterministic_and_matches_the_fma_kernel(ops, T):
             want = ops.Correlation(a, b, 1, 4, 1, 1, 4).clone()
             _lib.set_tuning(corr_variant=48, corr_rows=rows)
             assert T.equal(ops.Correlation(a, b, 1, 4, 1, 1, 4), want)
-    _lib.set_tuning(corr_variant=48, corr_rows=4)
-    assert T.equal(ops.Correlation(f1, f2, 1, 4, 1, 1, 4), first)
 
 
 @pytest.mark.parametrize("shape", CFG2 + CFG3)
@@ -567,6 +565,32 @@ def test_deform_conv_zero_offset_is_conv2d_at_full_size(ops, T):
     xs[:, :, 0:94, 3:128] = x[:, :, 2:96, 0:125]
     want = F.conv2d(xs, w, b, padding=1)
     assert (got[:, :, 2:90, 6:120] - want[:, :, 2:90, 6:120]).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+def test_deform_conv_on_views_that_are_not_16_byte_aligned(ops, oracle, dev, T):
+    """a call with raw weights whose x / out are views at an odd element offset cannot take the matrix-core kernel
+    (16 bytes per lane) and must run the fp32 kernel's plan instead of failing with MFN_E_ALIGN -- through the operator call, the
+    shared-offset call and the fused matching call; weights PACKED for the matrix-core layout are refused there, loudly."""
+    from maskflownet_amd import _lib
+    rng = np.random.default_rng(5)
+    N, C, H, W = 2, 32, 24, 32
+    x, w, b = pc.feat(rng, (N, C, H, W)), (rng.standard_normal((C, C, 3, 3)) * 0.1).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    fl = (rng.standard_normal((N, 2, H, W)) * 0.3).astype(np.float32)
+    off = np.repeat((fl * 20.0 / 4.0)[:, None], 9, 1).reshape(N, 18, H, W).astype(np.float32)
+    want = oracle.deformable_convolution(x, off, w, b, kernel=(3, 3), pad=(1, 1))
+    flat_x = T.zeros(x.size + 1, device="cuda")
+    flat_o = T.zeros(want.size + 3, device="cuda")
+    xv = flat_x[1:].view(N, C, H, W); xv.copy_(dev(x))
+    ov = flat_o[3:].view(N, C, H, W)
+    assert xv.data_ptr() % 16 and ov.data_ptr() % 16
+    got = ops.DeformableConvolution(xv, dev(off), dev(w), dev(b), kernel=(3, 3), pad=(1, 1), num_filter=C, out=ov)
+    pc.check_close(host(got), want, what="deformable convolution on unaligned views")
+    got = ops.deformable_convolution_shared(xv, dev(fl), 20.0, 4.0, dev(w), dev(b), out=ov)
+    pc.check_close(host(got), want, what="shared-offset deformable convolution on unaligned views")
+    packed = ops.pack_deform_weights(dev(w), (N, C, H, W), kernel=(3, 3), pad=(1, 1))
+    with pytest.raises(_lib.MfnError) as e:
+        ops.DeformableConvolution(xv, dev(off), dev(w), dev(b), kernel=(3, 3), pad=(1, 1), num_filter=C, out=ov, packed=packed)
+    assert "16-byte aligned" in str(e.value)
 
 
 # ---- backward: the gradients config 5 (train step) needs, at the network's level shapes ---------------------

@@ -618,3 +618,35 @@ def test_gpu_matching_level_custom_op(gpu_binding, oracle, level):
     C = {5: 128, 4: 96, 3: 64, 2: 32}[level]
     s = {5: 32, 4: 16, 3: 8, 2: 4}[level]
     _matching_level(mx, oracle, mx.gpu(0), 2, C, 384 // s, 512 // s, float(s), gated=(level == 3), seed=level)
+
+
+def test_customop_scratch_is_per_thread_and_outlives_its_replacement(cpu_binding):
+    """MXNet >= 1.3 runs CustomOps on a pool of worker threads and ctypes releases the GIL, so two operators can be
+    between their 'pack' and 'run' launches at once -- the workspace of a call must not be shared between threads, and a buffer a
+    larger request replaces has to stay alive until the call that may still be reading it has drained its stream."""
+    import threading
+    mx, m = cpu_binding
+    ctx = mx.cpu()      # the stub's host tensors stand in for device memory here
+    got = {}
+
+    def worker(name, need):
+        p, n = m._workspace(need, ctx)
+        got[name] = (p, n, m._thread_state()["scratch"][(ctx.device_type, ctx.device_id)])
+
+    ts = [threading.Thread(target=worker, args=("a", 4096)), threading.Thread(target=worker, args=("b", 1 << 20))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert got["a"][0] != got["b"][0] and got["a"][2] is not got["b"][2]      # never one buffer for two threads
+    assert got["a"][1] >= 4096 and got["b"][1] >= (1 << 20)
+    # same thread: a larger request replaces the buffer, the old one is retired (still referenced) until the stream was drained
+    p1, _ = m._workspace(1024, ctx)
+    old = m._thread_state()["scratch"][(ctx.device_type, ctx.device_id)]
+    p2, n2 = m._workspace(1 << 22, ctx)
+    assert p2 != p1 and n2 >= (1 << 22)
+    assert any(b is old for b in m._thread_state()["retired"])
+    m._release_retired()
+    assert not m._thread_state()["retired"]
+    # the size cache is per thread as well
+    lib = m._lib_ns()
+    v = m._bytes(lib, "correlation_workspace_bytes", 1, 32, 8, 8, 4, 1, 1, 1, 4, 1)
+    assert m._bytes(lib, "correlation_workspace_bytes", 1, 32, 8, 8, 4, 1, 1, 1, 4, 1) == v
