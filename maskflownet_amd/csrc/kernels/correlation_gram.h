@@ -1,7 +1,8 @@
 // correlation_gram.h -- the cost volume of 32-channel levels as a BANDED GRAM MATRIX on the bf16 matrix cores (gfx950).
 //
 // Replaces MXNet Correlation at /root/reference/network/MaskFlownet.py:193-195 (md=4, 81 ch) and :440-441 (md=2, 25 ch)
-// for C == 32 (level 2, the launch BASELINE.json's north_star names); semantics as oracle/mfn_ref_body.inc correlation_fwd.
+// for C == 32 (level 2, the launch BASELINE.json's north_star names) and, as a two-chunk K loop, C == 64 (level 3; round 6);
+// semantics as oracle/mfn_ref_body.inc correlation_fwd.
 //
 // Why another formulation (profiles/r03_corr_pmc.md): corr_dma_kernel (correlation.h) spends 36 packed
 // FMAs and 64 bytes of LDS operand reads per lane-channel; at level 2 that is 5.6 us of VALU issue + 3.2 us of LDS returns per
@@ -57,7 +58,8 @@ struct CorrGramParams {
   const float *f1;
   const float *f2;
   float *out;
-  int N, H, W;            // C == 32
+  int N, H, W;
+  int C;                  // 32, or 64 (two channel chunks; form 48 only)
   int rows;               // output rows per work item (even)
   int strips, segs;       // ceil(W / 8), ceil(H / rows)
   int bx_per_row;         // blocks along x: ceil(strips / waves per block)
@@ -155,7 +157,7 @@ struct GramSched {
 // run (995 k per level-2 launch against 498 k for the FMA kernel), 36 of 64 lanes per store instruction, and written through
 // they are partial-line writes (14.2 us for the volume alone), so the non-cooperative form stores plain and leaves the lines
 // to the L2 and to the flush at the end of the kernel.  One block barrier per step; `stg` = the block's two staging buffers.
-template <int D, int T, int NSLOT, int TERMS, int POL, bool LEAKY, int SP, int PAR, bool COOP = false>
+template <int D, int T, int NSLOT, int TERMS, int POL, bool LEAKY, int SP, int PAR, bool COOP = false, int NC = 1>
 __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *ring, int lane, int n, int ys, int x0,
                                                float *stg = nullptr, int wave = 0, int xb0 = 0) {
   using SC = GramSched<D, T, SP, PAR>;
@@ -174,15 +176,20 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   // barrier, read-back, stores) that nothing covered.
   constexpr bool MSPLIT = TERMS >= 4;
   constexpr bool PIPE = TERMS == 5;
+  // NC: chunks of 32 channels (C = 32 NC; round 6: level 3's 64 channels as a two-chunk K loop).  A logical tile of the sequence is
+  // NC raw tiles (one per chunk) in NC consecutive ring slots, an operand is NC register sets, a chain runs its six products once
+  // per chunk into its own accumulator (summed where the results leave the registers: no dependent chain of 6 NC instructions).
+  static_assert(NC == 1 || PIPE, "several channel chunks: the pipelined cooperative form only");
   static_assert(!PIPE || (COOP && MFN_GRAM_ABLATE == 0), "the pipelined way out is the cooperative form's");
 
   const int H = p.H, W = p.W;
   const int plane = H * W;
   const int R = min(2 * T, H - ys);      // output rows of this item (the last segment may be short)
-  const float *f1n = p.f1 + (size_t)n * 32 * plane;
-  const float *f2n = p.f2 + (size_t)n * 32 * plane;
+  const float *f1n = p.f1 + (size_t)n * (32 * NC) * plane;
+  const float *f2n = p.f2 + (size_t)n * (32 * NC) * plane;
   float *outn = p.out + (size_t)n * p.out_nstride;
-  const unsigned img_bytes = (unsigned)(32 * plane) * 4u;
+  const unsigned img_bytes = (unsigned)(32 * NC * plane) * 4u;
+  const unsigned chunk_bytes = (unsigned)(32 * plane) * 4u;
 
   // ---- per-lane constants --------------------------------------------------------------------------------------------
   // DMA of an f2 segment: instruction j covers channels 16j .. 16j+15, lane -> (channel lane/4, 16-byte quad lane%4)
@@ -222,24 +229,27 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   auto issue_tile = [&](auto k_c) __attribute__((always_inline)) {    // tile k of the sequence -> ring slot k % NSLOT
     constexpr int k = decltype(k_c)::value;
     constexpr int kd = SC::kind(k);
-    float *slot = ring + (k % NSLOT) * SLOT_F;
     if (MFN_GRAM_ABLATE & 8) { stamp[k] = n_issued; return; }
-    if (kd >= 0) {   // f1 block t: rows ys+2t, +1.  A second row that is row H (odd H) is NOT zero-filled except for channel 31: for
-      // c < 31 the transfer reads row 0 of channel c + 1 (voff + soff is still inside the image's 32 planes).  Those lanes' results
-      // are never stored -- the row masks vo_mid / vo_last (r1 false) and, in the cooperative store, rowok_bits drop them; the
-      // odd-H cases of tests/test_emu_parity.py::test_correlation_gram_band_on_matrix_cores ((2,32,13,20), (1,32,7,36)) pin that
-      const bool in = ys + 2 * kd < H;
-      const unsigned soff = (unsigned)((ys + 2 * kd) * W) * 4u;
-      mfn_dma16_row(f1n, img_bytes, soff, in, slot, voffM[0]);
-      mfn_dma16_row(f1n, img_bytes, soff, in, slot + 256, voffM[1]);
-    } else {         // f2 row ys-MD+s; rows outside the image (MXNet's pad_size border) read zeros
-      const int row = ys - MD + SC::step(-kd - 1);
-      const bool in = row >= 0 && row < H;
-      const unsigned soff = (unsigned)(row * W) * 4u;
-      mfn_dma16_row(f2n, img_bytes, soff, in, slot, voffN[0]);
-      mfn_dma16_row(f2n, img_bytes, soff, in, slot + 256, voffN[1]);
+    MFN_UNROLL
+    for (int cc = 0; cc < NC; ++cc) {
+      float *slot = ring + ((k % NSLOT) * NC + cc) * SLOT_F;
+      if (kd >= 0) {   // f1 block t: rows ys+2t, +1.  A second row that is row H (odd H) is NOT zero-filled except for the last channel: for
+        // c < C - 1 the transfer reads row 0 of channel c + 1 (voff + soff is still inside the image's planes).  Those lanes' results
+        // are never stored -- the row masks vo_mid / vo_last (r1 false) and, in the cooperative store, rowok_bits drop them; the
+        // odd-H cases of tests/test_emu_parity.py::test_correlation_gram_band_on_matrix_cores ((2,32,13,20), (1,32,7,36)) pin that
+        const bool in = ys + 2 * kd < H;
+        const unsigned soff = (unsigned)((ys + 2 * kd) * W) * 4u + cc * chunk_bytes;
+        mfn_dma16_row(f1n, img_bytes, soff, in, slot, voffM[0]);
+        mfn_dma16_row(f1n, img_bytes, soff, in, slot + 256, voffM[1]);
+      } else {         // f2 row ys-MD+s; rows outside the image (MXNet's pad_size border) read zeros
+        const int row = ys - MD + SC::step(-kd - 1);
+        const bool in = row >= 0 && row < H;
+        const unsigned soff = (unsigned)(row * W) * 4u + cc * chunk_bytes;
+        mfn_dma16_row(f2n, img_bytes, soff, in, slot, voffN[0]);
+        mfn_dma16_row(f2n, img_bytes, soff, in, slot + 256, voffN[1]);
+      }
     }
-    n_issued += 2;
+    n_issued += 2 * NC;
     stamp[k] = n_issued;
   };
   auto wait_tile = [&](int k) { mfn_wait_vm_dyn(n_issued - stamp[k]); };
@@ -249,14 +259,14 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   mfn_static_for<NSLOT>([&](auto k_c) __attribute__((always_inline)) { issue_tile(k_c); });
   MFN_SCHED_BARRIER();
   float raw[8];
-  auto read_raw = [&](int k) {
-    const float *su = ring + (k % NSLOT) * SLOT_F + rdoff;
+  auto read_raw = [&](int k, int cc = 0) {
+    const float *su = ring + ((k % NSLOT) * NC + cc) * SLOT_F + rdoff;
     MFN_UNROLL
     for (int j = 0; j < 8; ++j) raw[j] = su[64 * j];
   };
   typedef typename GramOpSel<(TERMS == 1 ? 1 : 3)>::type Op;
-  Op Mreg[T];
-  Op Ncur;
+  Op Mreg[T][NC];
+  Op Ncur[NC];
   GramSel sel;
   if constexpr (MSPLIT) sel = gram_make_sel(lane);
   auto convert = [&](Op &o, float scale) {
@@ -333,8 +343,11 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
 
   wait_tile(1);
   MFN_STAMP(p.timeline, 1);
-  read_raw(0); convert(Mreg[0], p.inv_c);
-  read_raw(1); convert(Ncur, 1.0f);
+  MFN_UNROLL
+  for (int cc = 0; cc < NC; ++cc) {
+    read_raw(0, cc); convert(Mreg[0][cc], p.inv_c);
+    read_raw(1, cc); convert(Ncur[cc], 1.0f);
+  }
   MFN_WAIT_LGKM0();
   mfn_static_for<2>([&](auto i_c) __attribute__((always_inline)) {
     constexpr int k = NSLOT + decltype(i_c)::value;
@@ -368,14 +381,17 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   };
 
   // de-skew + stage chain ci (block t_hi - ci) of step s out of a[] into sbuf: the cooperative form's way out of the registers
-  auto stage_chain = [&](int s, int ci, const f32x4 *a, float *sbuf, unsigned &valid_bits) __attribute__((always_inline)) {
+  auto stage_chain = [&](int s, int ci, const f32x4 (*a)[NC], float *sbuf, unsigned &valid_bits) __attribute__((always_inline)) {
     const int t = Ch::hi(s) - ci;
     const int e = s - 2 * t;
+    f32x4 sum = a[t][0];
+    MFN_UNROLL
+    for (int cc = 1; cc < NC; ++cc) { sum[0] += a[t][cc][0]; sum[1] += a[t][cc][1]; sum[2] += a[t][cc][2]; sum[3] += a[t][cc][3]; }   // chunks in order
     f32x4 v;
-    v[0] = a[t][0];
-    v[1] = mfn_dpp_row_shl<1>(a[t][1], a[t][1]);
-    v[2] = mfn_dpp_row_shl<2>(a[t][2], a[t][2]);
-    v[3] = mfn_dpp_row_shl<3>(a[t][3], a[t][3]);
+    v[0] = sum[0];
+    v[1] = mfn_dpp_row_shl<1>(sum[1], sum[1]);
+    v[2] = mfn_dpp_row_shl<2>(sum[2], sum[2]);
+    v[3] = mfn_dpp_row_shl<3>(sum[3], sum[3]);
     if (LEAKY) {
       MFN_UNROLL
       for (int i = 0; i < 4; ++i) v[i] = mfn_leaky01(v[i]);
@@ -384,7 +400,7 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     if (e >= 1) valid_bits |= ((rowok_bits >> (2 * t + 1)) & 1u) << (ci * 2 + 1);
     if (stw[ci] >= 0) *reinterpret_cast<f32x4 *>(sbuf + stw[ci]) = v;
   };
-  f32x4 accP[T];                    // PIPE: the previous step's accumulators
+  f32x4 accP[T][NC];                // PIPE: the previous step's accumulators (one per channel chunk)
   unsigned valid_staged = 0;        // PIPE: valid_bits of the lines staged during the previous step
 
   mfn_static_for<J>([&](auto j_c) __attribute__((always_inline)) {
@@ -396,11 +412,14 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     constexpr bool moreM = tM >= 0;
     constexpr int kN = more ? SC::seqN(j + 1) : 0;
     if (more) wait_tile(kN);
-    Op Nnext;
+    Op Nnext[NC];
     // raw tiles of the next step out of LDS first: their conversion (VALU) hides behind this step's matrix instructions
-    float rawM[8], rawN[8];
-    if (moreM) { read_raw(kN - 1); MFN_UNROLL for (int i = 0; i < 8; ++i) rawM[i] = raw[i] * p.inv_c; }
-    if (more) { read_raw(kN); MFN_UNROLL for (int i = 0; i < 8; ++i) rawN[i] = raw[i]; }
+    float rawM[NC][8], rawN[NC][8];
+    MFN_UNROLL
+    for (int cc = 0; cc < NC; ++cc) {
+      if (moreM) { read_raw(kN - 1, cc); MFN_UNROLL for (int i = 0; i < 8; ++i) rawM[cc][i] = raw[i] * p.inv_c; }
+      if (more) { read_raw(kN, cc); MFN_UNROLL for (int i = 0; i < 8; ++i) rawN[cc][i] = raw[i]; }
+    }
     GramWords wM, wN;
     // The chains of a step have independent accumulators: their matrix instructions are written interleaved (product k of
     // every active block, then product k+1 ...), so that a block's dependent accumulate never waits for its own predecessor,
@@ -410,39 +429,47 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     constexpr int NPROD = TERMS >= 3 ? 6 : (TERMS == 1 ? 8 : 3);
     constexpr int npairs = (TERMS == 1 || MSPLIT) ? 0 : (moreM ? 4 : 0) + (more ? 4 : 0);
     // MSPLIT: the next step's tiles as accumulator tiles; five split stages spread between this step's chains
-    f32x4 xM0, xM1, xN0, xN1;
-    mfn_bf16x8 cM[3], cN[3];
+    f32x4 xM0[NC], xM1[NC], xN0[NC], xN1[NC];
+    mfn_bf16x8 cM[NC][3], cN[NC][3];
     int next_stage = 0;
     if constexpr (MSPLIT) {
       MFN_UNROLL
       for (int q = 0; q < 4; ++q) {
-        if (moreM) { xM0[q] = rawM[q]; xM1[q] = rawM[4 + q]; }
-        if (more) { xN0[q] = rawN[q]; xN1[q] = rawN[4 + q]; }
+        MFN_UNROLL
+        for (int cc = 0; cc < NC; ++cc) {
+          if (moreM) { xM0[cc][q] = rawM[cc][q]; xM1[cc][q] = rawM[cc][4 + q]; }
+          if (more) { xN0[cc][q] = rawN[cc][q]; xN1[cc][q] = rawN[cc][4 + q]; }
+        }
       }
     }
     auto split_stage = [&]() {
       if constexpr (MSPLIT) {
-        if (moreM) gram_msplit_stage(next_stage, sel, xM0, xM1, cM);
-        if (more) gram_msplit_stage(next_stage, sel, xN0, xN1, cN);
+        MFN_UNROLL
+        for (int cc = 0; cc < NC; ++cc) {
+          if (moreM) gram_msplit_stage(next_stage, sel, xM0[cc], xM1[cc], cM[cc]);
+          if (more) gram_msplit_stage(next_stage, sel, xN0[cc], xN1[cc], cN[cc]);
+        }
         ++next_stage;
       }
     };
     int done_pairs = 0, unit = 0, nunits = 0;
     MFN_UNROLL
-    for (int t = 0; t < T; ++t) if (s - 2 * t >= 0 && s - 2 * t <= 2 * MD + 1) nunits += NPROD;
+    for (int t = 0; t < T; ++t) if (s - 2 * t >= 0 && s - 2 * t <= 2 * MD + 1) nunits += NPROD * NC;
     auto convert_next_pair = [&]() {
       if constexpr (TERMS != 1 && !MSPLIT) {
         if (done_pairs < npairs) {
           const int q = done_pairs & 3;
-          if (moreM && done_pairs < 4) gram_split_pair<TERMS>(rawM[2 * q], rawM[2 * q + 1], wM, q);
-          else gram_split_pair<TERMS>(rawN[2 * q], rawN[2 * q + 1], wN, q);
+          if (moreM && done_pairs < 4) gram_split_pair<TERMS>(rawM[0][2 * q], rawM[0][2 * q + 1], wM, q);
+          else gram_split_pair<TERMS>(rawN[0][2 * q], rawN[0][2 * q + 1], wN, q);
           ++done_pairs;
         }
       }
     };
-    f32x4 acc[T];
+    f32x4 acc[T][NC];
     MFN_UNROLL
-    for (int t = 0; t < T; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; acc[t][2] = 0.f; acc[t][3] = 0.f; }
+    for (int t = 0; t < T; ++t)
+      MFN_UNROLL
+      for (int cc = 0; cc < NC; ++cc) { acc[t][cc][0] = 0.f; acc[t][cc][1] = 0.f; acc[t][cc][2] = 0.f; acc[t][cc][3] = 0.f; }
     // PIPE: what leaves the registers behind this step's matrix instructions -- the chains of step j-1 (accP) into staging buffer
     // (j-1) & 1 and, read back first, the lines of step j-2 out of buffer j & 1 (staged during step j-1, barrier at its end)
     constexpr int sP = j > 0 ? SC::step(j > 0 ? j - 1 : 0) : 0;
@@ -467,25 +494,29 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
         for (int t = 0; t < T; ++t) {
           const int e = s - 2 * t;
           if (e >= 0 && e <= 2 * MD + 1) {
-            const Op &Mo = Mreg[t];
-            if constexpr (TERMS == 1) {
-              acc[t] = MFN_MFMA_16x16x4(Mo.r[k], Ncur.r[k], acc[t]);   // channels 4k .. 4k+3
-            } else {
-              // smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h (two terms: l*h, h*l, h*h)
-              const mfn_bf16x8 &a = TERMS >= 3 ? (k == 0 ? Mo.l : (k == 2 || k == 3 ? Mo.m : Mo.h)) : (k == 0 ? Mo.l : Mo.h);
-              const mfn_bf16x8 &b = TERMS >= 3 ? (k == 1 ? Ncur.l : (k == 2 || k == 4 ? Ncur.m : Ncur.h)) : (k == 1 ? Ncur.l : Ncur.h);
-              acc[t] = MFN_MFMA_16x16x32_BF16(a, b, acc[t]);
+            MFN_UNROLL
+            for (int cc = 0; cc < NC; ++cc) {
+              const Op &Mo = Mreg[t][cc];
+              const Op &No = Ncur[cc];
+              if constexpr (TERMS == 1) {
+                acc[t][cc] = MFN_MFMA_16x16x4(Mo.r[k], No.r[k], acc[t][cc]);   // channels 4k .. 4k+3
+              } else {
+                // smallest terms first: l*h, h*l, m*m, m*h, h*m, h*h (two terms: l*h, h*l, h*h)
+                const mfn_bf16x8 &a = TERMS >= 3 ? (k == 0 ? Mo.l : (k == 2 || k == 3 ? Mo.m : Mo.h)) : (k == 0 ? Mo.l : Mo.h);
+                const mfn_bf16x8 &b = TERMS >= 3 ? (k == 1 ? No.l : (k == 2 || k == 4 ? No.m : No.h)) : (k == 1 ? No.l : No.h);
+                acc[t][cc] = MFN_MFMA_16x16x32_BF16(a, b, acc[t][cc]);
+              }
+              if constexpr (MSPLIT) {   // stage i behind unit floor(i * nunits / 5)
+                while (more && next_stage < 5 && next_stage * nunits <= unit * 5) split_stage();
+                if constexpr (PIPE) while (post_done < nchP && post_done * nunits <= unit * nchP) post_chain();
+                MFN_SCHED_BARRIER();
+              }
+              if (MFN_GRAM_SCHED) {   // pair i behind unit floor(i * nunits / npairs)
+                while (done_pairs < npairs && done_pairs * nunits <= unit * npairs) convert_next_pair();
+                MFN_SCHED_BARRIER();
+              }
+              ++unit;
             }
-            if constexpr (MSPLIT) {   // stage i behind unit floor(i * nunits / 5)
-              while (more && next_stage < 5 && next_stage * nunits <= unit * 5) split_stage();
-              if constexpr (PIPE) while (post_done < nchP && post_done * nunits <= unit * nchP) post_chain();
-              MFN_SCHED_BARRIER();
-            }
-            if (MFN_GRAM_SCHED) {   // pair i behind unit floor(i * nunits / npairs)
-              while (done_pairs < npairs && done_pairs * nunits <= unit * npairs) convert_next_pair();
-              MFN_SCHED_BARRIER();
-            }
-            ++unit;
           }
         }
       }
@@ -493,14 +524,17 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     while (done_pairs < npairs) convert_next_pair();
     if constexpr (MSPLIT) {
       while (more && next_stage < 5) split_stage();
-      if (moreM) { Mreg[moreM ? tM : 0].h = cM[0]; Mreg[moreM ? tM : 0].m = cM[1]; Mreg[moreM ? tM : 0].l = cM[2]; }
-      if (more) { Nnext.h = cN[0]; Nnext.m = cN[1]; Nnext.l = cN[2]; }
+      MFN_UNROLL
+      for (int cc = 0; cc < NC; ++cc) {
+        if (moreM) { Mreg[moreM ? tM : 0][cc].h = cM[cc][0]; Mreg[moreM ? tM : 0][cc].m = cM[cc][1]; Mreg[moreM ? tM : 0][cc].l = cM[cc][2]; }
+        if (more) { Nnext[cc].h = cN[cc][0]; Nnext[cc].m = cN[cc][1]; Nnext[cc].l = cN[cc][2]; }
+      }
     } else if constexpr (TERMS == 1) {
-      if (moreM) { MFN_UNROLL for (int i = 0; i < 8; ++i) Mreg[moreM ? tM : 0].r[i] = rawM[i]; }
-      if (more) { MFN_UNROLL for (int i = 0; i < 8; ++i) Nnext.r[i] = rawN[i]; }
+      if (moreM) { MFN_UNROLL for (int i = 0; i < 8; ++i) Mreg[moreM ? tM : 0][0].r[i] = rawM[0][i]; }
+      if (more) { MFN_UNROLL for (int i = 0; i < 8; ++i) Nnext[0].r[i] = rawN[0][i]; }
     } else {
-      if (moreM) gram_words_to_op(wM, Mreg[moreM ? tM : 0]);
-      if (more) gram_words_to_op(wN, Nnext);
+      if (moreM) gram_words_to_op(wM, Mreg[moreM ? tM : 0][0]);
+      if (more) gram_words_to_op(wN, Nnext[0]);
     }
     MFN_WAIT_LGKM0();                      // the ring slots of the tiles just read are free: the next tiles of the sequence go there
     {
@@ -517,7 +551,9 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
       valid_staged = valid_bitsP;
       MFN_LDS_BARRIER();              // step j-1's lines are staged (read back in step j+1); buffer j & 1 is free for step j's
       MFN_UNROLL
-      for (int t = 0; t < T; ++t) accP[t] = acc[t];
+      for (int t = 0; t < T; ++t)
+        MFN_UNROLL
+        for (int cc = 0; cc < NC; ++cc) accP[t][cc] = acc[t][cc];
     } else if (!(MFN_GRAM_ABLATE & 1)) {
       // active chains of this step, highest block first (ci = 0, 1, ...): t_hi = min(T-1, s/2) downwards while e = s - 2t <= 2MD+1
       constexpr int t_hi = chains_hi(s);
@@ -541,10 +577,10 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
         const int e = s - 2 * t;
         // de-skew: register i of lane n holds (x = 4h+i, dx = n-XOFF-4h-i); lane n0 collects dx0 = n0-XOFF-4h from lanes n0+i
         f32x4 v;
-        v[0] = acc[t][0];
-        v[1] = mfn_dpp_row_shl<1>(acc[t][1], acc[t][1]);
-        v[2] = mfn_dpp_row_shl<2>(acc[t][2], acc[t][2]);
-        v[3] = mfn_dpp_row_shl<3>(acc[t][3], acc[t][3]);
+        v[0] = acc[t][0][0];
+        v[1] = mfn_dpp_row_shl<1>(acc[t][0][1], acc[t][0][1]);
+        v[2] = mfn_dpp_row_shl<2>(acc[t][0][2], acc[t][0][2]);
+        v[3] = mfn_dpp_row_shl<3>(acc[t][0][3], acc[t][0][3]);
         if (LEAKY) {
           MFN_UNROLL
           for (int i = 0; i < 4; ++i) v[i] = mfn_leaky01(v[i]);
@@ -563,7 +599,7 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
       if (COOP && j > 0) store_lines(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{}, vprev, valid_pending);
       valid_pending = valid_bits;
     }
-    if (more) Ncur = Nnext;
+    if (more) { MFN_UNROLL for (int cc = 0; cc < NC; ++cc) Ncur[cc] = Nnext[cc]; }
     if (j == J / 2 - 1) MFN_STAMP(p.timeline, 2);
     MFN_SCHED_BARRIER();
   });
@@ -600,7 +636,7 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     store_lines(std::integral_constant<int, J - 1>{}, vlast, valid_pending);
   }
   if (MFN_GRAM_ABLATE & 1) {   // keep the conversions live
-    float sink = mfn_bf16_at(reinterpret_cast<const float *>(&Ncur), 0) + mfn_bf16_at(reinterpret_cast<const float *>(&Mreg[T - 1]), 1);
+    float sink = mfn_bf16_at(reinterpret_cast<const float *>(&Ncur[0]), 0) + mfn_bf16_at(reinterpret_cast<const float *>(&Mreg[T - 1][0]), 1);
     if (sink == 1.2345e30f) outn[lane] = sink;
   }
   MFN_STAMP(p.timeline, 3);
@@ -608,13 +644,13 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
 
 // One wave per (image, row segment, strip, step parity); NWV adjacent strips per block.  COOP (NWV = 4, SP = 1): the block's
 // waves exchange their results through LDS (one barrier per step) and store full 128-byte lines.
-template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP, bool COOP>
+template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP, bool COOP, int NC = 1>
 __global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p) {
   static_assert(!COOP || (NWV == 4 && SP == 1), "cooperative stores: four strips = one 128-byte line, one wave per item");
   MFN_DYN_SHARED(float, lds_all);
   const int lane = threadIdx.x & 63;
   const int wave = MFN_UNIFORM(threadIdx.x >> 6);
-  float *ring = lds_all + (size_t)wave * NSLOT * 512;
+  float *ring = lds_all + (size_t)wave * NSLOT * NC * 512;
   MFN_STAMP(p.timeline, 0);
   int bid = blockIdx.x;
   if (p.xcd_swizzle) bid = (int)mfn_xcd_remap((unsigned)bid, (unsigned)p.xcd_swizzle);
@@ -628,14 +664,14 @@ __global__ __launch_bounds__(NWV * 64, 2) void corr_gram_kernel(CorrGramParams p
   const int sx = bxs * NWV + wave;
   if (!COOP && sx >= p.strips) return;   // COOP: a wave past the last strip keeps the block's barriers company (its lanes are all masked)
   const int x0 = sx * 8, ys = seg * (2 * T);
-  if constexpr (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * 512, wave, bxs * NWV * 8);
+  if constexpr (COOP) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, 1, 0, true, NC>(p, ring, lane, n, ys, x0, lds_all + (size_t)NWV * NSLOT * NC * 512, wave, bxs * NWV * 8);
   else {
     if (SP == 1 || par == 0) corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, 0>(p, ring, lane, n, ys, x0);
     else corr_gram_wave<D, T, NSLOT, TERMS, POL, LEAKY, SP, SP - 1>(p, ring, lane, n, ys, x0);
   }
 }
 
-template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP = 1, bool COOP = false>
+template <int D, int T, int NSLOT, int NWV, int TERMS, int POL, bool LEAKY, int SP = 1, bool COOP = false, int NC = 1>
 inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *name) {
   constexpr int MD = (D - 1) / 2;
   constexpr int MAXCH = T < MD + 1 ? T : MD + 1;
@@ -650,8 +686,8 @@ inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *na
   p.bx_magic = mfn_make_magic((unsigned)p.bx_per_row);
   p.segs_magic = mfn_make_magic((unsigned)p.segs);
   constexpr int NSJ_MAX = ((MAXCH * 2 * D + 7) / 8 + 3) / 4;
-  const size_t lds = ((size_t)NWV * NSLOT * 512 + (COOP ? 2 * NSJ_MAX * 4 * 8 * 32 : 0)) * sizeof(float);
-  return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
+  const size_t lds = ((size_t)NWV * NSLOT * NC * 512 + (COOP ? 2 * NSJ_MAX * 4 * 8 * 32 : 0)) * sizeof(float);
+  return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP, NC>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
 inline bool corr_variant_gram(int v) { return v == 40 || v == 46 || v == 48; }
@@ -659,7 +695,8 @@ inline bool corr_variant_gram(int v) { return v == 40 || v == 46 || v == 48; }
 // per CU (two blocks of four): the level-2 launch of 384x512 at batch 8 is 2048 items of 6 rows = one residency round.  Fewer
 // rows per item mean more halo (an item converts rows + 2*md f2 rows); 8 where 6 does not divide H and 8 does (448x1024:
 // 112 rows).  corr.rows overrides.
-inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows) {
+inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows, int C = 32) {
+  if (C == 64) return (override_rows == 2 || override_rows == 4 || override_rows == 6) ? override_rows : 2;
   if (override_rows == 6 || override_rows == 8) return override_rows;
   return (H % 6 != 0 && H % 8 == 0) ? 8 : 6;
 }
@@ -674,6 +711,13 @@ inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s
 #define MFN_GRAM_(TT_, TERMS_, NAME_) \
   (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, TERMS_, 2, true, 1, true>(p, s, NAME_) : corr_gram_launch<D, TT_, 4, 4, TERMS_, 0, true, 1, true>(p, s, NAME_)) \
            : (wt ? corr_gram_launch<D, TT_, 4, 4, TERMS_, 2, false, 1, true>(p, s, NAME_) : corr_gram_launch<D, TT_, 4, 4, TERMS_, 0, false, 1, true>(p, s, NAME_)))
+  if (p.C == 64) {   // two channel chunks (level 3): the plan's form only
+#define MFN_GRAM2_(TT_) \
+  (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, 5, 2, true, 1, true, 2>(p, s, "corr_gram_v48c2") : corr_gram_launch<D, TT_, 4, 4, 5, 0, true, 1, true, 2>(p, s, "corr_gram_v48c2")) \
+           : (wt ? corr_gram_launch<D, TT_, 4, 4, 5, 2, false, 1, true, 2>(p, s, "corr_gram_v48c2") : corr_gram_launch<D, TT_, 4, 4, 5, 0, false, 1, true, 2>(p, s, "corr_gram_v48c2")))
+    return p.rows == 2 ? MFN_GRAM2_(1) : (p.rows == 4 ? MFN_GRAM2_(2) : MFN_GRAM2_(3));
+#undef MFN_GRAM2_
+  }
   if (variant == 46) return p.rows == 8 ? MFN_GRAM_(4, 1, "corr_gram_v46") : MFN_GRAM_(3, 1, "corr_gram_v46");
   if (variant == 40) return p.rows == 8 ? MFN_GRAM_(4, 3, "corr_gram_v40") : MFN_GRAM_(3, 3, "corr_gram_v40");
   return p.rows == 8 ? MFN_GRAM_(4, 5, "corr_gram_v48") : MFN_GRAM_(3, 5, "corr_gram_v48");

@@ -10,10 +10,11 @@
 //                 48 / 40 / 46: corr_gram_kernel (32-channel levels: the band of the Gram matrix on the matrix cores) -- 48 the plan's form
 //                 (three bf16 terms split ON the matrix cores, results leaving one step behind the chains), 40 round 4's form (VALU
 //                 split; bit-identical results), 46 raw operands on the fp32 matrix instruction (an fmaf chain over the channels)
-//   corr.form     the form the PLAN gives a 32-channel level (0 = 48; 40 / 46 / 48): unlike corr.variant it leaves the other levels' plan alone
+//   corr.form     the form the PLAN gives a 32-channel level (0 = 48; 40 / 46 / 48) -- unlike corr.variant it leaves the other levels' plan alone --;
+//                 20: 64-channel levels stay on corr_dma_kernel (two channel groups) instead of the two-chunk Gram band
 //                 44 / 45: corr_gramk_kernel (coarse levels: the same band, a block = an 8 x 2 pixel block of f1 and two / half of the
 //                 f2 rows it meets, one wave per 32 channels)
-//   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 0 = the plan)
+//   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 64-channel levels 2, 4 or 6; 0 = the plan)
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt

@@ -52,6 +52,8 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     (48, (1, 32, 7, 36), 2, 6),      # md = 2 (25 channels), 5 strips = 2 blocks, a 1-row last item
     (48, (1, 32, 24, 8), 4, 0),      # 24 % 6 == 0 -> 6 rows; one strip: the f2 segment hangs over both image borders
     (48, (1, 32, 16, 16), 2, 0),     # 16 % 6 != 0, 16 % 8 == 0 -> the plan picks 8-row items
+    (48, (1, 64, 9, 24), 4, 2),      # 64 channels = two chunks of the K loop (level 3's form), 2-row items, odd H
+    (48, (1, 64, 10, 16), 2, 4),     # ... 4-row items, md = 2
     (46, (2, 32, 13, 20), 4, 8), (46, (1, 32, 7, 36), 2, 6),
     (40, (1, 32, 10, 24), 4, 0), (40, (1, 32, 7, 36), 2, 6)])
 def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows, variant):
@@ -62,7 +64,7 @@ def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows, var
     band on the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, raw operands, an fmaf chain over the channels)."""
     emu_ops.set_tuning(corr_variant=variant, corr_direct=2, corr_rows=rows)
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
-    assert "corr_gram_v%d" % variant in emu_ops.launch_log()
+    assert ("corr_gram_v%d" % variant) + ("c2" if shape[1] == 64 else "") in emu_ops.launch_log()
     pc.case_correlation_leaky(ops, oracle, ident, ident, shape, md)
     pc.case_correlation_into(ops, oracle, ident, ident, shape, md, c0=4)
 
