@@ -690,13 +690,13 @@ inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *na
   return launch(name, corr_gram_kernel<D, T, NSLOT, NWV, TERMS, POL, LEAKY, SP, COOP, NC>, dim3((unsigned)nblk), dim3(NWV * 64), lds, stream, p);
 }
 
-inline bool corr_variant_gram(int v) { return v == 40 || v == 46 || v == 48; }
+inline bool corr_variant_gram(int v) { return v == 46 || v == 48; }
 // Output rows per work item: 6 or 8 (T = 3 / 4 blocks; the schedule is compile-time).  One wave per item, eight resident waves
 // per CU (two blocks of four): the level-2 launch of 384x512 at batch 8 is 2048 items of 6 rows = one residency round.  Fewer
 // rows per item mean more halo (an item converts rows + 2*md f2 rows); 8 where 6 does not divide H and 8 does (448x1024:
 // 112 rows).  corr.rows overrides.
 inline int corr_gram_rows(int /*N*/, int H, int /*W*/, int override_rows, int C = 32) {
-  if (C == 64) return (override_rows == 2 || override_rows == 4 || override_rows == 6) ? override_rows : 2;
+  if (C == 64) return 2;
   if (override_rows == 6 || override_rows == 8) return override_rows;
   return (H % 6 != 0 && H % 8 == 0) ? 8 : 6;
 }
@@ -715,11 +715,10 @@ inline int corr_gram_variant(const CorrGramParams &p, int variant, hipStream_t s
 #define MFN_GRAM2_(TT_) \
   (p.leaky ? (wt ? corr_gram_launch<D, TT_, 4, 4, 5, 2, true, 1, true, 2>(p, s, "corr_gram_v48c2") : corr_gram_launch<D, TT_, 4, 4, 5, 0, true, 1, true, 2>(p, s, "corr_gram_v48c2")) \
            : (wt ? corr_gram_launch<D, TT_, 4, 4, 5, 2, false, 1, true, 2>(p, s, "corr_gram_v48c2") : corr_gram_launch<D, TT_, 4, 4, 5, 0, false, 1, true, 2>(p, s, "corr_gram_v48c2")))
-    return p.rows == 2 ? MFN_GRAM2_(1) : (p.rows == 4 ? MFN_GRAM2_(2) : MFN_GRAM2_(3));
+    return MFN_GRAM2_(1);   // 2-row items (4-row items tie, 6-row items lose: profiles/r06_corr_l3.txt)
 #undef MFN_GRAM2_
   }
   if (variant == 46) return p.rows == 8 ? MFN_GRAM_(4, 1, "corr_gram_v46") : MFN_GRAM_(3, 1, "corr_gram_v46");
-  if (variant == 40) return p.rows == 8 ? MFN_GRAM_(4, 3, "corr_gram_v40") : MFN_GRAM_(3, 3, "corr_gram_v40");
   return p.rows == 8 ? MFN_GRAM_(4, 5, "corr_gram_v48") : MFN_GRAM_(3, 5, "corr_gram_v48");
 #undef MFN_GRAM_
 }

@@ -7,14 +7,14 @@
 //   corr.variant  6: corr_tiled_kernel (images narrower than 16 columns), 16 / 20 / 22: corr_dma_kernel with 1 / 2 / 3 channel
 //                 groups, 26 / 31: the same with a tile's displacement rows spread over 5 / 3 blocks (coarse levels); -1 = the
 //                 plan (api_impl.inc corr_plan)
-//                 48 / 40 / 46: corr_gram_kernel (32-channel levels: the band of the Gram matrix on the matrix cores) -- 48 the plan's form
-//                 (three bf16 terms split ON the matrix cores, results leaving one step behind the chains), 40 round 4's form (VALU
-//                 split; bit-identical results), 46 raw operands on the fp32 matrix instruction (an fmaf chain over the channels)
-//   corr.form     the form the PLAN gives a 32-channel level (0 = 48; 40 / 46 / 48) -- unlike corr.variant it leaves the other levels' plan alone --;
+//                 48 / 46: corr_gram_kernel (32-channel levels, 48 also 64-channel ones: the band of the Gram matrix on the matrix cores) -- 48
+//                 the plan's form (three bf16 terms split ON the matrix cores, results leaving one step behind the chains), 46 raw operands
+//                 on the fp32 matrix instruction (an fmaf chain over the channels: the plan's form under MFN_ARITH_FP32)
+//   corr.form     the form the PLAN gives a 32-channel level (0 = 48 / 46 by arithmetic; 46 / 48; 16: corr_dma_kernel under MFN_ARITH_FP32) -- unlike corr.variant it leaves the other levels' plan alone --;
 //                 20: 64-channel levels stay on corr_dma_kernel (two channel groups) instead of the two-chunk Gram band
 //                 44 / 45: corr_gramk_kernel (coarse levels: the same band, a block = an 8 x 2 pixel block of f1 and two / half of the
 //                 f2 rows it meets, one wave per 32 channels)
-//   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 64-channel levels 2, 4 or 6; 0 = the plan)
+//   corr.rows     output rows per work item of corr_gram_kernel (6 or 8; 64-channel levels always 2; 0 = the plan)
 //   corr.direct   LDS-free kernel of the tiniest levels: 0 auto (< 180 px images), 1 always, 2 never
 //   store.policy  cache policy of the kernels' output stores: -1 auto (outputs >= 4 MB: sc0 sc1 for cost volumes and offsets,
 //                 nt for warp; deformable conv and everything smaller plain), 0 plain, 1 nt, 2 sc0 sc1 (write-through), 3 sc0 sc1 nt

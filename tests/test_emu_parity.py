@@ -44,8 +44,8 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     pc.case_correlation(ops, oracle, ident, ident, (1, C, 5, 32), 2, seed=2)
 
 
-# every shape on the plan's form (48); the other two forms share everything but the arithmetic of a step (46: raw operands on the fp32
-# matrix instruction; 40: the VALU split, results staged behind the chains) and run two shapes each -- the suite has a time budget
+# every shape on the plan's form (48); form 46 (raw operands on the fp32 matrix instruction, results staged behind the chains: the
+# non-pipelined way out) runs two shapes -- the suite has a time budget
 @pytest.mark.parametrize("variant,shape,md,rows", [
     (48, (1, 32, 10, 24), 4, 0),     # 6-row items: a full and a 4-row item per strip, three strips (one block)
     (48, (2, 32, 13, 20), 4, 8),     # 8-row items, odd H (a 5-row last item: half-filled last block), ragged last strip
@@ -53,14 +53,13 @@ def test_correlation_in_block_channel_groups(ops, oracle, variant, C):
     (48, (1, 32, 24, 8), 4, 0),      # 24 % 6 == 0 -> 6 rows; one strip: the f2 segment hangs over both image borders
     (48, (1, 32, 16, 16), 2, 0),     # 16 % 6 != 0, 16 % 8 == 0 -> the plan picks 8-row items
     (48, (1, 64, 9, 24), 4, 2),      # 64 channels = two chunks of the K loop (level 3's form), 2-row items, odd H
-    (48, (1, 64, 10, 16), 2, 4),     # ... 4-row items, md = 2
-    (46, (2, 32, 13, 20), 4, 8), (46, (1, 32, 7, 36), 2, 6),
-    (40, (1, 32, 10, 24), 4, 0), (40, (1, 32, 7, 36), 2, 6)])
+    (48, (1, 64, 10, 16), 2, 0),     # ... md = 2
+    (46, (2, 32, 13, 20), 4, 8), (46, (1, 32, 7, 36), 2, 6)])
 def test_correlation_gram_band_on_matrix_cores(ops, oracle, shape, md, rows, variant):
     """corr.variant 48 (the plan's): the band of the Gram matrix on the bf16 matrix cores, operands split into three bf16 terms
     (six products) with the residuals formed by selector matrix instructions (kernels/msplit.h) and the results leaving one step
     behind the chains: exact fp32 to the tolerance of every other cost-volume kernel.  Wave-private LDS-DMA rings, counted waits,
-    row-shift de-skew, cooperative full-line stores; LeakyReLU and the concat-slice form.  40: round 4's VALU split; 46: the same
+    row-shift de-skew, cooperative full-line stores; LeakyReLU and the concat-slice form.  46: the same
     band on the fp32 matrix instruction (v_mfma_f32_16x16x4_f32, raw operands, an fmaf chain over the channels)."""
     emu_ops.set_tuning(corr_variant=variant, corr_direct=2, corr_rows=rows)
     pc.case_correlation(ops, oracle, ident, ident, shape, md)
@@ -99,8 +98,8 @@ def test_correlation_gram_coarse_levels(ops, oracle, variant, shape, md):
 
 
 def test_correlation_gram_falls_back_off_its_shapes(ops, oracle):
-    """corr.variant 40 on a level that does not have 32 channels: the plan's kernel runs instead."""
-    emu_ops.set_tuning(corr_variant=40, corr_direct=2)
+    """corr.variant 48 on a level that has neither 32 nor 64 channels: the plan's kernel runs instead."""
+    emu_ops.set_tuning(corr_variant=48, corr_direct=2)
     emu_ops.launch_log()
     pc.case_correlation(ops, oracle, ident, ident, (1, 12, 6, 40), 4)
     assert "corr_gram" not in emu_ops.launch_log()

@@ -14,15 +14,15 @@ for shape, md in (((8, 32, 96, 128), 4), ((4, 32, 112, 256), 4), ((8, 32, 96, 12
     mag = (10.0 ** T.linspace(-18, 18, 32, device="cuda"))[None, :, None, None]
     for name, a, b in (("randn", f1, f2), ("wide", f1 * mag, f2 * mag)):
         out = {}
-        for v in (40, 47, 48):
+        for v in (45, 48):
             _lib.set_tuning(corr_variant=v)
             out[v] = ops.Correlation(a, b, 1, md, 1, 1, md).clone()
-        same = T.equal(out[40], out[47]) and T.equal(out[40], out[48])
-        d = (out[40] - out[47]).abs().max().item()
-        print(shape, md, name, "bit-identical" if same else "DIFFER max %.3e (scale %.3e)" % (d, out[40].abs().max().item()), flush=True)
+        same = T.equal(out[45], out[48])
+        d = (out[45] - out[47]).abs().max().item()
+        print(shape, md, name, "bit-identical" if same else "DIFFER max %.3e (scale %.3e)" % (d, out[45].abs().max().item()), flush=True)
 f1 = T.randn(1, 32, 24, 32, device="cuda", generator=g); f2 = T.randn(1, 32, 24, 32, device="cuda", generator=g)
 f2[0, 5, 10, 12] = float("inf")
-for v in (16, 40, 47, 48):
+for v in (16, 45, 48):
     _lib.set_tuning(corr_variant=v)
     o = ops.Correlation(f1, f2, 1, 4, 1, 1, 4)
     print("inf case variant", v, "non-finite outputs", int((~T.isfinite(o)).sum()), "nan", int(T.isnan(o).sum()))
