@@ -966,7 +966,7 @@ def main():
     if gpu and world == 1 and not args.no_side_configs and args.config == "cfg2" and args.mode == "dropin" and args.flow == "smooth" \
             and not args.no_graph and not args.tuning:
         # transparency: the same pass with EVERY operator on fp32 FMA chains / the fp32 MFMA (mfn_set_arithmetic(all, MFN_ARITH_FP32)):
-        # the cost volumes on corr_dma_kernel, the deformable convolutions on dc_lds_kernel (v_mfma_f32_32x32x2_f32) -- rounds 1-3's
+        # the cost volumes on corr_dma_kernel (level 2: the Gram band on v_mfma_f32_16x16x4_f32, raw operands), the deformable convolutions on dc_lds_kernel (v_mfma_f32_32x32x2_f32) -- rounds 1-3's
         # kernels -- instead of the bf16 x 3 matrix-core kernels (operands split into three bf16 terms, six of nine products: error
         # against fp64 within 1.25-2 x these kernels' (observed 0.7-1.1 x), not bit-identical to an FMA chain)
         try:
@@ -974,7 +974,7 @@ def main():
             _lg.set_arithmetic(all=_lg.ARITH_FP32)
             res["fp32_arithmetic"] = side_config("cfg2", "dropin", 200, torch, hotpath, want_roofline=True)
             res["fp32_arithmetic"]["what"] = ("mfn_set_arithmetic('all', MFN_ARITH_FP32): every kernel of the pass on fp32 FMA / fp32 MFMA "
-                                              "arithmetic (round 3's correlation and deformable-convolution kernels)")
+                                              "arithmetic (round 3's correlation and deformable-convolution kernels; the level-2 cost volume as the Gram band on the fp32 matrix instruction, an fmaf chain over the channels)")
         except Exception as e:
             res["fp32_arithmetic"] = {"error": repr(e)}
         finally:
