@@ -241,7 +241,7 @@ def roofline_of_dominant_kernel(wl, iters, torch, md=4):
         import re as _re
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.md")), reverse=True):
             for ln in open(f):
-                m_ = _re.match(r"\| `(corr_gram_kernel<[^`]*)` \| (\d+) \| [\d.]+ \| ([\d.]+) \|", ln)
+                m_ = _re.match(r"\| `(corr_gram_kernel<9, [34], [^`]*, 1>[^`]*)` \| (\d+) \| [\d.]+ \| ([\d.]+) \|", ln)   # the one-chunk (level 2) instantiation
                 if m_:
                     rp_kernel, rp_us, rp_src = m_.group(1), float(m_.group(3)), "profiles/" + os.path.basename(f)
                     break

@@ -38,6 +38,7 @@
 // Per-tap offsets (MXNet's general semantics, never hot in the reference) take a lean per-tap column path inside the same kernel.
 #pragma once
 #include "deform_conv.h"
+#include "msplit.h"
 
 namespace mfn {
 
@@ -94,6 +95,13 @@ constexpr int dcm_min_waves(int mt, int nw) {
 // 8 no operand split, 16 no interpolation, 32 no weight transfers, 64 no weight reads, 128 no block barrier in the loop
 #ifndef MFN_DCM_ABLATE
 #define MFN_DCM_ABLATE 0
+#endif
+// The column values' three bf16 terms by msplit.h (12 v_cvt_pk_bf16_f32 + 4 v_mfma_f32_4x4x4_16B_bf16 per K step, lane-local, the same
+// terms bit for bit) instead of the 46 VALU instructions of mfn_split3x8_scalar, where it pays: one or two filter tiles per wave (round 6,
+// same box: level 2 20.50 -> 19.57 us, level 3 17.53 -> 17.25, level 5 11.29 -> 10.97; three tiles per wave -- level 4, one wave per
+// SIMD -- 13.47 -> 13.82: stays on the VALU).  1 / 0 force it on / off (measurement builds).
+#ifndef MFN_DCM_MSPLIT
+#define MFN_DCM_MSPLIT (MT <= 2)
 #endif
 #ifndef MFN_DCM_MINW   // measurement builds override the register budget
 #define MFN_DCM_MINW(mt, nw) dcm_min_waves(mt, nw)
@@ -594,6 +602,8 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
     }
   };
   DcmB B;
+  GramSel sel;
+  if (MFN_DCM_MSPLIT) sel = gram_make_sel(lane);
   // the six products of one K step against the MT filter tiles.  a_read: this step's [term][ft] blocks from the stage buffer --
   // requested BEFORE the next pair's gather, so that the first matrix instruction waits for its own operand only (LDS returns in
   // order: behind the gather it would wait for all sixteen neighbourhood values as well)
@@ -674,7 +684,8 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
       cols_finish(x8, c8);
     }
     xt8[0] = c8;
-    mfn_split3x8(x8, B.h, B.m, B.l);
+    if (MFN_DCM_MSPLIT) gram_msplit8(x8, sel, B.h, B.m, B.l);
+    else mfn_split3x8(x8, B.h, B.m, B.l);
     MFN_STAMP2(p.timeline, 4);   // first operand formed (window 0 landed)
   };
 
@@ -731,7 +742,10 @@ __global__ __launch_bounds__(PT * KW * 64, MFN_DCM_MINW(MT, PT * KW)) void dc_mm
 #ifdef MFN_DCM_SPLIT_PACKED
         if (!(MFN_DCM_ABLATE & 8)) mfn_split3x8(x8, B.h, B.m, B.l);
 #else
-        if (!(MFN_DCM_ABLATE & 8)) mfn_split3x8_scalar(x8, B.h, B.m, B.l);
+        if (!(MFN_DCM_ABLATE & 8)) {
+          if (MFN_DCM_MSPLIT) gram_msplit8(x8, sel, B.h, B.m, B.l);
+          else mfn_split3x8_scalar(x8, B.h, B.m, B.l);
+        }
 #endif
         MFN_SCHED_BARRIER();
       });

@@ -7,26 +7,29 @@ namespace mfn {
 
 // The VALU form of the operand split (mfn_split3x8 of mfn_rt.h, correlation_gram.h TERMS == 3) is nine
 // VALU instructions per pair of values: three v_cvt_pk_bf16_f32 and, to get each residual x - float(bf16(x)), a shift, a mask and a
-// packed subtract -- 646 of a wave's 912 VALU instructions at level 2, on a SIMD whose issue slots are what bounds the kernel
-// (profiles/r04_corr_pmc.md).  But the accumulator layout of v_mfma_f32_16x16x32_bf16 (lane = column n + 16 g, register i = row
-// 4 g + i) IS the operand layout (lane = column + 16 k-block, eight K values) when rows are read as K slots: with the eight raw
-// values of a lane held as two accumulator tiles C0 = raw[0..3], C1 = raw[4..7] and their bf16 roundings as a B operand Hb,
-//   C0 <- Sel0 * Hb + C0,   Sel0[r][k] = -1 if k == 8 (r / 4) + r % 4 else 0     (Sel1: ... + 4)
-// subtracts from every register exactly the bf16 value the SAME lane holds in K slot i (i + 4): the residual, exact in fp32
-// (products -1 * h and 0 * h are exact, the sum has one non-zero term and x - h is representable).  A tile's split is then
-// 3 x 4 v_cvt_pk_bf16_f32 + 2 x 2 matrix instructions on a pipe that idles 78 % of the time, instead of 36 VALU instructions;
-// the terms are bit-identical to TERMS == 3's (same roundings).  Non-finite inputs: 0 * inf = NaN spreads an inf to the residuals
-// of the pixel's other channels of the tile -- every output that pixel takes part in is NaN (TERMS == 3: NaN as well, through
-// inf - inf in the channel itself): the documented behaviour (include/mfn_hip.h "Arithmetic") is unchanged.
-struct GramSel { mfn_bf16x8 s0, s1; };
+// packed subtract -- 646 of a wave's 912 VALU instructions at level 2 (profiles/r04_corr_pmc.md).  But a matrix instruction's
+// accumulator registers can BE the values to split: with a lane's eight raw values held as two accumulator tiles C0 = raw[0..3],
+// C1 = raw[4..7] and their bf16 roundings as the B operand,
+//   C <- Sel * Hb + C,   Sel = -identity
+// subtracts from every register exactly the bf16 value of the same slot: the residual, exact in fp32 (products -1 * h and 0 * h are
+// exact, the sum has one non-zero term and x - h is representable).  A tile's split is then 3 x 4 v_cvt_pk_bf16_f32 + 2 x 2 matrix
+// instructions instead of 36 VALU instructions; the terms are bit-identical to the VALU split's (same roundings).  Non-finite inputs:
+// 0 * inf = NaN spreads an inf to the residuals of the three other values of its lane's tile -- the same pixel's, in both users of
+// this header -- so every output that pixel takes part in is NaN (VALU split: NaN as well, through inf - inf in the slot itself): the
+// documented behaviour (include/mfn_hip.h "Arithmetic") is unchanged.
+// The instruction: v_mfma_f32_4x4x4_16B_bf16 -- sixteen independent 4 x 4 x 4 products, block = lane / 4; A: lane (b, i) holds row i's
+// four K values, B / C / D: lane (b, j) holds column j (four K values / registers i = 0..3).  With A = -identity in every block (lane l:
+// -1.0 in K slot l % 4) and B = the lane's own four bf16 roundings, D[i] = C[i] - B[i]: the subtraction never leaves the lane -- a
+// non-finite value poisons the other three values of ITS lane's tile (0 * inf), nobody else's (the first form of this header used
+// v_mfma_f32_16x16x32_bf16, whose columns span four lanes: fine for the cost volume, where those are one pixel, wrong for the deformable
+// convolution, where they are two) -- and the instruction is 2 passes: 0.65 of a 16 x 16 x 32's issue cost
+// (tools/ubench/msplit_4x4.hip: bit-identical to the VALU residual on 256 values over twelve orders of magnitude; 7.2 against
+// 10.8 cycles per instruction at four waves per SIMD).
+struct GramSel { mfn_bf16x4 s; };
 __device__ __forceinline__ GramSel gram_make_sel(int lane) {
-  const int m = lane & 15, kb = lane >> 4;
-  const bool on = kb == (m >> 2);
-  const unsigned one = 0xBF80u << (16 * (m & 1));          // -1.0 as bf16, in K slot m % 4 of the lane's k-block
-  const unsigned w0 = (on && (m & 2) == 0) ? one : 0u, w1 = (on && (m & 2) != 0) ? one : 0u;
+  const unsigned one = 0xBF80u << (16 * (lane & 1));       // -1.0 as bf16, in K slot lane % 4
   GramSel r;
-  r.s0 = mfn_words_to_bf16x8(w0, w1, 0u, 0u);
-  r.s1 = mfn_words_to_bf16x8(0u, 0u, w0, w1);
+  r.s = mfn_words_to_bf16x4((lane & 2) == 0 ? one : 0u, (lane & 2) != 0 ? one : 0u);
   return r;
 }
 // eight fp32 values (two accumulator tiles) -> their bf16 roundings as one operand: 4 x v_cvt_pk_bf16_f32
@@ -50,8 +53,8 @@ __device__ __forceinline__ mfn_bf16x8 gram_cvt8(const f32x4 &a, const f32x4 &b) 
 __device__ __forceinline__ void gram_msplit_stage(int st, const GramSel &sel, f32x4 &x0, f32x4 &x1, mfn_bf16x8 (&term)[3]) {
   if ((st & 1) == 0) term[st >> 1] = gram_cvt8(x0, x1);
   else {
-    x0 = MFN_MFMA_16x16x32_BF16(sel.s0, term[st >> 1], x0);
-    x1 = MFN_MFMA_16x16x32_BF16(sel.s1, term[st >> 1], x1);
+    x0 = MFN_MFMA_4x4x4_BF16(sel.s, mfn_bf16x8_half(term[st >> 1], 0), x0);
+    x1 = MFN_MFMA_4x4x4_BF16(sel.s, mfn_bf16x8_half(term[st >> 1], 1), x1);
   }
 }
 

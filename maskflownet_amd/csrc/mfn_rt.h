@@ -81,6 +81,10 @@ static inline float mfn_bf16_at(const float *base, int idx) {   // element idx o
 }
 // Gram-band cost volume (correlation_gram.h): bf16 matrix-core tile, DPP row shift, range-checked buffer store, counted wait
 #define MFN_MFMA_16x16x32_BF16(a, b, c) hipemu_mfma_16x16x32_bf16((a), (b), (c))
+typedef bf16x4_emu mfn_bf16x4;
+#define MFN_MFMA_4x4x4_BF16(a, b, c) hipemu_mfma_4x4x4_bf16((a), (b), (c))
+static inline mfn_bf16x4 mfn_bf16x8_half(const mfn_bf16x8 &v, int hi) { mfn_bf16x4 r; memcpy(&r, &v.v[4 * hi], 8); return r; }
+static inline mfn_bf16x4 mfn_words_to_bf16x4(unsigned w0, unsigned w1) { unsigned w[2] = {w0, w1}; mfn_bf16x4 r; memcpy(&r, w, 8); return r; }
 template <int N> static inline float mfn_dpp_row_shl(float old, float src) { return hipemu_dpp_row_shl(old, src, N); }
 static inline float mfn_dpp_wave_shr1(float old, float src) { return hipemu_dpp_wave_shift(old, src, -1); }   // lane i <- lane i-1
 static inline float mfn_dpp_wave_shl1(float old, float src) { return hipemu_dpp_wave_shift(old, src, +1); }   // lane i <- lane i+1
@@ -347,6 +351,21 @@ __device__ __forceinline__ float mfn_bf16_at(const float *base, int idx) {   // 
 }
 // ---- Gram-band cost volume on the bf16 matrix cores (correlation_gram.h) ------------------------------------------------
 #define MFN_MFMA_16x16x32_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// sixteen independent 4 x 4 x 4 products (block = lane / 4; A: lane (b, i) = row i, B / C / D: lane (b, j) = column j): 2 passes
+typedef short mfn_bf16x4 __attribute__((ext_vector_type(4)));
+#define MFN_MFMA_4x4x4_BF16(a, b, c) __builtin_amdgcn_mfma_f32_4x4x4bf16_1k((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ mfn_bf16x4 mfn_bf16x8_half(const mfn_bf16x8 &v, int hi) {
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const u32x4_ w = __builtin_bit_cast(u32x4_, v);
+  const u32x2_ h = {hi ? w[2] : w[0], hi ? w[3] : w[1]};
+  return __builtin_bit_cast(mfn_bf16x4, h);
+}
+__device__ __forceinline__ mfn_bf16x4 mfn_words_to_bf16x4(unsigned w0, unsigned w1) {
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const u32x2_ h = {w0, w1};
+  return __builtin_bit_cast(mfn_bf16x4, h);
+}
 // v_mov_b32_dpp row_shl:N -- lane i of every 16-lane row receives lane i+N of its row; lanes whose source is outside the row keep `old`
 template <int N> __device__ __forceinline__ float mfn_dpp_row_shl(float old, float src) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x100 + N, 0xf, 0xf, false));

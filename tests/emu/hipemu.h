@@ -270,6 +270,23 @@ static inline f32x4_emu hipemu_mfma_16x16x32_bf16(bf16x8_emu a, bf16x8_emu b, f3
   w.bar.arrive_and_wait();
   return c;
 }
+// v_mfma_f32_4x4x4_16B_bf16: sixteen independent 4 x 4 x 4 products, block b = lane / 4.  A: lane (b, i) holds row i's four K values;
+// B: lane (b, j) holds column j's four K values; C / D: lane (b, j), register i = element (i, j).
+struct bf16x4_emu { unsigned short v[4]; };
+static inline f32x4_emu hipemu_mfma_4x4x4_bf16(bf16x4_emu a, bf16x4_emu b, f32x4_emu c) {
+  hipemu::Wave &w = hipemu::wave();
+  const unsigned lane = hipemu::t_lane;
+  for (int e = 0; e < 4; ++e) { w.a8[lane][e] = a.v[e]; w.b8[lane][e] = b.v[e]; }
+  w.bar.arrive_and_wait();
+  const unsigned blk = lane & ~3u;
+  for (int i = 0; i < 4; ++i) {
+    float acc = c[i];
+    for (int k = 0; k < 4; ++k) acc += hipemu_bf16_to_f32(w.a8[blk + i][k]) * hipemu_bf16_to_f32(w.b8[lane][k]);
+    c[i] = acc;
+  }
+  w.bar.arrive_and_wait();
+  return c;
+}
 // DPP row_shl:n -- lane i of every 16-lane row receives the value of lane i+n of the same row; lanes whose source is
 // outside the row keep `old` (bound_ctrl off)
 static inline float hipemu_dpp_row_shl(float old, float src, int n) {

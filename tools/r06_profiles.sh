@@ -16,7 +16,7 @@ python bench.py --config cfg5 --no-side-configs --no-e2e --no-epe --no-cpu-basel
 python bench.py --config cfg4 --no-side-configs --no-e2e --no-epe --no-cpu-baseline > $G/r06p/bench_cfg4.log 2>> $G/r06p/bench.err
 fi
 timeout 600 rocprofv3 --kernel-trace --stats -d $G/prof_bench -o bench -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-side-configs --no-e2e > $G/r06p/prof_bench.log 2>&1
-python tools/kernel_durations.py $G/prof_bench/bench_results.db corr_gram_kernel 250 > $G/r06p/corr_l2_durations_by_context.txt 2>&1
+python tools/kernel_durations.py $G/prof_bench/bench_results.db "corr_gram_kernel<9, 3," 250 > $G/r06p/corr_l2_durations_by_context.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $G/prof_cfg5 -o cfg5 -- python bench.py --config cfg5 --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-e2e --no-side-configs > $G/r06p/prof_cfg5.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --pmc $c --kernel-trace -d $G/pmc_$c -o r -- python tools/prof_one.py corr 2 > $G/r06p/pmc_$c.log 2>&1
