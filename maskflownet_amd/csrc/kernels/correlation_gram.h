@@ -174,8 +174,9 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   // j-2's lines, so that a step is [operand reads] [matrix instructions with everything else between them] [DMA issue] [barrier]
   // instead of ending in a serial tail (row shifts that wait for the last matrix instruction, five masked 16-byte LDS writes,
   // barrier, read-back, stores) that nothing covered.
-  constexpr bool MSPLIT = TERMS >= 4;
-  constexpr bool PIPE = TERMS == 5;
+  constexpr bool MSPLIT = TERMS == 4 || TERMS == 5;
+  constexpr bool PIPE = TERMS >= 5;          // 6 (measurement): the pipelined way out with the VALU split
+  constexpr int ST = TERMS >= 3 ? 3 : TERMS;  // bf16 terms of the VALU split
   // NC: chunks of 32 channels (C = 32 NC; round 6: level 3's 64 channels as a two-chunk K loop).  A logical tile of the sequence is
   // NC raw tiles (one per chunk) in NC consecutive ring slots, an operand is NC register sets, a chain runs its six products once
   // per chunk into its own accumulator (summed where the results leave the registers: no dependent chain of 6 NC instructions).
@@ -268,7 +269,8 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
   Op Mreg[T][NC];
   Op Ncur[NC];
   GramSel sel;
-  if constexpr (MSPLIT) sel = gram_make_sel(lane);
+  constexpr bool WSEL = NC == 1;   // msplit.h: the wide selector at level 2 (faster inside the pass), the lane-local one with two chunks
+  if constexpr (MSPLIT) sel = gram_make_sel<WSEL>(lane);
   auto convert = [&](Op &o, float scale) {
     if constexpr (MSPLIT) {
       f32x4 x0, x1;
@@ -276,7 +278,7 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
       for (int q = 0; q < 4; ++q) { x0[q] = raw[q] * scale; x1[q] = raw[4 + q] * scale; }
       mfn_bf16x8 term[3];
       MFN_UNROLL
-      for (int st = 0; st < 5; ++st) gram_msplit_stage(st, sel, x0, x1, term);
+      for (int st = 0; st < 5; ++st) gram_msplit_stage<WSEL>(st, sel, x0, x1, term);
       o.h = term[0]; o.m = term[1]; o.l = term[2];
     } else if constexpr (TERMS == 1) {
       MFN_UNROLL
@@ -284,7 +286,7 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
     } else {
       GramWords w;
       MFN_UNROLL
-      for (int q = 0; q < 4; ++q) gram_split_pair<TERMS>(raw[2 * q] * scale, raw[2 * q + 1] * scale, w, q);
+      for (int q = 0; q < 4; ++q) gram_split_pair<ST>(raw[2 * q] * scale, raw[2 * q + 1] * scale, w, q);
       gram_words_to_op(w, o);
     }
   };
@@ -446,8 +448,8 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
       if constexpr (MSPLIT) {
         MFN_UNROLL
         for (int cc = 0; cc < NC; ++cc) {
-          if (moreM) gram_msplit_stage(next_stage, sel, xM0[cc], xM1[cc], cM[cc]);
-          if (more) gram_msplit_stage(next_stage, sel, xN0[cc], xN1[cc], cN[cc]);
+          if (moreM) gram_msplit_stage<WSEL>(next_stage, sel, xM0[cc], xM1[cc], cM[cc]);
+          if (more) gram_msplit_stage<WSEL>(next_stage, sel, xN0[cc], xN1[cc], cN[cc]);
         }
         ++next_stage;
       }
@@ -459,8 +461,8 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
       if constexpr (TERMS != 1 && !MSPLIT) {
         if (done_pairs < npairs) {
           const int q = done_pairs & 3;
-          if (moreM && done_pairs < 4) gram_split_pair<TERMS>(rawM[0][2 * q], rawM[0][2 * q + 1], wM, q);
-          else gram_split_pair<TERMS>(rawN[0][2 * q], rawN[0][2 * q + 1], wN, q);
+          if (moreM && done_pairs < 4) gram_split_pair<ST>(rawM[0][2 * q], rawM[0][2 * q + 1], wM, q);
+          else gram_split_pair<ST>(rawN[0][2 * q], rawN[0][2 * q + 1], wN, q);
           ++done_pairs;
         }
       }
@@ -506,8 +508,8 @@ __device__ __forceinline__ void corr_gram_wave(const CorrGramParams &p, float *r
                 const mfn_bf16x8 &b = TERMS >= 3 ? (k == 1 ? No.l : (k == 2 || k == 4 ? No.m : No.h)) : (k == 1 ? No.l : No.h);
                 acc[t][cc] = MFN_MFMA_16x16x32_BF16(a, b, acc[t][cc]);
               }
-              if constexpr (MSPLIT) {   // stage i behind unit floor(i * nunits / 5)
-                while (more && next_stage < 5 && next_stage * nunits <= unit * 5) split_stage();
+              if constexpr (MSPLIT || PIPE) {   // stage i behind unit floor(i * nunits / 5)
+                if constexpr (MSPLIT) while (more && next_stage < 5 && next_stage * nunits <= unit * 5) split_stage();
                 if constexpr (PIPE) while (post_done < nchP && post_done * nunits <= unit * nchP) post_chain();
                 MFN_SCHED_BARRIER();
               }
