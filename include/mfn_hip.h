@@ -347,7 +347,7 @@ int mfn_profile_dump(char *buf, int cap);
  * CustomOp on worker threads.  Set it before the calls it should govern; it is not one of the measurement knobs below:
  *   MFN_ARITH_DEFAULT  the library's choice: the bf16 x 3 matrix-core kernels wherever one exists for the call's shape
  *                      (level shapes of the network), the fp32 kernels elsewhere.
- *   MFN_ARITH_FP32     fp32 FMA chains everywhere (v_fma_f32 / v_mfma_f32_32x32x2_f32): the accumulation order of an fp32
+ *   MFN_ARITH_FP32     fp32 FMA chains everywhere (v_fma_f32 / v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32): the accumulation order of an fp32
  *                      inner product, bit-reproducible against itself across tilings of K only within one kernel.
  *   MFN_ARITH_BF16X3   as the default.
  * bf16 x 3: every fp32 operand is written exactly as hi + mid + lo with three bf16 terms (24 significant bits) and SIX of the
