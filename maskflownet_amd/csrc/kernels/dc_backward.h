@@ -17,21 +17,25 @@
 //     window of the tile arrives by LDS-DMA (3-deep ring, as in the forward kernel), 16 ds_read_b32 give the 4x4
 //     neighbourhood, the 18 coordinate-gradient terms are summed over the lane's channels IN THE LANE -- one cross-half
 //     add per tile instead of 18 DPP reductions per pixel;
-//   * phase B, input gradient: the block keeps ONE 22 x 32 LDS plane per channel for its whole region, placed by the
-//     offset of the region's centre pixel.  A wave adds its pixels' contributions with plain read-add-write,
-//     neighbourhood cell by neighbourhood cell: for a fixed cell (u, v) two lanes of a half-wave (two pixels) hit the same
-//     plane cell only if their neighbourhoods start at the same cell, which a flow that compresses the image produces
-//     (bench flows, level 2: 72 % of the tiles have such a pair); every pixel therefore gets a TURN, its rank among the
-//     pixels of its tile that share its cell (found once per tile through LDS), and the cells are walked once per turn.
-//     The LDS pipe keeps a wave's accesses in order and the two half-waves work on different channels; LDS float
-//     atomics would cost ~170 cycles per wave instruction against ~6 for read + write (tools/ubench/atomic_patterns.hip).
-//     The four waves never meet in a plane: wave w's MFMA rows are the channels permuted (slot ^ {0, 2, 8, 10}[w]), so at
-//     any step the waves hold different channels (a block barrier per step keeps them within the permutation).  Two
-//     channels' chains are interleaved per lane; the CU's other block covers the rest of the LDS round trips.  Neighbourhoods that leave the plane (a flow that tears) go to gx
-//     directly, 16 atomics per pixel and channel;
-//   * the merged planes are flushed to gx once per block with fp32 atomics over the touched box only: global atomics
-//     cost ~0.35 ns per wave INSTRUCTION chip-wide however few lanes are active (same microbenchmark), so what matters is
-//     how few instructions there are.
+//   * phase B, input gradient (round 6 form): every WAVE keeps planes of 13 x 24 cells for its tile, a cell = the four channels
+//     of an accumulator quad (16 bytes), placed around the tile's own neighbourhoods (or, where those spread too far, around what
+//     the tile's centre pixel predicts).  A wave adds its pixels' contributions with plain read-add-write, neighbourhood cell by
+//     neighbourhood cell, one ds_read_b128 + ds_write_b128 per cell and four channels: for a fixed cell (u, v) two lanes of a
+//     half-wave (two pixels) hit the same plane cell only if their neighbourhoods start at the same cell, which a flow that
+//     compresses the image produces (bench flows, level 2: 72 % of the tiles have such a pair); every pixel therefore gets a
+//     TURN, its rank among the pixels of its tile that share its cell (found once per tile through LDS), and the cells are
+//     walked once per turn (the second pixel of a pair hands its values to the first by lane shuffles instead).  The LDS pipe
+//     keeps a wave's accesses in order and the two half-waves work on different channel quads; LDS float atomics would cost
+//     ~170 cycles per wave instruction against ~6 for a read or write (tools/ubench/atomic_patterns.hip).  No barriers inside
+//     the phase.  Neighbourhoods that leave the planes (a flow that tears) go to gx directly, 16 atomics per pixel and channel.
+//     (Rounds 2-5: ONE 22 x 32 plane per channel for the block's whole region, a dword per instruction, the waves' channel sets
+//     kept apart by a permutation of the accumulator rows and a block barrier per group of two channels per lane -- 24.3 k of the
+//     kernel's 58 k cycles at level 2 against 21 k now; 107.6 / 76.4 / 47.1 / 35.7 us at levels 2..5 against 102.2 / 73.5 /
+//     43.5 / 30.8, profiles/r06_dc_bwd_input_planes.txt.  The rows' permutation is still there: phase A's channel pairs use it.)
+//   * the flush adds the four waves' planes cell by cell on its way to gx, once per block, with fp32 atomics over the union of the
+//     waves' touched boxes only: global atomics cost ~0.35 ns per wave INSTRUCTION chip-wide however few lanes are active (same
+//     microbenchmark), so what matters is how few instructions there are (64 cells of one channel each).  A union box of more
+//     than DCP_WFS slices (a flow that tears the region apart) is flushed by every wave for itself.
 // Tiles with per-tap offsets or irregular floors (never in the reference network) are done tap by tap and pixel by pixel
 // by the same block, straight to memory, from the same column gradients (round 2: a second launch behind a flag buffer).
 #pragma once
@@ -51,14 +55,22 @@ constexpr int DCP_ROWS = 16, DCP_COLS = 24;      // source window of a 4x8 tile
 constexpr int DCP_XW_NI = 3;                     // 2 channels x 16 rows x 6 float4 = 192 slots = 3 wave DMA instructions
 constexpr int DCP_XW_F = DCP_XW_NI * 256;        // floats of a channel-pair source window
 constexpr int DCP_RD = 3;                        // source windows in flight (the wave's own ring)
-constexpr int DCP_PR = 22, DCP_PC = 32;          // gx plane of the 8x16 region
-// row stride of a plane in LDS.  ds_read_b32 / ds_write_b32 serve a half-wave (one tile's 4 x 8 pixels on one channel plane) per
-// LDS cycle over 32 banks: with a stride of 32 the tile's four rows sit on the same banks (every access of the walk 4-way
-// conflicted), with 40 they sit 8 banks apart -- a regular tile touches 32 different banks
-constexpr int DCP_PS = 40;
-constexpr int DCP_PLANE = DCP_PR * DCP_PS + 8;
-constexpr int DCP_FS = (DCP_PR * DCP_PC + 63) / 64;  // most 64-cell slices a plane's flush can take
 constexpr int DCP_EXCH = 32;                     // ints of the block's touched-box exchange
+// Wave-private gx planes (phase B), four channels to a cell: 13 x 24 cells around the 7 x 11 box of a tile whose flow is a shift.
+// The planes take the block's WHOLE LDS (4 waves x 4 quads x 312 cells x 16 bytes = 79 872 bytes): what phase B needs from the
+// stash and the exchange area is in registers by then.
+#ifndef MFN_DCP_ABL   // measurement builds only (wrong results): 1 drop the neighbourhoods outside the planes, 2 no flush, 4 no walk
+#define MFN_DCP_ABL 0
+#endif
+#ifndef MFN_DCP_PERM
+#define MFN_DCP_PERM 1
+#endif
+#ifndef MFN_DCP_WFS
+#define MFN_DCP_WFS 8
+#endif
+constexpr int DCP_WR = 13, DCP_WC = 24, DCP_WS = 24;   // rows, columns, row stride in cells
+constexpr int DCP_WPL = DCP_WR * DCP_WS;
+constexpr int DCP_WFS = MFN_DCP_WFS;                       // slices of the merged flush: a regular region's union box is 11 x 19 = 209 cells
 constexpr int DCP_STASH = 21;                    // words a lane parks in LDS (what only phase B / the end needs)
 // K loop and phase A: two weight stages + dump + four x-window rings; phase B reuses the same memory for the 16 planes.
 // 80 000 bytes: TWO blocks per CU (round 3).  Round 2's block was 32 channels -- nine 32 x 32 accumulator tiles, 466
@@ -66,11 +78,13 @@ constexpr int DCP_STASH = 21;                    // words a lane parks in LDS (w
 // with nobody to fill them.  With 16 channels the MFMA's 32 rows are (channel, tap parity): five accumulator tiles
 // (80 registers) hold the nine taps (the tenth slot is dropped), the block fits twice, and the two blocks of a CU are in
 // different phases.
-constexpr int DCP_LDS_A = 2 * DCP_STAGE_F + DCP_DUMP_F + 4 * DCP_RD * DCP_XW_F, DCP_LDS_B = DCP_CB * DCP_PLANE;
-constexpr int DCP_LDS_MAIN = DCP_LDS_A > DCP_LDS_B ? DCP_LDS_A : DCP_LDS_B;
+constexpr int DCP_LDS_A = 2 * DCP_STAGE_F + DCP_DUMP_F + 4 * DCP_RD * DCP_XW_F, DCP_LDS_B = 4 * DCP_CB * DCP_WPL;
+constexpr int DCP_LDS_MAIN = DCP_LDS_A;
 constexpr size_t dc_bwd_input_pix_lds_bytes() { return ((size_t)DCP_LDS_MAIN + DCP_EXCH + 4 * DCP_STASH * 64) * sizeof(float); }
 static_assert(2 * dc_bwd_input_pix_lds_bytes() <= 160 * 1024, "two blocks per CU");
-static_assert(DCP_PR * DCP_PS <= DCP_RD * DCP_XW_F, "the turn map lives in a wave's window ring");
+static_assert((size_t)DCP_LDS_B * sizeof(float) <= dc_bwd_input_pix_lds_bytes(), "the wave-private planes take the whole block's LDS");
+static_assert(DCP_WFS % 2 == 0, "the merged flush takes its slices two at a time");
+static_assert(DCP_WPL <= DCP_RD * DCP_XW_F, "the turn map lives in a wave's window ring");
 
 struct DcBwdPParams {
   const float *gout, *x, *offset, *w;
@@ -91,9 +105,11 @@ struct DcBwdPParams {
 
 __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p) {
   constexpr int T = 9, TP = 5, KO = DCP_KO, KS = DCP_KS, NI = DCP_WNI, ROWS = DCP_ROWS, COLS = DCP_COLS, XW_NI = DCP_XW_NI;
-  constexpr int PR = DCP_PR, PC = DCP_PC, PS = DCP_PS, PL = DCP_PLANE, RD = DCP_RD, CB = DCP_CB;
+  constexpr int RD = DCP_RD, CB = DCP_CB;
   constexpr int NST = 8;        // channel pairs of a lane: phase A's steps
-  constexpr int CPG = 2;        // channels a lane walks at a time in phase B (four groups)
+  constexpr int CPG = 4;        // channels a lane walks at a time in phase B: an accumulator quad (two groups)
+  constexpr int PRe = DCP_WR, PCe = DCP_WC, PSe = DCP_WS, PLe = DCP_WPL;   // a wave's gx planes: rows, columns, row stride, cells
+  constexpr int WFS = DCP_WFS;
   MFN_DYN_SHARED(float, lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = MFN_UNIFORM(tid >> 6);
@@ -110,9 +126,12 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
   const int bx = p.xcd ? (int)mfn_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int cb = blockIdx.y * CB;
   // The MFMA's 32 rows: row i = (channel slot i & 15, tap parity i >> 4).  Slot sigma of wave w is channel
-  // cb + (sigma ^ xw): the waves' slots are the channels permuted so that at any step of phase B the four waves hold
-  // different channels (bits 1 and 3 flipped; bit 2 -- the two half-waves -- stays: a lane pair is channels c and c + 4).
-  const int xw = MFN_UNIFORM(((wave & 1) << 1) | ((wave & 2) << 2));
+  // cb + (sigma ^ xw): the waves' slots are the channels permuted (bits 1 and 3 flipped; bit 2 -- the two half-waves -- stays: a
+  // lane pair is channels c and c + 4).  Rounds 2-5 needed that to keep the waves apart in phase B's shared planes; with a wave's
+  // own planes it only decides which channel pair a wave's phase-A windows carry at a step (no measurable effect either way:
+  // MFN_DCP_PERM=0 builds time the same at every level, profiles/r06_dc_bwd_input_planes.txt).
+  auto xw_of = [](int w) { return MFN_DCP_PERM ? ((w & 1) << 1) | ((w & 2) << 2) : 0; };
+  const int xw = MFN_UNIFORM(xw_of(wave));
   // accumulator register 8 s + q of a lane (tap parity s, q = 0..7): slot (q & 3) + 8 (q >> 2) + 4 half
   auto slot_of = [&](int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; };
   auto chan_of = [&](int q, int h) { return slot_of(q, h) ^ xw; };  // channel inside the block
@@ -190,10 +209,10 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
   int lo0y, lo0x;
   const bool fm = p.flow != nullptr;  // uniform: the offsets come from the flow field (the forward's arithmetic, kernels/deform_conv.h)
   const float *offn = fm ? p.flow + (size_t)n * 2 * plane : p.offset + (size_t)n * 2 * T * plane;
-  // offsets of the tile's and the region's centre pixels (uniform): where the windows are placed -- and this pixel's own.
+  // offset of the tile's centre pixel (uniform): where its source window is placed -- and this pixel's own.
   // ALL requested before the first is used: written as `ok = ok && load == ...` hipcc made every load conditional on the one
   // before, twenty round trips one after the other (11 k of the 17 k cycles of this kernel's setup at level 2).
-  float ctile[2], creg[2];
+  float ctile[2];
   auto scaled = [&](float v) { return fm ? v * p.flow_scale / p.flow_stride : v; };
   auto centre_floor = [&](const float (&c)[2], int &fh, int &fw) {
     fh = MFN_UNIFORM((int)fminf(fmaxf(floorf(c[0]), -1.0e6f), 1.0e6f));
@@ -201,9 +220,8 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
   };
   {
     const float *o1 = offn + (size_t)min(tyi * 4 + 2, H - 1) * W + min(txi * 8 + 4, W - 1);
-    const float *o2 = offn + (size_t)min(ry0 + 4, H - 1) * W + min(rx0 + 8, W - 1);
     const float *op = offn + pix;
-    float cv[4] = {o1[0], o1[plane], o2[0], o2[plane]};
+    float cv[2] = {o1[0], o1[plane]};
     float ov[2 * T];
     ov[0] = op[0]; ov[1] = op[plane];
     if (!fm) {
@@ -211,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
       for (int t = 2; t < 2 * T; ++t) ov[t] = op[(size_t)t * plane];
     }
     MFN_COMPILER_FENCE();
-    ctile[0] = scaled(cv[0]); ctile[1] = scaled(cv[1]); creg[0] = scaled(cv[2]); creg[1] = scaled(cv[3]);
+    ctile[0] = scaled(cv[0]); ctile[1] = scaled(cv[1]);
     const float oh = scaled(ov[0]), ow = scaled(ov[1]);
     if (!fm) {  // one offset for all nine taps?
       int same = 1;
@@ -275,19 +293,27 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
   int py0, px0;
   {
     int fh, fw;
-    centre_floor(creg, fh, fw);
-    py0 = ry0 - p.ph + fh - (PR - 11) / 2;
-    px0 = rx0 - p.pw + fw - (PC - 19) / 2;
+    {   // this wave's planes: around the tile's neighbourhoods where they fit, else around what its centre pixel predicts
+      centre_floor(ctile, fh, fw);
+      py0 = tyi * 4 - p.ph + fh - (PRe - 7) / 2;
+      px0 = txi * 8 - p.pw + fw - (PCe - 11) / 2;
+      const int big = 1 << 28;
+      const int ymin = mfn_wave_min_i32(px_valid ? ly0 : big), ymax = mfn_wave_max_i32(px_valid ? ly0 : -big);
+      const int xmin = mfn_wave_min_i32(px_valid ? lx0 : big), xmax = mfn_wave_max_i32(px_valid ? lx0 : -big);
+      if (ymax >= ymin && ymax - ymin + 4 <= PRe) py0 = ymin - (PRe - (ymax - ymin + 4)) / 2;   // uniform
+      if (xmax >= xmin && xmax - xmin + 4 <= PCe) px0 = xmin - (PCe - (xmax - xmin + 4)) / 2;
+      py0 = MFN_UNIFORM(py0); px0 = MFN_UNIFORM(px0);
+    }
   }
   const int cry = ly0 - py0, crx = lx0 - px0;                 // the neighbourhood's corner (0, 0) in plane coordinates
-  const bool inplane = cry >= 0 && cry + 3 < PR && crx >= 0 && crx + 3 < PC;
+  const bool inplane = cry >= 0 && cry + 3 < PRe && crx >= 0 && crx + 3 < PCe;
   // turn of this pixel: its rank among the tile's pixels whose neighbourhoods start at the same plane cell; -1: none
   // (outside the image / the plane).  The map lives in this wave's (still idle) window ring.
   int turn = -1, nturns = 0;
   int partner = -1, merged = 0;  // lane j' of the pixel whose contributions this lane adds to its own (or -1); any pair in the tile
   if (fast && p.req_x) {
     int *map = reinterpret_cast<int *>(xwin);
-    const int key = cry * PS + crx;
+    const int key = cry * PSe + crx;
     bool pending = px_valid && inplane;
     while (__any(pending)) {
       if (pending) map[key] = j;   // both half-waves hold the same pixels: lane j and j + 32 write the same value
@@ -320,10 +346,18 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
     const int big = 1 << 28;
     const int y0 = mfn_wave_min_i32(mine ? cry : big), y1 = mfn_wave_max_i32(mine ? cry + 3 : -big);
     const int x0 = mfn_wave_min_i32(mine ? crx : big), x1 = mfn_wave_max_i32(mine ? crx + 3 : -big);
-    if (lane == 0) { int *e = exch + wave * 8; e[0] = y0; e[1] = y1; e[2] = x0; e[3] = x1; }
+    // (wave-private planes: the box in IMAGE coordinates, and where the wave's planes lie)
+    if (lane == 0) {
+      int *e = exch + wave * 8;
+      const bool anyb = y1 >= y0;
+      e[0] = anyb ? y0 + py0 : y0; e[1] = anyb ? y1 + py0 : y1;
+      e[2] = anyb ? x0 + px0 : x0; e[3] = anyb ? x1 + px0 : x1;
+      e[4] = py0; e[5] = px0;
+    }
   } else if (lane == 0) {
     int *e = exch + wave * 8;
     e[0] = 1 << 28; e[1] = -(1 << 28); e[2] = 1 << 28; e[3] = -(1 << 28);
+    e[4] = 0; e[5] = 0;
   }
   MFN_WAIT_LGKM0();
   // the first three source windows are requested behind the first weight chunk's barrier (K loop): requested here, the
@@ -343,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
       stash[(15 + i) * 64] = vx * geo[DCS_BX + i];
     }
     int *si = reinterpret_cast<int *>(stash);
-    si[18 * 64] = cry * PS + crx;
+    si[18 * 64] = cry * PSe + crx;
     si[19 * 64] = (px_valid && !inplane) ? -2 : turn;   // -2: the neighbourhood leaves the plane -> straight to gx
     si[20 * 64] = partner;
   }
@@ -605,36 +639,60 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
   const bool any_merged = MFN_UNIFORM(merged) != 0;
   // the flush plan: 64 consecutive cells of the planes' touched box per atomic instruction
   int fy0 = 1 << 28, fy1 = -(1 << 28), fx0 = 1 << 28, fx1 = -(1 << 28);
+  int woy[4], wox[4];   // wave-private planes: where every wave's planes lie (a wave without cells: far away, nothing is inside)
   MFN_UNROLL
   for (int w2 = 0; w2 < 4; ++w2) {
     const int *e = exch + w2 * 8;
     fy0 = min(fy0, e[0]); fy1 = max(fy1, e[1]); fx0 = min(fx0, e[2]); fx1 = max(fx1, e[3]);
+    woy[w2] = MFN_UNIFORM(e[1] >= e[0] ? e[4] : (1 << 28)); wox[w2] = MFN_UNIFORM(e[5]);
   }
   fy0 = MFN_UNIFORM(fy0); fy1 = MFN_UNIFORM(fy1); fx0 = MFN_UNIFORM(fx0); fx1 = MFN_UNIFORM(fx1);
   const bool any_cells = fy1 >= fy0;
   const int ncols = any_cells ? fx1 - fx0 + 1 : 1, ncells = any_cells ? (fy1 - fy0 + 1) * ncols : 0;
-  int floff[DCP_FS], fgoff[DCP_FS];
+  // cell e of the union box (image coordinates) in every wave's planes (its float offset inside a plane, or
+  // a zero mask where the cell lies outside them: untouched cells of a plane are zero)
+  constexpr int NWF = WFS;
+  int wfo[NWF][4], wgo[NWF];
+  unsigned wfm[NWF];
+  const bool merged_flush = ncells <= WFS * 64;   // uniform
   {
     const float inv_ncols = 1.f / (float)ncols;
     MFN_UNROLL
-    for (int sl = 0; sl < DCP_FS; ++sl) {
-      floff[sl] = 0; fgoff[sl] = -1;
-      if (sl * 64 >= ncells) continue;   // uniform: a regular region's box is 11 x 19 cells, four slices of the eleven
+    for (int sl = 0; sl < NWF; ++sl) {
+      wgo[sl] = -1; wfm[sl] = 0;
+      MFN_UNROLL
+      for (int w2 = 0; w2 < 4; ++w2) wfo[sl][w2] = 0;
+      if (!merged_flush || sl * 64 >= ncells) continue;   // uniform
       const int e = sl * 64 + lane;
       int row = (int)((float)e * inv_ncols), col = e - row * ncols;  // cell counts are far below 2^24: off by one at most
       if (col < 0) { --row; col += ncols; }
       if (col >= ncols) { ++row; col -= ncols; }
-      const int yy = py0 + fy0 + row, xx = px0 + fx0 + col;
-      floff[sl] = min(max((fy0 + row) * PS + fx0 + col, 0), PR * PS - 1);
-      fgoff[sl] = (e < ncells && yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
+      const int yy = fy0 + row, xx = fx0 + col;
+      wgo[sl] = (e < ncells && yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
+      MFN_UNROLL
+      for (int w2 = 0; w2 < 4; ++w2) {
+        const int oy = yy - woy[w2], ox = xx - wox[w2];
+        const bool in = oy >= 0 && oy < PRe && ox >= 0 && ox < PCe;
+        wfo[sl][w2] = in ? oy * PSe + ox : 0;
+        wfm[sl] |= in ? 1u << w2 : 0u;
+      }
     }
   }
   unsigned long long td0 = 0, td1 = 0, td2 = 0, td3 = 0;
 
-  for (int e = tid; e < CB * PL / 4; e += 256) reinterpret_cast<float4 *>(lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-  MFN_LDS_BARRIER();
+  float *const myplanes = lds + wave * (CB * PLe);
+  int oby0 = 0, oby1 = -1, obx0 = 0, obx1 = -1;   // this wave's own box (the flush of a torn region)
+  {
+    // the planes lie over the exchange area and the stashes: every wave has what it needs from them (above) behind this barrier.
+    // A wave zeroes its own planes: its LDS accesses stay in order, no barrier after
+    const int own0 = MFN_UNIFORM(exch[wave * 8 + 0]), own1 = MFN_UNIFORM(exch[wave * 8 + 1]), own2 = MFN_UNIFORM(exch[wave * 8 + 2]), own3 = MFN_UNIFORM(exch[wave * 8 + 3]);
+    oby0 = own0; oby1 = own1; obx0 = own2; obx1 = own3;
+    MFN_LDS_BARRIER();
+    for (int e = lane; e < CB * PLe / 4; e += 64) reinterpret_cast<float4 *>(myplanes)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    MFN_WAVE_SYNC_EMU();
+  }
   auto group_b = [&](auto g_c) {
-    constexpr int g = decltype(g_c)::value;   // chains c = 0, 1: the lane's channels q = 2 g + c
+    constexpr int g = decltype(g_c)::value;   // chains c = 0 .. CPG - 1: the lane's channels q = CPG g + c
     if (g == 0 && p.timeline) td0 = MFN_CYCLES();
     if (fast) {
       // the nine taps folded onto the 4x4 neighbourhood, along x first, then along y
@@ -644,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
         float R[3][4];
         MFN_UNROLL
         for (int i = 0; i < 3; ++i) {
-          const float c0 = DCP_ACC(3 * i, 2 * g + c), c1 = DCP_ACC(3 * i + 1, 2 * g + c), c2 = DCP_ACC(3 * i + 2, 2 * g + c);
+          const float c0 = DCP_ACC(3 * i, CPG * g + c), c1 = DCP_ACC(3 * i + 1, CPG * g + c), c2 = DCP_ACC(3 * i + 2, CPG * g + c);
           R[i][0] = c0 * ax[0];
           R[i][1] = fmaf(c0, bxw[0], c1 * ax[1]);
           R[i][2] = fmaf(c1, bxw[1], c2 * ax[2]);
@@ -667,34 +725,32 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
             for (int v = 0; v < 4; ++v) G[c][u][v] = fmaf(__shfl(G[c][u][v], psrc), pmask, G[c][u][v]);
       }
       if (g == 0 && p.timeline) { MFN_OPAQUE(G[CPG - 1][3][3]); td1 = MFN_CYCLES(); }
-      float *pl[CPG];
-      MFN_UNROLL
-      for (int c = 0; c < CPG; ++c) pl[c] = lds + (size_t)chan_of(2 * g + c, half) * PL + cell0;
+      // the lane's four channels of this group are accumulator slots c + 8 g + 4 half = quad 2 g + half of the
+      // wave's planes (kept in SLOT order: the flush undoes the waves' channel permutations), component c
+      float4 *pq = reinterpret_cast<float4 *>(myplanes + (size_t)(2 * g + half) * (4 * PLe)) + cell0;
       // (emulation: free-running lanes take a whole walk one lane at a time, mfn_rt.h)
-      for (int t = 0; t < nturns; ++t) {
+      for (int t = 0; t < ((MFN_DCP_ABL & 4) ? 0 : nturns); ++t) {
         if (myturn == t) {
           MFN_EMU_LOCK();
           MFN_UNROLL
           for (int u = 0; u < 4; ++u)
             MFN_UNROLL
             for (int v = 0; v < 4; ++v) {
-              float o[CPG];
-              MFN_UNROLL
-              for (int c = 0; c < CPG; ++c) o[c] = pl[c][u * PS + v];
-              MFN_UNROLL
-              for (int c = 0; c < CPG; ++c) pl[c][u * PS + v] = o[c] + G[c][u][v];
-              // the next cell's reads are ISSUED after this cell's writes: another lane's cell (u, v) is this lane's
+              float4 o4 = pq[u * PSe + v];
+              o4.x += G[0][u][v]; o4.y += G[1][u][v]; o4.z += G[2][u][v]; o4.w += G[3][u][v];
+              pq[u * PSe + v] = o4;
+              // the next cell's read is ISSUED after this cell's writes: another lane's cell (u, v) is this lane's
               // cell (u', v'); the in-order LDS pipe then orders them
               MFN_COMPILER_FENCE();
             }
           MFN_EMU_UNLOCK();
         }
       }
-      if (__any(myturn == -2)) {  // neighbourhoods outside the plane: straight to gx
+      if (!(MFN_DCP_ABL & 1) && __any(myturn == -2)) {  // neighbourhoods outside the plane: straight to gx
         if (myturn == -2) {
           MFN_UNROLL
           for (int c = 0; c < CPG; ++c) {
-            const int ch = cb + chan_of(2 * g + c, half);
+            const int ch = cb + chan_of(CPG * g + c, half);
             float *gim = p.gx + ((size_t)n * p.Cin + min(ch, p.Cin - 1)) * plane;
             MFN_UNROLL
             for (int u = 0; u < 4; ++u)
@@ -708,32 +764,71 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
         }
       }
     }
-    if (g == 0 && p.timeline) { MFN_WAIT_LGKM0(); td2 = MFN_CYCLES(); }
-    MFN_LDS_BARRIER();  // the waves stay within one group of each other: their permuted channel sets never meet
-    if (g == 0 && p.timeline) td3 = MFN_CYCLES();
+    if (g == 0 && p.timeline) { MFN_WAIT_LGKM0(); td2 = MFN_CYCLES(); td3 = td2; }   // (no barrier behind a group any more)
   };
-  group_b(DcInt<0>{}); group_b(DcInt<1>{}); group_b(DcInt<2>{}); group_b(DcInt<3>{});
+  group_b(DcInt<0>{}); group_b(DcInt<1>{});
+  MFN_LDS_BARRIER();   // the flush reads every wave's planes
 #undef DCP_ACC
-  // ---- flush: wave w takes planes w, w + 4, w + 8, w + 12 (plane = channel inside the block) -----------------------------
+  // ---- flush ------------------------------------------------------------------------------------------------------------
   if (p.timeline) tk3 = MFN_CYCLES();
-  // all of a plane's reads are requested before the first atomic (unconditional reads: a branch per slice would wait for each);
-  // a regular region's box (11 x 19 cells) is four slices
-  auto flush = [&](auto nsl_c) {
+  // wave w takes the channels 4 w .. 4 w + 3 and adds the four waves' planes cell by cell on the way out (a
+  // cell outside a wave's planes: masked).  Wave w2 keeps slot sigma = channel ^ xw(w2) at quad sigma >> 2, component sigma & 3:
+  // the block's channel quad w is its quad w ^ (xw(w2) >> 2), components swapped in pairs where xw(w2) has bit 1.
+  auto flush_merged = [&](auto nsl_c) {
     constexpr int NSL = decltype(nsl_c)::value;
-    for (int pi = wave; pi < CB; pi += 4) {
-      if (cb + pi >= p.Cin) continue;  // uniform
-      const float *pp = lds + (size_t)pi * PL;
-      float *gim = p.gx + ((size_t)n * p.Cin + cb + pi) * plane;
-      float fv[NSL];
+    if (cb + 4 * wave >= p.Cin) return;  // uniform
+    float *gim = p.gx + ((size_t)n * p.Cin + cb + 4 * wave) * plane;
+    MFN_UNROLL
+    for (int sl0 = 0; sl0 < NSL; sl0 += 2) {   // two slices' reads in flight (32 registers)
+    if (sl0 * 64 >= ncells) break;   // uniform
+    float4 fr[2][4];
+    MFN_UNROLL
+    for (int sl = sl0; sl < sl0 + 2; ++sl)
       MFN_UNROLL
-      for (int sl = 0; sl < NSL; ++sl) fv[sl] = pp[floff[sl]];
+      for (int w2 = 0; w2 < 4; ++w2)
+        fr[sl - sl0][w2] = reinterpret_cast<const float4 *>(lds + (size_t)w2 * (CB * PLe) + (size_t)(wave ^ (xw_of(w2) >> 2)) * (4 * PLe))[wfo[sl][w2]];
+    MFN_UNROLL
+    for (int sl = sl0; sl < sl0 + 2; ++sl) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
       MFN_UNROLL
-      for (int sl = 0; sl < NSL; ++sl)
-        if (sl * 64 < ncells && fgoff[sl] >= 0 && fv[sl] != 0.f) atomicAdd(gim + fgoff[sl], fv[sl]);
+      for (int w2 = 0; w2 < 4; ++w2) {
+        const bool in = ((wfm[sl] >> w2) & 1u) != 0;
+        const float4 f = fr[sl - sl0][w2];
+        if (xw_of(w2) & 2) { v[0] += in ? f.z : 0.f; v[1] += in ? f.w : 0.f; v[2] += in ? f.x : 0.f; v[3] += in ? f.y : 0.f; }
+        else { v[0] += in ? f.x : 0.f; v[1] += in ? f.y : 0.f; v[2] += in ? f.z : 0.f; v[3] += in ? f.w : 0.f; }
+      }
+      if (sl * 64 < ncells && wgo[sl] >= 0) {
+        MFN_UNROLL
+        for (int k = 0; k < 4; ++k)
+          if (cb + 4 * wave + k < p.Cin && v[k] != 0.f) atomicAdd(gim + (size_t)k * plane + wgo[sl], v[k]);
+      }
+    }
     }
   };
-  if (any_cells) {
-    if (ncells <= 256) flush(DcInt<4>{}); else flush(DcInt<DCP_FS>{});
+  // ... or, the union box being too large for that (a flow that tears the region apart): every wave its own planes, its own box
+  auto flush_own = [&]() {
+    if (oby1 < oby0) return;   // uniform
+    const int nc = obx1 - obx0 + 1, ncl = (oby1 - oby0 + 1) * nc;
+    for (int sl = 0; sl * 64 < ncl; ++sl) {
+      const int e1 = sl * 64 + lane;
+      const int row = e1 / nc, col = e1 - row * nc;
+      const int yy = oby0 + row, xx = obx0 + col;
+      const bool okc = e1 < ncl && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const int lo = min(max((yy - py0) * PSe + (xx - px0), 0), PLe - 1);
+      for (int sq = 0; sq < 4; ++sq) {
+        const float4 f = reinterpret_cast<const float4 *>(myplanes + (size_t)sq * (4 * PLe))[lo];
+        const float fv4[4] = {f.x, f.y, f.z, f.w};
+        MFN_UNROLL
+        for (int k = 0; k < 4; ++k) {
+          const int ch = cb + ((4 * sq + k) ^ xw);
+          if (okc && ch < p.Cin && fv4[k] != 0.f) atomicAdd(p.gx + ((size_t)n * p.Cin + ch) * plane + (size_t)yy * W + xx, fv4[k]);
+        }
+      }
+    }
+  };
+  if (any_cells && !(MFN_DCP_ABL & 2)) {
+    if (!merged_flush) flush_own();
+    else flush_merged(DcInt<WFS>{});
   }
   if (p.timeline && tid == 0) {
     unsigned long long *b_ = p.timeline + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;

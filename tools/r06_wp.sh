@@ -1,0 +1,11 @@
+#!/bin/bash
+# Measurement: dc_bwd_input_pix_kernel with wave-private planes (the library) against the region's shared planes (tools/ablate_build/libmfn_wp0.so,
+# built with -DMFN_DCP_WP=0): per-level durations, interleaved, then the phases, then the GPU parity tests of the deformable backward
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
+for i in 1 2; do
+  [ -f tools/ablate_build/libmfn_wp0.so ] && MFN_HIP_SO=tools/ablate_build/libmfn_wp0.so timeout 300 python tools/bwd_levels.py 2>&1 | grep '^L' | sed 's/^/shared  /'
+  timeout 300 python tools/bwd_levels.py 2>&1 | grep '^L' | sed 's/^/private /'
+done
+timeout 600 python tools/phase_bwd_pix.py 2>&1 | grep -v amdgpu.ids | grep "gx=write goffset=write"
+timeout 600 python tools/phase_bwd_pix.py detail 2>&1 | grep -v amdgpu.ids | grep "gx=write goffset=write"
+[ -n "$NOTEST" ] || timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "deform and (bwd or backward)" 2>&1 | tail -3
