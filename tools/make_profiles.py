@@ -19,8 +19,8 @@ if os.path.exists(db):
         f.write("# %s -- `rocprofv3 --kernel-trace --stats -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-epe --no-side-configs --no-e2e`\n\n" % tag)
         f.write("MI355X (gfx950), ROCm 7.2.  Source: gpurun_out/prof_bench/bench_results.db (top_kernels view); durations in "
                 "microseconds.\nOne hot-path pass (drop-in mode, weights packed once) = 5 correlation calls (levels 6 / 5 / 4: "
-                "`corr_gramk_kernel`, the Gram band on the bf16 matrix cores with a wave per 32 channels; level 3: `corr_dma_kernel`, two channel "
-                "groups; level 2: `corr_gram_kernel`, the Gram band with cooperative full-line stores -- template argument 5 = TERMS: 5 the round-6 form (operand split on the matrix cores, results one step behind the chains)), 4 x (`offsets_from_flow_v4_kernel`: the reference's separate offset tensor, + deformable conv `dc_mma_kernel<MT, PT, KW, RING>`: bf16 x 3 on the matrix cores, MT filter tiles x PT pixel tiles x KW K slices per block), 1 warp.  bench.py also runs the pass on two more "
+                "`corr_gramk_kernel`, the Gram band on the bf16 matrix cores with a wave per 32 channels; levels 3 and 2: `corr_gram_kernel`, the Gram band with cooperative "
+                "full-line stores -- last template argument 2: level 3's two-chunk K loop (64 channels), 1: level 2; fifth template argument = TERMS: 5 the round-6 form (operand split on the matrix cores, results one step behind the chains)), 4 x (`offsets_from_flow_v4_kernel`: the reference's separate offset tensor, + deformable conv `dc_mma_kernel<MT, PT, KW, RING>`: bf16 x 3 on the matrix cores, MT filter tiles x PT pixel tiles x KW K slices per block), 1 warp.  bench.py also runs the pass on two more "
                 "streams for its informational `pipelined` figure, the level-2 correlation 200 more times back to back, 200 eager "
                 "passes with every kernel timed (`roofline`, `kernels`), 18 launches on rotated buffers, the rough-flow batch and the pass with re-packed weights (`repack`: + `dcm_pack_weights_kernel`); "
                 "`profiles/%s_corr_l2_durations_by_context.txt` cuts the level-2 correlation's launches by context.\n" % tag +
