@@ -648,7 +648,10 @@ __global__ __launch_bounds__(256, 2) void dc_bwd_input_pix_kernel(DcBwdPParams p
   }
   fy0 = MFN_UNIFORM(fy0); fy1 = MFN_UNIFORM(fy1); fx0 = MFN_UNIFORM(fx0); fx1 = MFN_UNIFORM(fx1);
   const bool any_cells = fy1 >= fy0;
-  const int ncols = any_cells ? fx1 - fx0 + 1 : 1, ncells = any_cells ? (fy1 - fy0 + 1) * ncols : 0;
+  // (the waves' planes may lie hundreds of thousands of pixels apart -- a flow that sends tiles far away: the cell count in 64 bits)
+  const int ncols = any_cells ? fx1 - fx0 + 1 : 1;
+  const long long ncells64 = any_cells ? (long long)(fy1 - fy0 + 1) * (long long)ncols : 0;
+  const int ncells = ncells64 > (long long)(1 << 30) ? (1 << 30) : (int)ncells64;
   // cell e of the union box (image coordinates) in every wave's planes (its float offset inside a plane, or
   // a zero mask where the cell lies outside them: untouched cells of a plane are zero)
   constexpr int NWF = WFS;

@@ -350,7 +350,7 @@ def shared_offsets(rng, N, H, W, kind):
     shared-offset backward kernel takes in one pass.  kind: smooth (sub-pixel field + global shift), integer (floors
     on the lattice: clamp / zero rules at the borders), outside (a quarter of the image points far outside), rough
     (per-pixel noise: neighbourhoods leave the LDS window), mixed (some rows get per-tap offsets: those strips must
-    be left to the tap-by-tap kernel)."""
+    be left to the tap-by-tap kernel), far (tiles sent hundreds of thousands of pixels away: index arithmetic of the gradient planes' boxes)."""
     if kind == "integer":
         fl = rng.integers(-3, 4, (N, 2, 1, 1)).astype(np.float32) + np.zeros((N, 2, H, W), np.float32)
         fl[:, :, ::3, ::4] += 1.0
@@ -360,6 +360,12 @@ def shared_offsets(rng, N, H, W, kind):
     if kind == "outside":
         fl[:, :, : H // 2, : W // 2] += np.float32(1.5 * max(H, W))
         fl[:, 0, H // 2:, : W // 3] -= np.float32(H + 0.5)
+    if kind == "far":   # whole 4x8 tiles displaced by 3e5 .. 2.5e9 pixels, coherently: their neighbourhoods stay together, far from the image and from each other
+        fl[:, :, :4, :8] += np.float32(3.0e5)
+        fl[:, 0, :4, 8:16] -= np.float32(7.0e5)
+        fl[:, 1, :4, 8:16] += np.float32(2.5e9)   # (the fourth tile of the first 8x16 region stays where it is)
+        fl[:, 0, 4:8, :8] += np.float32(46341.0)
+        fl[:, 1, 4:8, :8] -= np.float32(46341.0)
     off = np.repeat(fl[:, None], 9, axis=1).reshape(N, 18, H, W).copy()
     if kind == "mixed":
         off[:, :, 1::4, :] += (rng.standard_normal((N, 18, len(range(1, H, 4)), W)) * 0.7).astype(np.float32)

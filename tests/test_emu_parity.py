@@ -472,7 +472,7 @@ def test_deform_conv_backward_shared_offsets(ops, oracle, kind):
                               req=("write", "write" if full else "null", "write", "write"))
 
 
-@pytest.mark.parametrize("kind", ["smooth", "integer", "outside", "rough", "mixed"])
+@pytest.mark.parametrize("kind", ["smooth", "integer", "outside", "rough", "mixed", "far"])
 def test_deform_conv_backward_lane_is_pixel(ops, oracle, kind):
     """dc_bwd_input_pix_kernel (W % 4 == 0, Cin % 4 == 0): 8x16 regions of four 4x8 tiles, ragged at the right and bottom
     edges; pixels that share a plane cell (turns and merged pairs: 'smooth' has sub-pixel noise, 'integer' lattice steps),

@@ -653,7 +653,7 @@ def test_deform_conv_backward_levels(ops, oracle, dev, C, H, W):
     pc.case_deform_bwd(ops, oracle, dev, host, 2, C, C, H, W, kernel=(3, 3), pad=(1, 1))
 
 
-@pytest.mark.parametrize("kind", ["smooth", "integer", "outside", "rough", "mixed"])
+@pytest.mark.parametrize("kind", ["smooth", "integer", "outside", "rough", "mixed", "far"])
 @pytest.mark.parametrize("N,C,H,W", [(2, 128, 12, 16), (2, 96, 24, 32), (1, 64, 48, 64), (1, 32, 96, 128), (2, 40, 11, 21)])
 def test_deform_conv_backward_shared_offsets(ops, oracle, dev, kind, N, C, H, W):
     """One (dy,dx) per pixel for all nine taps (MaskFlownet.py:230): dc_bwd_input_pix_kernel takes the tiles that
