@@ -172,6 +172,32 @@ def test_correlation_numeric_range_edge_cases(ops, oracle, dev):
             assert np.array_equal(got[inf], want[inf])
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 96, 128), (2, 64, 48, 64)])
+def test_correlation_gram_non_finite_values_stay_in_their_pixels(ops, oracle, dev, shape):
+    """The same rule for the Gram-band kernels whose operand split runs ON the matrix cores (kernels/msplit.h: the selector
+    instruction multiplies the other K slots by zero, and 0 x inf is NaN): an infinity or NaN in one channel of one pixel may turn
+    that PIXEL's terms non-finite -- every output it enters is non-finite in the oracle as well -- and nothing else.  32 channels:
+    the wide selector (level 2's kernel); 64: the lane-local one with the two-chunk K loop (level 3's)."""
+    from maskflownet_amd import _lib
+    rng = np.random.default_rng(78)
+    f1, f2 = pc.feat(rng, shape), pc.feat(rng, shape)
+    f1[0, 3, 10, 11] = np.inf
+    f2[0, 7, 12, 20] = -np.inf
+    f2[1, 0, 2, 2] = np.nan
+    f1[1, 5, 40, 33] = np.float32(3e38)     # the first term of the split rounds up to infinity
+    want = oracle.correlation(f1, f2, max_displacement=4, pad_size=4)
+    _lib.set_tuning(corr_variant=48)
+    got = host(ops.Correlation(dev(f1), dev(f2), 1, 4, 1, 1, 4))
+    bad = ~np.isfinite(want)
+    # 3e38: its products overflow in the oracle's fp32 chain where the kernel's pre-scaled operands (1 / C) may not, and its first bf16
+    # term rounds up to infinity where the oracle's value is finite -- outputs that pixel enters are left out of both checks
+    big = np.zeros_like(bad)
+    big[1, :, 36:45, 29:38] = True
+    assert not np.isfinite(got[bad & ~big]).any(), "a non-finite result came back finite"
+    assert np.isfinite(got[~bad & ~big]).all(), "a finite result was poisoned"
+    assert np.abs(got[~bad & ~big] - want[~bad & ~big]).max() <= 1e-5 * np.abs(want[~bad & ~big]).max()
+
+
 def test_deform_numeric_range_edge_cases(ops, oracle, dev):
     """The deformable convolution under both arithmetics on features spanning 1e-12 ... 1e12 across the channels, fp32 denormals, and
     +-inf / NaN in single input pixels: finite inputs agree with the oracle (to 1e-5 of the largest entry); wherever the oracle's
