@@ -198,6 +198,22 @@ def test_correlation_gram_non_finite_values_stay_in_their_pixels(ops, oracle, de
     assert np.abs(got[~bad & ~big] - want[~bad & ~big]).max() <= 1e-5 * np.abs(want[~bad & ~big]).max()
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 96, 128), (2, 64, 48, 64), (2, 128, 12, 16), (2, 40, 11, 20)])
+def test_deform_forward_tiles_displaced_far_away(ops, oracle, dev, shape):
+    """Forward DeformableConvolution under 'far' shared offsets (whole 4x8 tiles sent 3e5 .. 2.5e9 pixels away: the window placement's
+    index arithmetic), both arithmetics; the backward's counterpart is test_deform_conv_backward_shared_offsets[far]."""
+    from maskflownet_amd import _lib
+    N, C, H, W = shape
+    rng = np.random.default_rng(5)
+    x, w = pc.feat(rng, shape), (rng.standard_normal((C, C, 3, 3)) * 0.2).astype(np.float32)
+    b, off = rng.standard_normal(C).astype(np.float32), pc.shared_offsets(rng, N, H, W, "far")
+    want = oracle.deformable_convolution(x, off, w, b, kernel=(3, 3), pad=(1, 1))
+    for arith in (-1, 0):
+        _lib.set_tuning(dc_mma=arith)
+        got = host(ops.DeformableConvolution(dev(x), dev(off), dev(w), dev(b), kernel=(3, 3), pad=(1, 1)))
+        pc.check_close(got, want, what="far offsets %s arithmetic %d" % (shape, arith))
+
+
 def test_deform_numeric_range_edge_cases(ops, oracle, dev):
     """The deformable convolution under both arithmetics on features spanning 1e-12 ... 1e12 across the channels, fp32 denormals, and
     +-inf / NaN in single input pixels: finite inputs agree with the oracle (to 1e-5 of the largest entry); wherever the oracle's
