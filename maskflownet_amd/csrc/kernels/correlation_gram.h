@@ -693,6 +693,13 @@ inline int corr_gram_launch(CorrGramParams p, hipStream_t stream, const char *na
 }
 
 inline bool corr_variant_gram(int v) { return v == 46 || v == 48; }
+// the launch's index range (corr_gram_launch: block id x divisor below 2^32 for the magic divisions): images of a million rows do not
+// take this kernel -- the plan asks before it picks it, so that such a call runs on another kernel instead of failing
+inline bool corr_gram_range_ok(int N, int H, int W, int rows) {
+  const long segs = (H + rows - 1) / rows, bx = ((W + 7) / 8 + 3) / 4;
+  const long nblk = (long)N * segs * bx;
+  return nblk * (bx > segs ? bx : segs) < (1L << 32);
+}
 // Output rows per work item: 6 or 8 (T = 3 / 4 blocks; the schedule is compile-time).  One wave per item, eight resident waves
 // per CU (two blocks of four): the level-2 launch of 384x512 at batch 8 is 2048 items of 6 rows = one residency round.  Fewer
 // rows per item mean more halo (an item converts rows + 2*md f2 rows); 8 where 6 does not divide H and 8 does (448x1024:

@@ -172,6 +172,25 @@ def test_correlation_numeric_range_edge_cases(ops, oracle, dev):
             assert np.array_equal(got[inf], want[inf])
 
 
+def test_correlation_of_a_very_tall_image_leaves_the_gram_kernel(ops, oracle, dev, T):
+    """400 000 rows x 8 columns x 32 channels: beyond the Gram-band kernel's block-index range (its magic divisions need block id x
+    divisor < 2^32).  The plan asks (corr_gram_range_ok) and another kernel runs -- round 6 found the launch answering with an error
+    instead.  Checked on a crop against the oracle (the operator is local: rows y depend on rows y - 4 .. y + 4)."""
+    from maskflownet_amd import _lib
+    g = T.Generator(device="cuda").manual_seed(5)
+    f1 = T.randn(1, 32, 400000, 8, device="cuda", generator=g)
+    f2 = T.randn(1, 32, 400000, 8, device="cuda", generator=g)
+    for variant in (48, -1):
+        _lib.set_tuning(corr_variant=variant)
+        out = ops.Correlation(f1, f2, 1, 4, 1, 1, 4)
+        for y0 in (0, 199990, 399980):
+            a, b = max(y0 - 4, 0), min(y0 + 24, 400000)
+            want = oracle.correlation(f1[:, :, a:b].cpu().numpy(), f2[:, :, a:b].cpu().numpy(), max_displacement=4, pad_size=4)
+            lo, hi = (0 if a == 0 else 4), ((b - a) if b == 400000 else (b - a - 4))
+            pc.check_close(out[:, :, a + lo:a + hi].cpu().numpy(), want[:, :, lo:hi], what="tall image, rows %d.." % (a + lo))
+        del out
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 96, 128), (2, 64, 48, 64)])
 def test_correlation_gram_non_finite_values_stay_in_their_pixels(ops, oracle, dev, shape):
     """The same rule for the Gram-band kernels whose operand split runs ON the matrix cores (kernels/msplit.h: the selector
