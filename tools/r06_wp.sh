@@ -1,6 +1,7 @@
 #!/bin/bash
-# Measurement: dc_bwd_input_pix_kernel with wave-private planes (the library) against the region's shared planes (tools/ablate_build/libmfn_wp0.so,
-# built with -DMFN_DCP_WP=0): per-level durations, interleaved, then the phases, then the GPU parity tests of the deformable backward
+# Measurement (round 6, profiles/r06_dc_bwd_input_planes.txt): dc_bwd_input_pix_kernel with wave-private planes (the library) against the region's shared
+# planes of rounds 2-5 (tools/ablate_build/libmfn_wp0.so: a build of the sources of commit 3cc5511, or -DMFN_DCP_WP=0 while both forms existed; skipped if absent):
+# per-level durations, interleaved, then the phases, then the GPU parity tests of the deformable backward
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 for i in 1 2; do
   [ -f tools/ablate_build/libmfn_wp0.so ] && MFN_HIP_SO=tools/ablate_build/libmfn_wp0.so timeout 300 python tools/bwd_levels.py 2>&1 | grep '^L' | sed 's/^/shared  /'
