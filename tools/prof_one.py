@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run one kernel a few times (for rocprofv3 --pmc / --kernel-trace).  usage: prof_one.py corr|deform|warp [level]
+"""Run one kernel a few times (for rocprofv3 --pmc / --kernel-trace).  usage: prof_one.py corr|deform|warp|deform_bwd|corr_bwd [level]
 env: MFN_TUNE="corr_variant=20,dc_off=1" ITERS=20 ROTATE=1 (corr: inputs and outputs rotate through 7 buffer sets, > 256 MiB:
 the cache-cold case of bench.py's `hbm_rotated`)"""
 import os, sys
@@ -27,6 +27,22 @@ if what == "corr" and os.environ.get("ROTATE"):
         ops.Correlation(f1s[i], f2s[i], 1, 4, 1, 1, 4, True, out=outs[i])
     torch.cuda.synchronize()
     print("done", what, level, "rotated over", nsets, "sets")
+    sys.exit(0)
+if what in ("deform_bwd", "corr_bwd"):   # the backward entry points at the level's shape (drop-in offsets, all four gradients / both gradients)
+    wd = hotpath.HotPathWorkload("cfg2", mode="dropin"); wd.run_eager()
+    n, c, h, w = hotpath.level_shapes(wd.N, wd.H, wd.W)[level]
+    if what == "deform_bwd":
+        go = torch.randn(n, c, h, w, device="cuda")
+        outs = tuple(torch.empty_like(x) for x in (wd.t["c2_%d" % level], wd.o["offset%d" % level], wd.t["w_%d" % level], wd.t["b_%d" % level]))
+        fn = lambda: ops.DeformableConvolution_backward(go, wd.t["c2_%d" % level], wd.o["offset%d" % level], wd.t["w_%d" % level], kernel=(3, 3), pad=(1, 1), out=outs)
+    else:
+        go = torch.randn(n, 81, h, w, device="cuda")
+        g1, g2 = torch.empty_like(wd.t["c1_%d" % level]), torch.empty_like(wd.t["c2_%d" % level])
+        fn = lambda: ops.Correlation_backward(go, wd.t["c1_%d" % level], wd.t["c2_%d" % level], 1, 4, 1, 1, 4, True, g1=g1, g2=g2)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    print("done", what, level, tune)
     sys.exit(0)
 for _ in range(iters):
     if what == "corr":
