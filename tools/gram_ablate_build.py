@@ -2,7 +2,7 @@
 """Measurement only: builds of the library with parts of corr_gram_kernel compiled out (MFN_GRAM_ABLATE bit mask: 1 no matrix
 instructions / stores, 2 no stores, 4 no conversions, 8 no DMA) into tools/ablate_build/libmfn_gram_<mask>.so (git-ignored,
 travels with gpurun).  Results of those builds are wrong on purpose; time them with
-    MFN_HIP_SO=tools/ablate_build/libmfn_gram_<mask>.so python tools/corr_ab.py "corr_variant=40" 2 cfg2 5"""
+    MFN_HIP_SO=tools/ablate_build/libmfn_gram_<mask>.so python tools/corr_ab.py "" 2 cfg2 5     (the plan's form: corr.variant 48)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

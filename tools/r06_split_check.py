@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Measurement / check: corr.variant 47 (operand split on the matrix cores) against 40 (VALU split) at the cfg2 / cfg3 level-2 shapes:
-bit-identity of the outputs (same roundings), finite wide-range input, and what an inf does."""
+"""Measurement / check: the Gram band with the operand split on the matrix cores (corr.variant 48; 47 while it existed) against a kernel that splits on the
+VALU (45, corr_gramk_kernel; 40 while it existed) at the cfg2 / cfg3 level-2 shapes: bit-identity of the outputs (same roundings), finite wide-range input,
+and what an inf does."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
